@@ -1,0 +1,690 @@
+// srukf_api.hip — C-ABI (include/srukf.h) over the gfx950 kernels: context, HBM buffers,
+// per-frame launch sequences, profiling.  No CPU fallback: every numeric result is produced by
+// the kernels in srukf_predict.hip / srukf_factor.hip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "srukf_device.h"
+
+extern "C" {
+void srukf_launch_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, FrameScalars*, const double*, const double*);
+void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const double*, const double*, const double*, double*, double*);
+void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, int*, double*);
+void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
+                       const double*, const int*, const int*, const FrameScalars*, double*);
+void srukf_launch_state_update(hipStream_t, KDims, const double*, const double*, double*);
+void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
+void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
+void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
+void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*);
+void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*);
+void srukf_launch_gmw_panel(hipStream_t, int, int, int, double, const double*, double*, double*, double*, double*);
+void srukf_launch_gmw_trail(hipStream_t, int, int, const double*, const double*, double*);
+void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*);
+void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
+void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
+}
+
+// resets the per-refactor accumulators (theta row maxima, gamma/xi)
+__global__ void k_refactor_reset(int np, unsigned long long* theta_bits, FrameScalars* fs, int reset_stats)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) theta_bits[i] = 0ull;
+    if (i == 0 && reset_stats) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
+}
+__global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
+{
+    fs->frame = frame;
+    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; }
+}
+
+static thread_local std::string g_create_error;
+
+enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_XUPD, KC_SYRK, KC_GMW_PANEL, KC_GMW_TRAIL, KC_GMW_CHECK,
+              KC_GMW_COL, KC_MISC, KC_COUNT };
+static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_state_update", "k_syrk",
+                                             "k_gmw_panel", "k_gmw_trail", "k_gmw_check", "k_gmw_col", "misc" };
+
+struct ProfEvent { hipEvent_t a, b; int kc; };
+
+struct srukf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    srukf_params p;
+    KDims d;
+    KWeights w;
+    // HBM buffers
+    double *X = nullptr, *S = nullptr, *G = nullptr, *Gbak = nullptr, *Wf = nullptr;
+    double *sigR = nullptr, *Cmat = nullptr, *Z = nullptr, *DZ = nullptr, *Ut = nullptr;
+    double *h = nullptr, *Si = nullptr, *PxyR = nullptr, *y = nullptr, *D = nullptr, *Wp = nullptr, *Lp = nullptr;
+    double *zcur = nullptr, *odocur = nullptr, *small = nullptr;
+    int *vis = nullptr, *mcur = nullptr;
+    unsigned long long* theta = nullptr;
+    FrameScalars* fs = nullptr;
+    // staged sequence
+    int seqF = 0;
+    double *odo_seq = nullptr, *z_seq = nullptr;
+    int* m_seq = nullptr;
+    // pinned staging
+    double* hstage = nullptr; size_t hstage_bytes = 0;
+    FrameScalars* hfs = nullptr;
+    // state machine
+    int phase = 0;   // 0 idle, 1 after predict_motion, 2 after predict_measurement
+    bool async_pending = false;
+    std::string err;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfEvent> pev;
+    double prof_ms[KC_COUNT]; long long prof_n[KC_COUNT]; double prof_flops[KC_COUNT]; double prof_bytes[KC_COUNT];
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    (ctx)->err = b_; return SRUKF_ERR_HIP; } } while (0)
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static void host_weights(int Na, const srukf_params& p, KWeights& w)
+{
+    // calculateSampleParameter, SLAM.cpp:1050-1103
+    const double alpha = p.ut_alpha, beta = p.ut_beta;
+    const double Lammda = alpha * alpha * Na - Na;
+    switch (p.weight_type) {
+    case 0:
+        w.wm0 = 1.0 - Na / 3.0; w.wc0 = 1.0 - Na / 3.0; w.wi = (1.0 - w.wc0) / (2 * Na); w.wi_sr = sqrt(w.wi);
+        w.gamma = sqrt(Na / (1.0 - w.wm0));
+        break;
+    case 1:
+        w.gamma = sqrt(Na + Lammda); w.wm0 = Lammda / (Na + Lammda); w.wc0 = w.wm0 + (1 - alpha * alpha + beta);
+        w.wi = 1.0 / (2 * (Na + Lammda)); w.wi_sr = sqrt(fabs(w.wi));
+        break;
+    default:
+        w.gamma = sqrt(3.0 * Na / 2.0); w.wm0 = 1.0 / 3.0; w.wc0 = 1.0 / 3.0; w.wi = 1.0 / (3.0 * Na); w.wi_sr = sqrt(w.wi);
+        break;
+    }
+}
+
+// ---- profiling helpers -------------------------------------------------------------------------
+struct ProfScope {
+    srukf_ctx* c; int kc; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(srukf_ctx* c_, int kc_, double flops, double bytes) : c(c_), kc(kc_) {
+        if (c->profiling) {
+            hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream);
+            c->prof_flops[kc] += flops; c->prof_bytes[kc] += bytes;
+        }
+    }
+    ~ProfScope() {
+        if (c->profiling) { hipEventRecord(b, c->stream); c->pev.push_back({ a, b, kc }); }
+    }
+};
+static void prof_collect(srukf_ctx* c)
+{
+    for (auto& e : c->pev) {
+        float ms = 0.f;
+        hipEventSynchronize(e.b);
+        hipEventElapsedTime(&ms, e.a, e.b);
+        c->prof_ms[e.kc] += ms; c->prof_n[e.kc] += 1;
+        hipEventDestroy(e.a); hipEventDestroy(e.b);
+    }
+    c->pev.clear();
+}
+
+// ---- launch sequences --------------------------------------------------------------------------
+static void seq_predict_motion(srukf_ctx* c, const double* odo_pair_dev)
+{
+    const KDims& d = c->d;
+    ProfScope ps(c, KC_MOTION, 60.0 * d.L, 8.0 * (4.0 * d.n + 8.0 * d.L + 4.0 * d.n));
+    srukf_launch_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->fs, c->odo_seq, odo_pair_dev);
+}
+static void seq_predict_measurement(srukf_ctx* c)
+{
+    const KDims& d = c->d;
+    {
+        ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N));
+        srukf_launch_project(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Z, c->DZ);
+    }
+    {
+        ProfScope ps(c, KC_STATS, 30.0 * d.L * d.N, 8.0 * 3.0 * d.L * 2 * d.N);
+        srukf_launch_meas_stats(c->stream, d, c->w, c->X, c->sigR, c->Z, c->h, c->Si, c->vis, c->PxyR);
+    }
+}
+// one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path
+static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup)
+{
+    const KDims& d = c->d;
+    const int np = d.np, n = d.n;
+    {
+        ProfScope ps(c, KC_MISC, 0, 8.0 * np);
+        hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
+    }
+    {
+        const double nn = n;
+        ProfScope ps(c, KC_SYRK, nn * nn * nn / 3.0 + nn * nn * (ue - ub), 8.0 * (nn * nn + (double)(ue - ub) * nn));
+        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs);
+    }
+    if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
+    if (!slow) {
+        for (int j0 = 0; j0 < np; j0 += SRUKF_NB) {
+            const double rem = np - j0;
+            {
+                ProfScope ps(c, KC_GMW_PANEL, 32.0 * 32.0 * rem, 8.0 * 4.0 * 32.0 * rem);
+                srukf_launch_gmw_panel(c->stream, n, np, j0, c->p.epsilon, c->G, c->Wp, c->Lp, c->D, c->S);
+            }
+            if (j0 + SRUKF_NB < np) {
+                const double r2 = rem - 32;
+                ProfScope ps(c, KC_GMW_TRAIL, 32.0 * r2 * r2, 8.0 * (r2 * r2 + 2.0 * 32.0 * r2));
+                srukf_launch_gmw_trail(c->stream, np, j0, c->Lp, c->Wp, c->G);
+            }
+        }
+        ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
+        srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs);
+    } else {
+        ProfScope ps(c, KC_GMW_COL, (double)n * n * n / 3.0, 8.0 * (double)n * n * n / 3.0);
+        for (int j = 0; j < n; j++)
+            srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+    }
+}
+static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev)
+{
+    const KDims& d = c->d;
+    {
+        const double nn = d.n;
+        ProfScope ps(c, KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
+        srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut);
+    }
+    {
+        ProfScope ps(c, KC_GAIN, 6.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
+        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->y);
+    }
+    {
+        ProfScope ps(c, KC_XUPD, 2.0 * d.n * 2 * d.N, 8.0 * d.n * 2 * d.N);
+        srukf_launch_state_update(c->stream, d, c->Ut, c->y, c->X);
+    }
+}
+
+// ---- C-ABI --------------------------------------------------------------------------------------
+extern "C" {
+
+int srukf_abi_version(void) { return SRUKF_ABI_VERSION; }
+
+int srukf_default_params(srukf_params* p)
+{
+    if (!p) return SRUKF_ERR_BAD_ARG;
+    memset(p, 0, sizeof *p);
+    p->cam_dx = 0.0028; p->cam_dy = 0.0028; p->cam_cx = 310.1129; p->cam_cy = 236.7526;
+    p->cam_k1 = 0.0001; p->cam_k2 = 0.0; p->cam_f = 2.1735; p->image_w = 640; p->image_h = 480;
+    p->a1 = p->a2 = p->a3 = p->a4 = 8.0; p->sigma_measure = 3.0; p->rho0 = 1.0 / 3.0; p->sigma_rho = p->rho0 / 2.0;
+    p->sigma_x = 0.02; p->sigma_y = 0.02; p->sigma_z = 0.005; p->sigma_theta = 0.02;
+    p->epsilon = 1e-13; p->ut_alpha = 1e-3; p->ut_beta = 2.0;
+    p->weight_type = 0; p->noise_type = 0; p->newton_iters = 100;
+    return SRUKF_OK;
+}
+
+const char* srukf_last_error(const srukf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static int alloc_zero(srukf_ctx* c, void** p, size_t bytes)
+{
+    HIPCHK(c, hipMalloc(p, bytes));
+    HIPCHK(c, hipMemsetAsync(*p, 0, bytes, c->stream));
+    return SRUKF_OK;
+}
+#define ALLOC(ptr, count) do { int rc_ = alloc_zero(c, (void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)); if (rc_) { g_create_error = c->err; srukf_destroy(c); return rc_; } } while (0)
+
+int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void* stream)
+{
+    if (!out || !p || N < 1) { g_create_error = "bad argument"; return SRUKF_ERR_BAD_ARG; }
+    if (p->noise_type != 0) { g_create_error = "noise_type != 0 draws random numbers (SLAM.cpp:1505-1516) and is not built"; return SRUKF_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_create_error = "no HIP device (this library has no CPU fallback)";
+        return SRUKF_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return SRUKF_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return SRUKF_ERR_NO_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        return SRUKF_ERR_NO_DEVICE;
+    }
+    srukf_ctx* c = new srukf_ctx();
+    c->device = device; c->p = *p;
+    memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_n, 0, sizeof c->prof_n);
+    memset(c->prof_flops, 0, sizeof c->prof_flops); memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return SRUKF_ERR_HIP; }
+        c->own_stream = true;
+    }
+    KDims& d = c->d;
+    d.N = N; d.n = 6 * N + 4; d.Na = d.n + 5; d.L = 2 * d.Na + 1;
+    d.np = round_up(d.n, SRUKF_PAD); d.mp = round_up(2 * N, SRUKF_PAD);
+    host_weights(d.Na, c->p, c->w);
+    const size_t np = d.np, mp = d.mp;
+    ALLOC(c->X, np); ALLOC(c->S, np * np); ALLOC(c->G, np * np); ALLOC(c->Gbak, np * np); ALLOC(c->Wf, np * np);
+    ALLOC(c->sigR, (size_t)d.L * 8); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
+    ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)N); ALLOC(c->PxyR, 4 * mp); ALLOC(c->y, mp);
+    ALLOC(c->D, np); ALLOC(c->Wp, 32 * np); ALLOC(c->Lp, 32 * np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
+    ALLOC(c->vis, N); ALLOC(c->mcur, N); ALLOC(c->theta, np); ALLOC(c->fs, 1);
+    c->hstage_bytes = sizeof(double) * (np * np + 4096);
+    if (hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars)) != hipSuccess) {
+        g_create_error = "hipHostMalloc failed"; srukf_destroy(c); return SRUKF_ERR_NOMEM;
+    }
+    int rc = srukf_reset(c);
+    if (rc) { g_create_error = c->err; srukf_destroy(c); return rc; }
+    *out = c;
+    return SRUKF_OK;
+}
+
+int srukf_destroy(srukf_ctx* c)
+{
+    if (!c) return SRUKF_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
+                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq };
+    for (void* b : bufs) if (b) hipFree(b);
+    if (c->hstage) hipHostFree(c->hstage);
+    if (c->hfs) hipHostFree(c->hfs);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return SRUKF_OK;
+}
+
+int srukf_reset(srukf_ctx* c)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const KDims& d = c->d;
+    const size_t np = d.np;
+    HIPCHK(c, hipMemsetAsync(c->X, 0, sizeof(double) * np, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->S, 0, sizeof(double) * np * np, c->stream));
+    // initializeParameters, SLAM.cpp:226-231
+    double* hs = c->hstage;
+    hs[0] = c->p.sigma_x; hs[1] = c->p.sigma_y; hs[2] = c->p.sigma_z; hs[3] = c->p.sigma_theta;
+    for (int e = 0; e < 4; e++)
+        HIPCHK(c, hipMemcpyAsync(c->S + (size_t)(d.n - 4 + e) * np + (d.n - 4 + e), hs + e, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->phase = 0; c->async_pending = false;
+    return SRUKF_OK;
+}
+
+int srukf_dims(const srukf_ctx* c, int* N, int* n, int* Na, int* L)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    if (N) *N = c->d.N; if (n) *n = c->d.n; if (Na) *Na = c->d.Na; if (L) *L = c->d.L;
+    return SRUKF_OK;
+}
+
+int srukf_set_state(srukf_ctx* c, const double* X, const double* S)
+{
+    if (!c || !X || !S) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->d.n; const size_t np = c->d.np;
+    double* hs = c->hstage;
+    memset(hs, 0, sizeof(double) * np * np);
+    for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) hs[(size_t)r * np + cc] = S[(size_t)r * n + cc];   // upper triangle only
+    HIPCHK(c, hipMemcpyAsync(c->S, hs, sizeof(double) * np * np, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memset(hs, 0, sizeof(double) * np);
+    memcpy(hs, X, sizeof(double) * n);
+    HIPCHK(c, hipMemcpyAsync(c->X, hs, sizeof(double) * np, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->phase = 0;
+    return SRUKF_OK;
+}
+
+int srukf_get_state(srukf_ctx* c, double* X, double* S)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->d.n; const size_t np = c->d.np;
+    double* hs = c->hstage;
+    if (X) {
+        HIPCHK(c, hipMemcpyAsync(hs, c->X, sizeof(double) * np, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(X, hs, sizeof(double) * n);
+    }
+    if (S) {
+        HIPCHK(c, hipMemcpyAsync(hs, c->S, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int r = 0; r < n; r++) memcpy(S + (size_t)r * n, hs + (size_t)r * np, sizeof(double) * n);
+    }
+    return SRUKF_OK;
+}
+
+int srukf_set_state_device(srukf_ctx* c, const double* dX, const double* dS, int S_ld)
+{
+    if (!c || !dX || !dS || S_ld < c->d.n) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->d.n; const size_t np = c->d.np;
+    HIPCHK(c, hipMemsetAsync(c->S, 0, sizeof(double) * np * np, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->S, sizeof(double) * np, dS, sizeof(double) * S_ld, sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->X, 0, sizeof(double) * np, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->X, dX, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->phase = 0;
+    return SRUKF_OK;
+}
+
+int srukf_get_state_device(srukf_ctx* c, double* dX, double* dS, int S_ld)
+{
+    if (!c || S_ld < c->d.n) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->d.n; const size_t np = c->d.np;
+    if (dX) HIPCHK(c, hipMemcpyAsync(dX, c->X, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    if (dS) HIPCHK(c, hipMemcpy2DAsync(dS, sizeof(double) * S_ld, c->S, sizeof(double) * np, sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SRUKF_OK;
+}
+
+static int block_cov(srukf_ctx* c, int off, int bs, double* out)
+{
+    srukf_launch_block_cov(c->stream, c->d, c->S, off, bs, c->small);
+    HIPCHK(c, hipMemcpyAsync(c->hstage, c->small, sizeof(double) * bs * bs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->hstage, sizeof(double) * bs * bs);
+    return SRUKF_OK;
+}
+
+int srukf_get_robot(srukf_ctx* c, double pose4[4], double P4[16])
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->d.n;
+    if (pose4) {
+        HIPCHK(c, hipMemcpyAsync(c->hstage + 64, c->X + (n - 4), sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(pose4, c->hstage + 64, sizeof(double) * 4);
+    }
+    if (P4) return block_cov(c, n - 4, 4, P4);
+    return SRUKF_OK;
+}
+
+int srukf_get_landmark_block(srukf_ctx* c, int k, double X6[6], double P66[36])
+{
+    if (!c || k < 0 || k >= c->d.N) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (X6) {
+        HIPCHK(c, hipMemcpyAsync(c->hstage + 64, c->X + 6 * k, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(X6, c->hstage + 64, sizeof(double) * 6);
+    }
+    if (P66) return block_cov(c, 6 * k, 6, P66);
+    return SRUKF_OK;
+}
+
+int srukf_get_covariance(srukf_ctx* c, double* P)
+{
+    // m_P_k = S^T S (SLAM.cpp:2404): k_syrk with an empty downdate range
+    if (!c || !P) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->d.n; const size_t np = c->d.np;
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs);
+    HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) { const double v = c->hstage[(size_t)r * np + cc]; P[(size_t)r * n + cc] = v; P[(size_t)cc * n + r] = v; }
+    return SRUKF_OK;
+}
+
+int srukf_predict_motion(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
+{
+    if (!c || !odo_prev || !odo_cur) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    double* hs = c->hstage;
+    for (int e = 0; e < 3; e++) { hs[e] = odo_prev[e]; hs[3 + e] = odo_cur[e]; }
+    HIPCHK(c, hipMemcpyAsync(c->odocur, hs, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    seq_predict_motion(c, c->odocur);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->phase = 1;
+    return SRUKF_OK;
+}
+
+int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    if (c->phase < 1) { c->err = "predict_measurement before predict_motion"; return SRUKF_ERR_SEQUENCE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->d.N;
+    seq_predict_measurement(c);
+    double* hs = c->hstage;
+    HIPCHK(c, hipMemcpyAsync(hs, c->h, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + 2 * N, c->Si, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + 6 * N, c->vis, sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (h) memcpy(h, hs, sizeof(double) * 2 * N);
+    if (Si) memcpy(Si, hs + 2 * N, sizeof(double) * 4 * N);
+    if (visible) memcpy(visible, hs + 6 * N, sizeof(int) * N);
+    c->phase = 2;
+    return SRUKF_OK;
+}
+
+static int read_fs(srukf_ctx* c)
+{
+    HIPCHK(c, hipMemcpyAsync(c->hfs, c->fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SRUKF_OK;
+}
+
+int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder, int mode)
+{
+    if (!c || !z || !matched) return SRUKF_ERR_BAD_ARG;
+    if (c->phase < 2) { c->err = "update before predict_measurement"; return SRUKF_ERR_SEQUENCE; }
+    if (reorder != SRUKF_NEEDNOT_REORDER) { c->err = "NEED_REORDER (rank-aware pivoted path, SLAM.cpp:2122-2138) is not built yet"; return SRUKF_ERR_UNSUPPORTED; }
+    if (mode != SRUKF_UPDATE_SEQUENTIAL && mode != SRUKF_UPDATE_BATCHED) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const KDims& d = c->d;
+    const int N = d.N;
+    int nm = 0; for (int k = 0; k < N; k++) nm += matched[k] ? 1 : 0;
+    c->phase = 0;
+    if (nm == 0) return SRUKF_OK;                                        // SLAM.cpp:2050-2051
+    double* hs = c->hstage;
+    memcpy(hs, z, sizeof(double) * 2 * N);
+    int* hm = (int*)(hs + 2 * N);
+    memcpy(hm, matched, sizeof(int) * N);
+    HIPCHK(c, hipMemcpyAsync(c->zcur, hs, sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->mcur, hm, sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
+    seq_gain(c, c->zcur, c->mcur);
+    // visibility is needed on the host only to skip no-op refactors in SEQUENTIAL mode
+    if (mode == SRUKF_UPDATE_BATCHED) {
+        seq_refactor(c, 0, d.mp, false, true);
+        int rc = read_fs(c); if (rc) return rc;
+        if (c->hfs->clamp_rows > 0) {
+            // the reference's theta clamp would have been active: redo this refactor on the exact path
+            hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
+            hipLaunchKernelGGL(k_refactor_reset, dim3((d.np + 255) / 256), dim3(256), 0, c->stream, d.np, c->theta, c->fs, 0);
+            HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
+            ProfScope ps(c, KC_GMW_COL, 0, 0);
+            for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+        }
+    } else {
+        std::vector<int> visible(N);
+        HIPCHK(c, hipMemcpyAsync(hs + 4 * N, c->vis, sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(visible.data(), hs + 4 * N, sizeof(int) * N);
+        for (int k = 0; k < N; k++) {
+            if (!matched[k]) continue;                                   // SLAM.cpp:2068
+            for (int col = 0; col < 2; col++) {                          // SLAM.cpp:2116
+                const int m = 2 * k + col;
+                seq_refactor(c, m, m + 1, false, true);
+                int rc = read_fs(c); if (rc) return rc;
+                if (c->hfs->clamp_rows > 0) {
+                    hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
+                    hipLaunchKernelGGL(k_refactor_reset, dim3((d.np + 255) / 256), dim3(256), 0, c->stream, d.np, c->theta, c->fs, 0);
+                    HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
+                    for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+                    hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
+                }
+            }
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return SRUKF_OK;
+}
+
+int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z, const int* matched)
+{
+    if (!c || F < 1 || !odo || !z || !matched) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->d.N;
+    if (c->odo_seq) { hipFree(c->odo_seq); hipFree(c->z_seq); hipFree(c->m_seq); c->odo_seq = nullptr; c->z_seq = nullptr; c->m_seq = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&c->odo_seq, sizeof(double) * 3 * (F + 1)));
+    HIPCHK(c, hipMalloc((void**)&c->z_seq, sizeof(double) * (size_t)F * 2 * N));
+    HIPCHK(c, hipMalloc((void**)&c->m_seq, sizeof(int) * (size_t)F * N));
+    HIPCHK(c, hipMemcpy(c->odo_seq, odo, sizeof(double) * 3 * (F + 1), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->z_seq, z, sizeof(double) * (size_t)F * 2 * N, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->m_seq, matched, sizeof(int) * (size_t)F * N, hipMemcpyHostToDevice));
+    c->seqF = F;
+    return SRUKF_OK;
+}
+
+int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double* d_traj)
+{
+    if (!c || first < 0 || count < 1) return SRUKF_ERR_BAD_ARG;
+    if (!c->odo_seq || first + count > c->seqF) { c->err = "frames outside the staged sequence"; return SRUKF_ERR_DIM_MISMATCH; }
+    if (mode != SRUKF_UPDATE_BATCHED) { c->err = "run_frames_async supports BATCHED only (SEQUENTIAL needs a host check per column)"; return SRUKF_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const KDims& d = c->d;
+    hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1);
+    // traj rows are indexed by the absolute frame counter; offset so that frame `first` lands in row 0
+    double* traj = d_traj ? d_traj - (size_t)8 * first : nullptr;
+    for (int f = 0; f < count; f++) {
+        seq_predict_motion(c, nullptr);
+        seq_predict_measurement(c);
+        seq_gain(c, nullptr, nullptr);
+        seq_refactor(c, 0, d.mp, false, false);
+        ProfScope ps(c, KC_MISC, 0, 0);
+        srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, traj, 1);
+    }
+    c->async_pending = true;
+    c->phase = 0;
+    HIPCHK(c, hipGetLastError());
+    return SRUKF_OK;
+}
+
+int srukf_synchronize(srukf_ctx* c)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (c->async_pending) {
+        c->async_pending = false;
+        int rc = read_fs(c); if (rc) return rc;
+        if (c->hfs->clamp_rows > 0) {
+            char b[160]; snprintf(b, sizeof b, "GMW theta clamp active on %d pivot rows (first row %d) during async frames", c->hfs->clamp_rows, c->hfs->clamp_first);
+            c->err = b;
+            return SRUKF_ERR_CLAMP_PENDING;
+        }
+    }
+    return SRUKF_OK;
+}
+
+int srukf_set_profiling(srukf_ctx* c, int on)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    c->profiling = on != 0;
+    return SRUKF_OK;
+}
+int srukf_profile_count(srukf_ctx* c) { return c ? KC_COUNT : SRUKF_ERR_BAD_ARG; }
+int srukf_profile_get(srukf_ctx* c, int i, const char** name, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes)
+{
+    if (!c || i < 0 || i >= KC_COUNT) return SRUKF_ERR_BAD_ARG;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    if (name) *name = kclass_name[i];
+    if (total_ms) *total_ms = c->prof_ms[i];
+    if (launches) *launches = c->prof_n[i];
+    if (alg_flops) *alg_flops = c->prof_flops[i];
+    if (alg_bytes) *alg_bytes = c->prof_bytes[i];
+    return SRUKF_OK;
+}
+int srukf_profile_reset(srukf_ctx* c)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_n, 0, sizeof c->prof_n);
+    memset(c->prof_flops, 0, sizeof c->prof_flops); memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+    return SRUKF_OK;
+}
+
+// ---- stand-alone primitives for the parity tests ------------------------------------------------
+int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_out, double epsilon, int force_slow, int* clamp_hit)
+{
+    if (n < 1 || !G || !S_out) return SRUKF_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SRUKF_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SRUKF_ERR_NO_DEVICE;
+    const int np = round_up(n, SRUKF_PAD);
+    const size_t bytes = sizeof(double) * (size_t)np * np;
+    std::vector<double> hG((size_t)np * np, 0.0), hS((size_t)np * np, 0.0), hD(np, 0.0);
+    for (int r = 0; r < n; r++) for (int c = r; c < n; c++) hG[(size_t)r * np + c] = G[(size_t)r * n + c];
+    double *dG, *dS, *dWp, *dLp, *dD, *dWf; unsigned long long* dTh; FrameScalars* dFs;
+    if (hipMalloc((void**)&dG, bytes) != hipSuccess) return SRUKF_ERR_HIP;
+    hipMalloc((void**)&dS, bytes); hipMalloc((void**)&dWf, bytes); hipMalloc((void**)&dWp, sizeof(double) * 32 * np); hipMalloc((void**)&dLp, sizeof(double) * 32 * np);
+    hipMalloc((void**)&dD, sizeof(double) * np); hipMalloc((void**)&dTh, sizeof(unsigned long long) * np); hipMalloc((void**)&dFs, sizeof(FrameScalars));
+    hipMemcpy(dG, hG.data(), bytes, hipMemcpyHostToDevice);
+    hipMemset(dS, 0, bytes); hipMemset(dWf, 0, bytes); hipMemset(dTh, 0, sizeof(unsigned long long) * np); hipMemset(dFs, 0, sizeof(FrameScalars));
+    hipMemset(dD, 0, sizeof(double) * np);
+    hipStream_t st = nullptr;
+    srukf_launch_gmw_stats(st, n, np, dG, dFs);
+    FrameScalars fs;
+    if (!force_slow) {
+        for (int j0 = 0; j0 < np; j0 += SRUKF_NB) {
+            srukf_launch_gmw_panel(st, n, np, j0, epsilon, dG, dWp, dLp, dD, dS);
+            if (j0 + SRUKF_NB < np) srukf_launch_gmw_trail(st, np, j0, dLp, dWp, dG);
+        }
+        srukf_launch_gmw_check(st, n, np, dD, dS, dFs);
+        hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
+        if (clamp_hit) *clamp_hit = fs.clamp_rows;
+        if (fs.clamp_rows > 0) force_slow = 2;   // same contract as srukf_update: redo on the exact path
+    }
+    if (force_slow) {
+        hipMemcpy(dG, hG.data(), bytes, hipMemcpyHostToDevice);
+        hipMemset(dTh, 0, sizeof(unsigned long long) * np);
+        hipMemset(dS, 0, bytes);
+        for (int j = 0; j < n; j++) srukf_launch_gmw_col(st, n, np, j, epsilon, dG, dWf, dD, dTh, dFs, dS);
+        hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
+        if (clamp_hit && force_slow == 1) *clamp_hit = fs.clamp_rows;
+    }
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(hS.data(), dS, bytes, hipMemcpyDeviceToHost);
+    hipMemcpy(hD.data(), dD, sizeof(double) * np, hipMemcpyDeviceToHost);
+    for (int r = 0; r < n; r++) memcpy(S_out + (size_t)r * n, hS.data() + (size_t)r * np, sizeof(double) * n);
+    if (D_out) memcpy(D_out, hD.data(), sizeof(double) * n);
+    hipFree(dG); hipFree(dS); hipFree(dWf); hipFree(dWp); hipFree(dLp); hipFree(dD); hipFree(dTh); hipFree(dFs);
+    return e == hipSuccess ? SRUKF_OK : SRUKF_ERR_HIP;
+}
+
+int srukf_project_host(int device, const srukf_params* p, int count, const double* feat6, const double* pos3, const double* psi,
+                       const double* err2, double* uv_out)
+{
+    if (!p || count < 1 || !feat6 || !pos3 || !psi || !err2 || !uv_out) return SRUKF_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SRUKF_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SRUKF_ERR_NO_DEVICE;
+    double *df, *dp, *ds, *de, *dout;
+    hipMalloc((void**)&df, sizeof(double) * 6 * count); hipMalloc((void**)&dp, sizeof(double) * 3 * count);
+    hipMalloc((void**)&ds, sizeof(double) * count); hipMalloc((void**)&de, sizeof(double) * 2 * count); hipMalloc((void**)&dout, sizeof(double) * 2 * count);
+    hipMemcpy(df, feat6, sizeof(double) * 6 * count, hipMemcpyHostToDevice); hipMemcpy(dp, pos3, sizeof(double) * 3 * count, hipMemcpyHostToDevice);
+    hipMemcpy(ds, psi, sizeof(double) * count, hipMemcpyHostToDevice); hipMemcpy(de, err2, sizeof(double) * 2 * count, hipMemcpyHostToDevice);
+    srukf_launch_project_points(nullptr, *p, count, df, dp, ds, de, dout);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(uv_out, dout, sizeof(double) * 2 * count, hipMemcpyDeviceToHost);
+    hipFree(df); hipFree(dp); hipFree(ds); hipFree(de); hipFree(dout);
+    return e == hipSuccess ? SRUKF_OK : SRUKF_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// srukf_device.h — shared definitions for the gfx950 SRUKF kernels.
+//
+// Data layout in HBM (one filter; all fp64, row-major, leading dimensions padded):
+//   X    [np]            state, n = 6N+4 live entries            (m_X_k, SLAM.h:271)
+//   S    [np][np]        upper-triangular sqrt covariance, P = S^T S; rows/cols >= n and the
+//                        strictly lower triangle are kept zero   (m_S_k, SLAM.h:272)
+//   sigR [L][8]          robot part of every sigma point after the motion model:
+//                        (x, y, z, theta, cos theta, sin theta, -, -)   L = 2*Na+1, Na = n+5
+//   Z    [L][mp]         projected pixels, row = sigma point, col = 2k / 2k+1 of landmark k
+//                        (m_sigma_allPixel, SLAM.h:285, stored transposed so that the
+//                        contraction over sigma points is K-major for MFMA)
+//   DZ   [np][mp]        DZ[i] = Z[1+i] - Z[1+Na+i]  for i < n (rows >= n zero)
+//   Ut   [mp][np]        U^T: row c = measurement column, col r = state row
+//   G    [np][np]        S^T S - U U^T (upper), factorised in place by the GMW kernels
+// The full Na x L sigma matrix (m_sigma, SLAM.h:284; 23 MB at N = 200) is never materialised:
+// sigma_c[0:n-4] = X +- gamma * S.row(i) is read straight from S.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/srukf.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define SRUKF_NB 32            // GMW panel height
+#define SRUKF_PAD 64           // np, mp are multiples of this
+
+struct KDims {
+    int N, n, Na, L;           // landmarks, state dim, augmented dim, sigma count
+    int np, mp;                // padded n, padded 2N
+};
+
+struct KWeights { double wm0, wc0, wi, wi_sr, gamma; };
+
+// device-resident per-frame scalars
+struct FrameScalars {
+    double Ut[3];              // rot1, trans, rot2                    SLAM.cpp:1452-1454
+    double Mt[3];              // control "sqrt" noise diag            SLAM.cpp:1456-1458
+    double Xr0[4];             // robot mean before the motion step
+    unsigned long long gmax_bits;   // max diag(G)      (as ordered bits of a non-negative double)
+    unsigned long long ximax_bits;  // max(0, max offdiag(G))
+    int clamp_rows;            // rows where the GMW theta clamp would have been active
+    int clamp_first;           // first such row
+    int frame;                 // frame counter for staged sequences
+    int pad_;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Block-wide sum of NV values per thread (blockDim.x multiple of 64, <= 1024).  red: LDS scratch
+// of at least 16*NV doubles.  Every thread gets the totals.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; q++) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; q++) red[wid * NV + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+        double s = 0.0;
+        for (int w = 0; w < nw; w++) s += red[w * NV + q];
+        v[q] = s;
+    }
+}
+
+// ---- camera model (device restatement of SLAM.cpp:1634-1674, 3177-3213, 3250-3347) ----------
+// feat = (xi yi zi theta phi rho), robot = (x y z), cs/sn = cos/sin of robot theta,
+// err = pixel-noise sigma rows.  Returns uvd = (x, y) = Z[2k], Z[2k+1].
+__device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, double f2,
+                                              const double feat[6], double px, double py, double pz,
+                                              double cs, double sn, double e0, double e1,
+                                              double& ox, double& oy)
+{
+    const double xi = feat[0], yi = feat[1], zi = feat[2], th = feat[3], ph = feat[4], rho = feat[5];
+    double sth, cth, sph, cph;
+    sincos(th, &sth, &cth);
+    sincos(ph, &sph, &cph);
+    const double ir = 1.0 / rho;
+    // coordinatesState2World, SLAM.cpp:3272-3275
+    const double hx = xi + ir * cph * sth - px;
+    const double hy = yi - ir * sph - py;
+    const double hz = zi + ir * cph * cth - pz;
+    // Rcw = Rwc.inv() (SLAM.cpp:1642-1643): closed-form cofactor inverse, det = c^2 + s^2
+    const double det = cs * cs + sn * sn;
+    const double id = 1.0 / det;
+    const double rx = (cs * id) * hx + (sn * id) * hy;        // coordinatesWorld2Camera, 3292
+    const double ry = (-sn * id) * hx + (cs * id) * hy;
+    const double rz = (det * id) * hz;
+    double ux, uy;
+    if (rz == 0.0) { ux = 0.0; uy = 0.0; }                    // coordinatesCamera2Image, 3331-3335
+    else {
+        uy = p.cam_cx + f1 * rx / rz + e0;                    // 3338 (x/y swap)
+        ux = p.cam_cy + f2 * ry / rz + e1;                    // 3339
+        if (ux < 10.0 || ux > p.image_w - 10.0 || uy < 10.0 || uy > p.image_h - 10.0) { ux = 0.0; uy = 0.0; }   // 3341-3345
+    }
+    // distortOnePointRW, 3177-3213
+    const double k1 = p.cam_k1, k2 = p.cam_k2;
+    const double xu = (ux - p.cam_cx) * p.cam_dx;
+    const double yu = (uy - p.cam_cy) * p.cam_dy;
+    const double ru = sqrt(xu * xu + yu * yu);
+    const double ru2 = ru * ru;
+    double rd = ru / (1.0 + k1 * ru2 + k2 * ru2 * ru2);
+    // 100 Newton iterations (3188-3193); leaving the loop once rd is a fixed point is bit-exact
+    // because every later iteration reproduces the same rd.
+    for (int it = 0; it < p.newton_iters; it++) {
+        const double rd2 = rd * rd;
+        const double f  = rd + k1 * rd2 * rd + k2 * rd2 * rd2 * rd - ru;
+        const double ff = 1.0 + 3.0 * k1 * rd2 + 5.0 * k2 * rd2 * rd2;
+        const double rn = rd - f / ff;
+        if (rn == rd) break;
+        rd = rn;
+    }
+    double d = 1.0 + k1 * rd * rd + k2 * rd * rd * rd * rd;
+    if (d == 0.0) d = p.epsilon;
+    const double vx = p.cam_cx + (xu / d) / p.cam_dx;
+    const double vy = p.cam_cy + (yu / d) / p.cam_dy;
+    const bool vis = (vx >= 0.0) && (vx <= p.image_w) && (vy >= 0.0) && (vy <= p.image_h);
+    ox = vis ? vx : 0.0;
+    oy = vis ? vy : 0.0;
+}
+
+// ---- launch prototypes (host side, implemented in the .hip files) ---------------------------
+struct LaunchCtx;   // defined in srukf_api.hip

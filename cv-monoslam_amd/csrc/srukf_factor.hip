@@ -1,0 +1,361 @@
+// srukf_factor.hip — FP64-MFMA contractions (cross covariance, S^T S - U U^T, trailing updates)
+// and the Gill-Murray-Wright modified Cholesky that maintains the sqrt covariance.  gfx950 only.
+//
+// All contractions are "TN": D[m][nn] = sum_k A[k][m] * B[k][nn] with both operands K-major
+// (row k contiguous), which is how S (rows = sigma directions), DZ, U^T and the GMW panels
+// sit in HBM.  v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md §3):
+//   A: lane l holds A_op[i = l&15][k = l>>4]  -> A[k0 + (l>>4)][m0 + (l&15)]   (16 contiguous doubles per k)
+//   B: lane l holds B_op[k = l>>4][j = l&15]  -> B[k0 + (l>>4)][n0 + (l&15)]
+//   D: reg t of lane l is D[row = (l>>4) + 4t][col = l&15]
+#include "srukf_device.h"
+
+// one wave: 32x32 output tile at (m0, n0), K range [kb, ke) (multiple of 4 long), accumulate
+template <bool NEG>
+__device__ __forceinline__ void tile32_tn(d4 (&acc)[2][2], const double* __restrict__ A, int lda,
+                                          const double* __restrict__ B, int ldb, int m0, int n0, int kb, int ke, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    const double* pa = A + (size_t)(kb + lk) * lda + m0 + lr;
+    const double* pb = B + (size_t)(kb + lk) * ldb + n0 + lr;
+    const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
+#pragma unroll 4
+    for (int k = kb; k < ke; k += 4) {
+        double a0 = pa[0], a1 = pa[16], b0 = pb[0], b1 = pb[16];
+        if (NEG) { a0 = -a0; a1 = -a1; }
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        pa += sa; pb += sb;
+    }
+}
+
+__device__ __forceinline__ void zero_acc(d4 (&acc)[2][2])
+{
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (d4){0, 0, 0, 0};
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pxy: landmark rows of all cross covariances in one contraction
+//   Ut[c][r] = sum_{i <= r, i < n} DZ[i][c] * S[i][r]          c < 2N (mp padded), r < np
+// = (S^T DZ)^T, i.e. the L rank-1 updates per landmark of calculateOneFeatureCrossCovariance
+// (SLAM.cpp:2028-2037) for ALL landmarks at once; the wi*gamma scale and the robot rows are
+// applied in k_gain.  S upper triangular => K range truncated at r0+32.
+// grid = (np/64, mp/64), block = 256 (4 waves, 2x2 tiles of 32x32).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__ DZ, const double* __restrict__ S,
+                                             double* __restrict__ Ut)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 64 + (wv >> 1) * 32;    // c
+    const int n0 = blockIdx.x * 64 + (wv & 1) * 32;     // r
+    d4 acc[2][2];
+    zero_acc(acc);
+    int ke = n0 + 32; if (ke > d.np) ke = d.np;
+    tile32_tn<false>(acc, DZ, d.mp, S, d.np, m0, n0, 0, ke, lane);
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                Ut[(size_t)(m0 + 16 * a + lk + 4 * t) * d.np + n0 + 16 * b + lr] = acc[a][b][t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_syrk: G = S^T S - U U^T on the upper triangle (SLAM.cpp:2118-2120, 2149 batched over all
+// measurement columns; rows [ub, ue) of Ut select the columns that are downdated — all of them
+// in BATCHED mode, a single one in SEQUENTIAL mode).  Also accumulates gamma = max diag(G) and
+// xi = max(0, max offdiag(G)) for the GMW bound beta^2 (SLAM.cpp:2204-2211).
+// grid = (np/64, np/64), block = 256; blocks strictly below the diagonal exit.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
+                                              int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs)
+{
+    if (blockIdx.x < blockIdx.y) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 64 + (wv >> 1) * 32;    // row r
+    const int n0 = blockIdx.x * 64 + (wv & 1) * 32;     // col c
+    if (n0 + 32 <= m0) return;                           // wave tile strictly below the diagonal
+    d4 acc[2][2];
+    zero_acc(acc);
+    int ke = m0 + 32; if (ke > d.np) ke = d.np;          // S[k][r] = 0 for k > r
+    tile32_tn<false>(acc, S, d.np, S, d.np, m0, n0, 0, ke, lane);
+    const int u0 = ub & ~3, u1 = (ue + 3) & ~3;
+    if (ub == u0 && ue == u1) {
+        tile32_tn<true>(acc, Ut, d.np, Ut, d.np, m0, n0, u0, u1, lane);
+    } else {
+        // partial K group (single-column downdate): mask rows outside [ub, ue)
+        const int lr = lane & 15, lk = lane >> 4;
+        for (int k = u0; k < u1; k += 4) {
+            const int kk = k + lk;
+            const bool in = (kk >= ub) && (kk < ue);
+            const double a0 = in ? -Ut[(size_t)kk * d.np + m0 + lr] : 0.0, a1 = in ? -Ut[(size_t)kk * d.np + m0 + 16 + lr] : 0.0;
+            const double b0 = in ? Ut[(size_t)kk * d.np + n0 + lr] : 0.0, b1 = in ? Ut[(size_t)kk * d.np + n0 + 16 + lr] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    const int lr = lane & 15, lk = lane >> 4;
+    double gmax = 0.0, xmax = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
+                const double v = acc[a][b][t];
+                G[(size_t)r * d.np + c] = v;
+                if (r < d.n && c < d.n) {
+                    if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v);
+                }
+            }
+    gmax = wave_max(gmax); xmax = wave_max(xmax);
+    if (lane == 0) {
+        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GMW modified Cholesky (modifiedCholeskyDecomposition, SLAM.cpp:2197-2327), blocked.
+// Storage: W[j][i] = C[i][j] (the reference's column j below the diagonal is our row j right of
+// the diagonal), so the final S[j][i] = sqrt(D_j) * L[i][j] = sqrt(D_j) * (W[j][i] / D_j) is a
+// row scaling of W.  Fast path pivots with D_j = max(EPSILON, |C_jj|); the third candidate
+// theta_j^2 / beta^2 (2279-2285) is evaluated afterwards from the row maxima theta_j collected
+// here (k_gmw_check) — if it never wins, the result equals the reference algorithm's exactly;
+// if it does, the caller reruns the frame on the column-by-column path (k_gmw_col_*).
+// ------------------------------------------------------------------------------------------------
+
+// k_gmw_panel: rows [j0, j0+32).  Wave 0 of every block factors the 32x32 diagonal block
+// (redundantly — cheaper than a cross-workgroup hand-off), then each thread solves the 32-step
+// forward substitution for one column i >= j0+32.
+// Out: Wp[32][ld] final W rows, Lp[32][ld] = W/D, D[j], S rows j (final sqrt covariance).
+__global__ __launch_bounds__(256) void k_gmw_panel(int n, int ld, int j0, double eps, const double* __restrict__ G,
+                                                   double* __restrict__ Wp, double* __restrict__ Lp, double* __restrict__ D,
+                                                   double* __restrict__ Sout)
+{
+    __shared__ double Wd[32][33];
+    __shared__ double Ld[32][33];
+    __shared__ double Dd[32];
+    __shared__ double SqD[32];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        // wave 0, wave-synchronous: the 32x32 block lives in LDS (Wd); lane pair (ii, half) owns
+        // column ii and updates rows rr = jj+1+half, jj+3+half, ... of it at step jj.
+        const int ii = tid & 31, half = tid >> 5;
+        for (int jj = half; jj < 32; jj += 2) Wd[jj][ii] = (jj <= ii) ? G[(size_t)(j0 + jj) * ld + j0 + ii] : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int jj = 0; jj < 32; jj++) {
+            const double piv = Wd[jj][jj];
+            const double dj = fmax(eps, fabs(piv));
+            const double wv = Wd[jj][ii];
+            const double l = wv / dj;
+            if (half == 0) { Ld[jj][ii] = (ii >= jj) ? l : 0.0; if (ii == jj) { Dd[jj] = dj; SqD[jj] = sqrt(dj); } }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int rr = jj + 1 + half; rr <= ii; rr += 2) Wd[rr][ii] -= Ld[jj][rr] * wv;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+
+    // diagonal block outputs (block 0 only)
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int jj = e >> 5, ii = e & 31;
+            const int j = j0 + jj, i = j0 + ii;
+            const double wv = Wd[jj][ii];
+            Wp[(size_t)jj * ld + i] = wv;
+            Lp[(size_t)jj * ld + i] = Ld[jj][ii];
+            if (j < n && i < n) {
+                const double dj = Dd[jj];
+                Sout[(size_t)j * ld + i] = (ii > jj) ? SqD[jj] * Ld[jj][ii] : ((ii == jj) ? SqD[jj] : 0.0);
+            }
+        }
+        if (tid < 32) D[j0 + tid] = Dd[tid];
+    }
+
+    // forward substitution for column i
+    const int i = j0 + 32 + blockIdx.x * 256 + tid;
+    const bool act = i < ld;
+    {
+        double wcol[32];
+#pragma unroll
+        for (int jj = 0; jj < 32; jj++) wcol[jj] = act ? G[(size_t)(j0 + jj) * ld + i] : 0.0;
+        // right-looking: once wcol[kk] is final, fold it into every later row (row kk of Ld is contiguous)
+#pragma unroll
+        for (int kk = 0; kk < 31; kk++) {
+            const double wk = wcol[kk];
+#pragma unroll
+            for (int jj = kk + 1; jj < 32; jj++) wcol[jj] -= Ld[kk][jj] * wk;
+        }
+        if (act) {
+#pragma unroll
+            for (int jj = 0; jj < 32; jj++) {
+                const double dj = Dd[jj];
+                const double l = wcol[jj] / dj;
+                Wp[(size_t)jj * ld + i] = wcol[jj];
+                Lp[(size_t)jj * ld + i] = l;
+                Sout[(size_t)(j0 + jj) * ld + i] = SqD[jj] * l;   // padded rows/cols: W = 0 there, so this writes zeros
+            }
+        }
+    }
+}
+
+// k_gmw_trail: G[r][c] -= sum_{jj<32} Lp[jj][r] * Wp[jj][c]   for r, c >= j0+32, c >= r (upper).
+// grid = (T, T) blocks of 64x64 over the trailing square, block = 256.
+__global__ __launch_bounds__(256) void k_gmw_trail(int ld, int j0, const double* __restrict__ Lp, const double* __restrict__ Wp,
+                                                   double* __restrict__ G)
+{
+    if (blockIdx.x < blockIdx.y) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int base = j0 + 32;
+    const int m0 = base + blockIdx.y * 64 + (wv >> 1) * 32;
+    const int n0 = base + blockIdx.x * 64 + (wv & 1) * 32;
+    if (m0 >= ld || n0 >= ld || n0 + 32 <= m0) return;
+    const int lr = lane & 15, lk = lane >> 4;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr];
+    tile32_tn<true>(acc, Lp, ld, Wp, ld, m0, n0, 0, 32, lane);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr] = acc[a][b][t];
+}
+
+// k_gmw_check: was the reference's third pivot candidate theta_j^2/beta^2 ever the largest?
+// theta_j = max_{i>j} |C[i][j]| = sqrt(D_j) * max_{i>j} |S[j][i]|  (S[j][i] = C[i][j]/sqrt(D_j)),
+// beta^2 = max(gamma, xi/nu, 1e-15), nu = max(1, sqrt(n^2-1))   (SLAM.cpp:2204-2211, 2264-2285).
+// One workgroup per pivot row.
+__global__ __launch_bounds__(256) void k_gmw_check(int n, int ld, const double* __restrict__ D, const double* __restrict__ S,
+                                                   FrameScalars* __restrict__ fs)
+{
+    __shared__ double red[4];
+    const int j = blockIdx.x;
+    double mx = 0.0;
+    for (int i = j + 1 + threadIdx.x; i < n; i += 256) mx = fmax(mx, fabs(S[(size_t)j * ld + i]));
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        const double gamma = __longlong_as_double((long long)fs->gmax_bits);
+        const double xi = __longlong_as_double((long long)fs->ximax_bits);
+        const double nu = fmax(1.0, sqrt((double)n * n - 1.0));
+        const double beta2 = fmax(fmax(gamma, xi / nu), 1e-15);
+        const double dj = D[j];
+        const double th = mx * sqrt(dj);
+        if (th * th / beta2 > dj) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, j); }
+    }
+}
+
+// ---- column-by-column path: evaluates every pivot exactly as the reference does -----------------
+// k_gmw_col_a(j): W[j][i] = G[j][i] - sum_{k<j} (W[k][j]/D[k]) * W[k][i]  for i >= j; theta_j.
+// W is stored in Wf (full n x n, upper).  grid over i.
+__global__ __launch_bounds__(256) void k_gmw_col_a(int ld, int j, const double* __restrict__ G, double* __restrict__ Wf,
+                                                   const double* __restrict__ D, unsigned long long* __restrict__ theta_bits)
+{
+    const int i = j + blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (i < ld) {
+        double acc = 0.0;
+        for (int k = 0; k < j; k++) acc += (Wf[(size_t)k * ld + j] / D[k]) * Wf[(size_t)k * ld + i];
+        v = G[(size_t)j * ld + i] - acc;
+        Wf[(size_t)j * ld + i] = v;
+    }
+    double mx = (i < ld && i > j) ? fabs(v) : 0.0;
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(&theta_bits[j], (unsigned long long)__double_as_longlong(mx));
+}
+// k_gmw_col_b(j): D_j = max(EPSILON, |C_jj|, theta_j^2/beta^2); S row j.
+__global__ __launch_bounds__(256) void k_gmw_col_b(int n, int ld, int j, double eps, const double* __restrict__ Wf, double* __restrict__ D,
+                                                   const unsigned long long* __restrict__ theta_bits, FrameScalars* __restrict__ fs,
+                                                   double* __restrict__ Sout)
+{
+    const double gamma = __longlong_as_double((long long)fs->gmax_bits);
+    const double xi = __longlong_as_double((long long)fs->ximax_bits);
+    const double nu = fmax(1.0, sqrt((double)n * n - 1.0));
+    const double beta2 = fmax(fmax(gamma, xi / nu), 1e-15);
+    const double th = __longlong_as_double((long long)theta_bits[j]);
+    const double cjj = fabs(Wf[(size_t)j * ld + j]);
+    const double t2 = th * th / beta2;
+    const double dj = fmax(fmax(eps, cjj), t2);
+    const int i = j + blockIdx.x * 256 + threadIdx.x;
+    if (i == j) { D[j] = dj; if (t2 > fmax(eps, cjj)) atomicAdd(&fs->clamp_rows, 1); }
+    if (i < n && j < n) Sout[(size_t)j * ld + i] = (i == j) ? sqrt(dj) : sqrt(dj) * (Wf[(size_t)j * ld + i] / dj);
+}
+
+// k_gmw_stats: gamma / xi of an arbitrary symmetric G (stand-alone GMW entry point)
+__global__ __launch_bounds__(256) void k_gmw_stats(int n, int ld, const double* __restrict__ G, FrameScalars* __restrict__ fs)
+{
+    const int r = blockIdx.x;
+    double gmax = 0.0, xmax = 0.0;
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const double v = (c >= r) ? G[(size_t)r * ld + c] : G[(size_t)c * ld + r];
+        if (c == r) gmax = fmax(gmax, v); else xmax = fmax(xmax, v);
+    }
+    gmax = wave_max(gmax); xmax = wave_max(xmax);
+    if ((threadIdx.x & 63) == 0) {
+        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
+    }
+}
+
+extern "C" {
+void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S, double* Ut)
+{
+    hipLaunchKernelGGL(k_pxy, dim3(d.np / 64, d.mp / 64), dim3(256), 0, st, d, DZ, S, Ut);
+}
+void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs)
+{
+    hipLaunchKernelGGL(k_syrk, dim3(d.np / 64, d.np / 64), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs);
+}
+void srukf_launch_gmw_panel(hipStream_t st, int n, int ld, int j0, double eps, const double* G, double* Wp, double* Lp, double* D,
+                            double* Sout)
+{
+    const int cols = ld - j0 - 32;
+    const int blocks = cols > 0 ? (cols + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_gmw_panel, dim3(blocks), dim3(256), 0, st, n, ld, j0, eps, G, Wp, Lp, D, Sout);
+}
+void srukf_launch_gmw_trail(hipStream_t st, int ld, int j0, const double* Lp, const double* Wp, double* G)
+{
+    const int rem = ld - j0 - 32;
+    if (rem <= 0) return;
+    const int T = (rem + 63) / 64;
+    hipLaunchKernelGGL(k_gmw_trail, dim3(T, T), dim3(256), 0, st, ld, j0, Lp, Wp, G);
+}
+void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs)
+{
+    hipLaunchKernelGGL(k_gmw_check, dim3(n), dim3(256), 0, st, n, ld, D, S, fs);
+}
+void srukf_launch_gmw_col(hipStream_t st, int n, int ld, int j, double eps, const double* G, double* Wf, double* D,
+                          unsigned long long* theta_bits, FrameScalars* fs, double* Sout)
+{
+    const int blocks = (ld - j + 255) / 256;
+    hipLaunchKernelGGL(k_gmw_col_a, dim3(blocks), dim3(256), 0, st, ld, j, G, Wf, D, theta_bits);
+    hipLaunchKernelGGL(k_gmw_col_b, dim3(blocks), dim3(256), 0, st, n, ld, j, eps, Wf, D, theta_bits, fs, Sout);
+}
+void srukf_launch_gmw_stats(hipStream_t st, int n, int ld, const double* G, FrameScalars* fs)
+{
+    hipLaunchKernelGGL(k_gmw_stats, dim3(n), dim3(256), 0, st, n, ld, G, fs);
+}
+}  // extern "C"

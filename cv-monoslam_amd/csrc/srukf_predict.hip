@@ -1,0 +1,477 @@
+// srukf_predict.hip — sigma points, motion model, structured re-triangularisation, camera
+// projection of every sigma point, measurement statistics (h, Si, robot rows of Pxy).
+// gfx950 only.  See srukf_device.h for the HBM layout.
+#include "srukf_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// k_motion: predictMotion numeric tail (SLAM.cpp:1430-1465) fused:
+//   control Ut/Mt from two odometry poses (1444-1458);
+//   robot rows of all L sigma points through the odometry model (generateSigmaPoints 1148-1162
+//   restricted to rows n-4..n-1 and the control-noise rows, passSigmaThroughMotionFunction
+//   1476-1532); weighted mean -> X[n-4:n] (1526-1531);
+//   QrAndCholeskyForMotion (1539-1555) in its structured form: the QR matrix
+//   A = wi_sr*(sigma_{i+1}-sigma_0)^T has A[:, :n-4] = (1/sqrt2) [E; -E] S[:n-4,:n-4]... so
+//   R11 = S11 (unchanged), R12[i] = wi_sr/sqrt2 * (dev+_i - dev-_i), and R22 is the R factor of
+//   the (n-4+18) x 4 matrix of residual rows wi_sr/sqrt2 * (dev+_i + dev-_i) (i < n-4) and
+//   wi_sr*dev+-_i (n-4 <= i < Na).  Only the last four columns of S are rewritten: O(n) instead
+//   of the reference's 2n^2(2Na - n/3) flop Householder QR (DESIGN.md "Motion step").
+// One workgroup (1024 threads): L <= 6019 sigma columns, everything else is reductions.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_motion(KDims d, KWeights w, srukf_params p,
+                                                 double* __restrict__ X, double* __restrict__ S,
+                                                 double* __restrict__ sigR, double* __restrict__ Cmat,
+                                                 FrameScalars* __restrict__ fs,
+                                                 const double* __restrict__ odo_seq, const double* odo_pair)
+{
+    __shared__ double red[16 * 4];
+    __shared__ double sh[24];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n = d.n, Na = d.Na, L = d.L, ld = d.np;
+
+    // ---- control (SLAM.cpp:1444-1458) ----
+    if (tid == 0) {
+        const double* o = odo_pair ? odo_pair : (odo_seq + 3 * fs->frame);
+        const double dx = o[3] - o[0], dy = o[4] - o[1];
+        const double rot1 = atan2(dy, dx) - o[2];
+        const double trans = sqrt(dy * dy + dx * dx);
+        const double rot2 = o[5] - o[2] - rot1;
+        sh[0] = rot1; sh[1] = trans; sh[2] = rot2;
+        sh[3] = p.a1 * rot1 * rot1 + p.a2 * trans * trans;
+        sh[4] = p.a3 * trans * trans + p.a4 * rot1 * rot1 + p.a4 * rot2 * rot2;
+        sh[5] = p.a1 * rot2 * rot2 + p.a2 * trans * trans;
+        for (int q = 0; q < 4; q++) sh[6 + q] = X[n - 4 + q];
+        for (int q = 0; q < 3; q++) { fs->Ut[q] = sh[q]; fs->Mt[q] = sh[3 + q]; }
+        for (int q = 0; q < 4; q++) fs->Xr0[q] = sh[6 + q];
+        fs->gmax_bits = 0ull; fs->ximax_bits = 0ull;
+    }
+    __syncthreads();
+    const double rot1 = sh[0], trans = sh[1], rot2 = sh[2];
+    const double xr[4] = { sh[6], sh[7], sh[8], sh[9] };
+
+    // ---- sigma robot rows through the motion model ----
+    double acc[4] = { 0, 0, 0, 0 };
+    for (int c = tid; c < L; c += nt) {
+        double r[4] = { xr[0], xr[1], xr[2], xr[3] };
+        double q[3] = { 0, 0, 0 };
+        if (c > 0) {
+            const int i = (c - 1) % Na;
+            const double sg = (c <= Na) ? w.gamma : -w.gamma;
+            if (i < n) {
+                // mu + (+-gamma) * S.row(i) restricted to the robot columns (upper triangle only)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int col = n - 4 + e;
+                    const double s = (col >= i) ? S[(size_t)i * ld + col] : 0.0;
+                    r[e] = xr[e] * 1 + s * sg + 0;
+                }
+            } else if (i < n + 3) {
+                q[i - n] = 0.0 * 1 + sh[3 + (i - n)] * sg + 0;   // control-noise sigma rows (sr = blockdiag(S, Mt, Qt))
+            }
+        }
+        const double r1 = rot1 - q[0], tr = trans - q[1], r2 = rot2 - q[2];     // 1492-1494
+        double sn, cs;
+        sincos(r[3] + r1, &sn, &cs);
+        r[0] += tr * cs;                                                         // 1518-1523
+        r[1] += tr * sn;
+        r[2] += 0.0;
+        r[3] += r1 + r2;
+        double s2, c2;
+        sincos(r[3], &s2, &c2);
+        double* o = sigR + (size_t)c * 8;
+        o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = c2; o[5] = s2; o[6] = 0; o[7] = 0;
+        const double wt = (c == 0) ? w.wm0 : w.wi;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] += wt * r[e];
+    }
+    block_sum<4>(acc, red);
+    if (tid < 4) X[n - 4 + tid] = acc[tid];                                      // 1531
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- structured QR: R12 rows and the residual matrix C ((n-4)+18 rows x 4) ----
+    const double k2 = w.wi_sr * 0.70710678118654752440;
+    const int m = (n - 4) + 2 * (Na - (n - 4));
+    const double* s0 = sigR;   // sigma_0 robot rows (post-motion)
+    for (int i = tid; i < Na; i += nt) {
+        const double* sp = sigR + (size_t)(1 + i) * 8;
+        const double* sm = sigR + (size_t)(1 + Na + i) * 8;
+        double dp[4], dm[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { dp[e] = sp[e] - s0[e]; dm[e] = sm[e] - s0[e]; }
+        if (i < n - 4) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                S[(size_t)i * ld + (n - 4 + e)] = k2 * (dp[e] - dm[e]);
+                Cmat[(size_t)i * 4 + e] = k2 * (dp[e] + dm[e]);
+            }
+        } else {
+            const int rp = (n - 4) + 2 * (i - (n - 4));
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                Cmat[(size_t)rp * 4 + e] = w.wi_sr * dp[e];
+                Cmat[(size_t)(rp + 1) * 4 + e] = w.wi_sr * dm[e];
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- Householder QR of C (m x 4), GSL conventions (see oracle/srukf_oracle.c orc_qr_r) ----
+    for (int j = 0; j < 4; j++) {
+        double v1[1] = { 0.0 };
+        for (int r = j + 1 + tid; r < m; r += nt) { const double x = Cmat[(size_t)r * 4 + j]; v1[0] += x * x; }
+        block_sum<1>(v1, red);
+        const double xnorm = sqrt(v1[0]);
+        const double alpha = Cmat[(size_t)j * 4 + j];
+        double tau = 0.0, beta = alpha;
+        if (xnorm != 0.0) {
+            beta = -(alpha >= 0.0 ? 1.0 : -1.0) * hypot(alpha, xnorm);
+            tau = (beta - alpha) / beta;
+            const double is = 1.0 / (alpha - beta);
+            for (int r = j + 1 + tid; r < m; r += nt) Cmat[(size_t)r * 4 + j] *= is;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) Cmat[(size_t)j * 4 + j] = beta;
+        if (tau != 0.0 && j < 3) {
+            double wj[3] = { 0, 0, 0 };
+            for (int r = j + 1 + tid; r < m; r += nt) {
+                const double v = Cmat[(size_t)r * 4 + j];
+                for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cmat[(size_t)r * 4 + jj] * v;
+            }
+            block_sum<3>(wj, red);
+            for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cmat[(size_t)j * 4 + jj];
+            __syncthreads();
+            for (int r = j + 1 + tid; r < m; r += nt) {
+                const double v = Cmat[(size_t)r * 4 + j];
+                for (int jj = j + 1; jj < 4; jj++) Cmat[(size_t)r * 4 + jj] -= tau * v * wj[jj - j - 1];
+            }
+            if (tid == 0) for (int jj = j + 1; jj < 4; jj++) Cmat[(size_t)j * 4 + jj] -= tau * wj[jj - j - 1];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid < 16) {
+        const int a = tid >> 2, b = tid & 3;
+        S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = (b >= a) ? Cmat[(size_t)a * 4 + b] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_project: passSigmaThroughMesaurementFunction (SLAM.cpp:1615-1674).  Thread (k, ii): landmark
+// k and sigma "direction" ii: ii = 0 is the centre column, ii >= 1 handles the +/- pair built
+// from row i = ii-1 of the augmented sqrt matrix, so every S row is read once and
+// DZ[i] = Z[1+i] - Z[1+Na+i] falls out for the cross-covariance contraction.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_params p,
+                                                 const double* __restrict__ X, const double* __restrict__ S,
+                                                 const double* __restrict__ sigR,
+                                                 double* __restrict__ Z, double* __restrict__ DZ)
+{
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ii = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (k >= d.N || ii > d.Na) return;
+    const int n = d.n, Na = d.Na, ld = d.np, mp = d.mp;
+    const double f1 = p.cam_f / p.cam_dx, f2 = p.cam_f / p.cam_dy;
+    double base[6];
+#pragma unroll
+    for (int e = 0; e < 6; e++) base[e] = X[6 * k + e];
+
+    if (ii == 0) {
+        const double* r = sigR;
+        double ox, oy;
+        srukf_project(p, f1, f2, base, r[0], r[1], r[2], r[4], r[5], 0.0, 0.0, ox, oy);
+        *reinterpret_cast<double2*>(Z + 2 * k) = make_double2(ox, oy);
+        return;
+    }
+    const int i = ii - 1;
+    double dev[6] = { 0, 0, 0, 0, 0, 0 };
+    if (i < n) {
+#pragma unroll
+        for (int e = 0; e < 6; e++) { const int col = 6 * k + e; dev[e] = (col >= i) ? S[(size_t)i * ld + col] : 0.0; }
+    }
+    double e0 = 0.0, e1 = 0.0;                       // pixel-noise sigma rows n+3, n+4 (Qt on the sqrt diagonal)
+    if (i == n + 3) e0 = p.sigma_measure; else if (i == n + 4) e1 = p.sigma_measure;
+    double zp[2], zm[2];
+#pragma unroll
+    for (int sgn = 0; sgn < 2; sgn++) {
+        const double g = sgn ? -w.gamma : w.gamma;
+        const int c = sgn ? (1 + Na + i) : (1 + i);
+        double feat[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) feat[e] = base[e] * 1 + dev[e] * g + 0;     // addWeighted, 1159-1160
+        const double* r = sigR + (size_t)c * 8;
+        const double q0 = 0.0 * 1 + e0 * g + 0, q1 = 0.0 * 1 + e1 * g + 0;
+        double ox, oy;
+        srukf_project(p, f1, f2, feat, r[0], r[1], r[2], r[4], r[5], q0, q1, ox, oy);
+        *reinterpret_cast<double2*>(Z + (size_t)c * mp + 2 * k) = make_double2(ox, oy);
+        if (sgn) { zm[0] = ox; zm[1] = oy; } else { zp[0] = ox; zp[1] = oy; }
+    }
+    if (i < n) *reinterpret_cast<double2*>(DZ + (size_t)i * mp + 2 * k) = make_double2(zp[0] - zm[0], zp[1] - zm[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_meas_stats: per landmark k (one thread-row of 8 slices): predicted pixel
+//   h = wm0*Z_0 + wi*sum Z_c                       (SLAM.cpp:1678-1681),
+//   Si = R factor of wi_sr*(Z_{c+1}-Z_0) (2Na x 2)  (calculateOneFeatureCovariance 1759-1775,
+//        GSL Householder sign rule; residual norm by an explicit second pass),
+//   visible = (h.x != 0 && h.y != 0)               (1727),
+//   and the 4 robot rows of the cross covariance
+//   PxyR[e][col] = wc0*(sigR_0[e]-Xr[e])(Z_0[col]-h[col]) + wi*sum_c (sigR_c[e]-Xr[e])(Z_c[col]-h[col])
+//                                                  (calculateOneFeatureCrossCovariance 2028-2037).
+// Block = (32 landmarks) x (8 row slices).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_meas_stats(KDims d, KWeights w,
+                                                    const double* __restrict__ X, const double* __restrict__ sigR,
+                                                    const double* __restrict__ Z,
+                                                    double* __restrict__ h, double* __restrict__ Si,
+                                                    int* __restrict__ vis, double* __restrict__ PxyR)
+{
+    __shared__ double sm[8][32][12];
+    const int lx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + lx;
+    const bool live = k < d.N;
+    const int L = d.L, mp = d.mp, n = d.n;
+    const int kk = live ? k : 0;
+    const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * kk);
+
+    // pass 1: weighted mean
+    double s0 = 0, s1 = 0;
+    for (int c = 1 + sl; c < L; c += 8) {
+        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
+        s0 += z.x; s1 += z.y;
+    }
+    sm[sl][lx][0] = s0; sm[sl][lx][1] = s1;
+    __syncthreads();
+    double t0 = 0, t1 = 0;
+    for (int q = 0; q < 8; q++) { t0 += sm[q][lx][0]; t1 += sm[q][lx][1]; }
+    const double hx = w.wm0 * z0.x + w.wi * t0;
+    const double hy = w.wm0 * z0.y + w.wi * t1;
+    __syncthreads();
+
+    // pass 2: sum a^2, sum ab, sum b^2 (a, b = wi_sr * deviations from Z_0) and robot cross terms
+    double xr[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) xr[e] = X[n - 4 + e];
+    double saa = 0, sab = 0, sbb = 0, px[4] = { 0, 0, 0, 0 }, py[4] = { 0, 0, 0, 0 };
+    for (int c = sl; c < L; c += 8) {
+        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
+        const double* r = sigR + (size_t)c * 8;
+        const double wt = (c == 0) ? w.wc0 : w.wi;
+        const double dzx = z.x - hx, dzy = z.y - hy;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); px[e] += dr * dzx; py[e] += dr * dzy; }
+        if (c > 0) {
+            const double a = w.wi_sr * (z.x - z0.x), b = w.wi_sr * (z.y - z0.y);
+            saa += a * a; sab += a * b; sbb += b * b;
+        }
+    }
+    sm[sl][lx][0] = saa; sm[sl][lx][1] = sab; sm[sl][lx][2] = sbb;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { sm[sl][lx][3 + e] = px[e]; sm[sl][lx][7 + e] = py[e]; }
+    __syncthreads();
+    double tot[11];
+#pragma unroll
+    for (int q = 0; q < 11; q++) { double s = 0; for (int u = 0; u < 8; u++) s += sm[u][lx][q]; tot[q] = s; }
+    __syncthreads();
+
+    // Householder on column a (GSL: beta = -sign(alpha)*hypot(alpha, xnorm); tau = 0 if xnorm == 0)
+    const double2 z1 = *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * kk);
+    const double a0 = w.wi_sr * (z1.x - z0.x), b0 = w.wi_sr * (z1.y - z0.y);
+    const double xn2 = fmax(tot[0] - a0 * a0, 0.0);
+    double R00 = a0, R01 = b0, tau = 0.0, wv = 0.0, inv_s = 0.0;
+    if (xn2 > 0.0) {
+        const double beta = -(a0 >= 0.0 ? 1.0 : -1.0) * sqrt(tot[0]);
+        tau = (beta - a0) / beta;
+        inv_s = 1.0 / (a0 - beta);
+        wv = b0 + (tot[1] - a0 * b0) * inv_s;           // w = B_0 + sum_{r>=1} B_r v_r
+        R00 = beta;
+        R01 = b0 - tau * wv;
+    }
+    // pass 3: b'_r = B_r - tau * v_r * w (r >= 1); R11 = -sign(b'_1) * |b'[1:]|
+    double sr2 = 0.0;
+    for (int c = 2 + sl; c < L; c += 8) {
+        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
+        const double a = w.wi_sr * (z.x - z0.x), b = w.wi_sr * (z.y - z0.y);
+        const double bp = b - tau * (a * inv_s) * wv;
+        if (c > 2) sr2 += bp * bp;
+    }
+    sm[sl][lx][0] = sr2;
+    __syncthreads();
+    double rest2 = 0; for (int u = 0; u < 8; u++) rest2 += sm[u][lx][0];
+    const double2 z2 = *reinterpret_cast<const double2*>(Z + (size_t)2 * mp + 2 * kk);
+    const double a1 = w.wi_sr * (z2.x - z0.x), b1 = w.wi_sr * (z2.y - z0.y);
+    const double bp1 = b1 - tau * (a1 * inv_s) * wv;
+    double R11 = bp1;
+    if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(bp1 * bp1 + rest2);
+
+    if (live && sl == 0) {
+        const bool v = (hx != 0.0) && (hy != 0.0);
+        h[2 * k] = hx; h[2 * k + 1] = hy;
+        vis[k] = v ? 1 : 0;
+        Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { PxyR[(size_t)e * mp + 2 * k] = tot[3 + e]; PxyR[(size_t)e * mp + 2 * k + 1] = tot[7 + e]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gain: per landmark k and state row r (KalmanUpdate, SLAM.cpp:2070-2080):
+//   sii = Si^{-1} (OpenCV closed-form 2x2 inverse), U = Ki*Si^T = Pxy*sii,
+//   y   = sii^T (z - h)  so that  X += Ki (z - h) = U y.
+// In : Ut rows 2k, 2k+1 hold wi*gamma * (S^T DZ) for r < n-4 (k_gemm), PxyR holds rows n-4..n-1.
+// Out: Ut rows become U^T (zero for unmatched / invisible landmarks); y[2k], y[2k+1].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
+                                              double* __restrict__ Ut, const double* __restrict__ PxyR,
+                                              const double* __restrict__ Si, const int* __restrict__ vis,
+                                              const double* __restrict__ h, const double* __restrict__ z_seq,
+                                              const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
+                                              const FrameScalars* __restrict__ fs, double* __restrict__ y)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (r >= d.np) return;
+    const int n = d.n, ld = d.np, mp = d.mp;
+    const double* z = z_cur ? z_cur : (z_seq + (size_t)fs->frame * 2 * d.N);
+    const int* mt = m_cur ? m_cur : (m_seq + (size_t)fs->frame * d.N);
+    const bool on = (mt[k] != 0) && (vis[k] != 0);
+    const double s00 = Si[4 * k], s01 = Si[4 * k + 1], s10 = Si[4 * k + 2], s11 = Si[4 * k + 3];
+    double det = s00 * s11 - s01 * s10;
+    double i00 = 0, i01 = 0, i10 = 0, i11 = 0;
+    if (det != 0.0) { det = 1.0 / det; i00 = s11 * det; i01 = -s01 * det; i10 = -s10 * det; i11 = s00 * det; }
+    double u0 = 0.0, u1 = 0.0;
+    if (on && r < n) {
+        double p0, p1;
+        if (r < n - 4) {
+            const double sc = w.wi * w.gamma;
+            p0 = sc * Ut[(size_t)(2 * k) * ld + r];
+            p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
+        } else {
+            p0 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k];
+            p1 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k + 1];
+        }
+        u0 = p0 * i00 + p1 * i10;
+        u1 = p0 * i01 + p1 * i11;
+    }
+    Ut[(size_t)(2 * k) * ld + r] = u0;
+    Ut[(size_t)(2 * k + 1) * ld + r] = u1;
+    if (r == 0) {
+        const double v0 = z[2 * k] - h[2 * k], v1 = z[2 * k + 1] - h[2 * k + 1];
+        y[2 * k]     = on ? (i00 * v0 + i10 * v1) : 0.0;
+        y[2 * k + 1] = on ? (i01 * v0 + i11 * v1) : 0.0;
+    }
+}
+
+// k_state_update: X[r] += sum_c Ut[c][r] * y[c]   (m_X_k += Ki*(zi - hi) summed over landmarks, 2079)
+__global__ __launch_bounds__(256) void k_state_update(KDims d, const double* __restrict__ Ut,
+                                                      const double* __restrict__ y, double* __restrict__ X)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= d.n) return;
+    double acc = 0.0;
+    const int M2 = 2 * d.N;
+    for (int c = 0; c < M2; c++) acc += Ut[(size_t)c * d.np + r] * y[c];
+    X[r] += acc;
+}
+
+// k_traj: per-frame record (x, y, z, theta, P00, P01, P10, P11) of the robot = RobotPath.txt
+// columns (SLAM.cpp:3549-3556) with P = S^T S restricted to the robot x/y block (2404); also
+// advances the staged-sequence frame counter.  One workgroup.
+__global__ __launch_bounds__(256) void k_traj(KDims d, const double* __restrict__ X, const double* __restrict__ S,
+                                              FrameScalars* __restrict__ fs, double* __restrict__ traj, int advance)
+{
+    __shared__ double red[16 * 3];
+    const int n = d.n, ld = d.np;
+    double v[3] = { 0, 0, 0 };
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const double a = S[(size_t)k * ld + (n - 4)], b = S[(size_t)k * ld + (n - 3)];
+        v[0] += a * a; v[1] += a * b; v[2] += b * b;
+    }
+    block_sum<3>(v, red);
+    if (threadIdx.x == 0) {
+        if (traj) {
+            double* t = traj + (size_t)8 * fs->frame;
+            for (int e = 0; e < 4; e++) t[e] = X[n - 4 + e];
+            t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
+        }
+        if (advance) fs->frame += 1;
+    }
+}
+
+// k_block_cov: small diagonal blocks of P = S^T S for the accessors (robot 4x4: SLAM.cpp:3539-3556;
+// landmark 6x6: 2748).  out[bs*bs], block starts at row/col `off`.  One workgroup.
+__global__ __launch_bounds__(256) void k_block_cov(KDims d, const double* __restrict__ S, int off, int bs, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    const int ld = d.np;
+    for (int a = 0; a < bs; a++)
+        for (int b = a; b < bs; b++) {
+            double v[1] = { 0.0 };
+            const int kmax = off + a;   // S upper triangular: S[k][off+a] = 0 for k > off+a
+            for (int k = threadIdx.x; k <= kmax; k += blockDim.x) v[0] += S[(size_t)k * ld + off + a] * S[(size_t)k * ld + off + b];
+            block_sum<1>(v, red);
+            if (threadIdx.x == 0) { out[a * bs + b] = v[0]; out[b * bs + a] = v[0]; }
+            __syncthreads();
+        }
+}
+
+// ---- host-callable launchers -------------------------------------------------------------------
+extern "C" {
+void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, double* X, double* S, double* sigR, double* Cmat,
+                         FrameScalars* fs, const double* odo_seq, const double* odo_pair)
+{
+    hipLaunchKernelGGL(k_motion, dim3(1), dim3(1024), 0, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair);
+}
+void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
+                          double* Z, double* DZ)
+{
+    dim3 grid((d.N + 63) / 64, (d.Na + 1 + 3) / 4);
+    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, d, w, p, X, S, sigR, Z, DZ);
+}
+void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* X, const double* sigR, const double* Z,
+                             double* h, double* Si, int* vis, double* PxyR)
+{
+    hipLaunchKernelGGL(k_meas_stats, dim3((d.N + 31) / 32), dim3(256), 0, st, d, w, X, sigR, Z, h, Si, vis, PxyR);
+}
+void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
+                       const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
+                       const FrameScalars* fs, double* y)
+{
+    dim3 grid((d.np + 255) / 256, d.N);
+    hipLaunchKernelGGL(k_gain, grid, dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, y);
+}
+void srukf_launch_state_update(hipStream_t st, KDims d, const double* Ut, const double* y, double* X)
+{
+    hipLaunchKernelGGL(k_state_update, dim3((d.n + 255) / 256), dim3(256), 0, st, d, Ut, y, X);
+}
+void srukf_launch_traj(hipStream_t st, KDims d, const double* X, const double* S, FrameScalars* fs, double* traj, int advance)
+{
+    hipLaunchKernelGGL(k_traj, dim3(1), dim3(256), 0, st, d, X, S, fs, traj, advance);
+}
+void srukf_launch_block_cov(hipStream_t st, KDims d, const double* S, int off, int bs, double* out)
+{
+    hipLaunchKernelGGL(k_block_cov, dim3(1), dim3(256), 0, st, d, S, off, bs, out);
+}
+}  // extern "C"
+
+// stand-alone projection kernel for the parity tests (srukf_project_host)
+__global__ void k_project_points(srukf_params p, int count, const double* feat6, const double* pos3, const double* psi,
+                                 const double* err2, double* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double f[6];
+    for (int e = 0; e < 6; e++) f[e] = feat6[6 * i + e];
+    double sn, cs;
+    sincos(psi[i], &sn, &cs);
+    double ox, oy;
+    srukf_project(p, p.cam_f / p.cam_dx, p.cam_f / p.cam_dy, f, pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2], cs, sn,
+                  err2[2 * i], err2[2 * i + 1], ox, oy);
+    out[2 * i] = ox; out[2 * i + 1] = oy;
+}
+extern "C" void srukf_launch_project_points(hipStream_t st, srukf_params p, int count, const double* feat6, const double* pos3,
+                                            const double* psi, const double* err2, double* out)
+{
+    hipLaunchKernelGGL(k_project_points, dim3((count + 255) / 256), dim3(256), 0, st, p, count, feat6, pos3, psi, err2, out);
+}

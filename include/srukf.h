@@ -1,0 +1,172 @@
+/*
+ * srukf.h — C-ABI of the MI355X-native SRUKF predict/update hot path.
+ *
+ * This is the drop-in boundary for ONE path of junliu111/CV-MonoSLAM: the per-frame
+ * square-root unscented Kalman filter inside class CSLAM (reference MonoSLAM/SLAM.cpp,
+ * MonoSLAM/SLAM.h:118-398).  The reference has no plugin/FFI interface: CSLAM is a concrete
+ * class embedded by value in the MFC view (MonoSLAMView.h:44) whose methods are called and
+ * whose public fields are read directly.  The entry points below are what a CSLAM facade
+ * (cv-monoslam_amd/host/cslam.hpp) binds to; each one cites the reference member(s) it
+ * replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns an int: SRUKF_OK (0) or a negative srukf_status; never aborts,
+ *     never prints (the reference prints + system("pause"), SLAM.cpp:297,324,2702,3526).
+ *   - one context = one filter = one HIP stream; a context is not thread-safe, independent
+ *     contexts are fully concurrent (multi-GPU / Monte-Carlo model).
+ *   - the caller owns every pointer it passes; nothing is retained past the call.
+ *   - all matrices are row-major fp64.  State layout (SLAM.cpp:226-231,1371,2427-2435):
+ *       X = [ N x (xi yi zi theta phi rho) | x y z theta ]      n = 6N+4
+ *       S = n x n upper triangular, P = S^T S                   (SLAM.h:272, SLAM.cpp:2118,2404)
+ *   - there is NO CPU fallback: if the HIP device/kernels are unavailable srukf_create fails
+ *     with SRUKF_ERR_NO_DEVICE.
+ */
+#ifndef SRUKF_H_
+#define SRUKF_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRUKF_ABI_VERSION 1
+
+typedef enum srukf_status {
+    SRUKF_OK                =  0,
+    SRUKF_ERR_BAD_ARG       = -1,  /* NULL pointer, negative size, unknown enum            */
+    SRUKF_ERR_DIM_MISMATCH  = -2,  /* sizes inconsistent with the context                  */
+    SRUKF_ERR_HIP           = -3,  /* a HIP runtime call failed; see srukf_last_error      */
+    SRUKF_ERR_NO_DEVICE     = -4,  /* no gfx950 device / code object not loadable          */
+    SRUKF_ERR_SEQUENCE      = -5,  /* call order violated (e.g. update before predict)     */
+    SRUKF_ERR_UNSUPPORTED   = -6,  /* feature outside the built hot path   */
+    SRUKF_ERR_CLAMP_PENDING = -7,  /* async replay hit the GMW theta-clamp; rerun sync      */
+    SRUKF_ERR_NOMEM         = -8
+} srukf_status;
+
+/* Tunables of the hot path.  Defaults = the reference's debug-model values
+ * (SLAM.cpp:172-198, 221-224, 238, 241-242, 263-264, 329-337, 52, 3186). */
+typedef struct srukf_params {
+    double cam_dx, cam_dy;          /* 0.0028, 0.0028          SLAM.cpp:329-330 */
+    double cam_cx, cam_cy;          /* 310.1129, 236.7526      SLAM.cpp:331-332 */
+    double cam_k1, cam_k2;          /* 1e-4, 0                 SLAM.cpp:333-334 */
+    double cam_f;                   /* 2.1735                  SLAM.cpp:335     */
+    double image_w, image_h;        /* 640, 480                SLAM.cpp:312-313 */
+    double a1, a2, a3, a4;          /* 8,8,8,8                 SLAM.cpp:195-198 */
+    double sigma_measure;           /* 3.0 (Qt = 3*I2)         SLAM.cpp:189,238 */
+    double rho0, sigma_rho;         /* 1/3, 1/6                SLAM.cpp:173,190 */
+    double sigma_x, sigma_y, sigma_z, sigma_theta; /* .02 .02 .005 .02  SLAM.cpp:221-224 */
+    double epsilon;                 /* 1e-13 (EPSILON)         SLAM.cpp:52      */
+    double ut_alpha, ut_beta;       /* 1e-3, 2                 SLAM.cpp:263-264 */
+    int    weight_type;             /* 0 (FLAG_4_WEIGHT1)      SLAM.cpp:241     */
+    int    noise_type;              /* 0 (FLAG_4_NOISE1); others unsupported  SLAM.cpp:242 */
+    int    newton_iters;            /* 100                     SLAM.cpp:3186    */
+    int    reserved_;
+} srukf_params;
+
+/* How the square-root covariance is maintained in srukf_update.
+ *  SEQUENTIAL: the reference's structure — for every matched landmark and each of its two
+ *              measurement columns u:  S <- gmw(S^T S - u u^T)   (SLAM.cpp:2066-2095, 2116-2154).
+ *  BATCHED   : one  S <- gmw(S^T S - U U^T)  per frame (gains do not depend on the S updates,
+ *              SLAM.cpp:2070-2080; see DESIGN.md for the equivalence evidence).               */
+typedef enum srukf_update_mode { SRUKF_UPDATE_SEQUENTIAL = 0, SRUKF_UPDATE_BATCHED = 1 } srukf_update_mode;
+
+/* SLAM.cpp:36-37 FLAG_4_NEED_REORDER(0) / FLAG_4_NEEDNOT_REORDER(1) */
+typedef enum srukf_reorder { SRUKF_NEED_REORDER = 0, SRUKF_NEEDNOT_REORDER = 1 } srukf_reorder;
+
+typedef struct srukf_ctx srukf_ctx;   /* opaque; owns all device buffers + pinned staging */
+
+int  srukf_abi_version(void);
+
+/* Fill *p with the reference defaults.  Replaces the constant block of
+ * CSLAM::initializeParameters (SLAM.cpp:158-343). */
+int  srukf_default_params(srukf_params* p);
+
+/* Create a filter for N landmarks (n = 6N+4) on HIP device `device`.
+ * `stream` is an existing hipStream_t to launch on (so a host can time with its own events) or
+ * NULL to let the context create one.  Replaces CSLAM::CSLAM + the allocation side of
+ * initializeParameters (SLAM.cpp:21-57, 226-239).  Initial state: robot X=0, S=diag(sigma_x,
+ * sigma_y, sigma_z, sigma_theta) in the robot block, landmark rows zero until srukf_set_state. */
+int  srukf_create(srukf_ctx** out, int n_landmarks, const srukf_params* p, int device, void* stream);
+int  srukf_destroy(srukf_ctx* ctx);                                  /* CSLAM::~CSLAM, SLAM.cpp:64-78      */
+int  srukf_reset(srukf_ctx* ctx);                                    /* resetAllParameters, SLAM.cpp:3090-3128 */
+const char* srukf_last_error(const srukf_ctx* ctx);                  /* NULL ctx -> last create() error    */
+
+/* Upload / download the filter state (host pointers).  m_X_k / m_S_k mirrors, SLAM.h:271-272.
+ * S is n*n row-major; only the upper triangle is read.  S may be NULL in get. */
+int  srukf_set_state(srukf_ctx* ctx, const double* X, const double* S);
+int  srukf_get_state(srukf_ctx* ctx, double* X, double* S);
+/* Same, from/to DEVICE pointers on the context's device (e.g. a tensor that arrived by RCCL
+ * broadcast); S_ld = row stride of the device matrix in elements (>= n). */
+int  srukf_set_state_device(srukf_ctx* ctx, const double* dX, const double* dS, int S_ld);
+int  srukf_get_state_device(srukf_ctx* ctx, double* dX, double* dS, int S_ld);
+
+/* Robot pose X[n-4:n] and the 4x4 robot block of P = S^T S.  Replaces the reads at
+ * SLAM.cpp:2963-2965, 3539-3556 and OpenGlDisplay.cpp:386-391 without forming the full
+ * m_P_k = S^T S of SLAM.cpp:2404. */
+int  srukf_get_robot(srukf_ctx* ctx, double pose4[4], double P4[16]);
+/* Landmark k: its 6 state rows and the 6x6 diagonal block of P (SLAM.cpp:2427-2432, 2748). */
+int  srukf_get_landmark_block(srukf_ctx* ctx, int k, double X6[6], double P66[36]);
+/* Full covariance m_P_k = S^T S (SLAM.cpp:2404), n*n row-major, for hosts that want it. */
+int  srukf_get_covariance(srukf_ctx* ctx, double* P);
+
+/* ---- the per-frame numeric seam (CSLAM::SLAM, SLAM.cpp:87-112) -------------------------- */
+
+/* predictMotion numeric tail (SLAM.cpp:1430-1465): control from two consecutive odometry
+ * poses (x, y, theta), sigma points, motion model, re-triangularisation of S.            */
+int  srukf_predict_motion(srukf_ctx* ctx, const double odo_prev[3], const double odo_cur[3]);
+
+/* predictMeasurement (SLAM.cpp:1604-1608): h[2N] predicted pixels (m_allPredictSet),
+ * Si[4N] per-landmark 2x2 upper-triangular sqrt innovation covariance (PointsMap::Si),
+ * visible[N] (PointsMap::isVisible, SLAM.cpp:1727).  Outputs are host pointers, any may be NULL. */
+int  srukf_predict_measurement(srukf_ctx* ctx, double* h, double* Si, int* visible);
+
+/* KalmanUpdate (SLAM.cpp:2048-2104): z[2N] matched pixels (PointsMap::matchLocation),
+ * matched[N] (PointsMap::isMatching).  reorder = SRUKF_NEEDNOT_REORDER for steady state;
+ * SRUKF_NEED_REORDER (the frame right after landmarks were added) is not built yet and
+ * returns SRUKF_ERR_UNSUPPORTED. */
+int  srukf_update(srukf_ctx* ctx, const double* z, const int* matched, int reorder, int mode);
+
+/* ---- benchmark seam: whole frames with inputs pre-staged in HBM --------------------------- */
+
+/* Stage F frames of inputs on the device: odo[(F+1)*3] odometry poses (frame f uses f, f+1),
+ * z[F*2N] measurements, matched[F*N].  Host pointers. */
+int  srukf_stage_sequence(srukf_ctx* ctx, int n_frames, const double* odo, const double* z, const int* matched);
+/* Run frames [first, first+count) back to back (predictMotion + predictMeasurement +
+ * KalmanUpdate per frame, no host round trip in between), asynchronously on the context's
+ * stream.  traj, if not NULL, is a DEVICE buffer of count*8 doubles receiving per frame
+ * (x, y, z, theta, P00, P01, P10, P11) — the RobotPath.txt columns of SLAM.cpp:3549-3556. */
+int  srukf_run_frames_async(srukf_ctx* ctx, int first, int count, int mode, double* d_traj);
+/* Wait for the stream; reports SRUKF_ERR_CLAMP_PENDING if any async frame needed the
+ * reference's theta-clamp branch of the modified Cholesky (results then invalid). */
+int  srukf_synchronize(srukf_ctx* ctx);
+
+/* ---- instrumentation ------------------------------------------------------------------------ */
+
+/* When on, every kernel launch is bracketed by HIP events on the context's stream and the
+ * durations are accumulated per kernel class (no graph replay in this mode). */
+int  srukf_set_profiling(srukf_ctx* ctx, int on);
+/* Number of kernel classes; then name / total ms / launch count / algorithmic flops and bytes
+ * (summed over launches) of class i since the last srukf_profile_reset. */
+int  srukf_profile_count(srukf_ctx* ctx);
+int  srukf_profile_get(srukf_ctx* ctx, int i, const char** name, double* total_ms, long long* launches,
+                       double* alg_flops, double* alg_bytes);
+int  srukf_profile_reset(srukf_ctx* ctx);
+
+/* Problem sizes of a context: N, n, Na, L. */
+int  srukf_dims(const srukf_ctx* ctx, int* N, int* n, int* Na, int* L);
+
+/* Stand-alone numeric primitives on DEVICE buffers (used by the parity tests; same kernels the
+ * frame path launches).
+ *   gmw   : S_out(upper) = modifiedCholeskyDecomposition(G)      SLAM.cpp:2197-2327
+ *           G is n*n row-major symmetric (upper triangle read). force_slow=1 takes the
+ *           column-by-column path that evaluates theta_j exactly as the reference does.
+ *           clamp_hit (host int*, may be NULL) reports whether the theta clamp was active.  */
+int  srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_out, double epsilon,
+                    int force_slow, int* clamp_hit);
+/*   project: one camera projection, SLAM.cpp:1634-1674 + 3177-3347 (host in/out, runs the device fn) */
+int  srukf_project_host(int device, const srukf_params* p, int count, const double* feat6, const double* pos3,
+                        const double* psi, const double* err2, double* uv_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRUKF_H_ */
