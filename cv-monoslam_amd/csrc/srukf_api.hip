@@ -571,6 +571,20 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     return SRUKF_OK;
 }
 
+int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_host)
+{
+    if (!c || count < 1) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    double* dt = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dt, sizeof(double) * 8 * (size_t)count));
+    int rc = srukf_run_frames_async(c, first, count, mode, dt);
+    if (rc == SRUKF_OK) rc = srukf_synchronize(c);
+    if (traj_host && (rc == SRUKF_OK || rc == SRUKF_ERR_CLAMP_PENDING))
+        hipMemcpy(traj_host, dt, sizeof(double) * 8 * (size_t)count, hipMemcpyDeviceToHost);
+    hipFree(dt);
+    return rc;
+}
+
 int srukf_synchronize(srukf_ctx* c)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;

@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -98,6 +98,7 @@ def load_library():
     L.srukf_update.argtypes = [C.c_void_p, _dp, _ip, C.c_int, C.c_int]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.srukf_run_frames_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.srukf_run_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
     L.srukf_synchronize.argtypes = [C.c_void_p]
     L.srukf_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.srukf_profile_count.argtypes = [C.c_void_p]
@@ -219,6 +220,11 @@ class Filter:
     def run_frames_async(self, first, count, mode=UPDATE_BATCHED, d_traj_ptr=None):
         self._chk(self._lib.srukf_run_frames_async(self._h, first, count, mode,
                                                    C.c_void_p(d_traj_ptr) if d_traj_ptr else None))
+
+    def run_frames(self, first, count, mode=UPDATE_BATCHED):
+        traj = np.empty((count, 8))
+        self._chk(self._lib.srukf_run_frames(self._h, first, count, mode, _d(traj)))
+        return traj
 
     def synchronize(self):
         self._chk(self._lib.srukf_synchronize(self._h))

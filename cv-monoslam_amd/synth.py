@@ -7,7 +7,8 @@ produces, for a landmark count N, a seed and a frame count F:
 * ``X0``/``S0``: the filter state after the reference's *joint initialisation* of N landmarks
   seen in the first frame (integrateFeaturesInformation numeric part, SLAM.cpp:826-871,
   1177-1334) — a faithful rank-deficient sqrt-covariance, ``rank(S0^T S0) = 4 + 3N``;
-* ``odo[(F+1), 3]``: odometry poses (x, y, theta) on a small closed circle;
+* ``odo[(F+1), 3]``: odometry poses (x, y, theta) on a small closed figure-8 (heading stays
+  inside (-pi, pi), see figure8_odometry);
 * ``z[F, 2N]``: pixel measurements = the reference's own projection model (quirks included,
   SLAM.cpp:1634-1674, 3177-3347) of the true landmarks from the true pose + N(0, 0.5^2) noise;
 * ``matched[F, N]``: all ones (every landmark visible and matched, M = N).
@@ -185,18 +186,23 @@ def permutation(dim, K):
     return perm
 
 
-def circle_odometry(F, rot1=0.05, trans=0.01, rot2=0.05):
-    """(F+1) odometry poses (x, y, theta) of the odometry motion model driven with a constant
-    (rot1, trans, rot2): a circle of radius trans / (rot1 + rot2) = 0.1 m."""
+def figure8_odometry(F, period=60, step=0.01, amplitude=2.404825557695773):
+    """(F+1) odometry poses (x, y, theta) of a robot driving forward `step` metres per frame with
+    heading theta_t = A sin(2 pi t / period).  A = 2.4048 (first zero of J0) makes the path a
+    closed figure-8 (0.09 m x 0.23 m at period 60), and keeps |theta| < pi: the reference's
+    control extraction rot1 = atan2(dy, dx) - theta_prev has no angle wrap (SLAM.cpp:1448), so a
+    heading that crosses +-pi injects a 2*pi "rotation" and its process noise."""
+    th = amplitude * np.sin(2 * np.pi * np.arange(F + 1) / period)
     odo = np.zeros((F + 1, 3))
     for t in range(F):
-        x, y, th = odo[t]
-        th1 = th + rot1
-        odo[t + 1] = (x + trans * np.cos(th1), y + trans * np.sin(th1), th1 + rot2)
+        d = th[t + 1] - th[t]
+        x, y, h = odo[t]
+        h1 = h + d / 2                       # rot1 = rot2 = d/2
+        odo[t + 1] = (x + step * np.cos(h1), y + step * np.sin(h1), h1 + d / 2)
     return odo
 
 
-def make_scene(N, F, seed=0, p=None, meas_sigma=0.5, disc_radius=100.0, ceiling=3.0, init="joint",
+def make_scene(N, F, seed=0, p=None, meas_sigma=0.5, disc_radius=80.0, ceiling=3.0, init="joint",
                obs_seed=None):
     """Build one synthetic sequence.  See module docstring.
 
@@ -223,7 +229,7 @@ def make_scene(N, F, seed=0, p=None, meas_sigma=0.5, disc_radius=100.0, ceiling=
         n = 6 * N + 4
         X0 = np.concatenate([np.column_stack([np.zeros((N, 3)), th, ph, np.full(N, p["rho0"])]).ravel(), X4])
         S0 = np.triu(rng.normal(0, 0.01, (n, n)), 1) + np.diag(rng.uniform(0.02, 0.1, n))
-    odo = circle_odometry(F)
+    odo = figure8_odometry(F)
     orng = np.random.default_rng(seed if obs_seed is None else obs_seed + 7919)
     z = np.zeros((F, 2 * N))
     for t in range(F):

@@ -135,6 +135,9 @@ int  srukf_stage_sequence(srukf_ctx* ctx, int n_frames, const double* odo, const
  * stream.  traj, if not NULL, is a DEVICE buffer of count*8 doubles receiving per frame
  * (x, y, z, theta, P00, P01, P10, P11) — the RobotPath.txt columns of SLAM.cpp:3549-3556. */
 int  srukf_run_frames_async(srukf_ctx* ctx, int first, int count, int mode, double* d_traj);
+/* Synchronous convenience form: runs the frames, waits, and copies the trajectory to the HOST
+ * buffer traj_host[count*8] (may be NULL). */
+int  srukf_run_frames(srukf_ctx* ctx, int first, int count, int mode, double* traj_host);
 /* Wait for the stream; reports SRUKF_ERR_CLAMP_PENDING if any async frame needed the
  * reference's theta-clamp branch of the modified Cholesky (results then invalid). */
 int  srukf_synchronize(srukf_ctx* ctx);

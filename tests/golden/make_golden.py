@@ -1,0 +1,110 @@
+"""Generates the golden fixtures in tests/golden/ from the CPU oracle (oracle/srukf_oracle.c).
+
+The reference ships no golden vectors for this path and cannot be compiled here,
+so these vectors pin the ORACLE (and, through it, the HIP path) against regressions; the oracle
+itself is cross-checked against the independent numpy restatement in tests/np_filter.py and
+cv-monoslam_amd/synth.py.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+pkg = ge.load_package()
+synth = pkg.synth
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def g1_weights():
+    rows = []
+    for wt in (0, 1, 2):
+        for Na in (9, 129, 309, 1209, 3009):
+            w = O.sample_parameter(Na, wt)
+            rows.append([wt, Na] + [w[k] for k in ("wm0", "wc0", "wi", "wi_sr", "gamma", "wm0_sr", "wc0_sr")])
+    return np.array(rows)
+
+
+def g2_projection():
+    p = synth.default_params()
+    rng = np.random.default_rng(11)
+    sc = synth.make_scene(24, 1, seed=5, p=synth.scene_params())
+    feat = sc["truth"].copy()
+    feat[:, :3] = rng.normal(0, 0.02, (24, 3))
+    pos = rng.normal(0, 0.05, (24, 3))
+    psi = rng.normal(0, 0.4, 24)
+    err = rng.normal(0, 2.0, (24, 2))
+    # force the special branches: Hlr.z == 0, outside the 10-px border, far outside the image
+    feat[0, 2] = 0.0; feat[0, 3] = np.pi / 2; feat[0, 4] = 0.0; pos[0, 2] = 0.0   # cos(phi)cos(theta)/rho ~ 6e-17 != 0: stays a huge ratio
+    feat[1, 3] = 1.2                                                               # projects outside -> zeroed by the border test
+    feat[2, 4] = -1.3
+    feat[3, 5] = 1e-3                                                              # very far point
+    uv = O.project(p, feat, pos, psi, err, early_exit=0)
+    return dict(feat=feat, pos=pos, psi=psi, err=err, uv=uv)
+
+
+def g3_gmw():
+    rng = np.random.default_rng(3)
+    out = {}
+    A = rng.normal(size=(8, 8)); spd = A @ A.T + 0.5 * np.eye(8)
+    B = rng.integers(-3, 4, size=(10, 4)).astype(float); psd = B @ B.T   # integer entries: null pivots ~1e-16 -> EPSILON clamp
+    C = rng.normal(size=(6, 6)); ind = C + C.T
+    for name, G in (("spd", spd), ("psd", psd), ("ind", ind)):
+        S, D, L, ce, ct = O.gmw(G)
+        out[name + "_G"], out[name + "_S"], out[name + "_D"], out[name + "_L"] = G, S, D, L
+        out[name + "_clamps"] = np.array([ce, ct])
+    return out
+
+
+def g4_joint_init():
+    p = synth.default_params()
+    out = {}
+    for K in (1, 2, 8):
+        sc = synth.make_scene(K, 1, seed=20 + K, p=synth.scene_params())
+        X, S = O.joint_init(p, np.zeros(4), np.diag([.02, .02, .005, .02]), sc["uv0"])
+        out[f"K{K}_uv"], out[f"K{K}_X"], out[f"K{K}_S"] = sc["uv0"], X, S
+    return out
+
+
+def g5_frame():
+    p = synth.scene_params()
+    N = 8
+    sc = synth.make_scene(N, 1, seed=31, p=p)
+    o = O.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    out = dict(X0=sc["X0"], S0=sc["S0"], odo=sc["odo"], z=sc["z"], matched=sc["matched"])
+    o.predict_motion(sc["odo"][0], sc["odo"][1])
+    out["X_motion"], S = o.get_state(); out["P_motion"] = S.T @ S
+    h, Si, vis = o.predict_measurement()
+    out["h"], out["Si"], out["vis"] = h, Si, vis
+    o.update(sc["z"][0], sc["matched"][0], 1, 0, 0)
+    out["X_post"], S = o.get_state(); out["P_post"] = S.T @ S
+    return out
+
+
+def g6_trajectory():
+    p = synth.scene_params()
+    N, F = 20, 50
+    sc = synth.make_scene(N, F, seed=42, p=p)
+    o = O.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    traj_seq = o.run_frames(sc["odo"], sc["z"], sc["matched"], O.Oracle.SEQUENTIAL)
+    Xs, Ss = o.get_state()
+    o2 = O.Oracle(N, p); o2.set_state(sc["X0"], sc["S0"])
+    traj_bat = o2.run_frames(sc["odo"], sc["z"], sc["matched"], O.Oracle.BATCHED)
+    return dict(N=N, F=F, seed=42, traj_sequential=traj_seq, traj_batched=traj_bat, X_final=Xs, P_final_diag=np.diag(Ss.T @ Ss),
+                clamps_seq=np.array(list(o.clamp_stats().values())), clamps_bat=np.array(list(o2.clamp_stats().values())))
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(OUT, "g1_weights.npz"), table=g1_weights())
+    np.savez_compressed(os.path.join(OUT, "g2_projection.npz"), **g2_projection())
+    np.savez_compressed(os.path.join(OUT, "g3_gmw.npz"), **g3_gmw())
+    np.savez_compressed(os.path.join(OUT, "g4_joint_init.npz"), **g4_joint_init())
+    np.savez_compressed(os.path.join(OUT, "g5_frame_n8.npz"), **g5_frame())
+    np.savez_compressed(os.path.join(OUT, "g6_trajectory_n20.npz"), **g6_trajectory())
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))

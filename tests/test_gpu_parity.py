@@ -1,0 +1,250 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle
+on identical seeded inputs, against the committed golden fixtures, and — at the benchmark's full
+size — through size-independent properties.
+
+Tolerances (fp64): the north star asks for pose RMSE within 1e-6 of the reference; the tests
+hold the HIP path to |dX| <= 1e-9 and |dP| <= 1e-11 against the oracle per frame and <= 1e-9 in
+pose over 50-frame trajectories.  Comparisons are on X and P = S^T S (never S element-wise:
+row signs and null-space rows of S are not unique)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_X, TOL_P, TOL_H = 1e-9, 1e-11, 1e-8
+
+
+def _pair(srukf, oracle, synth, N, F, seed, params=None):
+    p = params or synth.scene_params()
+    sc = synth.make_scene(N, F, seed=seed, p=p)
+    f = srukf.Filter(N, p)
+    f.set_state(sc["X0"], sc["S0"])
+    o = oracle.Oracle(N, p)
+    o.set_state(sc["X0"], sc["S0"])
+    return sc, f, o
+
+
+def test_projection_matches_oracle_and_golden(srukf, oracle, golden, synth):
+    g = golden["g2_projection"]
+    p = synth.default_params()
+    uv = srukf.project(p, g["feat"], g["pos"], g["psi"], g["err"])
+    np.testing.assert_allclose(uv, g["uv"], rtol=0, atol=1e-9)          # includes both zeroing branches
+    rng = np.random.default_rng(5)
+    sc = synth.make_scene(512, 1, seed=6)
+    feat = sc["truth"] + rng.normal(0, 1e-3, sc["truth"].shape)
+    pos, psi, err = rng.normal(0, 0.05, (512, 3)), rng.normal(0, 0.5, 512), rng.normal(0, 3, (512, 2))
+    np.testing.assert_allclose(srukf.project(p, feat, pos, psi, err), oracle.project(p, feat, pos, psi, err), rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 64, 100, 257])
+def test_gmw_spd_sizes(srukf, oracle, n):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n))
+    G = A @ A.T + 0.1 * np.eye(n)
+    S, D, hit = srukf.gmw(G)
+    So, Do, Lo, ce, ct = oracle.gmw(G)
+    assert hit == 0 and ct == 0
+    np.testing.assert_allclose(S, So, atol=1e-11 * np.abs(So).max())
+    np.testing.assert_allclose(D, Do, rtol=1e-11)
+    assert np.allclose(np.tril(S, -1), 0)
+
+
+def test_gmw_golden_and_clamps(srukf, oracle, golden):
+    g = golden["g3_gmw"]
+    S, D, hit = srukf.gmw(g["spd_G"])
+    np.testing.assert_allclose(S, g["spd_S"], atol=1e-13)
+    # rank-deficient PSD: EPSILON clamp on the null pivots, compare on P
+    S, D, hit = srukf.gmw(g["psd_G"])
+    np.testing.assert_allclose(S.T @ S, g["psd_S"].T @ g["psd_S"], atol=1e-12)
+    assert hit == 0 and (D <= 1e-13 * (1 + 1e-9)).sum() == (g["psd_D"] <= 1e-13 * (1 + 1e-9)).sum()
+    # indefinite: the fast path detects that the theta clamp would fire and the exact
+    # column-by-column path reproduces the reference pivots
+    S, D, hit = srukf.gmw(g["ind_G"])
+    assert hit > 0
+    np.testing.assert_allclose(D, g["ind_D"], rtol=1e-12)
+    np.testing.assert_allclose(S, g["ind_S"], atol=1e-12)
+    S2, D2, hit2 = srukf.gmw(g["ind_G"], force_slow=True)
+    assert hit2 == g["ind_clamps"][1]
+    np.testing.assert_allclose(S2, g["ind_S"], atol=1e-12)
+    # slow path == fast path on SPD input
+    S3, D3, _ = srukf.gmw(g["spd_G"], force_slow=True)
+    np.testing.assert_allclose(S3, g["spd_S"], atol=1e-13)
+
+
+def test_gmw_random_indefinite_matches_oracle(srukf, oracle):
+    rng = np.random.default_rng(8)
+    for n in (20, 70):
+        G = rng.normal(size=(n, n)); G = G + G.T
+        S, D, hit = srukf.gmw(G)
+        So, Do, Lo, ce, ct = oracle.gmw(G)
+        assert hit > 0 and ct > 0
+        np.testing.assert_allclose(D, Do, rtol=1e-10)
+        np.testing.assert_allclose(S, So, atol=1e-10 * np.abs(So).max())
+
+
+def test_one_frame_stage_by_stage_golden(srukf, oracle, golden, synth):
+    g = golden["g5_frame_n8"]
+    p = synth.scene_params()
+    f = srukf.Filter(8, p)
+    f.set_state(g["X0"], g["S0"])
+    f.predict_motion(g["odo"][0], g["odo"][1])
+    X, S = f.get_state()
+    np.testing.assert_allclose(X, g["X_motion"], atol=1e-13)
+    np.testing.assert_allclose(S.T @ S, g["P_motion"], atol=1e-15)
+    assert np.allclose(np.tril(S, -1), 0)
+    h, Si, vis = f.predict_measurement()
+    np.testing.assert_allclose(h, g["h"], atol=TOL_H)
+    np.testing.assert_allclose(np.abs(Si), np.abs(g["Si"]), atol=1e-10)
+    np.testing.assert_allclose(np.einsum("kab,kac->kbc", Si, Si), np.einsum("kab,kac->kbc", g["Si"], g["Si"]), atol=1e-9)
+    assert np.array_equal(vis, g["vis"])
+    f.update(g["z"][0], g["matched"][0], mode=srukf.UPDATE_SEQUENTIAL)      # the reference's structure
+    X, S = f.get_state()
+    np.testing.assert_allclose(X, g["X_post"], atol=TOL_X)
+    np.testing.assert_allclose(S.T @ S, g["P_post"], atol=TOL_P)
+
+
+@pytest.mark.parametrize("N,F,mode", [(1, 4, 0), (2, 6, 0), (8, 6, 1), (20, 5, 1), (50, 3, 1)])
+def test_frames_against_oracle(srukf, oracle, synth, N, F, mode):
+    sc, f, o = _pair(srukf, oracle, synth, N, F, seed=100 + N)
+    for t in range(F):
+        f.predict_motion(sc["odo"][t], sc["odo"][t + 1])
+        o.predict_motion(sc["odo"][t], sc["odo"][t + 1])
+        h, Si, vis = f.predict_measurement()
+        ho, Sio, viso = o.predict_measurement()
+        np.testing.assert_allclose(h, ho, atol=TOL_H)
+        np.testing.assert_allclose(np.abs(Si), np.abs(Sio), atol=1e-9)
+        assert np.array_equal(vis, viso)
+        f.update(sc["z"][t], sc["matched"][t], mode=mode)
+        o.update(sc["z"][t], sc["matched"][t], 1, 0, mode)
+        X, S = f.get_state()
+        Xo, So = o.get_state()
+        np.testing.assert_allclose(X, Xo, atol=TOL_X)
+        np.testing.assert_allclose(S.T @ S, So.T @ So, atol=TOL_P)
+    pose, P4 = f.get_robot()
+    np.testing.assert_allclose(pose, Xo[-4:], atol=TOL_X)
+    np.testing.assert_allclose(P4, (So.T @ So)[-4:, -4:], atol=TOL_P)
+    x6, P6 = f.get_landmark_block(N - 1)
+    np.testing.assert_allclose(P6, (So.T @ So)[6 * (N - 1):6 * N, 6 * (N - 1):6 * N], atol=TOL_P)
+    np.testing.assert_allclose(f.get_covariance(), So.T @ So, atol=TOL_P)
+
+
+def test_unmatched_and_partial_matches(srukf, oracle, synth):
+    sc, f, o = _pair(srukf, oracle, synth, 12, 3, seed=77)
+    rng = np.random.default_rng(1)
+    for t in range(3):
+        m = (rng.uniform(size=12) < 0.6).astype(np.int32)
+        if t == 1:
+            m[:] = 0                                   # KalmanUpdate returns early (SLAM.cpp:2050)
+        f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); o.predict_motion(sc["odo"][t], sc["odo"][t + 1])
+        f.predict_measurement(); o.predict_measurement()
+        f.update(sc["z"][t], m, mode=srukf.UPDATE_BATCHED); o.update(sc["z"][t], m, 1, 0, 1)
+        X, S = f.get_state(); Xo, So = o.get_state()
+        np.testing.assert_allclose(X, Xo, atol=TOL_X)
+        np.testing.assert_allclose(S.T @ S, So.T @ So, atol=TOL_P)
+
+
+def test_trajectory_golden_n20(srukf, golden, synth):
+    """50 frames, N = 20, staged sequence replayed on the device without host round trips."""
+    g = golden["g6_trajectory_n20"]
+    p = synth.scene_params()
+    sc = synth.make_scene(20, 50, seed=int(g["seed"]), p=p)
+    f = srukf.Filter(20, p)
+    f.set_state(sc["X0"], sc["S0"])
+    f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    traj = np.vstack([f.run_frames(0, 20), f.run_frames(20, 30)])
+    # against the reference-structured (sequential) oracle trajectory: pose and robot covariance
+    np.testing.assert_allclose(traj[:, :4], g["traj_sequential"][:, :4], atol=1e-9)
+    np.testing.assert_allclose(traj[:, 4:], g["traj_sequential"][:, 4:], atol=1e-13)
+    rmse = np.sqrt(np.mean((traj[:, :2] - g["traj_sequential"][:, :2]) ** 2))
+    assert rmse < 1e-9                                  # north star: <= 1e-6
+    X, S = f.get_state()
+    np.testing.assert_allclose(X, g["X_final"], atol=1e-9)
+    np.testing.assert_allclose(np.diag(S.T @ S), g["P_final_diag"], atol=1e-12)
+
+
+def test_sequential_equals_batched_on_device(srukf, synth):
+    p = synth.scene_params()
+    sc = synth.make_scene(8, 8, seed=12, p=p)
+    out = []
+    for mode in (srukf.UPDATE_SEQUENTIAL, srukf.UPDATE_BATCHED):
+        f = srukf.Filter(8, p)
+        f.set_state(sc["X0"], sc["S0"])
+        for t in range(8):
+            f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); f.predict_measurement()
+            f.update(sc["z"][t], sc["matched"][t], mode=mode)
+        out.append(f.get_state())
+    np.testing.assert_allclose(out[0][0], out[1][0], atol=1e-11)
+    np.testing.assert_allclose(out[0][1].T @ out[0][1], out[1][1].T @ out[1][1], atol=1e-14)
+
+
+def test_step_api_equals_staged_replay(srukf, synth):
+    p = synth.scene_params()
+    sc = synth.make_scene(20, 6, seed=3, p=p)
+    a = srukf.Filter(20, p); a.set_state(sc["X0"], sc["S0"])
+    for t in range(6):
+        a.predict_motion(sc["odo"][t], sc["odo"][t + 1]); a.predict_measurement(); a.update(sc["z"][t], sc["matched"][t])
+    b = srukf.Filter(20, p); b.set_state(sc["X0"], sc["S0"]); b.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    b.run_frames(0, 6)
+    Xa, Sa = a.get_state(); Xb, Sb = b.get_state()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Sa, Sb)       # same kernels, same order: bit-identical
+
+
+def test_row_sign_invariance(srukf, synth):
+    """P = S^T S is invariant under row sign flips of S; so is the whole frame (the sigma set
+    {X +- gamma S_i} is the same set)."""
+    p = synth.scene_params()
+    sc = synth.make_scene(10, 2, seed=21, p=p)
+    rng = np.random.default_rng(0)
+    flip = np.where(rng.uniform(size=sc["S0"].shape[0]) < 0.5, -1.0, 1.0)
+    res = []
+    for S0 in (sc["S0"], flip[:, None] * sc["S0"]):
+        f = srukf.Filter(10, p); f.set_state(sc["X0"], S0)
+        for t in range(2):
+            f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); f.predict_measurement(); f.update(sc["z"][t], sc["matched"][t])
+        res.append(f.get_state())
+    np.testing.assert_allclose(res[0][0], res[1][0], atol=1e-10)
+    np.testing.assert_allclose(res[0][1].T @ res[0][1], res[1][1].T @ res[1][1], atol=1e-12)
+
+
+def test_error_behaviour(srukf, synth):
+    p = synth.scene_params()
+    sc = synth.make_scene(4, 2, seed=2, p=p)
+    f = srukf.Filter(4, p); f.set_state(sc["X0"], sc["S0"])
+    with pytest.raises(srukf.SrukfError) as e:
+        f.update(sc["z"][0], sc["matched"][0])                  # update before predict
+    assert e.value.rc == -5
+    f.predict_motion(sc["odo"][0], sc["odo"][1]); f.predict_measurement()
+    with pytest.raises(srukf.SrukfError) as e:
+        f.update(sc["z"][0], sc["matched"][0], reorder=srukf.NEED_REORDER)
+    assert e.value.rc == -6
+    with pytest.raises(srukf.SrukfError) as e:
+        f.run_frames(0, 1)                                      # nothing staged
+    assert e.value.rc == -2
+    f.reset()
+    X, S = f.get_state()
+    assert np.array_equal(X, np.zeros(28)) and S[-1, -1] == 0.02 and S[-2, -2] == 0.005
+
+
+def test_full_size_properties_n200(srukf, synth):
+    """BASELINE config 3 (N = 200, n = 1204): no oracle at this size inside a unit test; check
+    size-independent properties of the device results."""
+    p = synth.scene_params()
+    N, F = 200, 6
+    sc = synth.make_scene(N, F, seed=0, p=p)
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    traj = f.run_frames(0, F)
+    X, S = f.get_state()
+    assert np.isfinite(X).all() and np.isfinite(S).all()
+    assert np.allclose(np.tril(S, -1), 0)                                       # upper triangular
+    P = f.get_covariance()
+    np.testing.assert_allclose(P, S.T @ S, atol=1e-15)                          # device S^T S == host S^T S
+    assert np.linalg.eigvalsh(P).min() > -1e-14                                 # PSD
+    pose, P4 = f.get_robot()
+    np.testing.assert_allclose(P4, P[-4:, -4:], atol=1e-16)
+    np.testing.assert_allclose(traj[-1, :4], pose, atol=0)
+    np.testing.assert_allclose(traj[-1, 4:], P[-4:-2, -4:-2].ravel(), atol=1e-16)
+    assert np.abs(traj[:, :2] - sc["odo"][1:, :2]).max() < 2e-4                 # the filter tracks the truth
+    assert np.diag(S).min() >= np.sqrt(1e-13) * (1 - 1e-9)                      # EPSILON clamp floor on every pivot
+    # landmark anchors never move relative to each other by more than the clamp allows (null space kept)
+    anchors = X[:-4].reshape(N, 6)[:, :3]
+    assert np.abs(anchors - anchors[0]).max() < 1e-3

@@ -1,0 +1,85 @@
+"""CPU tests of the host side: the C-ABI library loads, exports every symbol include/srukf.h
+declares, refuses to run without a GPU (no fallback), and the scene generator is deterministic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "srukf.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(srukf_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.srukf.load_library()
+    names = _header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"libsrukf_hip.so does not export {n}"
+    assert sorted(pkg.srukf.EXPORTS) == names
+    assert lib.srukf_abi_version() == 1
+
+
+def test_default_params_match_reference_constants(pkg):
+    d = pkg.srukf.default_params()
+    ref = pkg.synth.default_params()
+    for k, v in ref.items():
+        assert d[k] == pytest.approx(v), k
+    assert d["a1"] == 8 and d["epsilon"] == 1e-13 and d["newton_iters"] == 100     # SLAM.cpp:195, 52, 3186
+    assert d["cam_f"] / d["cam_dx"] == pytest.approx(776.25, abs=0.01)             # f1 = f/dx, SLAM.cpp:336
+
+
+def test_params_struct_layout_matches_oracle_binding(pkg, oracle):
+    assert C.sizeof(pkg.srukf.Params) == C.sizeof(oracle.Params) == 23 * 8 + 4 * 4
+    assert [f[0] for f in pkg.srukf.Params._fields_] == [f[0] for f in oracle.Params._fields_]
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_gpu_fails_loudly(pkg):
+    """The product path has no CPU fallback: without a device, create() reports NO_DEVICE."""
+    with pytest.raises(pkg.srukf.SrukfError) as e:
+        pkg.srukf.Filter(8, pkg.synth.scene_params())
+    assert e.value.rc == -4
+    with pytest.raises(pkg.srukf.SrukfError):
+        pkg.srukf.gmw(np.eye(4))
+
+
+def test_bad_arguments(pkg):
+    lib = pkg.srukf.load_library()
+    assert lib.srukf_default_params(None) == -1
+    h = C.c_void_p()
+    p = pkg.srukf.Params.from_dict(pkg.synth.scene_params())
+    assert lib.srukf_create(C.byref(h), 0, C.byref(p), 0, None) == -1
+    p.noise_type = 1
+    assert lib.srukf_create(C.byref(h), 4, C.byref(p), 0, None) == -6            # random-noise models unsupported
+    assert lib.srukf_destroy(None) == 0
+    assert lib.srukf_update(None, None, None, 1, 1) == -1
+
+
+def test_scene_is_deterministic_and_inside_the_image(synth):
+    a = synth.make_scene(20, 30, seed=7)
+    b = synth.make_scene(20, 30, seed=7)
+    for k in ("X0", "S0", "odo", "z"):
+        assert np.array_equal(a[k], b[k])
+    c = synth.make_scene(20, 30, seed=7, obs_seed=3)
+    assert np.array_equal(a["X0"], c["X0"]) and not np.array_equal(a["z"], c["z"])   # shared map, own noise
+    # measurements stay clear of the 10-px zeroing border (SLAM.cpp:3341) and 20-px deletion border (2443-2446)
+    zx, zy = a["z"][:, 0::2], a["z"][:, 1::2]
+    assert zx.min() > 40 and zx.max() < 600 and zy.min() > 40 and zy.max() < 440
+    # heading never crosses +-pi (no angle wrap in SLAM.cpp:1448)
+    assert np.abs(a["odo"][:, 2]).max() < 2.5
+    # S0 upper triangular, rank-deficient
+    assert np.allclose(np.tril(a["S0"], -1), 0)
+    assert np.linalg.matrix_rank(a["S0"].T @ a["S0"], tol=1e-12) == 4 + 3 * 20
+
+
+def test_figure8_closes(synth):
+    odo = synth.figure8_odometry(600)
+    assert np.abs(odo[600, :2] - odo[0, :2]).max() < 0.05
+    assert np.ptp(odo[:, 0]) < 0.12 and np.ptp(odo[:, 1]) < 0.3

@@ -1,0 +1,209 @@
+"""CPU tests: the oracle against its golden vectors, against numpy/scipy factorizations and
+against the independent numpy restatement (tests/np_filter.py, cv-monoslam_amd/synth.py)."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+from np_filter import NpFilter, gmw as np_gmw
+
+
+def test_g1_weights(oracle, golden, synth):
+    tab = golden["g1_weights"]["table"]
+    for row in tab:
+        wt, Na = int(row[0]), int(row[1])
+        w = oracle.sample_parameter(Na, wt)
+        got = [w[k] for k in ("wm0", "wc0", "wi", "wi_sr", "gamma", "wm0_sr", "wc0_sr")]
+        assert np.array_equal(got, row[2:])
+        wm0, wc0, wi, wi_sr, gamma = synth.ut_weights(Na, wt)
+        np.testing.assert_allclose([wm0, wc0, wi, wi_sr, gamma], row[2:7], rtol=1e-14)
+        assert abs(wm0 + 2 * Na * wi - 1.0) < 1e-9 * max(1, abs(wm0))      # weights sum to one
+        assert abs(wi * gamma ** 2 - 0.5) < 1e-12                          # => motion QR keeps S11
+    assert golden["g1_weights"]["table"][3][2] == pytest.approx(1 - 1209 / 3.0)   # N=200: wm0 = -402
+
+
+def test_g2_projection_golden_and_numpy(oracle, golden, synth):
+    g = golden["g2_projection"]
+    p = synth.default_params()
+    uv = oracle.project(p, g["feat"], g["pos"], g["psi"], g["err"], early_exit=0)
+    assert np.array_equal(uv, g["uv"])                       # bit-stable restatement
+    uv_fast = oracle.project(p, g["feat"], g["pos"], g["psi"], g["err"], early_exit=1)
+    assert np.array_equal(uv, uv_fast)                       # early Newton exit is bit-exact
+    uv_np = synth.project(g["feat"], g["pos"], g["psi"], g["err"], p)
+    np.testing.assert_allclose(uv_np, uv, rtol=0, atol=1e-9)
+    # a zeroed undistorted pixel still passes through the distortion model (quirk): not (0, 0)
+    assert np.allclose(g["uv"][1], g["uv"][2]) and 0 < g["uv"][1][0] < 0.1
+
+
+def test_projection_quirks(oracle, synth):
+    p = synth.default_params()
+    feat = np.array([[0, 0, 0, 0.05, -0.02, 1 / 3.0]])
+    z = np.zeros((1, 3))
+    uv = oracle.project(p, feat, z, [0.0], np.zeros((1, 2)))[0]
+    # x/y swap (SLAM.cpp:3338-3339): world +x (theta > 0) moves the SECOND undistorted coordinate,
+    # which is centred on cam_cx; the first is centred on cam_cy
+    assert uv[1] > p["cam_cx"] and abs(uv[0] - p["cam_cy"]) < 20
+    # pixel noise rows add to (uvu.y, uvu.x) = (err0, err1)
+    uv2 = oracle.project(p, feat, z, [0.0], np.array([[2.0, 0.0]]))[0]
+    assert uv2[1] - uv[1] == pytest.approx(2.0, abs=1e-2) and abs(uv2[0] - uv[0]) < 1e-3
+
+
+def test_qr_matches_numpy_up_to_row_signs(oracle):
+    rng = np.random.default_rng(0)
+    for m, k in ((7, 3), (40, 12), (130, 60), (5, 5), (3, 6)):
+        A = rng.normal(size=(m, k))
+        R = oracle.qr_r(A)
+        assert np.allclose(np.tril(R, -1), 0)
+        np.testing.assert_allclose(R.T @ R, (A.T @ A) if m >= k else R.T @ R, atol=1e-11)
+        if m >= k:
+            Rn = np.linalg.qr(A, mode="r")
+            np.testing.assert_allclose(np.abs(R), np.abs(Rn), atol=1e-11)
+            # GSL sign rule: R_jj = -sign(leading element) * norm
+            assert np.sign(R[0, 0]) == -np.sign(A[0, 0])
+    # tau = 0 when the sub-column is already zero: R_jj keeps the element
+    A = np.array([[2.0, 1.0], [0.0, 3.0], [0.0, 0.0]])
+    R = oracle.qr_r(A)
+    assert R[0, 0] == 2.0 and R[0, 1] == 1.0
+
+
+def test_g3_gmw(oracle, golden):
+    g = golden["g3_gmw"]
+    for name in ("spd", "psd", "ind"):
+        S, D, L, ce, ct = oracle.gmw(g[name + "_G"])
+        assert np.array_equal(S, g[name + "_S"]) and np.array_equal(D, g[name + "_D"]) and np.array_equal(L, g[name + "_L"])
+        assert [ce, ct] == list(g[name + "_clamps"])
+        Sn, Dn, ne, nt, _ = np_gmw(g[name + "_G"])
+        # rows of S that belong to clamped (null) pivots are rounding noise / sqrt(EPSILON):
+        # compare on P = S^T S, never on S element-wise
+        np.testing.assert_allclose(Sn.T @ Sn, S.T @ S, atol=1e-12)
+        if name != "psd":
+            np.testing.assert_allclose(Sn, S, atol=1e-12)
+        assert (ne, nt) == (ce, ct)
+    # SPD: equals the Cholesky factor; nothing is clamped
+    G = g["spd_G"]
+    np.testing.assert_allclose(g["spd_S"], scipy.linalg.cholesky(G), atol=1e-12)
+    # PSD rank-deficient: S^T S = G + E with diagonal E >= 0 small
+    P = g["psd_S"].T @ g["psd_S"]
+    E = P - g["psd_G"]
+    assert np.abs(E - np.diag(np.diag(E))).max() < 1e-12 and np.diag(E).min() > -1e-12
+    assert g["psd_clamps"][0] >= 5 and g["psd_clamps"][1] == 0      # EPSILON clamp on the null pivots
+    # indefinite: theta clamp active, result is PD
+    assert g["ind_clamps"][1] > 0 and np.linalg.eigvalsh(g["ind_S"].T @ g["ind_S"]).min() > 0
+
+
+def test_g4_joint_init_rank_and_numpy(oracle, golden, synth):
+    g = golden["g4_joint_init"]
+    p = synth.default_params()
+    for K in (1, 2, 8):
+        X, S = oracle.joint_init(p, np.zeros(4), np.diag([.02, .02, .005, .02]), g[f"K{K}_uv"])
+        assert np.array_equal(X, g[f"K{K}_X"]) and np.array_equal(S, g[f"K{K}_S"])
+        P = S.T @ S
+        assert np.linalg.matrix_rank(P, tol=1e-12) == 4 + 3 * K
+        Xn, Sn = synth.joint_init(np.zeros(4), np.diag([.02, .02, .005, .02]), g[f"K{K}_uv"], p)
+        np.testing.assert_allclose(Xn, X, atol=1e-13)
+        np.testing.assert_allclose(Sn.T @ Sn, P, atol=1e-15)
+        # anchors are copies of the robot position
+        for k in range(K):
+            assert np.array_equal(X[6 * k:6 * k + 3], np.zeros(3))
+            assert X[6 * k + 5] == pytest.approx(1 / 3.0)
+
+
+def test_g5_one_frame(oracle, golden, synth):
+    g = golden["g5_frame_n8"]
+    p = synth.scene_params()
+    o = oracle.Oracle(8, p)
+    o.set_state(g["X0"], g["S0"])
+    o.predict_motion(g["odo"][0], g["odo"][1])
+    X, S = o.get_state()
+    assert np.array_equal(X, g["X_motion"])
+    np.testing.assert_allclose(S.T @ S, g["P_motion"], atol=1e-18)
+    # motion re-triangularisation only changes the last four columns of S
+    np.testing.assert_allclose(np.abs(S[:-4, :-4]), np.abs(np.triu(g["S0"])[:-4, :-4]), atol=1e-16)
+    h, Si, vis = o.predict_measurement()
+    assert np.array_equal(h, g["h"]) and np.array_equal(Si, g["Si"]) and np.array_equal(vis, g["vis"])
+    o.update(g["z"][0], g["matched"][0], 1, 0, 0)
+    X, S = o.get_state()
+    assert np.array_equal(X, g["X_post"])
+    np.testing.assert_allclose(S.T @ S, g["P_post"], atol=1e-18)
+    # independent numpy restatement of the same frame
+    f = NpFilter(8, p, synth)
+    f.set_state(g["X0"], g["S0"])
+    f.predict_motion(g["odo"][0], g["odo"][1])
+    np.testing.assert_allclose(f.X, g["X_motion"], atol=1e-13)
+    np.testing.assert_allclose(f.S.T @ f.S, g["P_motion"], atol=1e-15)
+    hn, Sin, visn = f.predict_measurement()
+    np.testing.assert_allclose(hn, g["h"], atol=1e-9)
+    np.testing.assert_allclose(np.abs(Sin), np.abs(g["Si"]), atol=1e-10)
+    f.update(g["z"][0], g["matched"][0], mode=0)
+    np.testing.assert_allclose(f.X, g["X_post"], atol=1e-11)
+    np.testing.assert_allclose(f.S.T @ f.S, g["P_post"], atol=1e-13)
+
+
+def test_g6_trajectory(oracle, golden, synth):
+    g = golden["g6_trajectory_n20"]
+    p = synth.scene_params()
+    N, F = int(g["N"]), int(g["F"])
+    sc = synth.make_scene(N, F, seed=int(g["seed"]), p=p)
+    o = oracle.Oracle(N, p)
+    o.set_state(sc["X0"], sc["S0"])
+    traj = o.run_frames(sc["odo"][:11], sc["z"][:10], sc["matched"][:10], oracle.Oracle.SEQUENTIAL)
+    np.testing.assert_allclose(traj, g["traj_sequential"][:10], rtol=0, atol=1e-12)
+    # the filter tracks: estimated pose within 0.1 mm of the true pose, all 50 frames
+    assert np.abs(g["traj_sequential"][:, :2] - sc["odo"][1:, :2]).max() < 1e-4
+    # one batched refactor per frame == 2M sequential ones, N = 20
+    assert np.abs(g["traj_sequential"][:, :4] - g["traj_batched"][:, :4]).max() < 1e-11
+    assert np.abs(g["traj_sequential"][:, 4:] - g["traj_batched"][:, 4:]).max() < 1e-15
+    # the theta clamp never fires on this scene, the eps clamp fires on every refactor (rank-deficient P)
+    assert g["clamps_seq"][1] == 0 and g["clamps_bat"][1] == 0 and g["clamps_bat"][0] >= F
+    # numpy restatement, batched, first 10 frames
+    f = NpFilter(N, p, synth)
+    f.set_state(sc["X0"], sc["S0"])
+    tn = f.run(sc, mode=1, frames=10)
+    np.testing.assert_allclose(tn[:, :4], g["traj_batched"][:10, :4], atol=1e-10)
+    np.testing.assert_allclose(tn[:, 4:], g["traj_batched"][:10, 4:], atol=1e-13)
+
+
+def test_need_reorder_path(oracle, synth):
+    """Frame right after landmarks were added (m_nAddings != 0): rank-aware pivoted refactor
+    (SLAM.cpp:2122-2138, 2158-2179).  P must stay PSD with rank <= 4 + 3K + 3K and close to the
+    NEEDNOT_REORDER result in X (the gains are the same)."""
+    p = synth.scene_params()
+    N = 4
+    sc = synth.make_scene(N, 1, seed=9, p=p)
+    res = {}
+    for reorder in (0, 1):
+        o = oracle.Oracle(N, p)
+        o.set_state(sc["X0"], sc["S0"])
+        o.predict_motion(sc["odo"][0], sc["odo"][1])
+        o.predict_measurement()
+        o.update(sc["z"][0], sc["matched"][0], reorder, N, 0)
+        res[reorder] = o.get_state()
+    np.testing.assert_allclose(res[0][0], res[1][0], atol=1e-12)
+    P0, P1 = res[0][1].T @ res[0][1], res[1][1].T @ res[1][1]
+    assert np.linalg.eigvalsh(P0).min() > -1e-12
+    assert np.abs(P0 - P1).max() < 1e-6
+
+
+def test_sequential_equals_batched_small(oracle, synth):
+    p = synth.scene_params()
+    for N, seed in ((2, 1), (8, 2)):
+        sc = synth.make_scene(N, 12, seed=seed, p=p)
+        out = []
+        for mode in (0, 1):
+            o = oracle.Oracle(N, p)
+            o.set_state(sc["X0"], sc["S0"])
+            out.append(o.run_frames(sc["odo"], sc["z"], sc["matched"], mode))
+        assert np.abs(out[0][:, :4] - out[1][:, :4]).max() < 1e-11
+        assert np.abs(out[0][:, 4:] - out[1][:, 4:]).max() < 1e-15
+
+
+def test_default_gain_structure_diverges_with_large_process_noise(oracle, synth):
+    """Documents WHY the synthetic scene uses the reference's alternative a1..a4 (SLAM.cpp:191-194):
+    with a = 8 and >= 8 landmarks matched per frame the reference update over-subtracts and the
+    theta clamp / negative pivots appear (DESIGN.md 'Synthetic scene')."""
+    p = synth.default_params()          # a1..a4 = 8
+    sc = synth.make_scene(8, 8, seed=1, p=p)
+    sc["odo"] = synth.circle_odometry(8) if hasattr(synth, "circle_odometry") else sc["odo"]
+    o = oracle.Oracle(8, p)
+    o.set_state(sc["X0"], sc["S0"])
+    o.run_frames(sc["odo"], sc["z"], sc["matched"], 1)
+    assert o.clamp_stats()["theta"] > 0
