@@ -101,6 +101,7 @@ ORC_API void orc_qr_r(const double *A_in, int m, int k, double *R /* k*k */)
 {
     double *A = (double *)malloc(sizeof(double) * (size_t)m * k);
     memcpy(A, A_in, sizeof(double) * (size_t)m * k);
+    double *wrow = (double *)malloc(sizeof(double) * (size_t)k);
     int steps = m < k ? m : k;
     for (int i = 0; i < steps; i++) {
         int len = m - i;
@@ -128,18 +129,28 @@ ORC_API void orc_qr_r(const double *A_in, int m, int k, double *R /* k*k */)
             }
         }
         if (tau != 0.0 && i + 1 < k) {
-            for (int j = i + 1; j < k; j++) {
-                double wj = A[(size_t)i * k + j];
-                for (int r = i + 1; r < m; r++) wj += A[(size_t)r * k + j] * A[(size_t)r * k + i];
-                A[(size_t)i * k + j] -= tau * wj;
-                for (int r = i + 1; r < m; r++) A[(size_t)r * k + j] -= tau * A[(size_t)r * k + i] * wj;
+            /* householder_hm: per column j, wj = A0j + sum_r Arj*vr (r increasing), then
+             * Aij -= tau*vi*wj.  Loops are ordered row-major (r outer) for speed; every wj still
+             * accumulates its terms in the same r order as GSL's column loop, so results are
+             * bit-identical. */
+            for (int j = i + 1; j < k; j++) wrow[j] = A[(size_t)i * k + j];
+            for (int r = i + 1; r < m; r++) {
+                const double vr = A[(size_t)r * k + i];
+                const double *Ar = A + (size_t)r * k;
+                for (int j = i + 1; j < k; j++) wrow[j] += Ar[j] * vr;
+            }
+            for (int j = i + 1; j < k; j++) A[(size_t)i * k + j] -= tau * wrow[j];
+            for (int r = i + 1; r < m; r++) {
+                const double vr = A[(size_t)r * k + i];
+                double *Ar = A + (size_t)r * k;
+                for (int j = i + 1; j < k; j++) Ar[j] -= tau * vr * wrow[j];
             }
         }
     }
     memset(R, 0, sizeof(double) * (size_t)k * k);                 /* 2341 */
     for (int i = 0; i < k && i < m; i++)                          /* 2343-2349 */
         for (int j = i; j < k; j++) R[(size_t)i * k + j] = A[(size_t)i * k + j];
-    free(A);
+    free(A); free(wrow);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -486,12 +497,17 @@ ORC_API int orc_predict_measurement(orc_state *st, double *h_out, double *Si_out
  * changes no bit of any product (only possibly the sign of a zero).                          */
 static void sts(const double *S, int n, double *P)
 {
-    for (int r = 0; r < n; r++)
-        for (int c = r; c < n; c++) {
-            double acc = 0.0;
-            for (int k = 0; k <= r; k++) acc += S[(size_t)k * n + r] * S[(size_t)k * n + c];
-            P[(size_t)r * n + c] = acc; P[(size_t)c * n + r] = acc;
+    /* row-major rank-1 accumulation; each P[r][c] still sums its terms in increasing k */
+    for (int r = 0; r < n; r++) memset(P + (size_t)r * n + r, 0, sizeof(double) * (size_t)(n - r));
+    for (int k = 0; k < n; k++) {
+        const double *Sk = S + (size_t)k * n;
+        for (int r = k; r < n; r++) {
+            const double a = Sk[r];
+            double *Pr = P + (size_t)r * n;
+            for (int c = r; c < n; c++) Pr[c] += a * Sk[c];
         }
+    }
+    for (int r = 0; r < n; r++) for (int c = r + 1; c < n; c++) P[(size_t)c * n + r] = P[(size_t)r * n + c];
 }
 ORC_API void orc_sts(const double *S, int n, double *P) { sts(S, n, P); }
 
