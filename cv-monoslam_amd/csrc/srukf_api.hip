@@ -12,17 +12,18 @@
 extern "C" {
 void srukf_launch_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, FrameScalars*, const double*, const double*);
 void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const double*, const double*, const double*, double*, double*);
-void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, int*, double*);
+void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
+int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, const FrameScalars*, double*);
-void srukf_launch_state_update(hipStream_t, KDims, const double*, const double*, double*);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*);
 void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*);
-void srukf_launch_gmw_panel(hipStream_t, int, int, int, double, const double*, double*, double*, double*, double*);
-void srukf_launch_gmw_trail(hipStream_t, int, int, const double*, const double*, double*);
+void srukf_launch_gmw_first(hipStream_t, int, int, double, const double*, void*, double*, double*);
+void srukf_launch_gmw_step(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
+int srukf_gmw_panel_bytes(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
@@ -46,7 +47,7 @@ static thread_local std::string g_create_error;
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_XUPD, KC_SYRK, KC_GMW_PANEL, KC_GMW_TRAIL, KC_GMW_CHECK,
               KC_GMW_COL, KC_MISC, KC_COUNT };
 static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_state_update", "k_syrk",
-                                             "k_gmw_panel", "k_gmw_trail", "k_gmw_check", "k_gmw_col", "misc" };
+                                             "k_gmw_first", "k_gmw_step", "k_gmw_check", "k_gmw_col", "misc" };
 
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
@@ -61,9 +62,10 @@ struct srukf_ctx {
     double *X = nullptr, *S = nullptr, *G = nullptr, *Gbak = nullptr, *Wf = nullptr;
     double *sigR = nullptr, *Cmat = nullptr, *Z = nullptr, *DZ = nullptr, *Ut = nullptr;
     double *h = nullptr, *Si = nullptr, *PxyR = nullptr, *y = nullptr, *D = nullptr, *Wp = nullptr, *Lp = nullptr;
-    double *zcur = nullptr, *odocur = nullptr, *small = nullptr;
+    double *zcur = nullptr, *odocur = nullptr, *small = nullptr, *mpart = nullptr;
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
+    void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered)
     FrameScalars* fs = nullptr;
     // staged sequence
     int seqF = 0;
@@ -149,7 +151,7 @@ static void seq_predict_measurement(srukf_ctx* c)
     }
     {
         ProfScope ps(c, KC_STATS, 30.0 * d.L * d.N, 8.0 * 3.0 * d.L * 2 * d.N);
-        srukf_launch_meas_stats(c->stream, d, c->w, c->X, c->sigR, c->Z, c->h, c->Si, c->vis, c->PxyR);
+        srukf_launch_meas_stats(c->stream, d, c->w, c->X, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR);
     }
 }
 // one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path
@@ -168,17 +170,16 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
     if (!slow) {
-        for (int j0 = 0; j0 < np; j0 += SRUKF_NB) {
-            const double rem = np - j0;
-            {
-                ProfScope ps(c, KC_GMW_PANEL, 32.0 * 32.0 * rem, 8.0 * 4.0 * 32.0 * rem);
-                srukf_launch_gmw_panel(c->stream, n, np, j0, c->p.epsilon, c->G, c->Wp, c->Lp, c->D, c->S);
-            }
-            if (j0 + SRUKF_NB < np) {
-                const double r2 = rem - 32;
-                ProfScope ps(c, KC_GMW_TRAIL, 32.0 * r2 * r2, 8.0 * (r2 * r2 + 2.0 * 32.0 * r2));
-                srukf_launch_gmw_trail(c->stream, np, j0, c->Lp, c->Wp, c->G);
-            }
+        {
+            ProfScope ps(c, KC_GMW_PANEL, 32.0 * 32.0 * 32.0 / 3.0, 8.0 * 32.0 * 32.0);
+            srukf_launch_gmw_first(c->stream, n, np, c->p.epsilon, c->G, c->pan[0], c->D, c->S);
+        }
+        int pb = 0;
+        for (int j0 = 0; j0 + SRUKF_NB < np; j0 += SRUKF_NB, pb ^= 1) {
+            const double r2 = np - j0 - 32;
+            // per launch: trailing update 32*r2^2 (upper half, 2 flop) + slab recompute + next diagonal block
+            ProfScope ps(c, KC_GMW_TRAIL, 32.0 * r2 * r2 + 2.0 * 32.0 * 32.0 * r2 + 32.0 * 32.0 * 32.0 / 3.0, 8.0 * (r2 * r2 + 2.0 * 32.0 * r2));
+            srukf_launch_gmw_step(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb], c->pan[pb ^ 1], c->D, c->S);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
         srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs);
@@ -197,12 +198,8 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev)
         srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut);
     }
     {
-        ProfScope ps(c, KC_GAIN, 6.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
-        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->y);
-    }
-    {
-        ProfScope ps(c, KC_XUPD, 2.0 * d.n * 2 * d.N, 8.0 * d.n * 2 * d.N);
-        srukf_launch_state_update(c->stream, d, c->Ut, c->y, c->X);
+        ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
+        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->X);
     }
 }
 
@@ -265,10 +262,11 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     host_weights(d.Na, c->p, c->w);
     const size_t np = d.np, mp = d.mp;
     ALLOC(c->X, np); ALLOC(c->S, np * np); ALLOC(c->G, np * np); ALLOC(c->Gbak, np * np); ALLOC(c->Wf, np * np);
-    ALLOC(c->sigR, (size_t)d.L * 8); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
+    ALLOC(c->sigR, (size_t)d.L * 8 + 8); ALLOC(c->mpart, srukf_meas_part_doubles(d.mp)); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
     ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)N); ALLOC(c->PxyR, 4 * mp); ALLOC(c->y, mp);
     ALLOC(c->D, np); ALLOC(c->Wp, 32 * np); ALLOC(c->Lp, 32 * np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
     ALLOC(c->vis, N); ALLOC(c->mcur, N); ALLOC(c->theta, np); ALLOC(c->fs, 1);
+    { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
     c->hstage_bytes = sizeof(double) * (np * np + 4096);
     if (hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars)) != hipSuccess) {
         g_create_error = "hipHostMalloc failed"; srukf_destroy(c); return SRUKF_ERR_NOMEM;
@@ -286,7 +284,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_collect(c);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
-                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq };
+                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart };
     for (void* b : bufs) if (b) hipFree(b);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->hfs) hipHostFree(c->hfs);
@@ -656,10 +654,14 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
     srukf_launch_gmw_stats(st, n, np, dG, dFs);
     FrameScalars fs;
     if (!force_slow) {
-        for (int j0 = 0; j0 < np; j0 += SRUKF_NB) {
-            srukf_launch_gmw_panel(st, n, np, j0, epsilon, dG, dWp, dLp, dD, dS);
-            if (j0 + SRUKF_NB < np) srukf_launch_gmw_trail(st, np, j0, dLp, dWp, dG);
-        }
+        void* pan[2];
+        hipMalloc(&pan[0], srukf_gmw_panel_bytes()); hipMalloc(&pan[1], srukf_gmw_panel_bytes());
+        srukf_launch_gmw_first(st, n, np, epsilon, dG, pan[0], dD, dS);
+        int pb = 0;
+        for (int j0 = 0; j0 + SRUKF_NB < np; j0 += SRUKF_NB, pb ^= 1)
+            srukf_launch_gmw_step(st, n, np, j0, epsilon, dG, pan[pb], pan[pb ^ 1], dD, dS);
+        hipDeviceSynchronize();
+        hipFree(pan[0]); hipFree(pan[1]);
         srukf_launch_gmw_check(st, n, np, dD, dS, dFs);
         hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
         if (clamp_hit) *clamp_hit = fs.clamp_rows;

@@ -9,6 +9,13 @@
 //   D: reg t of lane l is D[row = (l>>4) + 4t][col = l&15]
 #include "srukf_device.h"
 
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // one wave: 32x32 output tile at (m0, n0), K range [kb, ke) (multiple of 4 long), accumulate
 template <bool NEG>
 __device__ __forceinline__ void tile32_tn(d4 (&acc)[2][2], const double* __restrict__ A, int lda,
@@ -125,7 +132,8 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// GMW modified Cholesky (modifiedCholeskyDecomposition, SLAM.cpp:2197-2327), blocked.
+// GMW modified Cholesky (modifiedCholeskyDecomposition, SLAM.cpp:2197-2327), blocked,
+// right-looking, one launch per 32-row panel.
 // Storage: W[j][i] = C[i][j] (the reference's column j below the diagonal is our row j right of
 // the diagonal), so the final S[j][i] = sqrt(D_j) * L[i][j] = sqrt(D_j) * (W[j][i] / D_j) is a
 // row scaling of W.  Fast path pivots with D_j = max(EPSILON, |C_jj|); the third candidate
@@ -134,112 +142,158 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
 // if it does, the caller reruns the frame on the column-by-column path (k_gmw_col_*).
 // ------------------------------------------------------------------------------------------------
 
-// k_gmw_panel: rows [j0, j0+32).  Wave 0 of every block factors the 32x32 diagonal block
-// (redundantly — cheaper than a cross-workgroup hand-off), then each thread solves the 32-step
-// forward substitution for one column i >= j0+32.
-// Out: Wp[32][ld] final W rows, Lp[32][ld] = W/D, D[j], S rows j (final sqrt covariance).
-__global__ __launch_bounds__(256) void k_gmw_panel(int n, int ld, int j0, double eps, const double* __restrict__ G,
-                                                   double* __restrict__ Wp, double* __restrict__ Lp, double* __restrict__ D,
-                                                   double* __restrict__ Sout)
+// Panel buffer handed from one step to the next (double-buffered in HBM).
+//   Tt[kk][jj] = T[jj][kk],  T = (I + M^T)^{-1},  M[kk][jj] = L[kk][jj] = W[kk][jj]/D_kk (kk < jj):
+//   the forward substitution  w[jj] = g[jj] - sum_{kk<jj} L[kk][jj] w[kk]  of a panel column is
+//   w = T g, so the whole panel "TRSM" becomes one 32x32 by 32xcols MFMA product.
+struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; };
+
+// Factor the 32x32 diagonal block held in LDS (Wt[row jj][col ii], upper part valid) with one wave.
+// Lanes 0..31: lane ii keeps column ii in registers; pivots/multipliers cross lanes by
+// v_readlane (constant lane after unrolling).  Lanes 32..63 run the SAME multiplier stream on the
+// identity columns, which yields T at no extra instruction.  Writes the next panel buffer, the
+// pivots D and the diagonal-block part of S rows j0..j0+31.
+__device__ __forceinline__ void gmw_factor_block(const double (*Wt)[33], double eps, int lane, int n, int ld, int j0,
+                                                 GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout)
 {
-    __shared__ double Wd[32][33];
-    __shared__ double Ld[32][33];
-    __shared__ double Dd[32];
-    __shared__ double SqD[32];
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        // wave 0, wave-synchronous: the 32x32 block lives in LDS (Wd); lane pair (ii, half) owns
-        // column ii and updates rows rr = jj+1+half, jj+3+half, ... of it at step jj.
-        const int ii = tid & 31, half = tid >> 5;
-        for (int jj = half; jj < 32; jj += 2) Wd[jj][ii] = (jj <= ii) ? G[(size_t)(j0 + jj) * ld + j0 + ii] : 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        for (int jj = 0; jj < 32; jj++) {
-            const double piv = Wd[jj][jj];
-            const double dj = fmax(eps, fabs(piv));
-            const double wv = Wd[jj][ii];
-            const double l = wv / dj;
-            if (half == 0) { Ld[jj][ii] = (ii >= jj) ? l : 0.0; if (ii == jj) { Dd[jj] = dj; SqD[jj] = sqrt(dj); } }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            for (int rr = jj + 1 + half; rr <= ii; rr += 2) Wd[rr][ii] -= Ld[jj][rr] * wv;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
+    const int ii = lane & 31;
+    const bool tl = lane >= 32;
+    double col[32], lrow[32];
+#pragma unroll
+    for (int jj = 0; jj < 32; jj++) col[jj] = tl ? ((jj == ii) ? 1.0 : 0.0) : ((jj <= ii) ? Wt[jj][ii] : 0.0);
+    // the 32-pivot chain: nothing but pivot broadcast, one division and the rank-1 update
+#pragma unroll
+    for (int jj = 0; jj < 32; jj++) {
+        const double wv = (tl || ii >= jj) ? col[jj] : 0.0;
+        const double piv = readlane_d(wv, jj);
+        const double dj = fmax(eps, fabs(piv));               // fast path: theta clamp checked afterwards (k_gmw_check)
+        const double l = wv / dj;
+        lrow[jj] = l;
+#pragma unroll
+        for (int rr = jj + 1; rr < 32; rr++) col[rr] -= readlane_d(l, rr) * wv;
     }
-    __syncthreads();
-
-    // diagonal block outputs (block 0 only)
-    if (blockIdx.x == 0) {
-        for (int e = tid; e < 32 * 32; e += 256) {
-            const int jj = e >> 5, ii = e & 31;
-            const int j = j0 + jj, i = j0 + ii;
-            const double wv = Wd[jj][ii];
-            Wp[(size_t)jj * ld + i] = wv;
-            Lp[(size_t)jj * ld + i] = Ld[jj][ii];
-            if (j < n && i < n) {
-                const double dj = Dd[jj];
-                Sout[(size_t)j * ld + i] = (ii > jj) ? SqD[jj] * Ld[jj][ii] : ((ii == jj) ? SqD[jj] : 0.0);
-            }
-        }
-        if (tid < 32) D[j0 + tid] = Dd[tid];
-    }
-
-    // forward substitution for column i
-    const int i = j0 + 32 + blockIdx.x * 256 + tid;
-    const bool act = i < ld;
-    {
-        double wcol[32];
+    // outputs, off the chain.  Lane jj still holds pivot jj in col[jj] (later steps only touch rows > jj).
 #pragma unroll
-        for (int jj = 0; jj < 32; jj++) wcol[jj] = act ? G[(size_t)(j0 + jj) * ld + i] : 0.0;
-        // right-looking: once wcol[kk] is final, fold it into every later row (row kk of Ld is contiguous)
-#pragma unroll
-        for (int kk = 0; kk < 31; kk++) {
-            const double wk = wcol[kk];
-#pragma unroll
-            for (int jj = kk + 1; jj < 32; jj++) wcol[jj] -= Ld[kk][jj] * wk;
-        }
-        if (act) {
-#pragma unroll
-            for (int jj = 0; jj < 32; jj++) {
-                const double dj = Dd[jj];
-                const double l = wcol[jj] / dj;
-                Wp[(size_t)jj * ld + i] = wcol[jj];
-                Lp[(size_t)jj * ld + i] = l;
-                Sout[(size_t)(j0 + jj) * ld + i] = SqD[jj] * l;   // padded rows/cols: W = 0 there, so this writes zeros
-            }
+    for (int jj = 0; jj < 32; jj++) {
+        const double dj = fmax(eps, fabs(readlane_d(col[jj], jj)));
+        const double sq = sqrt(dj);
+        if (!tl) {
+            if (ii == jj) { out->D[jj] = dj; out->sq[jj] = sq; Dall[j0 + jj] = dj; }
+            if (j0 + jj < n && j0 + ii < n && ii >= jj) Sout[(size_t)(j0 + jj) * ld + j0 + ii] = (ii == jj) ? sq : sq * lrow[jj];
+        } else {
+            out->Tt[ii * 32 + jj] = col[jj];                                  // Tt[kk = ii][jj] = T[jj][ii]
         }
     }
 }
 
-// k_gmw_trail: G[r][c] -= sum_{jj<32} Lp[jj][r] * Wp[jj][c]   for r, c >= j0+32, c >= r (upper).
-// grid = (T, T) blocks of 64x64 over the trailing square, block = 256.
-__global__ __launch_bounds__(256) void k_gmw_trail(int ld, int j0, const double* __restrict__ Lp, const double* __restrict__ Wp,
-                                                   double* __restrict__ G)
+// k_gmw_first: factor the first diagonal block (j0 = 0).  One wave.
+__global__ __launch_bounds__(64) void k_gmw_first(int n, int ld, double eps, const double* __restrict__ G, GmwPanel* __restrict__ out,
+                                                  double* __restrict__ Dall, double* __restrict__ Sout)
+{
+    __shared__ double Wt[32][33];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 1024; e += 64) Wt[e >> 5][e & 31] = G[(size_t)(e >> 5) * ld + (e & 31)];
+    __syncthreads();
+    gmw_factor_block(Wt, eps, lane, n, ld, 0, out, Dall, Sout);
+}
+
+// k_gmw_step: one launch per panel J = [j0, j0+32).  Every 64x64 block of the trailing square
+// (base = j0+32):
+//   1. recomputes the panel rows it needs, W[J][slab] = T * G[J][slab]  (MFMA, K = 32), for its
+//      row slab and its column slab, and keeps L = W/D (row slab) and W (column slab) in LDS;
+//   2. updates its tile  G[r][c] -= sum_kk L[kk][r] W[kk][c]  (MFMA from LDS);
+//   3. first block row only: writes the final S rows j0..j0+31 for its column slab;
+//   4. block (0,0), wave 0: its freshly updated tile IS the next diagonal block — factor it and
+//      publish the next panel buffer (visible to the next launch).
+// grid = (T, T), T = ceil((ld - base)/64); blocks strictly below the diagonal exit.
+__global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double eps, double* __restrict__ G,
+                                                  const GmwPanel* __restrict__ cur, GmwPanel* __restrict__ nxt,
+                                                  double* __restrict__ Dall, double* __restrict__ Sout)
 {
     if (blockIdx.x < blockIdx.y) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int base = j0 + 32;
-    const int m0 = base + blockIdx.y * 64 + (wv >> 1) * 32;
-    const int n0 = base + blockIdx.x * 64 + (wv & 1) * 32;
-    if (m0 >= ld || n0 >= ld || n0 + 32 <= m0) return;
+    __shared__ double Lr[32][80];      // stride 80 doubles: lanes l / l+16 land on opposite bank halves
+    __shared__ double Wc[32][80];
+    __shared__ double Wt[32][33];
+    __shared__ double Dd[32], Sq[32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
+    const int base = j0 + 32;
+    const int R0 = base + 64 * blockIdx.y, C0 = base + 64 * blockIdx.x;
+    const bool diagblk = blockIdx.x == blockIdx.y;
+    if (tid < 32) { Dd[tid] = cur->D[tid]; Sq[tid] = cur->sq[tid]; }
+    __syncthreads();
+
+    // 1. panel slabs by MFMA: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
+    {
+        const int which = wv >> 1, half = wv & 1;
+        const int n0 = (which ? C0 : R0) + 32 * half;
+        if (n0 < ld && !(diagblk && which == 1)) {
+            d4 acc[2][2];
+            zero_acc(acc);
+            tile32_tn<false>(acc, cur->Tt, 32, G + (size_t)j0 * ld, ld, 0, n0, 0, 32, lane);
+            const bool write_s = (blockIdx.y == 0) && (which == 1 || diagblk);
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
+                        const double w = acc[a][b][t];
+                        const double l = w / Dd[jj];
+                        if (which == 0) { Lr[jj][cc] = l; if (diagblk) Wc[jj][cc] = w; }
+                        else Wc[jj][cc] = w;
+                        if (write_s && j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = Sq[jj] * l;
+                    }
+        }
+    }
+    __syncthreads();
+
+    // 2. tile update from LDS fragments
+    const int m0 = R0 + 32 * (wv >> 1), c0 = C0 + 32 * (wv & 1);
+    const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
     d4 acc[2][2];
+    zero_acc(acc);
+    if (live) {
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+        for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+            for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr];
-    tile32_tn<true>(acc, Lp, ld, Wp, ld, m0, n0, 0, 32, lane);
+                for (int t = 0; t < 4; t++)
+                    acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+        const int ro = m0 - R0, co = c0 - C0;
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+        for (int k = 0; k < 32; k += 4) {
+            const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
+            const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr] = acc[a][b][t];
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
+    }
+
+    // 4. next diagonal block: tile (base, base) of block (0,0), wave 0
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (wv == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) Wt[16 * a + lk + 4 * t][16 * b + lr] = acc[a][b][t];
+        }
+        __syncthreads();
+        if (wv == 0) gmw_factor_block(Wt, eps, lane, n, ld, base, nxt, Dall, Sout);
+    }
 }
 
 // k_gmw_check: was the reference's third pivot candidate theta_j^2/beta^2 ever the largest?
@@ -329,20 +383,19 @@ void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* U
 {
     hipLaunchKernelGGL(k_syrk, dim3(d.np / 64, d.np / 64), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs);
 }
-void srukf_launch_gmw_panel(hipStream_t st, int n, int ld, int j0, double eps, const double* G, double* Wp, double* Lp, double* D,
-                            double* Sout)
+// whole fast-path factorisation: first diagonal block, then one launch per panel
+void srukf_launch_gmw_first(hipStream_t st, int n, int ld, double eps, const double* G, void* pan0, double* D, double* Sout)
 {
-    const int cols = ld - j0 - 32;
-    const int blocks = cols > 0 ? (cols + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_gmw_panel, dim3(blocks), dim3(256), 0, st, n, ld, j0, eps, G, Wp, Lp, D, Sout);
+    hipLaunchKernelGGL(k_gmw_first, dim3(1), dim3(64), 0, st, n, ld, eps, G, (GmwPanel*)pan0, D, Sout);
 }
-void srukf_launch_gmw_trail(hipStream_t st, int ld, int j0, const double* Lp, const double* Wp, double* G)
+void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)
 {
     const int rem = ld - j0 - 32;
     if (rem <= 0) return;
     const int T = (rem + 63) / 64;
-    hipLaunchKernelGGL(k_gmw_trail, dim3(T, T), dim3(256), 0, st, ld, j0, Lp, Wp, G);
+    hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, eps, G, (const GmwPanel*)cur, (GmwPanel*)nxt, D, Sout);
 }
+int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel); }
 void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs)
 {
     hipLaunchKernelGGL(k_gmw_check, dim3(n), dim3(256), 0, st, n, ld, D, S, fs);

@@ -87,6 +87,18 @@ __global__ __launch_bounds__(1024) void k_motion(KDims d, KWeights w, srukf_para
     if (tid < 4) X[n - 4 + tid] = acc[tid];                                      // 1531
     __threadfence_block();
     __syncthreads();
+    // rs[e] = sum_c wc_c (sigma_c[e] - X[e]) with the covariance weights (wc0 for the centre): the
+    // constant that k_meas_final needs to re-centre the robot rows of Pxy on the mean h
+    {
+        double rs[4] = { 0, 0, 0, 0 };
+        for (int c = tid; c < L; c += nt) {
+            const double wt = (c == 0) ? w.wc0 : w.wi;
+#pragma unroll
+            for (int e = 0; e < 4; e++) rs[e] += wt * (sigR[(size_t)c * 8 + e] - acc[e]);
+        }
+        block_sum<4>(rs, red);
+        if (tid < 4) sigR[(size_t)L * 8 + tid] = rs[tid];
+    }
 
     // ---- structured QR: R12 rows and the residual matrix C ((n-4)+18 rows x 4) ----
     const double k2 = w.wi_sr * 0.70710678118654752440;
@@ -211,168 +223,168 @@ __global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_para
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_meas_stats: per landmark k (one thread-row of 8 slices): predicted pixel
-//   h = wm0*Z_0 + wi*sum Z_c                       (SLAM.cpp:1678-1681),
-//   Si = R factor of wi_sr*(Z_{c+1}-Z_0) (2Na x 2)  (calculateOneFeatureCovariance 1759-1775,
-//        GSL Householder sign rule; residual norm by an explicit second pass),
-//   visible = (h.x != 0 && h.y != 0)               (1727),
-//   and the 4 robot rows of the cross covariance
-//   PxyR[e][col] = wc0*(sigR_0[e]-Xr[e])(Z_0[col]-h[col]) + wi*sum_c (sigR_c[e]-Xr[e])(Z_c[col]-h[col])
-//                                                  (calculateOneFeatureCrossCovariance 2028-2037).
-// Block = (32 landmarks) x (8 row slices).
+// Measurement statistics (QrAndCholeskyForMeasurement / calculateOneFeatureCovariance,
+// SLAM.cpp:1700-1775, and the robot rows of calculateOneFeatureCrossCovariance, 2028-2037).
+// One pass over Z.  All sums use deviations from the centre column Z_0, so nothing depends on the
+// mean h inside the pass:
+//   s[0..1]  = sum_{c>=1} (Z_c - Z_0)                                  -> h = Z_0 + wi * s   (sum of weights = 1)
+//   s[2..4]  = sum_{c>=1} a_c^2, a_c b_c, b_c^2   (a, b = wi_sr * (Z_c - Z_0))
+//   s[5..12] = sum_c w_c (sigR_c[e] - Xr[e]) (Z_c[col] - Z_0[col])     e = 0..3, col = x, y
+// k_meas_partial: block (32 landmarks x 8 row sub-slices), grid.y = MEAS_SLICES row slices; writes
+// per-slice partial sums (fixed order => run-to-run deterministic).  k_meas_final reduces the slices
+// and finishes h, Si (GSL Householder sign rule), visible, PxyR.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_meas_stats(KDims d, KWeights w,
-                                                    const double* __restrict__ X, const double* __restrict__ sigR,
-                                                    const double* __restrict__ Z,
-                                                    double* __restrict__ h, double* __restrict__ Si,
-                                                    int* __restrict__ vis, double* __restrict__ PxyR)
+#define MEAS_SLICES 16
+#define MEAS_NS 13
+__global__ __launch_bounds__(256) void k_meas_partial(KDims d, KWeights w, const double* __restrict__ X,
+                                                      const double* __restrict__ sigR, const double* __restrict__ Z,
+                                                      double* __restrict__ part /* [MEAS_SLICES][MEAS_NS][mp/2] */)
 {
-    __shared__ double sm[8][32][12];
+    __shared__ double sm[8][32][MEAS_NS];
     const int lx = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + lx;
-    const bool live = k < d.N;
+    const int kk = (k < d.N) ? k : 0;
     const int L = d.L, mp = d.mp, n = d.n;
-    const int kk = live ? k : 0;
+    const int rows = (L + MEAS_SLICES - 1) / MEAS_SLICES;
+    const int c_beg = blockIdx.y * rows, c_end = min(L, c_beg + rows);
     const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * kk);
-
-    // pass 1: weighted mean
-    double s0 = 0, s1 = 0;
-    for (int c = 1 + sl; c < L; c += 8) {
-        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
-        s0 += z.x; s1 += z.y;
-    }
-    sm[sl][lx][0] = s0; sm[sl][lx][1] = s1;
-    __syncthreads();
-    double t0 = 0, t1 = 0;
-    for (int q = 0; q < 8; q++) { t0 += sm[q][lx][0]; t1 += sm[q][lx][1]; }
-    const double hx = w.wm0 * z0.x + w.wi * t0;
-    const double hy = w.wm0 * z0.y + w.wi * t1;
-    __syncthreads();
-
-    // pass 2: sum a^2, sum ab, sum b^2 (a, b = wi_sr * deviations from Z_0) and robot cross terms
     double xr[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) xr[e] = X[n - 4 + e];
-    double saa = 0, sab = 0, sbb = 0, px[4] = { 0, 0, 0, 0 }, py[4] = { 0, 0, 0, 0 };
-    for (int c = sl; c < L; c += 8) {
+    double s[MEAS_NS];
+#pragma unroll
+    for (int q = 0; q < MEAS_NS; q++) s[q] = 0.0;
+    for (int c = c_beg + sl; c < c_end; c += 8) {
         const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
         const double* r = sigR + (size_t)c * 8;
+        const double dx = z.x - z0.x, dy = z.y - z0.y;
         const double wt = (c == 0) ? w.wc0 : w.wi;
-        const double dzx = z.x - hx, dzy = z.y - hy;
+        s[0] += dx; s[1] += dy;
+        const double a = w.wi_sr * dx, b = w.wi_sr * dy;
+        s[2] += a * a; s[3] += a * b; s[4] += b * b;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); px[e] += dr * dzx; py[e] += dr * dzy; }
-        if (c > 0) {
-            const double a = w.wi_sr * (z.x - z0.x), b = w.wi_sr * (z.y - z0.y);
-            saa += a * a; sab += a * b; sbb += b * b;
-        }
+        for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); s[5 + e] += dr * dx; s[9 + e] += dr * dy; }
     }
-    sm[sl][lx][0] = saa; sm[sl][lx][1] = sab; sm[sl][lx][2] = sbb;
 #pragma unroll
-    for (int e = 0; e < 4; e++) { sm[sl][lx][3 + e] = px[e]; sm[sl][lx][7 + e] = py[e]; }
+    for (int q = 0; q < MEAS_NS; q++) sm[sl][lx][q] = s[q];
     __syncthreads();
-    double tot[11];
+    const int half = mp / 2;
+    for (int e = threadIdx.x; e < 32 * MEAS_NS; e += 256) {
+        const int q = e / 32, l2 = e % 32;
+        double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 11; q++) { double s = 0; for (int u = 0; u < 8; u++) s += sm[u][lx][q]; tot[q] = s; }
-    __syncthreads();
-
-    // Householder on column a (GSL: beta = -sign(alpha)*hypot(alpha, xnorm); tau = 0 if xnorm == 0)
-    const double2 z1 = *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * kk);
-    const double a0 = w.wi_sr * (z1.x - z0.x), b0 = w.wi_sr * (z1.y - z0.y);
-    const double xn2 = fmax(tot[0] - a0 * a0, 0.0);
-    double R00 = a0, R01 = b0, tau = 0.0, wv = 0.0, inv_s = 0.0;
-    if (xn2 > 0.0) {
-        const double beta = -(a0 >= 0.0 ? 1.0 : -1.0) * sqrt(tot[0]);
-        tau = (beta - a0) / beta;
-        inv_s = 1.0 / (a0 - beta);
-        wv = b0 + (tot[1] - a0 * b0) * inv_s;           // w = B_0 + sum_{r>=1} B_r v_r
-        R00 = beta;
-        R01 = b0 - tau * wv;
-    }
-    // pass 3: b'_r = B_r - tau * v_r * w (r >= 1); R11 = -sign(b'_1) * |b'[1:]|
-    double sr2 = 0.0;
-    for (int c = 2 + sl; c < L; c += 8) {
-        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
-        const double a = w.wi_sr * (z.x - z0.x), b = w.wi_sr * (z.y - z0.y);
-        const double bp = b - tau * (a * inv_s) * wv;
-        if (c > 2) sr2 += bp * bp;
-    }
-    sm[sl][lx][0] = sr2;
-    __syncthreads();
-    double rest2 = 0; for (int u = 0; u < 8; u++) rest2 += sm[u][lx][0];
-    const double2 z2 = *reinterpret_cast<const double2*>(Z + (size_t)2 * mp + 2 * kk);
-    const double a1 = w.wi_sr * (z2.x - z0.x), b1 = w.wi_sr * (z2.y - z0.y);
-    const double bp1 = b1 - tau * (a1 * inv_s) * wv;
-    double R11 = bp1;
-    if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(bp1 * bp1 + rest2);
-
-    if (live && sl == 0) {
-        const bool v = (hx != 0.0) && (hy != 0.0);
-        h[2 * k] = hx; h[2 * k + 1] = hy;
-        vis[k] = v ? 1 : 0;
-        Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) { PxyR[(size_t)e * mp + 2 * k] = tot[3 + e]; PxyR[(size_t)e * mp + 2 * k + 1] = tot[7 + e]; }
+        for (int u = 0; u < 8; u++) t += sm[u][l2][q];
+        const int k2 = blockIdx.x * 32 + l2;
+        if (k2 < d.N) part[((size_t)blockIdx.y * MEAS_NS + q) * half + k2] = t;
     }
 }
 
+__global__ __launch_bounds__(256) void k_meas_final(KDims d, KWeights w, const double* __restrict__ X, const double* __restrict__ sigR,
+                                                    const double* __restrict__ Z, const double* __restrict__ part,
+                                                    double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
+                                                    double* __restrict__ PxyR)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.N) return;
+    const int mp = d.mp, half = mp / 2, n = d.n;
+    double t[MEAS_NS];
+#pragma unroll
+    for (int q = 0; q < MEAS_NS; q++) {
+        double acc = 0.0;
+        for (int u = 0; u < MEAS_SLICES; u++) acc += part[((size_t)u * MEAS_NS + q) * half + k];
+        t[q] = acc;
+    }
+    const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * k);
+    // h = wm0*Z0 + wi*sum_{c>=1} Z_c = Z0*(wm0 + 2Na*wi) + wi*sum (Z_c - Z0)      (SLAM.cpp:1678-1681)
+    const double wsum = w.wm0 + 2.0 * d.Na * w.wi;
+    const double hx = wsum * z0.x + w.wi * t[0], hy = wsum * z0.y + w.wi * t[1];
+    // robot rows of Pxy: sum_c w_c (r_c - xr)(Z_c - h) = sum_c w_c (r_c - xr)(Z_c - Z0) - (h - Z0) * sum_c w_c (r_c - xr)
+    double rs[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) rs[e] = sigR[(size_t)d.L * 8 + e];      // sum_c w_c (r_c - xr), from k_motion
+    const bool v = (hx != 0.0) && (hy != 0.0);
+    h[2 * k] = hx; h[2 * k + 1] = hy;
+    vis[k] = v ? 1 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        PxyR[(size_t)e * mp + 2 * k]     = t[5 + e] - (hx - z0.x) * rs[e];
+        PxyR[(size_t)e * mp + 2 * k + 1] = t[9 + e] - (hy - z0.y) * rs[e];
+    }
+    // Householder R of the 2Na x 2 matrix [a b] (GSL: beta = -sign(alpha) hypot(alpha, xnorm); tau = 0 if xnorm == 0)
+    const double2 z1 = *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * k);
+    const double2 z2 = *reinterpret_cast<const double2*>(Z + (size_t)2 * mp + 2 * k);
+    const double a0 = w.wi_sr * (z1.x - z0.x), b0 = w.wi_sr * (z1.y - z0.y);
+    const double a1 = w.wi_sr * (z2.x - z0.x), b1 = w.wi_sr * (z2.y - z0.y);
+    const double saa = t[2], sab = t[3], sbb = t[4];
+    const double xn2 = fmax(saa - a0 * a0, 0.0);
+    double R00 = a0, R01 = b0, tau = 0.0, wv = 0.0, inv_s = 0.0;
+    if (xn2 > 0.0) {
+        const double beta = -(a0 >= 0.0 ? 1.0 : -1.0) * sqrt(saa);
+        tau = (beta - a0) / beta;
+        inv_s = 1.0 / (a0 - beta);
+        wv = b0 + (sab - a0 * b0) * inv_s;              // w = B_0 + sum_{r>=1} B_r v_r
+        R00 = beta;
+        R01 = b0 - tau * wv;
+    }
+    // second column: b' = H1 b; |b'[1:]|^2 = |b|^2 - R01^2 (H1 orthogonal); R11 = -sign(b'_1) |b'[1:]|,
+    // or b'_1 itself when the rest of the sub-column is zero
+    const double bp1 = b1 - tau * (a1 * inv_s) * wv;
+    const double nrm2 = fmax(sbb - R01 * R01, 0.0);
+    const double rest2 = nrm2 - bp1 * bp1;
+    double R11 = bp1;
+    if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(nrm2);
+    Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------
-// k_gain: per landmark k and state row r (KalmanUpdate, SLAM.cpp:2070-2080):
-//   sii = Si^{-1} (OpenCV closed-form 2x2 inverse), U = Ki*Si^T = Pxy*sii,
-//   y   = sii^T (z - h)  so that  X += Ki (z - h) = U y.
-// In : Ut rows 2k, 2k+1 hold wi*gamma * (S^T DZ) for r < n-4 (k_gemm), PxyR holds rows n-4..n-1.
-// Out: Ut rows become U^T (zero for unmatched / invisible landmarks); y[2k], y[2k+1].
+// k_gain: KalmanUpdate gains for all landmarks + state update (SLAM.cpp:2070-2080):
+//   sii = Si^{-1} (OpenCV closed-form 2x2 inverse), U = Ki*Si^T = Pxy*sii, y = sii^T (z - h),
+//   X += sum_k Ki (z - h) = sum_k U_k y_k.
+// In : Ut rows 2k, 2k+1 hold S^T DZ for r < n-4 (k_pxy; scaled here by wi*gamma), PxyR rows n-4..n-1.
+// Out: Ut rows become U^T (zero for unmatched / invisible landmarks); X updated.
+// Block = 64 state rows x 4 landmark slices; partial dX reduced through LDS in fixed order.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               double* __restrict__ Ut, const double* __restrict__ PxyR,
                                               const double* __restrict__ Si, const int* __restrict__ vis,
                                               const double* __restrict__ h, const double* __restrict__ z_seq,
                                               const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
-                                              const FrameScalars* __restrict__ fs, double* __restrict__ y)
+                                              const FrameScalars* __restrict__ fs, double* __restrict__ X)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    const int k = blockIdx.y;
-    if (r >= d.np) return;
-    const int n = d.n, ld = d.np, mp = d.mp;
-    const double* z = z_cur ? z_cur : (z_seq + (size_t)fs->frame * 2 * d.N);
-    const int* mt = m_cur ? m_cur : (m_seq + (size_t)fs->frame * d.N);
-    const bool on = (mt[k] != 0) && (vis[k] != 0);
-    const double s00 = Si[4 * k], s01 = Si[4 * k + 1], s10 = Si[4 * k + 2], s11 = Si[4 * k + 3];
-    double det = s00 * s11 - s01 * s10;
-    double i00 = 0, i01 = 0, i10 = 0, i11 = 0;
-    if (det != 0.0) { det = 1.0 / det; i00 = s11 * det; i01 = -s01 * det; i10 = -s10 * det; i11 = s00 * det; }
-    double u0 = 0.0, u1 = 0.0;
-    if (on && r < n) {
-        double p0, p1;
-        if (r < n - 4) {
-            const double sc = w.wi * w.gamma;
-            p0 = sc * Ut[(size_t)(2 * k) * ld + r];
-            p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
-        } else {
-            p0 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k];
-            p1 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k + 1];
+    __shared__ double red[4][64];
+    const int rl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + rl;
+    const int n = d.n, ld = d.np, mp = d.mp, N = d.N;
+    const double* z = z_cur ? z_cur : (z_seq + (size_t)fs->frame * 2 * N);
+    const int* mt = m_cur ? m_cur : (m_seq + (size_t)fs->frame * N);
+    const double sc = w.wi * w.gamma;
+    double dx = 0.0;
+    for (int k = sl; k < N; k += 4) {
+        const bool on = (mt[k] != 0) && (vis[k] != 0);
+        double u0 = 0.0, u1 = 0.0;
+        if (on && r < n) {
+            const double s00 = Si[4 * k], s01 = Si[4 * k + 1], s10 = Si[4 * k + 2], s11 = Si[4 * k + 3];
+            double det = s00 * s11 - s01 * s10;
+            double i00 = 0, i01 = 0, i10 = 0, i11 = 0;
+            if (det != 0.0) { det = 1.0 / det; i00 = s11 * det; i01 = -s01 * det; i10 = -s10 * det; i11 = s00 * det; }
+            double p0, p1;
+            if (r < n - 4) {
+                p0 = sc * Ut[(size_t)(2 * k) * ld + r];
+                p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
+            } else {
+                p0 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k];
+                p1 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k + 1];
+            }
+            u0 = p0 * i00 + p1 * i10;
+            u1 = p0 * i01 + p1 * i11;
+            const double v0 = z[2 * k] - h[2 * k], v1 = z[2 * k + 1] - h[2 * k + 1];
+            dx += u0 * (i00 * v0 + i10 * v1) + u1 * (i01 * v0 + i11 * v1);
         }
-        u0 = p0 * i00 + p1 * i10;
-        u1 = p0 * i01 + p1 * i11;
+        if (r < ld) { Ut[(size_t)(2 * k) * ld + r] = u0; Ut[(size_t)(2 * k + 1) * ld + r] = u1; }
     }
-    Ut[(size_t)(2 * k) * ld + r] = u0;
-    Ut[(size_t)(2 * k + 1) * ld + r] = u1;
-    if (r == 0) {
-        const double v0 = z[2 * k] - h[2 * k], v1 = z[2 * k + 1] - h[2 * k + 1];
-        y[2 * k]     = on ? (i00 * v0 + i10 * v1) : 0.0;
-        y[2 * k + 1] = on ? (i01 * v0 + i11 * v1) : 0.0;
-    }
-}
-
-// k_state_update: X[r] += sum_c Ut[c][r] * y[c]   (m_X_k += Ki*(zi - hi) summed over landmarks, 2079)
-__global__ __launch_bounds__(256) void k_state_update(KDims d, const double* __restrict__ Ut,
-                                                      const double* __restrict__ y, double* __restrict__ X)
-{
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= d.n) return;
-    double acc = 0.0;
-    const int M2 = 2 * d.N;
-    for (int c = 0; c < M2; c++) acc += Ut[(size_t)c * d.np + r] * y[c];
-    X[r] += acc;
+    red[sl][rl] = dx;
+    __syncthreads();
+    if (sl == 0 && r < n) X[r] += (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
 }
 
 // k_traj: per-frame record (x, y, z, theta, P00, P01, P10, P11) of the robot = RobotPath.txt
@@ -430,20 +442,17 @@ void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, c
     hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, d, w, p, X, S, sigR, Z, DZ);
 }
 void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* X, const double* sigR, const double* Z,
-                             double* h, double* Si, int* vis, double* PxyR)
+                             double* part, double* h, double* Si, int* vis, double* PxyR)
 {
-    hipLaunchKernelGGL(k_meas_stats, dim3((d.N + 31) / 32), dim3(256), 0, st, d, w, X, sigR, Z, h, Si, vis, PxyR);
+    hipLaunchKernelGGL(k_meas_partial, dim3((d.N + 31) / 32, MEAS_SLICES), dim3(256), 0, st, d, w, X, sigR, Z, part);
+    hipLaunchKernelGGL(k_meas_final, dim3((d.N + 255) / 256), dim3(256), 0, st, d, w, X, sigR, Z, part, h, Si, vis, PxyR);
 }
+int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
-                       const FrameScalars* fs, double* y)
+                       const FrameScalars* fs, double* X)
 {
-    dim3 grid((d.np + 255) / 256, d.N);
-    hipLaunchKernelGGL(k_gain, grid, dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, y);
-}
-void srukf_launch_state_update(hipStream_t st, KDims d, const double* Ut, const double* y, double* X)
-{
-    hipLaunchKernelGGL(k_state_update, dim3((d.n + 255) / 256), dim3(256), 0, st, d, Ut, y, X);
+    hipLaunchKernelGGL(k_gain, dim3(d.np / 64), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, X);
 }
 void srukf_launch_traj(hipStream_t st, KDims d, const double* X, const double* S, FrameScalars* fs, double* traj, int advance)
 {
