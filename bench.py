@@ -127,8 +127,11 @@ def main():
     sc = build_inputs(synth, N, F, rank)
     X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, device)
 
-    stream = torch.cuda.current_stream().cuda_stream
-    f = srukf.Filter(N, sc["params"], device=local, stream=stream)
+    # a dedicated HIP stream shared by torch (events, barriers) and the filter (kernel launches):
+    # torch.cuda.Event only sees work on the stream it is recorded on
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)
+    f = srukf.Filter(N, sc["params"], device=local, stream=tstream.cuda_stream)
     f.set_state_device(X0.data_ptr(), S0.data_ptr(), n)
     f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
     traj = torch.zeros(F, 8, dtype=torch.float64, device=device)

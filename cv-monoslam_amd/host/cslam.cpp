@@ -1,0 +1,223 @@
+// cslam.cpp — CSLAM facade implementation (see cslam.hpp).  Host-side bookkeeping only; every
+// numeric step is a C-ABI call into the gfx950 kernels.  No CPU fallback.
+#include "cslam.hpp"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace monoslam {
+
+static const double kPi = 3.14159265358979323846;
+
+CSLAM::CSLAM(int device) : device_(device)
+{
+    initializeParameters();
+}
+
+CSLAM::~CSLAM()
+{
+    if (ctx_) srukf_destroy(ctx_);
+    if (robotFile_) fclose(robotFile_);
+}
+
+bool CSLAM::check(int rc)
+{
+    if (rc == SRUKF_OK) return true;
+    const char* m = srukf_last_error(ctx_);
+    lastError = std::string("srukf error ") + std::to_string(rc) + ": " + (m ? m : "");
+    return false;
+}
+
+// SLAM.cpp:158-353: numeric defaults; the image / video / dialog parts are the host's.
+void CSLAM::initializeParameters()
+{
+    srukf_default_params(&m_params);
+    m_X_k.create(4, 1);
+    m_S_k.create(4, 4);
+    m_S_k.at(0, 0) = m_params.sigma_x; m_S_k.at(1, 1) = m_params.sigma_y;        // 226-231
+    m_S_k.at(2, 2) = m_params.sigma_z; m_S_k.at(3, 3) = m_params.sigma_theta;
+    m_P_k.create(4, 4);
+    m_odoXY.assign(2 * (CAPACITY + 1), 0.0);
+    m_path.assign(2 * (CAPACITY + 1), 0.0);
+    m_odoTheta.create(3, CAPACITY + 1);                                            // 235
+    m_frame = FrameInfo();
+    m_frame.stop = m_frame.start + CAPACITY;                                       // 244-246
+    m_frame.index = m_frame.start;
+    m_frame.counter = 1;
+    m_odoCounter = 0; m_showCounter = 1;
+    m_nMapFeatures = m_nPredicts = m_nMatches = m_nAddings = 0;
+    m_frameTime = m_totalTime = 0;
+    map.clear();
+}
+
+void CSLAM::resetAllParameters()
+{
+    if (ctx_) { srukf_destroy(ctx_); ctx_ = nullptr; }
+    if (robotFile_) { fclose(robotFile_); robotFile_ = nullptr; }
+    initializeParameters();
+}
+
+bool CSLAM::setMap(int N, const double* X, const double* S, const double* px)
+{
+    if (ctx_) { srukf_destroy(ctx_); ctx_ = nullptr; }
+    if (!check(srukf_create(&ctx_, N, &m_params, device_, nullptr))) return false;
+    if (!check(srukf_set_state(ctx_, X, S))) return false;
+    const int n = 6 * N + 4;
+    m_X_k.create(n, 1); m_S_k.create(n, n); m_P_k.create(n, n);
+    map.assign(N, PointsMap());
+    for (int k = 0; k < N; k++) { map[k].ID = k + 1; if (px) { map[k].initPixel.x = px[2 * k]; map[k].initPixel.y = px[2 * k + 1]; } }
+    m_nMapFeatures = N;
+    m_nAddings = 0;          // steady state: FLAG_4_NEEDNOT_REORDER (SLAM.cpp:2083-2090)
+    refreshMirrors();
+    return true;
+}
+
+// SLAM.cpp:462-496 + 363-450: "%d : %*lf %lf %lf %lf" lines, first sample is the origin, samples
+// closer than MIN_STEP in both x and y are skipped, turns above MIN_STEP_THETA flag a redirection.
+bool CSLAM::loadOdometryData(const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) { lastError = "cannot open " + path; return false; }
+    char line[500];
+    m_odoCounter = 0;
+    auto one = [&](int counter) -> bool {
+        if (!fgets(line, sizeof line, f)) return false;
+        int id = 0; double x = 0, y = 0, th = 0;
+        if (sscanf(line, "%d : %*lf %lf %lf %lf", &id, &x, &y, &th) < 4) return false;
+        m_odoTheta.at(0, counter) = id; m_odoTheta.at(1, counter) = th;
+        if (counter == 0) {
+            initOdo_[0] = x; initOdo_[1] = y;
+            initPos_[0] = m_X_k.rows >= 4 ? m_X_k.at(m_X_k.rows - 4, 0) : 0; initPos_[1] = m_X_k.rows >= 4 ? m_X_k.at(m_X_k.rows - 3, 0) : 0;
+            m_odoXY[0] = initPos_[0]; m_odoXY[1] = initPos_[1];
+        } else {
+            m_odoXY[2 * counter] = initPos_[0] + (x - initOdo_[0]);
+            m_odoXY[2 * counter + 1] = initPos_[1] + (y - initOdo_[1]);
+        }
+        return true;
+    };
+    if (!one(0)) { fclose(f); lastError = "empty odometry file"; return false; }
+    m_odoCounter = 1;
+    m_odoTheta.at(2, 0) = 0;
+    while (m_odoCounter <= CAPACITY) {
+        if (!one(m_odoCounter)) break;
+        bool ok = true;
+        while (std::fabs(m_odoXY[2 * m_odoCounter] - m_odoXY[2 * m_odoCounter - 2]) < MIN_STEP_X &&
+               std::fabs(m_odoXY[2 * m_odoCounter + 1] - m_odoXY[2 * m_odoCounter - 1]) < MIN_STEP_Y) {          // 419-432
+            if (!one(m_odoCounter)) { ok = false; break; }
+        }
+        if (!ok) break;
+        double d = m_odoTheta.at(1, m_odoCounter) - m_odoTheta.at(1, m_odoCounter - 1);
+        if (d > kPi) d -= 2 * kPi; else if (d < -kPi) d += 2 * kPi;                                              // wrapAngle 507-519
+        m_odoTheta.at(2, m_odoCounter) = (std::fabs(d) > MIN_STEP_THETA * kPi / 180) ? 1 : 0;                    // 438-445
+        m_odoCounter++;
+    }
+    fclose(f);
+    return true;
+}
+
+// SLAM.cpp:1430-1465.  The redirection sub-map restart (1354-1428) needs landmark augmentation and
+// is not built; a flagged frame is reported through lastError and processed as an ordinary frame.
+void CSLAM::predictMotion()
+{
+    if (!ctx_) { lastError = "predictMotion before setMap"; return; }
+    const int c = m_frame.counter;
+    m_frame.index = (int)m_odoTheta.at(0, c);                                                                  // 1351
+    if (m_odoTheta.at(2, c) == 1) lastError = "redirection frame (SLAM.cpp:1354-1428) is outside the built path";
+    const double prev[3] = { m_odoXY[2 * c - 2], m_odoXY[2 * c - 1], m_odoTheta.at(1, c - 1) };               // 1444-1450
+    const double cur[3]  = { m_odoXY[2 * c], m_odoXY[2 * c + 1], m_odoTheta.at(1, c) };
+    check(srukf_predict_motion(ctx_, prev, cur));
+}
+
+// SLAM.cpp:1604-1608 + the bookkeeping of QrAndCholeskyForMeasurement (1724-1745)
+void CSLAM::predictMeasurement()
+{
+    if (!ctx_) return;
+    const int N = m_nMapFeatures;
+    std::vector<double> h(2 * N), Si(4 * N);
+    std::vector<int> vis(N);
+    if (!check(srukf_predict_measurement(ctx_, h.data(), Si.data(), vis.data()))) return;
+    m_nPredicts = 0;
+    for (int k = 0; k < N; k++) {
+        PointsMap& p = map[k];
+        p.isVisible = vis[k] != 0;
+        if (p.isVisible) {                                                                                     // 1727-1738
+            m_nPredicts++;
+            p.isMatching = false;
+            p.nPredictTimes++;
+            p.predictLocation.x = h[2 * k]; p.predictLocation.y = h[2 * k + 1];
+            memcpy(p.Si, &Si[4 * k], sizeof p.Si);
+        }
+    }
+}
+
+// SLAM.cpp:2048-2104
+void CSLAM::KalmanUpdate()
+{
+    if (!ctx_) return;
+    const int N = m_nMapFeatures;
+    std::vector<double> z(2 * N, 0.0);
+    std::vector<int> m(N, 0);
+    m_nMatches = 0;
+    for (int k = 0; k < N; k++)
+        if (map[k].isMatching) { m[k] = 1; z[2 * k] = map[k].matchLocation.x; z[2 * k + 1] = map[k].matchLocation.y; m_nMatches++; map[k].nMatchTimes++; }
+    if (m_nMatches == 0) return;                                                                               // 2050-2051
+    const int reorder = (m_nAddings != 0) ? FLAG_4_NEED_REORDER : FLAG_4_NEEDNOT_REORDER;                      // 2083-2090
+    check(srukf_update(ctx_, z.data(), m.data(), reorder, m_updateMode));
+}
+
+void CSLAM::refreshMirrors()
+{
+    if (!ctx_) return;
+    const int n = m_X_k.rows;
+    if (fullCovariance) {
+        check(srukf_get_state(ctx_, m_X_k.data.data(), m_S_k.data.data()));
+        check(srukf_get_covariance(ctx_, m_P_k.data.data()));                                                  // 2404
+    } else {
+        check(srukf_get_state(ctx_, m_X_k.data.data(), nullptr));
+        double pose[4], P4[16];
+        check(srukf_get_robot(ctx_, pose, P4));                                                                // the 2x2 / 4x4 block the host reads (3539-3556)
+        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) m_P_k.at(n - 4 + a, n - 4 + b) = P4[4 * a + b];
+    }
+}
+
+// SLAM.cpp:2957-3000: trajectory buffer the OpenGL view draws (m_path)
+void CSLAM::updateRobotInformation()
+{
+    const int n = m_X_k.rows, c = m_frame.counter;
+    if (c <= CAPACITY) { m_path[2 * c] = m_X_k.at(n - 4, 0); m_path[2 * c + 1] = m_X_k.at(n - 3, 0); }
+}
+
+// SLAM.cpp:3512-3562: idx \t odoX \t odoY \t x \t y \t P00 \t P01 \t P10 \t P11
+void CSLAM::recordRobotInformation()
+{
+    if (!isRecordRobotInfo) return;
+    const int n = m_X_k.rows, c = m_frame.counter;
+    if (!robotFile_) {
+        robotFile_ = fopen(m_recordRobotDir.c_str(), "a");
+        if (!robotFile_) { lastError = "cannot open " + m_recordRobotDir; return; }
+    }
+    fprintf(robotFile_, "%d\t%f\t%f\t%f\t%f\t%f\t%f\t%f\t%f\t\n", m_showCounter, m_odoXY[2 * c], m_odoXY[2 * c + 1],
+            m_X_k.at(n - 4, 0), m_X_k.at(n - 3, 0), m_P_k.at(n - 4, n - 4), m_P_k.at(n - 4, n - 3), m_P_k.at(n - 3, n - 4), m_P_k.at(n - 3, n - 3));
+    fflush(robotFile_);
+}
+
+// SLAM.cpp:87-112
+void CSLAM::SLAM()
+{
+    const auto t0 = std::chrono::steady_clock::now();                                                          // startTimer 122-132
+    m_showCounter++;
+    predictMotion();
+    predictMeasurement();
+    if (dataAssociation) dataAssociation(*this);                                                               // loadPictures + dataAssociation (95-97)
+    KalmanUpdate();
+    refreshMirrors();                                                                                          // updateFeaturesInformation: m_P_k (2404)
+    updateRobotInformation();
+    recordRobotInformation();
+    m_nAddings = 0;                                                                                            // addFeatures (552-554)
+    m_frame.counter++;                                                                                         // stopTimer 142-151
+    m_frameTime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    m_totalTime += m_frameTime;
+}
+
+}  // namespace monoslam

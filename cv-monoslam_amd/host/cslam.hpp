@@ -1,0 +1,106 @@
+// cslam.hpp — CSLAM-shaped C++ facade over the C-ABI (include/srukf.h).
+//
+// The reference host (MFC view, MonoSLAMView.h:44) embeds `CSLAM SLAM;` by value, calls
+// SLAM.SLAM() per frame (MonoSLAMView.cpp:513,554), initializeParameters() / resetAllParameters()
+// (:377,:577) and reads public fields (m_X_k, m_S_k, m_P_k, m_frame, m_nMapFeatures, m_nPredicts,
+// m_nMatches, m_frameTime, m_totalTime, m_path, m_odoXY, map ...; MonoSLAMView.cpp:76-93,
+// OpenGlDisplay.cpp:386-571).  This class keeps those names and meanings for the SRUKF path and
+// routes the numerics to the MI355X kernels.  What is NOT here (out of scope): image
+// I/O, feature detection, patch matching, drawing, MFC controls.  The step between
+// predictMeasurement() and KalmanUpdate() — loadPictures() + dataAssociation() in the reference
+// (SLAM.cpp:95-97) — is a host callback: it receives the predicted pixels / Si / visibility the
+// reference's dataAssociation consumes and fills matchLocation / isMatching.
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+#include "../../include/srukf.h"
+
+namespace monoslam {
+
+// minimal row-major fp64 stand-in for the cv::Mat members the host reads (rows/cols/ptr(i))
+struct Mat {
+    int rows = 0, cols = 0;
+    std::vector<double> data;
+    void create(int r, int c) { rows = r; cols = c; data.assign((size_t)r * c, 0.0); }
+    double* ptr(int i) { return data.data() + (size_t)i * cols; }
+    const double* ptr(int i) const { return data.data() + (size_t)i * cols; }
+    double& at(int i, int j) { return data[(size_t)i * cols + j]; }
+    double at(int i, int j) const { return data[(size_t)i * cols + j]; }
+};
+
+struct Point2d { double x = 0, y = 0; };
+struct Point3d { double x = 0, y = 0, z = 0; };
+
+// SLAM.h:47-70 (numeric fields only)
+struct PointsMap {
+    int     ID = 0;
+    bool    isVisible = false;
+    bool    isMatching = false;
+    int     nPredictTimes = 0;
+    int     nMatchTimes = 0;
+    Point2d predictLocation;
+    Point2d matchLocation;
+    double  Si[4] = {0, 0, 0, 0};     // 2x2 upper-triangular sqrt innovation covariance
+    Point2d initPixel;
+    Point3d xyz;
+};
+
+// SLAM.h:85-92
+struct FrameInfo { int rate = 0, start = 1, stop = 0, index = 0, counter = 1; };
+
+class CSLAM {
+public:
+    static const int CAPACITY = 3000;                          // SLAM.h:127
+    const int FLAG_4_NEED_REORDER = 0, FLAG_4_NEEDNOT_REORDER = 1;   // SLAM.cpp:36-37
+
+    explicit CSLAM(int device = 0);
+    ~CSLAM();
+    CSLAM(const CSLAM&) = delete;
+    CSLAM& operator=(const CSLAM&) = delete;
+
+    // ---- members the reference host calls (same names) ------------------------------------
+    void initializeParameters();                               // SLAM.cpp:158-353 (numeric defaults only)
+    void resetAllParameters();                                 // SLAM.cpp:3090-3128
+    void SLAM();                                               // SLAM.cpp:87-112
+    void predictMotion();                                      // SLAM.cpp:1343-1466 (numeric tail 1430-1465)
+    void predictMeasurement();                                 // SLAM.cpp:1604-1608
+    void KalmanUpdate();                                       // SLAM.cpp:2048-2104
+    void updateRobotInformation();                             // SLAM.cpp:2957-3000 (m_path only)
+    void recordRobotInformation();                             // SLAM.cpp:3512-3562 (RobotPath.txt rows)
+    bool loadOdometryData(const std::string& path);            // SLAM.cpp:363-496 ("%d : %*lf %lf %lf %lf")
+
+    // ---- map set-up (the reference builds it inside addFeatures -> integrateFeaturesInformation,
+    //      SLAM.cpp:552-562, 818-1018; landmark augmentation on the device is a "next" row, so the
+    //      host supplies the augmented state) ------------------------------------------------
+    bool setMap(int n_landmarks, const double* X, const double* S, const double* init_pixels /*2N or null*/);
+
+    // the reference's loadPictures()+dataAssociation() slot (SLAM.cpp:95-97)
+    std::function<void(CSLAM&)> dataAssociation;
+
+    // ---- public state, reference names (SLAM.h:154-290) -----------------------------------------
+    std::vector<PointsMap> map;          // linked list in the reference; order = state order
+    FrameInfo m_frame;
+    srukf_params m_params;               // the tunables of SLAM.cpp:172-198, 221-224, 329-337
+    int    m_updateMode = SRUKF_UPDATE_BATCHED;
+    int    m_nMapFeatures = 0, m_nPredicts = 0, m_nMatches = 0, m_nAddings = 0, m_odoCounter = 0, m_showCounter = 1;
+    double m_frameTime = 0, m_totalTime = 0;
+    std::vector<double> m_odoXY, m_path; // 2*(CAPACITY+1) each (SLAM.h:188-189)
+    Mat    m_odoTheta;                   // 3 x (CAPACITY+1): index, theta, redirection flag (SLAM.cpp:235)
+    Mat    m_X_k, m_S_k, m_P_k;          // host mirrors, refreshed after every frame (m_P_k: robot block only unless fullCovariance)
+    bool   fullCovariance = false;       // true: m_P_k = S^T S in full (SLAM.cpp:2404), false: only the blocks the host reads
+    bool   isRecordRobotInfo = false;
+    std::string m_recordRobotDir = "RobotPath.txt";
+    double MIN_STEP_X = 0.01, MIN_STEP_Y = 0.01, MIN_STEP_THETA = 45;   // SLAM.cpp:45-47
+    std::string lastError;
+
+private:
+    void refreshMirrors();
+    bool check(int rc);
+    srukf_ctx* ctx_ = nullptr;
+    int device_ = 0;
+    FILE* robotFile_ = nullptr;
+    double initOdo_[2] = {0, 0}, initPos_[2] = {0, 0};
+};
+
+}  // namespace monoslam

@@ -1,0 +1,57 @@
+// cslam_replay — minimal C++ host that drives the CSLAM facade exactly the way the MFC view drives
+// the reference class (construct, initializeParameters, loop SLAM(), read fields), with the image
+// pipeline replaced by pre-computed "matched pixels" (synthetic data association).
+//   cslam_replay scene.bin odometry.txt RobotPath.txt traj.bin [sequential]
+// scene.bin: int32 N, int32 F, double a1..a4, double X0[n], double S0[n*n], double z[F][2N]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "cslam.hpp"
+
+int main(int argc, char** argv)
+{
+    if (argc < 5) { fprintf(stderr, "usage: %s scene.bin odometry.txt RobotPath.txt traj.bin [sequential]\n", argv[0]); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 2; }
+    int N = 0, F = 0; double a[4];
+    if (fread(&N, 4, 1, f) != 1 || fread(&F, 4, 1, f) != 1 || fread(a, 8, 4, f) != 4) return 2;
+    const int n = 6 * N + 4;
+    std::vector<double> X0(n), S0((size_t)n * n), z((size_t)F * 2 * N);
+    if (fread(X0.data(), 8, n, f) != (size_t)n || fread(S0.data(), 8, (size_t)n * n, f) != (size_t)n * n ||
+        fread(z.data(), 8, z.size(), f) != z.size()) { fprintf(stderr, "short scene file\n"); return 2; }
+    fclose(f);
+
+    monoslam::CSLAM SLAM;                                   // MonoSLAMView.h:44
+    SLAM.m_params.a1 = a[0]; SLAM.m_params.a2 = a[1]; SLAM.m_params.a3 = a[2]; SLAM.m_params.a4 = a[3];   // CSetParameters dialog (MonoSLAMView.cpp:386-443)
+    if (argc > 5 && !strcmp(argv[5], "sequential")) SLAM.m_updateMode = SRUKF_UPDATE_SEQUENTIAL;
+    if (!SLAM.setMap(N, X0.data(), S0.data(), nullptr)) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+    SLAM.MIN_STEP_X = SLAM.MIN_STEP_Y = 0.0;             // the synthetic odometry is already one pose per frame: keep every sample
+    if (!SLAM.loadOdometryData(argv[2])) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+    SLAM.isRecordRobotInfo = true;
+    SLAM.m_recordRobotDir = argv[3];
+    remove(argv[3]);
+    SLAM.dataAssociation = [&](monoslam::CSLAM& s) {        // stands in for loadPictures + dataAssociation
+        const int fr = s.m_frame.counter - 1;
+        for (int k = 0; k < N; k++) {
+            monoslam::PointsMap& p = s.map[k];
+            p.isMatching = p.isVisible;
+            p.matchLocation.x = z[(size_t)fr * 2 * N + 2 * k];
+            p.matchLocation.y = z[(size_t)fr * 2 * N + 2 * k + 1];
+        }
+    };
+    std::vector<double> traj((size_t)F * 8);
+    for (int fr = 0; fr < F; fr++) {                        // OnBnClickedAuto loop, MonoSLAMView.cpp:526-572
+        SLAM.SLAM();
+        if (!SLAM.lastError.empty()) { fprintf(stderr, "frame %d: %s\n", fr, SLAM.lastError.c_str()); return 1; }
+        const int nn = SLAM.m_X_k.rows;
+        for (int e = 0; e < 4; e++) traj[8 * fr + e] = SLAM.m_X_k.at(nn - 4 + e, 0);
+        traj[8 * fr + 4] = SLAM.m_P_k.at(nn - 4, nn - 4); traj[8 * fr + 5] = SLAM.m_P_k.at(nn - 4, nn - 3);
+        traj[8 * fr + 6] = SLAM.m_P_k.at(nn - 3, nn - 4); traj[8 * fr + 7] = SLAM.m_P_k.at(nn - 3, nn - 3);
+    }
+    FILE* o = fopen(argv[4], "wb");
+    fwrite(traj.data(), 8, traj.size(), o);
+    fclose(o);
+    printf("frames %d  landmarks %d  predicts %d  matches %d  total %.3f s\n", F, SLAM.m_nMapFeatures, SLAM.m_nPredicts, SLAM.m_nMatches, SLAM.m_totalTime);
+    return 0;
+}

@@ -1,0 +1,37 @@
+"""N > 1 path on CPU: two processes, gloo backend (the GPU run uses the same code with nccl = RCCL).
+Checks the only collectives the path has: broadcast of the shared initial map from rank 0 at the
+start, all-gather of the trajectories and max-over-ranks of the wall time at the end."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo(tmp_path):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    assert all(o["same_map"] for o in out)                       # broadcast delivered rank 0's map everywhere
+    assert out[0]["wall_max"] == out[1]["wall_max"] == 0.2       # max over ranks
+    t0, t1 = np.array(out[0]["trajs"]), np.array(out[1]["trajs"])
+    assert np.array_equal(t0, t1) and t0.shape == (2, 5, 8)      # all-gather: same view on both ranks
+    assert not np.array_equal(t0[0], t0[1])                      # independent measurement noise per rank
+    assert out[0]["z0"] != out[1]["z0"]
+    assert np.abs(t0[0][:, :2] - t0[1][:, :2]).max() < 1e-3      # ...but the same underlying trajectory

@@ -1,0 +1,55 @@
+"""GPU test of the drop-in boundary in the reference's own language: the CSLAM-shaped C++ facade
+(cv-monoslam_amd/host) driven by a small C++ host the way the MFC view drives the reference
+class, checked against the oracle's golden trajectory."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPLAY = os.path.join(ROOT, "cv-monoslam_amd", "cslam_replay.bin")
+
+
+def _write_inputs(tmp, sc, p):
+    N, F = sc["N"], sc["F"]
+    with open(os.path.join(tmp, "scene.bin"), "wb") as f:
+        f.write(struct.pack("ii", N, F))
+        f.write(np.array([p["a1"], p["a2"], p["a3"], p["a4"]], dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(sc["X0"]).tobytes())
+        f.write(np.ascontiguousarray(sc["S0"]).tobytes())
+        f.write(np.ascontiguousarray(sc["z"]).tobytes())
+    # the reference's odometry text format: "%d : %*lf %lf %lf %lf"  (SLAM.cpp:475)
+    with open(os.path.join(tmp, "odo.txt"), "w") as f:
+        for i, (x, y, th) in enumerate(sc["odo"]):
+            f.write(f"{i + 1} : {0.1 * i:.3f} {float(x)!r} {float(y)!r} {float(th)!r}\n")
+
+
+@pytest.mark.parametrize("mode", ["batched", "sequential"])
+def test_cslam_facade_replay_matches_golden(tmp_path, golden, synth, mode):
+    assert os.path.exists(REPLAY), "run __graft_entry__.build() first"
+    g = golden["g6_trajectory_n20"]
+    p = synth.scene_params()
+    F = 50 if mode == "batched" else 12
+    sc = synth.make_scene(20, 50, seed=int(g["seed"]), p=p)
+    sc = dict(sc, F=F, z=sc["z"][:F], odo=sc["odo"][:F + 1])
+    tmp = str(tmp_path)
+    _write_inputs(tmp, sc, p)
+    args = [REPLAY, f"{tmp}/scene.bin", f"{tmp}/odo.txt", f"{tmp}/RobotPath.txt", f"{tmp}/traj.bin"]
+    if mode == "sequential":
+        args.append("sequential")
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    traj = np.fromfile(f"{tmp}/traj.bin").reshape(F, 8)
+    np.testing.assert_allclose(traj[:, :4], g["traj_sequential"][:F, :4], atol=1e-9)
+    np.testing.assert_allclose(traj[:, 4:], g["traj_sequential"][:F, 4:], atol=1e-13)
+    # RobotPath.txt: idx, odoX, odoY, x, y, P00, P01, P10, P11 with %f (SLAM.cpp:3546-3561)
+    rows = [l.rstrip("\n").split("\t") for l in open(f"{tmp}/RobotPath.txt")]
+    assert len(rows) == F and all(len(r) >= 9 for r in rows)
+    rp = np.array([[float(v) for v in r[:9]] for r in rows])
+    assert rp[0, 0] == 2 and rp[-1, 0] == F + 1                       # m_showCounter starts at 1 and is bumped before recording
+    np.testing.assert_allclose(rp[:, 1:3], sc["odo"][1:F + 1, :2], atol=1e-6)
+    np.testing.assert_allclose(rp[:, 3:5], traj[:, :2], atol=1e-6)
+    assert f"frames {F}  landmarks 20  predicts 20  matches 20" in out.stdout
