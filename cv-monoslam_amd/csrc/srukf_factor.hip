@@ -16,7 +16,9 @@ __device__ __forceinline__ double readlane_d(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// one wave: 32x32 output tile at (m0, n0), K range [kb, ke) (multiple of 4 long), accumulate
+// one wave: 32x32 output tile at (m0, n0), K range [kb, ke) — (ke - kb) a multiple of 16 —, accumulate.
+// Software-pipelined: the 16 fragment loads of the next group of four k-steps are in flight while the
+// 16 MFMAs of the current group issue (hipcc otherwise waits for each group's loads before its MFMAs).
 template <bool NEG>
 __device__ __forceinline__ void tile32_tn(d4 (&acc)[2][2], const double* __restrict__ A, int lda,
                                           const double* __restrict__ B, int ldb, int m0, int n0, int kb, int ke, int lane)
@@ -25,15 +27,33 @@ __device__ __forceinline__ void tile32_tn(d4 (&acc)[2][2], const double* __restr
     const double* pa = A + (size_t)(kb + lk) * lda + m0 + lr;
     const double* pb = B + (size_t)(kb + lk) * ldb + n0 + lr;
     const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
-#pragma unroll 4
-    for (int k = kb; k < ke; k += 4) {
-        double a0 = pa[0], a1 = pa[16], b0 = pb[0], b1 = pb[16];
-        if (NEG) { a0 = -a0; a1 = -a1; }
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        pa += sa; pb += sb;
+    const int ng = (ke - kb) >> 4;
+    if (ng <= 0) return;
+    double ca0[4], ca1[4], cb0[4], cb1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { ca0[u] = pa[0]; ca1[u] = pa[16]; cb0[u] = pb[0]; cb1[u] = pb[16]; pa += sa; pb += sb; }
+    for (int g = 0; g + 1 < ng; g++) {
+        double na0[4], na1[4], nb0[4], nb1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { na0[u] = pa[0]; na1[u] = pa[16]; nb0[u] = pb[0]; nb1[u] = pb[16]; pa += sa; pb += sb; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double a0 = NEG ? -ca0[u] : ca0[u], a1 = NEG ? -ca1[u] : ca1[u];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb1[u], acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ca0[u] = na0[u]; ca1[u] = na1[u]; cb0[u] = nb0[u]; cb1[u] = nb1[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const double a0 = NEG ? -ca0[u] : ca0[u], a1 = NEG ? -ca1[u] : ca1[u];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb0[u], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb1[u], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb0[u], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb1[u], acc[1][1], 0, 0, 0);
     }
 }
 
@@ -148,53 +168,124 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
 //   w = T g, so the whole panel "TRSM" becomes one 32x32 by 32xcols MFMA product.
 struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; };
 
-// Factor the 32x32 diagonal block held in LDS (Wt[row jj][col ii], upper part valid) with one wave.
-// Lanes 0..31: lane ii keeps column ii in registers; pivots/multipliers cross lanes by
-// v_readlane (constant lane after unrolling).  Lanes 32..63 run the SAME multiplier stream on the
-// identity columns, which yields T at no extra instruction.  Writes the next panel buffer, the
-// pivots D and the diagonal-block part of S rows j0..j0+31.
-__device__ __forceinline__ void gmw_factor_block(const double (*Wt)[33], double eps, int lane, int n, int ld, int j0,
+// Factor a 32x32 diagonal block held in MFMA C-layout registers (one wave):
+//   A[a][b] (a, b in {0,1}):  element (row 16a + lk + 4t, col 16b + lr) in register t of lane (lk, lr).
+// Works on 4-row micro-panels (rows 4s..4s+3 = register t = s&3 of tile row a = s>>2 of EVERY lane):
+//   1. the 4x4 diagonal micro-block is read with v_readlane and factored on wave-uniform values
+//      (the reference's recurrence: L = C/D, C -= L*C; D = max(EPSILON, |C_jj|));
+//   2. the within-strip elimination  W[q] = in[q] - sum_{q''<q} L[q''][q] W[q'']  is one MFMA per
+//      column tile with the 4x4 unit-triangular micro-inverse as the A operand;
+//   3. rows below the strip get the rank-4 update  C[r][c] -= L[k][r] W[k][c]  by MFMA — the strip
+//      registers are, as they stand, valid A (k = lk, i = lr) and B (k = lk, j = lr) operands.
+// The same operations applied to identity columns (I[a][b]) give T = (I + M^T)^{-1} for the panel.
+// Out: next panel buffer (Tt, D, sqrt D), pivots D, and the diagonal-block part of S rows j0..j0+31.
+__device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int lane, int n, int ld, int j0,
                                                  GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout)
 {
-    const int ii = lane & 31;
-    const bool tl = lane >= 32;
-    double col[32], lrow[32];
+    const int lr = lane & 15, lk = lane >> 4;
+    d4 I[2][2];
 #pragma unroll
-    for (int jj = 0; jj < 32; jj++) col[jj] = tl ? ((jj == ii) ? 1.0 : 0.0) : ((jj <= ii) ? Wt[jj][ii] : 0.0);
-    // the 32-pivot chain: nothing but pivot broadcast, one division and the rank-1 update
+    for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int jj = 0; jj < 32; jj++) {
-        const double wv = (tl || ii >= jj) ? col[jj] : 0.0;
-        const double piv = readlane_d(wv, jj);
-        const double dj = fmax(eps, fabs(piv));               // fast path: theta clamp checked afterwards (k_gmw_check)
-        const double l = wv / dj;
-        lrow[jj] = l;
+        for (int b = 0; b < 2; b++)
 #pragma unroll
-        for (int rr = jj + 1; rr < 32; rr++) col[rr] -= readlane_d(l, rr) * wv;
-    }
-    // outputs, off the chain.  Lane jj still holds pivot jj in col[jj] (later steps only touch rows > jj).
+            for (int t = 0; t < 4; t++) I[a][b][t] = (a == b && lk + 4 * t == lr) ? 1.0 : 0.0;
+    double Drow[2][4];          // pivot of each of this lane's 8 rows
 #pragma unroll
-    for (int jj = 0; jj < 32; jj++) {
-        const double dj = fmax(eps, fabs(readlane_d(col[jj], jj)));
-        const double sq = sqrt(dj);
-        if (!tl) {
-            if (ii == jj) { out->D[jj] = dj; out->sq[jj] = sq; Dall[j0 + jj] = dj; }
-            if (j0 + jj < n && j0 + ii < n && ii >= jj) Sout[(size_t)(j0 + jj) * ld + j0 + ii] = (ii == jj) ? sq : sq * lrow[jj];
-        } else {
-            out->Tt[ii * 32 + jj] = col[jj];                                  // Tt[kk = ii][jj] = T[jj][ii]
+    for (int s = 0; s < 8; s++) {
+        const int a = s >> 2, t = s & 3;
+        // 1. 4x4 diagonal micro-block: element (4s+q, 4s+q') sits in lane 16q + 4t + q' of A[a][a][t]
+        const double st = A[a][a][t];
+        const double m00 = readlane_d(st, 0 + 4 * t + 0), m01 = readlane_d(st, 0 + 4 * t + 1), m02 = readlane_d(st, 0 + 4 * t + 2), m03 = readlane_d(st, 0 + 4 * t + 3);
+        const double m11 = readlane_d(st, 16 + 4 * t + 1), m12 = readlane_d(st, 16 + 4 * t + 2), m13 = readlane_d(st, 16 + 4 * t + 3);
+        const double m22 = readlane_d(st, 32 + 4 * t + 2), m23 = readlane_d(st, 32 + 4 * t + 3);
+        const double m33 = readlane_d(st, 48 + 4 * t + 3);
+        const double D0 = fmax(eps, fabs(m00));
+        const double l01 = m01 / D0, l02 = m02 / D0, l03 = m03 / D0;
+        const double c11 = m11 - l01 * m01, c12 = m12 - l01 * m02, c13 = m13 - l01 * m03;
+        double c22 = m22 - l02 * m02, c23 = m23 - l02 * m03, c33 = m33 - l03 * m03;
+        const double D1 = fmax(eps, fabs(c11));
+        const double l12 = c12 / D1, l13 = c13 / D1;
+        c22 -= l12 * c12; c23 -= l12 * c13; c33 -= l13 * c13;
+        const double D2 = fmax(eps, fabs(c22));
+        const double l23 = c23 / D2;
+        c33 -= l23 * c23;
+        const double D3 = fmax(eps, fabs(c33));
+        // micro-inverse rows (unit lower triangular): row q = e_q - sum_{q''<q} l[q''][q] row q''
+        const double t10 = -l01, t21 = -l12, t32 = -l23;
+        const double t20 = -l02 - l12 * t10;
+        const double t31 = -l13 - l23 * t21;
+        const double t30 = -l03 - l13 * t10 - l23 * t20;
+        // 2. strip apply: A operand lane (lk = k, lr = i): Tm[i - 4t][k] for i in [4t, 4t+4), else 0
+        const int qi = lr - 4 * t;
+        double aop = 0.0;
+        if (qi >= 0 && qi < 4) {
+            const double r0 = (lk == 0) ? 1.0 : 0.0;
+            const double r1 = (lk == 0) ? t10 : ((lk == 1) ? 1.0 : 0.0);
+            const double r2 = (lk == 0) ? t20 : ((lk == 1) ? t21 : ((lk == 2) ? 1.0 : 0.0));
+            const double r3 = (lk == 0) ? t30 : ((lk == 1) ? t31 : ((lk == 2) ? t32 : 1.0));
+            aop = (qi == 0) ? r0 : ((qi == 1) ? r1 : ((qi == 2) ? r2 : r3));
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            if (b >= a) {                                  // A part: upper tiles only
+                d4 c = A[a][b]; const double bop = c[t]; c[t] = 0.0;
+                A[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, c, 0, 0, 0);
+            }
+            if (b <= a) {                                  // identity part: columns <= current rows only
+                d4 c = I[a][b]; const double bop = c[t]; c[t] = 0.0;
+                I[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, c, 0, 0, 0);
+            }
+        }
+        const double Dsel = (lk == 0) ? D0 : ((lk == 1) ? D1 : ((lk == 2) ? D2 : D3));
+        Drow[a][t] = Dsel;
+        // 3. rank-4 update of the rows below the strip
+#pragma unroll
+        for (int ap = 0; ap < 2; ap++) {
+            if (ap < a) continue;
+            if (16 * ap + 15 <= 4 * s + 3) continue;       // no rows of this tile below the strip
+            // multipliers L[k][r] = W[k][r] / D_k for r = 16ap + lr > 4s+3 (rows already final keep their values)
+            const double wkr = A[a][ap][t];
+            const double lop = (16 * ap + lr > 4 * s + 3) ? -(wkr / Dsel) : 0.0;
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                if (b >= ap) A[ap][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, A[a][b][t], A[ap][b], 0, 0, 0);
+                if (b <= a) I[ap][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, I[a][b][t], I[ap][b], 0, 0, 0);
+            }
         }
     }
+    // outputs
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int r = 16 * a + lk + 4 * t;
+            const double dj = Drow[a][t], sq = sqrt(dj);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int c = 16 * b + lr;
+                if (b >= a) {
+                    if (c == r) { out->D[r] = dj; out->sq[r] = sq; Dall[j0 + r] = dj; }
+                    if (c >= r && j0 + r < n && j0 + c < n) Sout[(size_t)(j0 + r) * ld + j0 + c] = (c == r) ? sq : sq * (A[a][b][t] / dj);
+                }
+                out->Tt[c * 32 + r] = (b <= a) ? I[a][b][t] : 0.0;       // Tt[kk = c][jj = r] = T[r][c]
+            }
+        }
 }
 
 // k_gmw_first: factor the first diagonal block (j0 = 0).  One wave.
 __global__ __launch_bounds__(64) void k_gmw_first(int n, int ld, double eps, const double* __restrict__ G, GmwPanel* __restrict__ out,
                                                   double* __restrict__ Dall, double* __restrict__ Sout)
 {
-    __shared__ double Wt[32][33];
-    const int lane = threadIdx.x;
-    for (int e = lane; e < 1024; e += 64) Wt[e >> 5][e & 31] = G[(size_t)(e >> 5) * ld + (e & 31)];
-    __syncthreads();
-    gmw_factor_block(Wt, eps, lane, n, ld, 0, out, Dall, Sout);
+    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    d4 A[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) A[a][b][t] = G[(size_t)(16 * a + lk + 4 * t) * ld + 16 * b + lr];
+    gmw_factor_block(A, eps, lane, n, ld, 0, out, Dall, Sout);
 }
 
 // k_gmw_step: one launch per panel J = [j0, j0+32).  Every 64x64 block of the trailing square
@@ -213,7 +304,6 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
     if (blockIdx.x < blockIdx.y) return;
     __shared__ double Lr[32][80];      // stride 80 doubles: lanes l / l+16 land on opposite bank halves
     __shared__ double Wc[32][80];
-    __shared__ double Wt[32][33];
     __shared__ double Dd[32], Sq[32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -281,19 +371,8 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
                     G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
     }
 
-    // 4. next diagonal block: tile (base, base) of block (0,0), wave 0
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (wv == 0) {
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) Wt[16 * a + lk + 4 * t][16 * b + lr] = acc[a][b][t];
-        }
-        __syncthreads();
-        if (wv == 0) gmw_factor_block(Wt, eps, lane, n, ld, base, nxt, Dall, Sout);
-    }
+    // 4. next diagonal block: tile (base, base) of block (0,0), wave 0 — already in C-layout registers
+    if (blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) gmw_factor_block(acc, eps, lane, n, ld, base, nxt, Dall, Sout);
 }
 
 // k_gmw_check: was the reference's third pivot candidate theta_j^2/beta^2 ever the largest?
