@@ -15,7 +15,8 @@ void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const doub
 void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
-                       const double*, const int*, const int*, const FrameScalars*, double*);
+                       const double*, const int*, const int*, const FrameScalars*, double*, double*);
+int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
@@ -39,8 +40,10 @@ __global__ void k_refactor_reset(int np, unsigned long long* theta_bits, FrameSc
 __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
 {
     fs->frame = frame;
+    fs->traj_base = nullptr;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; }
 }
+__global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base = traj_base; }
 
 static thread_local std::string g_create_error;
 
@@ -62,7 +65,7 @@ struct srukf_ctx {
     double *X = nullptr, *S = nullptr, *G = nullptr, *Gbak = nullptr, *Wf = nullptr;
     double *sigR = nullptr, *Cmat = nullptr, *Z = nullptr, *DZ = nullptr, *Ut = nullptr;
     double *h = nullptr, *Si = nullptr, *PxyR = nullptr, *y = nullptr, *D = nullptr, *Wp = nullptr, *Lp = nullptr;
-    double *zcur = nullptr, *odocur = nullptr, *small = nullptr, *mpart = nullptr;
+    double *zcur = nullptr, *odocur = nullptr, *small = nullptr, *mpart = nullptr, *dxp = nullptr;
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered)
@@ -78,6 +81,10 @@ struct srukf_ctx {
     int phase = 0;   // 0 idle, 1 after predict_motion, 2 after predict_measurement
     bool async_pending = false;
     std::string err;
+    // one captured frame (BATCHED, staged inputs): replayed by srukf_run_frames_async
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool use_graph = true;
     // profiling
     bool profiling = false;
     std::vector<ProfEvent> pev;
@@ -199,7 +206,7 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev)
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
-        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->X);
+        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X);
     }
 }
 
@@ -262,7 +269,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     host_weights(d.Na, c->p, c->w);
     const size_t np = d.np, mp = d.mp;
     ALLOC(c->X, np); ALLOC(c->S, np * np); ALLOC(c->G, np * np); ALLOC(c->Gbak, np * np); ALLOC(c->Wf, np * np);
-    ALLOC(c->sigR, (size_t)d.L * 8 + 8); ALLOC(c->mpart, srukf_meas_part_doubles(d.mp)); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
+    ALLOC(c->sigR, (size_t)d.L * 8 + 8); ALLOC(c->mpart, srukf_meas_part_doubles(d.mp)); ALLOC(c->dxp, srukf_gain_part_doubles(d.np)); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
     ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)N); ALLOC(c->PxyR, 4 * mp); ALLOC(c->y, mp);
     ALLOC(c->D, np); ALLOC(c->Wp, 32 * np); ALLOC(c->Lp, 32 * np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
     ALLOC(c->vis, N); ALLOC(c->mcur, N); ALLOC(c->theta, np); ALLOC(c->fs, 1);
@@ -283,8 +290,10 @@ int srukf_destroy(srukf_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_collect(c);
+    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) hipGraphDestroy(c->graph);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
-                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart };
+                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp };
     for (void* b : bufs) if (b) hipFree(b);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->hfs) hipHostFree(c->hfs);
@@ -535,6 +544,8 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->d.N;
     if (c->odo_seq) { hipFree(c->odo_seq); hipFree(c->z_seq); hipFree(c->m_seq); c->odo_seq = nullptr; c->z_seq = nullptr; c->m_seq = nullptr; }
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     HIPCHK(c, hipMalloc((void**)&c->odo_seq, sizeof(double) * 3 * (F + 1)));
     HIPCHK(c, hipMalloc((void**)&c->z_seq, sizeof(double) * (size_t)F * 2 * N));
     HIPCHK(c, hipMalloc((void**)&c->m_seq, sizeof(int) * (size_t)F * N));
@@ -555,13 +566,27 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1);
     // traj rows are indexed by the absolute frame counter; offset so that frame `first` lands in row 0
     double* traj = d_traj ? d_traj - (size_t)8 * first : nullptr;
-    for (int f = 0; f < count; f++) {
+    hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, traj);
+    auto one_frame = [&]() {
         seq_predict_motion(c, nullptr);
         seq_predict_measurement(c);
         seq_gain(c, nullptr, nullptr);
         seq_refactor(c, 0, d.mp, false, false);
         ProfScope ps(c, KC_MISC, 0, 0);
-        srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, traj, 1);
+        srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
+    };
+    if (c->use_graph && !c->profiling) {
+        // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
+        // captured frame replays for all frames: the 45 launches cost one hipGraphLaunch on the host
+        if (!c->graph_exec) {
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            one_frame();
+            HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
+            HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        }
+        for (int f = 0; f < count; f++) HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+    } else {
+        for (int f = 0; f < count; f++) one_frame();
     }
     c->async_pending = true;
     c->phase = 0;

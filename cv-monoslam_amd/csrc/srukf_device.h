@@ -41,6 +41,7 @@ struct FrameScalars {
     int clamp_first;           // first such row
     int frame;                 // frame counter for staged sequences
     int pad_;
+    double* traj_base;         // device trajectory buffer of the current replay (row = absolute frame), or null
 };
 
 __device__ __forceinline__ double wave_sum(double v)

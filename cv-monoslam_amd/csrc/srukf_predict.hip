@@ -88,19 +88,12 @@ __global__ __launch_bounds__(1024) void k_motion(KDims d, KWeights w, srukf_para
     __threadfence_block();
     __syncthreads();
     // rs[e] = sum_c wc_c (sigma_c[e] - X[e]) with the covariance weights (wc0 for the centre): the
-    // constant that k_meas_final needs to re-centre the robot rows of Pxy on the mean h
-    {
-        double rs[4] = { 0, 0, 0, 0 };
-        for (int c = tid; c < L; c += nt) {
-            const double wt = (c == 0) ? w.wc0 : w.wi;
-#pragma unroll
-            for (int e = 0; e < 4; e++) rs[e] += wt * (sigR[(size_t)c * 8 + e] - acc[e]);
-        }
-        block_sum<4>(rs, red);
-        if (tid < 4) sigR[(size_t)L * 8 + tid] = rs[tid];
-    }
+    // constant that k_meas_final needs to re-centre the robot rows of Pxy on the mean h.
+    //   sum_c wc_c sigma_c = mean + (wc0 - wm0) sigma_0,  sum_c wc_c = wc0 + 2 Na wi
+    if (tid < 4) sigR[(size_t)L * 8 + tid] = acc[tid] * (1.0 - (w.wc0 + 2.0 * Na * w.wi)) + (w.wc0 - w.wm0) * sigR[tid];
 
-    // ---- structured QR: R12 rows and the residual matrix C ((n-4)+18 rows x 4) ----
+    // ---- structured QR: R12 rows and the residual matrix C ((n-4)+18 rows x 4), kept in LDS ----
+    extern __shared__ __attribute__((aligned(16))) double Cm[];      // [(n+14)][4]
     const double k2 = w.wi_sr * 0.70710678118654752440;
     const int m = (n - 4) + 2 * (Na - (n - 4));
     const double* s0 = sigR;   // sigma_0 robot rows (post-motion)
@@ -114,58 +107,55 @@ __global__ __launch_bounds__(1024) void k_motion(KDims d, KWeights w, srukf_para
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 S[(size_t)i * ld + (n - 4 + e)] = k2 * (dp[e] - dm[e]);
-                Cmat[(size_t)i * 4 + e] = k2 * (dp[e] + dm[e]);
+                Cm[(size_t)i * 4 + e] = k2 * (dp[e] + dm[e]);
             }
         } else {
             const int rp = (n - 4) + 2 * (i - (n - 4));
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                Cmat[(size_t)rp * 4 + e] = w.wi_sr * dp[e];
-                Cmat[(size_t)(rp + 1) * 4 + e] = w.wi_sr * dm[e];
+                Cm[(size_t)rp * 4 + e] = w.wi_sr * dp[e];
+                Cm[(size_t)(rp + 1) * 4 + e] = w.wi_sr * dm[e];
             }
         }
     }
-    __threadfence_block();
     __syncthreads();
 
     // ---- Householder QR of C (m x 4), GSL conventions (see oracle/srukf_oracle.c orc_qr_r) ----
     for (int j = 0; j < 4; j++) {
         double v1[1] = { 0.0 };
-        for (int r = j + 1 + tid; r < m; r += nt) { const double x = Cmat[(size_t)r * 4 + j]; v1[0] += x * x; }
+        for (int r = j + 1 + tid; r < m; r += nt) { const double x = Cm[(size_t)r * 4 + j]; v1[0] += x * x; }
         block_sum<1>(v1, red);
         const double xnorm = sqrt(v1[0]);
-        const double alpha = Cmat[(size_t)j * 4 + j];
+        const double alpha = Cm[(size_t)j * 4 + j];
         double tau = 0.0, beta = alpha;
         if (xnorm != 0.0) {
             beta = -(alpha >= 0.0 ? 1.0 : -1.0) * hypot(alpha, xnorm);
             tau = (beta - alpha) / beta;
             const double is = 1.0 / (alpha - beta);
-            for (int r = j + 1 + tid; r < m; r += nt) Cmat[(size_t)r * 4 + j] *= is;
+            for (int r = j + 1 + tid; r < m; r += nt) Cm[(size_t)r * 4 + j] *= is;
         }
-        __threadfence_block();
         __syncthreads();
-        if (tid == 0) Cmat[(size_t)j * 4 + j] = beta;
+        if (tid == 0) Cm[(size_t)j * 4 + j] = beta;
         if (tau != 0.0 && j < 3) {
             double wj[3] = { 0, 0, 0 };
             for (int r = j + 1 + tid; r < m; r += nt) {
-                const double v = Cmat[(size_t)r * 4 + j];
-                for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cmat[(size_t)r * 4 + jj] * v;
+                const double v = Cm[(size_t)r * 4 + j];
+                for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cm[(size_t)r * 4 + jj] * v;
             }
             block_sum<3>(wj, red);
-            for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cmat[(size_t)j * 4 + jj];
+            for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cm[(size_t)j * 4 + jj];
             __syncthreads();
             for (int r = j + 1 + tid; r < m; r += nt) {
-                const double v = Cmat[(size_t)r * 4 + j];
-                for (int jj = j + 1; jj < 4; jj++) Cmat[(size_t)r * 4 + jj] -= tau * v * wj[jj - j - 1];
+                const double v = Cm[(size_t)r * 4 + j];
+                for (int jj = j + 1; jj < 4; jj++) Cm[(size_t)r * 4 + jj] -= tau * v * wj[jj - j - 1];
             }
-            if (tid == 0) for (int jj = j + 1; jj < 4; jj++) Cmat[(size_t)j * 4 + jj] -= tau * wj[jj - j - 1];
+            if (tid == 0) for (int jj = j + 1; jj < 4; jj++) Cm[(size_t)j * 4 + jj] -= tau * wj[jj - j - 1];
         }
-        __threadfence_block();
         __syncthreads();
     }
     if (tid < 16) {
         const int a = tid >> 2, b = tid & 3;
-        S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = (b >= a) ? Cmat[(size_t)a * 4 + b] : 0.0;
+        S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = (b >= a) ? Cm[(size_t)a * 4 + b] : 0.0;
     }
 }
 
@@ -341,15 +331,17 @@ __global__ __launch_bounds__(256) void k_meas_final(KDims d, KWeights w, const d
 //   sii = Si^{-1} (OpenCV closed-form 2x2 inverse), U = Ki*Si^T = Pxy*sii, y = sii^T (z - h),
 //   X += sum_k Ki (z - h) = sum_k U_k y_k.
 // In : Ut rows 2k, 2k+1 hold S^T DZ for r < n-4 (k_pxy; scaled here by wi*gamma), PxyR rows n-4..n-1.
-// Out: Ut rows become U^T (zero for unmatched / invisible landmarks); X updated.
-// Block = 64 state rows x 4 landmark slices; partial dX reduced through LDS in fixed order.
+// Out: Ut rows become U^T (zero for unmatched / invisible landmarks); per-slice partial dX.
+// grid = (np/64, GAIN_SLICES): block = 64 state rows x 4 sub-slices of one landmark slice; k_gain_dx
+// adds the slice partials to X in fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
+#define GAIN_SLICES 8
 __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               double* __restrict__ Ut, const double* __restrict__ PxyR,
                                               const double* __restrict__ Si, const int* __restrict__ vis,
                                               const double* __restrict__ h, const double* __restrict__ z_seq,
                                               const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
-                                              const FrameScalars* __restrict__ fs, double* __restrict__ X)
+                                              const FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */)
 {
     __shared__ double red[4][64];
     const int rl = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -358,8 +350,10 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     const double* z = z_cur ? z_cur : (z_seq + (size_t)fs->frame * 2 * N);
     const int* mt = m_cur ? m_cur : (m_seq + (size_t)fs->frame * N);
     const double sc = w.wi * w.gamma;
+    const int per = (N + GAIN_SLICES - 1) / GAIN_SLICES;
+    const int k_beg = blockIdx.y * per, k_end = min(N, k_beg + per);
     double dx = 0.0;
-    for (int k = sl; k < N; k += 4) {
+    for (int k = k_beg + sl; k < k_end; k += 4) {
         const bool on = (mt[k] != 0) && (vis[k] != 0);
         double u0 = 0.0, u1 = 0.0;
         if (on && r < n) {
@@ -380,11 +374,21 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
             const double v0 = z[2 * k] - h[2 * k], v1 = z[2 * k + 1] - h[2 * k + 1];
             dx += u0 * (i00 * v0 + i10 * v1) + u1 * (i01 * v0 + i11 * v1);
         }
-        if (r < ld) { Ut[(size_t)(2 * k) * ld + r] = u0; Ut[(size_t)(2 * k + 1) * ld + r] = u1; }
+        Ut[(size_t)(2 * k) * ld + r] = u0;
+        Ut[(size_t)(2 * k + 1) * ld + r] = u1;
     }
     red[sl][rl] = dx;
     __syncthreads();
-    if (sl == 0 && r < n) X[r] += (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
+    if (sl == 0) dxp[(size_t)blockIdx.y * ld + r] = (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
+}
+__global__ __launch_bounds__(256) void k_gain_dx(KDims d, const double* __restrict__ dxp, double* __restrict__ X)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= d.n) return;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < GAIN_SLICES; u++) acc += dxp[(size_t)u * d.np + r];
+    X[r] += acc;
 }
 
 // k_traj: per-frame record (x, y, z, theta, P00, P01, P10, P11) of the robot = RobotPath.txt
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(256) void k_traj(KDims d, const double* __restrict_
     }
     block_sum<3>(v, red);
     if (threadIdx.x == 0) {
+        if (!traj) traj = fs->traj_base;
         if (traj) {
             double* t = traj + (size_t)8 * fs->frame;
             for (int e = 0; e < 4; e++) t[e] = X[n - 4 + e];
@@ -433,7 +438,10 @@ extern "C" {
 void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, double* X, double* S, double* sigR, double* Cmat,
                          FrameScalars* fs, const double* odo_seq, const double* odo_pair)
 {
-    hipLaunchKernelGGL(k_motion, dim3(1), dim3(1024), 0, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair);
+    const size_t lds = sizeof(double) * 4 * (size_t)(d.n + 16);
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) { hipFuncSetAttribute((const void*)k_motion, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+    hipLaunchKernelGGL(k_motion, dim3(1), dim3(1024), lds, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair);
 }
 void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
                           double* Z, double* DZ)
@@ -450,10 +458,12 @@ void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* 
 int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
-                       const FrameScalars* fs, double* X)
+                       const FrameScalars* fs, double* dxp, double* X)
 {
-    hipLaunchKernelGGL(k_gain, dim3(d.np / 64), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, X);
+    hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
+    hipLaunchKernelGGL(k_gain_dx, dim3((d.n + 255) / 256), dim3(256), 0, st, d, dxp, X);
 }
+int srukf_gain_part_doubles(int np) { return GAIN_SLICES * np; }
 void srukf_launch_traj(hipStream_t st, KDims d, const double* X, const double* S, FrameScalars* fs, double* traj, int advance)
 {
     hipLaunchKernelGGL(k_traj, dim3(1), dim3(256), 0, st, d, X, S, fs, traj, advance);
