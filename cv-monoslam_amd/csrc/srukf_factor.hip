@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
 //   Tt[kk][jj] = T[jj][kk],  T = (I + M^T)^{-1},  M[kk][jj] = L[kk][jj] = W[kk][jj]/D_kk (kk < jj):
 //   the forward substitution  w[jj] = g[jj] - sum_{kk<jj} L[kk][jj] w[kk]  of a panel column is
 //   w = T g, so the whole panel "TRSM" becomes one 32x32 by 32xcols MFMA product.
-struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; };
+struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; double rD[32]; };
 
 // Factor a 32x32 diagonal block held in MFMA C-layout registers (one wave):
 //   A[a][b] (a, b in {0,1}):  element (row 16a + lk + 4t, col 16b + lr) in register t of lane (lk, lr).
@@ -190,7 +190,7 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int t = 0; t < 4; t++) I[a][b][t] = (a == b && lk + 4 * t == lr) ? 1.0 : 0.0;
-    double Drow[2][4];          // pivot of each of this lane's 8 rows
+    double Drow[2][4], Rrow[2][4];     // pivot (and its reciprocal) of each of this lane's 8 rows
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const int a = s >> 2, t = s & 3;
@@ -200,17 +200,19 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
         const double m11 = readlane_d(st, 16 + 4 * t + 1), m12 = readlane_d(st, 16 + 4 * t + 2), m13 = readlane_d(st, 16 + 4 * t + 3);
         const double m22 = readlane_d(st, 32 + 4 * t + 2), m23 = readlane_d(st, 32 + 4 * t + 3);
         const double m33 = readlane_d(st, 48 + 4 * t + 3);
-        const double D0 = fmax(eps, fabs(m00));
-        const double l01 = m01 / D0, l02 = m02 / D0, l03 = m03 / D0;
+        // multipliers use one reciprocal per pivot (1/D by IEEE division, then products): <= 1 ulp from the
+        // reference's C/D quotients, and three divisions instead of six on the pivot chain
+        const double D0 = fmax(eps, fabs(m00)), r0 = 1.0 / D0;
+        const double l01 = m01 * r0, l02 = m02 * r0, l03 = m03 * r0;
         const double c11 = m11 - l01 * m01, c12 = m12 - l01 * m02, c13 = m13 - l01 * m03;
         double c22 = m22 - l02 * m02, c23 = m23 - l02 * m03, c33 = m33 - l03 * m03;
-        const double D1 = fmax(eps, fabs(c11));
-        const double l12 = c12 / D1, l13 = c13 / D1;
+        const double D1 = fmax(eps, fabs(c11)), r1 = 1.0 / D1;
+        const double l12 = c12 * r1, l13 = c13 * r1;
         c22 -= l12 * c12; c23 -= l12 * c13; c33 -= l13 * c13;
-        const double D2 = fmax(eps, fabs(c22));
-        const double l23 = c23 / D2;
+        const double D2 = fmax(eps, fabs(c22)), r2 = 1.0 / D2;
+        const double l23 = c23 * r2;
         c33 -= l23 * c23;
-        const double D3 = fmax(eps, fabs(c33));
+        const double D3 = fmax(eps, fabs(c33)), r3 = 1.0 / D3;
         // micro-inverse rows (unit lower triangular): row q = e_q - sum_{q''<q} l[q''][q] row q''
         const double t10 = -l01, t21 = -l12, t32 = -l23;
         const double t20 = -l02 - l12 * t10;
@@ -220,11 +222,11 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
         const int qi = lr - 4 * t;
         double aop = 0.0;
         if (qi >= 0 && qi < 4) {
-            const double r0 = (lk == 0) ? 1.0 : 0.0;
-            const double r1 = (lk == 0) ? t10 : ((lk == 1) ? 1.0 : 0.0);
-            const double r2 = (lk == 0) ? t20 : ((lk == 1) ? t21 : ((lk == 2) ? 1.0 : 0.0));
-            const double r3 = (lk == 0) ? t30 : ((lk == 1) ? t31 : ((lk == 2) ? t32 : 1.0));
-            aop = (qi == 0) ? r0 : ((qi == 1) ? r1 : ((qi == 2) ? r2 : r3));
+            const double w0 = (lk == 0) ? 1.0 : 0.0;
+            const double w1 = (lk == 0) ? t10 : ((lk == 1) ? 1.0 : 0.0);
+            const double w2 = (lk == 0) ? t20 : ((lk == 1) ? t21 : ((lk == 2) ? 1.0 : 0.0));
+            const double w3 = (lk == 0) ? t30 : ((lk == 1) ? t31 : ((lk == 2) ? t32 : 1.0));
+            aop = (qi == 0) ? w0 : ((qi == 1) ? w1 : ((qi == 2) ? w2 : w3));
         }
 #pragma unroll
         for (int b = 0; b < 2; b++) {
@@ -238,7 +240,8 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
             }
         }
         const double Dsel = (lk == 0) ? D0 : ((lk == 1) ? D1 : ((lk == 2) ? D2 : D3));
-        Drow[a][t] = Dsel;
+        const double rsel = (lk == 0) ? r0 : ((lk == 1) ? r1 : ((lk == 2) ? r2 : r3));
+        Drow[a][t] = Dsel; Rrow[a][t] = rsel;
         // 3. rank-4 update of the rows below the strip
 #pragma unroll
         for (int ap = 0; ap < 2; ap++) {
@@ -246,7 +249,7 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
             if (16 * ap + 15 <= 4 * s + 3) continue;       // no rows of this tile below the strip
             // multipliers L[k][r] = W[k][r] / D_k for r = 16ap + lr > 4s+3 (rows already final keep their values)
             const double wkr = A[a][ap][t];
-            const double lop = (16 * ap + lr > 4 * s + 3) ? -(wkr / Dsel) : 0.0;
+            const double lop = (16 * ap + lr > 4 * s + 3) ? -(wkr * rsel) : 0.0;
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 if (b >= ap) A[ap][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, A[a][b][t], A[ap][b], 0, 0, 0);
@@ -260,13 +263,13 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int r = 16 * a + lk + 4 * t;
-            const double dj = Drow[a][t], sq = sqrt(dj);
+            const double dj = Drow[a][t], sq = sqrt(dj), isq = sq * Rrow[a][t];
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 const int c = 16 * b + lr;
                 if (b >= a) {
-                    if (c == r) { out->D[r] = dj; out->sq[r] = sq; Dall[j0 + r] = dj; }
-                    if (c >= r && j0 + r < n && j0 + c < n) Sout[(size_t)(j0 + r) * ld + j0 + c] = (c == r) ? sq : sq * (A[a][b][t] / dj);
+                    if (c == r) { out->D[r] = dj; out->sq[r] = isq; out->rD[r] = Rrow[a][t]; Dall[j0 + r] = dj; }
+                    if (c >= r && j0 + r < n && j0 + c < n) Sout[(size_t)(j0 + r) * ld + j0 + c] = (c == r) ? sq : isq * A[a][b][t];
                 }
                 out->Tt[c * 32 + r] = (b <= a) ? I[a][b][t] : 0.0;       // Tt[kk = c][jj = r] = T[r][c]
             }
@@ -304,42 +307,14 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
     if (blockIdx.x < blockIdx.y) return;
     __shared__ double Lr[32][80];      // stride 80 doubles: lanes l / l+16 land on opposite bank halves
     __shared__ double Wc[32][80];
-    __shared__ double Dd[32], Sq[32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     const int base = j0 + 32;
     const int R0 = base + 64 * blockIdx.y, C0 = base + 64 * blockIdx.x;
     const bool diagblk = blockIdx.x == blockIdx.y;
-    if (tid < 32) { Dd[tid] = cur->D[tid]; Sq[tid] = cur->sq[tid]; }
-    __syncthreads();
 
-    // 1. panel slabs by MFMA: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
-    {
-        const int which = wv >> 1, half = wv & 1;
-        const int n0 = (which ? C0 : R0) + 32 * half;
-        if (n0 < ld && !(diagblk && which == 1)) {
-            d4 acc[2][2];
-            zero_acc(acc);
-            tile32_tn<false>(acc, cur->Tt, 32, G + (size_t)j0 * ld, ld, 0, n0, 0, 32, lane);
-            const bool write_s = (blockIdx.y == 0) && (which == 1 || diagblk);
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
-                        const double w = acc[a][b][t];
-                        const double l = w / Dd[jj];
-                        if (which == 0) { Lr[jj][cc] = l; if (diagblk) Wc[jj][cc] = w; }
-                        else Wc[jj][cc] = w;
-                        if (write_s && j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = Sq[jj] * l;
-                    }
-        }
-    }
-    __syncthreads();
-
-    // 2. tile update from LDS fragments
+    // issue every global read this wave needs up front: its output tile (for step 2) and the
+    // pivots of its eight panel rows; their latency hides behind the slab MFMAs
     const int m0 = R0 + 32 * (wv >> 1), c0 = C0 + 32 * (wv & 1);
     const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
     d4 acc[2][2];
@@ -352,6 +327,40 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
 #pragma unroll
                 for (int t = 0; t < 4; t++)
                     acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+    }
+    double dr[2][4], sqr[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) { dr[a][t] = cur->rD[16 * a + lk + 4 * t]; sqr[a][t] = cur->sq[16 * a + lk + 4 * t]; }   // 1/D_j, sqrt(D_j)/D_j
+
+    // 1. panel slabs by MFMA: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
+    {
+        const int which = wv >> 1, half = wv & 1;
+        const int n0 = (which ? C0 : R0) + 32 * half;
+        if (n0 < ld && !(diagblk && which == 1)) {
+            d4 sl[2][2];
+            zero_acc(sl);
+            tile32_tn<false>(sl, cur->Tt, 32, G + (size_t)j0 * ld, ld, 0, n0, 0, 32, lane);
+            const bool write_s = (blockIdx.y == 0) && (which == 1 || diagblk);
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
+                        const double w = sl[a][b][t];
+                        if (which == 0) { Lr[jj][cc] = w * dr[a][t]; if (diagblk) Wc[jj][cc] = w; }   // L = W * (1/D)
+                        else Wc[jj][cc] = w;
+                        if (write_s && j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = w * sqr[a][t];   // S = W / sqrt(D)
+                    }
+        }
+    }
+    __syncthreads();
+
+    // 2. tile update from LDS fragments
+    if (live) {
         const int ro = m0 - R0, co = c0 - C0;
 #pragma unroll
         for (int k = 0; k < 32; k += 4) {
