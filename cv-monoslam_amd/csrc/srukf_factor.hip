@@ -65,24 +65,56 @@ __device__ __forceinline__ void zero_acc(d4 (&acc)[2][2])
         for (int b = 0; b < 2; b++) acc[a][b] = (d4){0, 0, 0, 0};
 }
 
+// Split-K helper: the four waves of a workgroup share ONE 32x32 output tile, each contracting a
+// quarter of the K range (in groups of 16); partial tiles are summed through LDS in fixed wave
+// order (deterministic) and wave 0 owns the result.  Balances the triangular K ranges (S is upper
+// triangular, so K grows with the tile's row index) and quadruples the waves in flight.
+__device__ __forceinline__ void splitk_reduce(d4 (&acc)[2][2], double (*red)[64][17], int wv, int lane)
+{
+    if (wv > 0) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) red[wv - 1][lane][(a * 2 + b) * 4 + t] = acc[a][b][t];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] += red[u][lane][(a * 2 + b) * 4 + t];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_pxy: landmark rows of all cross covariances in one contraction
 //   Ut[c][r] = sum_{i <= r, i < n} DZ[i][c] * S[i][r]          c < 2N (mp padded), r < np
 // = (S^T DZ)^T, i.e. the L rank-1 updates per landmark of calculateOneFeatureCrossCovariance
 // (SLAM.cpp:2028-2037) for ALL landmarks at once; the wi*gamma scale and the robot rows are
 // applied in k_gain.  S upper triangular => K range truncated at r0+32.
-// grid = (np/64, mp/64), block = 256 (4 waves, 2x2 tiles of 32x32).
+// grid = (np/32, mp/32): one 32x32 tile per workgroup, 4-way split-K.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__ DZ, const double* __restrict__ S,
                                              double* __restrict__ Ut)
 {
+    __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 64 + (wv >> 1) * 32;    // c
-    const int n0 = blockIdx.x * 64 + (wv & 1) * 32;     // r
+    const int m0 = blockIdx.y * 32;    // c
+    const int n0 = blockIdx.x * 32;    // r
     d4 acc[2][2];
     zero_acc(acc);
     int ke = n0 + 32; if (ke > d.np) ke = d.np;
-    tile32_tn<false>(acc, DZ, d.mp, S, d.np, m0, n0, 0, ke, lane);
+    const int ng = ke >> 4;
+    const int g0 = (ng * wv) >> 2, g1 = (ng * (wv + 1)) >> 2;
+    tile32_tn<false>(acc, DZ, d.mp, S, d.np, m0, n0, g0 << 4, g1 << 4, lane);
+    splitk_reduce(acc, red, wv, lane);
+    if (wv != 0) return;
     const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -98,25 +130,28 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // measurement columns; rows [ub, ue) of Ut select the columns that are downdated — all of them
 // in BATCHED mode, a single one in SEQUENTIAL mode).  Also accumulates gamma = max diag(G) and
 // xi = max(0, max offdiag(G)) for the GMW bound beta^2 (SLAM.cpp:2204-2211).
-// grid = (np/64, np/64), block = 256; blocks strictly below the diagonal exit.
+// grid = (np/32, np/32): one 32x32 tile per workgroup (tiles below the diagonal exit), 4-way
+// split-K over the concatenated K range [S rows 0..r0+32) ++ [Ut rows).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
                                               int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs)
 {
     if (blockIdx.x < blockIdx.y) return;
+    __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 64 + (wv >> 1) * 32;    // row r
-    const int n0 = blockIdx.x * 64 + (wv & 1) * 32;     // col c
-    if (n0 + 32 <= m0) return;                           // wave tile strictly below the diagonal
+    const int m0 = blockIdx.y * 32;    // row r
+    const int n0 = blockIdx.x * 32;    // col c
     d4 acc[2][2];
     zero_acc(acc);
     int ke = m0 + 32; if (ke > d.np) ke = d.np;          // S[k][r] = 0 for k > r
-    tile32_tn<false>(acc, S, d.np, S, d.np, m0, n0, 0, ke, lane);
     const int u0 = ub & ~3, u1 = (ue + 3) & ~3;
-    if (ub == u0 && ue == u1) {
-        tile32_tn<true>(acc, Ut, d.np, Ut, d.np, m0, n0, u0, u1, lane);
-    } else {
-        // partial K group (single-column downdate): mask rows outside [ub, ue)
+    const bool full = (ub == u0) && (ue == u1) && (((u1 - u0) & 15) == 0);
+    const int ngs = ke >> 4, ngu = full ? ((u1 - u0) >> 4) : 0, ng = ngs + ngu;
+    const int g0 = (ng * wv) >> 2, g1 = (ng * (wv + 1)) >> 2;
+    if (g0 < ngs) tile32_tn<false>(acc, S, d.np, S, d.np, m0, n0, g0 << 4, min(g1, ngs) << 4, lane);
+    if (g1 > ngs) tile32_tn<true>(acc, Ut, d.np, Ut, d.np, m0, n0, u0 + ((max(g0, ngs) - ngs) << 4), u0 + ((g1 - ngs) << 4), lane);
+    if (!full && wv == 0) {
+        // partial K group (single-column downdate of SEQUENTIAL mode): mask rows outside [ub, ue)
         const int lr = lane & 15, lk = lane >> 4;
         for (int k = u0; k < u1; k += 4) {
             const int kk = k + lk;
@@ -129,6 +164,8 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+    splitk_reduce(acc, red, wv, lane);
+    if (wv != 0) return;
     const int lr = lane & 15, lk = lane >> 4;
     double gmax = 0.0, xmax = 0.0;
 #pragma unroll
@@ -465,11 +502,11 @@ __global__ __launch_bounds__(256) void k_gmw_stats(int n, int ld, const double* 
 extern "C" {
 void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S, double* Ut)
 {
-    hipLaunchKernelGGL(k_pxy, dim3(d.np / 64, d.mp / 64), dim3(256), 0, st, d, DZ, S, Ut);
+    hipLaunchKernelGGL(k_pxy, dim3(d.np / 32, d.mp / 32), dim3(256), 0, st, d, DZ, S, Ut);
 }
 void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs)
 {
-    hipLaunchKernelGGL(k_syrk, dim3(d.np / 64, d.np / 64), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs);
+    hipLaunchKernelGGL(k_syrk, dim3(d.np / 32, d.np / 32), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs);
 }
 // whole fast-path factorisation: first diagonal block, then one launch per panel
 void srukf_launch_gmw_first(hipStream_t st, int n, int ld, double eps, const double* G, void* pan0, double* D, double* Sout)
