@@ -205,6 +205,12 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
 //   w = T g, so the whole panel "TRSM" becomes one 32x32 by 32xcols MFMA product.
 struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; double rD[32]; };
 
+#ifdef SRUKF_STAMPS   // diagnostic build only (scripts/mb): cycle stamps of block (0,0) wave 0
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); srukf_stamps[i] = t_; } } while (0)
+__device__ unsigned long long srukf_stamps[16];
+#else
+#define STAMP(i)
+#endif
 // Factor a 32x32 diagonal block held in MFMA C-layout registers (one wave):
 //   A[a][b] (a, b in {0,1}):  element (row 16a + lk + 4t, col 16b + lr) in register t of lane (lk, lr).
 // Works on 4-row micro-panels (rows 4s..4s+3 = register t = s&3 of tile row a = s>>2 of EVERY lane):
@@ -227,16 +233,18 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int t = 0; t < 4; t++) I[a][b][t] = (a == b && lk + 4 * t == lr) ? 1.0 : 0.0;
-    double Drow[2][4], Rrow[2][4];     // pivot (and its reciprocal) of each of this lane's 8 rows
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const int a = s >> 2, t = s & 3;
+        if (s == 2) STAMP(11);
+        if (s == 3) STAMP(9);
         // 1. 4x4 diagonal micro-block: element (4s+q, 4s+q') sits in lane 16q + 4t + q' of A[a][a][t]
         const double st = A[a][a][t];
         const double m00 = readlane_d(st, 0 + 4 * t + 0), m01 = readlane_d(st, 0 + 4 * t + 1), m02 = readlane_d(st, 0 + 4 * t + 2), m03 = readlane_d(st, 0 + 4 * t + 3);
         const double m11 = readlane_d(st, 16 + 4 * t + 1), m12 = readlane_d(st, 16 + 4 * t + 2), m13 = readlane_d(st, 16 + 4 * t + 3);
         const double m22 = readlane_d(st, 32 + 4 * t + 2), m23 = readlane_d(st, 32 + 4 * t + 3);
         const double m33 = readlane_d(st, 48 + 4 * t + 3);
+        if (s == 2) STAMP(6);
         // multipliers use one reciprocal per pivot (1/D by IEEE division, then products): <= 1 ulp from the
         // reference's C/D quotients, and three divisions instead of six on the pivot chain
         const double D0 = fmax(eps, fabs(m00)), r0 = 1.0 / D0;
@@ -250,35 +258,30 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
         const double l23 = c23 * r2;
         c33 -= l23 * c23;
         const double D3 = fmax(eps, fabs(c33)), r3 = 1.0 / D3;
+        if (s == 2) STAMP(7);
         // micro-inverse rows (unit lower triangular): row q = e_q - sum_{q''<q} l[q''][q] row q''
         const double t10 = -l01, t21 = -l12, t32 = -l23;
         const double t20 = -l02 - l12 * t10;
         const double t31 = -l13 - l23 * t21;
         const double t30 = -l03 - l13 * t10 - l23 * t20;
-        // 2. strip apply: A operand lane (lk = k, lr = i): Tm[i - 4t][k] for i in [4t, 4t+4), else 0
+        // 2. strip apply: D = (Tm - I) * strip + tile  (the tile's strip rows come through the C operand, so
+        //    nothing has to be zeroed).  A operand lane (lk = k, lr = i): (Tm - I)[i - 4t][k] for i in [4t, 4t+4)
         const int qi = lr - 4 * t;
         double aop = 0.0;
-        if (qi >= 0 && qi < 4) {
-            const double w0 = (lk == 0) ? 1.0 : 0.0;
-            const double w1 = (lk == 0) ? t10 : ((lk == 1) ? 1.0 : 0.0);
-            const double w2 = (lk == 0) ? t20 : ((lk == 1) ? t21 : ((lk == 2) ? 1.0 : 0.0));
-            const double w3 = (lk == 0) ? t30 : ((lk == 1) ? t31 : ((lk == 2) ? t32 : 1.0));
-            aop = (qi == 0) ? w0 : ((qi == 1) ? w1 : ((qi == 2) ? w2 : w3));
+        if (qi >= 1 && qi < 4) {
+            const double w1 = (lk == 0) ? t10 : 0.0;
+            const double w2 = (lk == 0) ? t20 : ((lk == 1) ? t21 : 0.0);
+            const double w3 = (lk == 0) ? t30 : ((lk == 1) ? t31 : ((lk == 2) ? t32 : 0.0));
+            aop = (qi == 1) ? w1 : ((qi == 2) ? w2 : w3);
         }
 #pragma unroll
         for (int b = 0; b < 2; b++) {
-            if (b >= a) {                                  // A part: upper tiles only
-                d4 c = A[a][b]; const double bop = c[t]; c[t] = 0.0;
-                A[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, c, 0, 0, 0);
-            }
-            if (b <= a) {                                  // identity part: columns <= current rows only
-                d4 c = I[a][b]; const double bop = c[t]; c[t] = 0.0;
-                I[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, c, 0, 0, 0);
-            }
+            if (b >= a) A[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, A[a][b][t], A[a][b], 0, 0, 0);   // upper tiles only
+            if (b <= a) I[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, I[a][b][t], I[a][b], 0, 0, 0);   // columns <= current rows only
         }
+        if (s == 2) STAMP(8);
         const double Dsel = (lk == 0) ? D0 : ((lk == 1) ? D1 : ((lk == 2) ? D2 : D3));
         const double rsel = (lk == 0) ? r0 : ((lk == 1) ? r1 : ((lk == 2) ? r2 : r3));
-        Drow[a][t] = Dsel; Rrow[a][t] = rsel;
         // 3. rank-4 update of the rows below the strip
 #pragma unroll
         for (int ap = 0; ap < 2; ap++) {
@@ -293,24 +296,22 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
                 if (b <= a) I[ap][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, I[a][b][t], I[ap][b], 0, 0, 0);
             }
         }
-    }
-    // outputs
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int r = 16 * a + lk + 4 * t;
-            const double dj = Drow[a][t], sq = sqrt(dj), isq = sq * Rrow[a][t];
+        // 4. rows 4s..4s+3 are final: write their outputs now, in the shadow of the MFMAs just issued
+        {
+            const int r = 4 * s + lk;
+            const double sq = sqrt(Dsel), isq = sq * rsel;
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 const int c = 16 * b + lr;
                 if (b >= a) {
-                    if (c == r) { out->D[r] = dj; out->sq[r] = isq; out->rD[r] = Rrow[a][t]; Dall[j0 + r] = dj; }
+                    if (c == r) { out->D[r] = Dsel; out->sq[r] = isq; out->rD[r] = rsel; Dall[j0 + r] = Dsel; }
                     if (c >= r && j0 + r < n && j0 + c < n) Sout[(size_t)(j0 + r) * ld + j0 + c] = (c == r) ? sq : isq * A[a][b][t];
                 }
-                out->Tt[c * 32 + r] = (b <= a) ? I[a][b][t] : 0.0;       // Tt[kk = c][jj = r] = T[r][c]
+                if (b <= a) out->Tt[c * 32 + r] = I[a][b][t];            // Tt[kk = c][jj = r] = T[r][c]; entries with c > r stay 0
             }
         }
+    }
+    STAMP(10);
 }
 
 // k_gmw_first: factor the first diagonal block (j0 = 0).  One wave.
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
                                                   double* __restrict__ Dall, double* __restrict__ Sout)
 {
     if (blockIdx.x < blockIdx.y) return;
+    STAMP(0);
     __shared__ double Lr[32][80];      // stride 80 doubles: lanes l / l+16 land on opposite bank halves
     __shared__ double Wc[32][80];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
 #pragma unroll
         for (int t = 0; t < 4; t++) { dr[a][t] = cur->rD[16 * a + lk + 4 * t]; sqr[a][t] = cur->sq[16 * a + lk + 4 * t]; }   // 1/D_j, sqrt(D_j)/D_j
 
+    STAMP(1);
     // 1. panel slabs by MFMA: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
     {
         const int which = wv >> 1, half = wv & 1;
@@ -394,7 +397,9 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
                     }
         }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
 
     // 2. tile update from LDS fragments
     if (live) {
@@ -417,8 +422,10 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
                     G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
     }
 
+    STAMP(4);
     // 4. next diagonal block: tile (base, base) of block (0,0), wave 0 — already in C-layout registers
     if (blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) gmw_factor_block(acc, eps, lane, n, ld, base, nxt, Dall, Sout);
+    STAMP(5);
 }
 
 // k_gmw_check: was the reference's third pivot candidate theta_j^2/beta^2 ever the largest?
