@@ -39,6 +39,20 @@ def w_alg(N, M=None):
     return 2.0 * n * n * M + n ** 3 / 3.0 + 2.0 * M * n * n + n ** 3 / 3.0 + 60.0 * L * N
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
+    rocprofv3 --pmc passes, gfx950 correction applied) recorded in the newest
+    profiles/*_pmc_traffic.json.  Counters cannot be read from inside this process, so the value
+    comes from the committed profile of this same workload; None if there is no profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    k = d.get("kernels", {}).get(kernel)
+    return (k["traffic_bytes"] if k else None), os.path.relpath(files[-1], ROOT)
+
+
 def dist_env():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,7 +233,7 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
         roof["kernel"] = dom
         roof["avg_launch_us"] = avg_s * 1e6
         roof["launches_per_frame"] = d["launches"] / PF

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -256,6 +257,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     }
     srukf_ctx* c = new srukf_ctx();
     c->device = device; c->p = *p;
+    { const char* e = getenv("SRUKF_NO_GRAPH"); if (e && e[0] == '1') c->use_graph = false; }   // eager launches (profilers)
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_n, 0, sizeof c->prof_n);
     memset(c->prof_flops, 0, sizeof c->prof_flops); memset(c->prof_bytes, 0, sizeof c->prof_bytes);
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
