@@ -16,17 +16,17 @@ void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const doub
 void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
-                       const double*, const int*, const int*, const FrameScalars*, double*, double*);
+                       const double*, const int*, const int*, FrameScalars*, double*, double*);
 int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*);
-void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*);
+void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, double, void*, double*, double*);
 void srukf_launch_gmw_first(hipStream_t, int, int, double, const double*, void*, double*, double*);
 void srukf_launch_gmw_step(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
 int srukf_gmw_panel_bytes(void);
-void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*);
+void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
 }
@@ -51,7 +51,7 @@ static thread_local std::string g_create_error;
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_XUPD, KC_SYRK, KC_GMW_PANEL, KC_GMW_TRAIL, KC_GMW_CHECK,
               KC_GMW_COL, KC_MISC, KC_COUNT };
 static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_state_update", "k_syrk",
-                                             "k_gmw_first", "k_gmw_step", "k_gmw_check", "k_gmw_col", "misc" };
+                                             "k_gmw_first(standalone)", "k_gmw_step", "k_gmw_check", "k_gmw_col", "misc" };
 
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
@@ -162,26 +162,25 @@ static void seq_predict_measurement(srukf_ctx* c)
         srukf_launch_meas_stats(c->stream, d, c->w, c->X, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR);
     }
 }
-// one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path
-static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup)
+// one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path.
+// need_reset: the gamma/xi accumulators were not just cleared by k_gain_dx (SEQUENTIAL mode, fallbacks).
+// frame_tail: the check kernel also records the trajectory row and advances the staged frame counter.
+static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
 {
     const KDims& d = c->d;
     const int np = d.np, n = d.n;
-    {
+    if (need_reset || slow) {
         ProfScope ps(c, KC_MISC, 0, 8.0 * np);
         hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
     }
     {
         const double nn = n;
         ProfScope ps(c, KC_SYRK, nn * nn * nn / 3.0 + nn * nn * (ue - ub), 8.0 * (nn * nn + (double)(ue - ub) * nn));
-        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs);
+        // the block that owns tile (0,0) also factors it = first diagonal block of the GMW (fast path)
+        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->p.epsilon, slow ? nullptr : c->pan[0], c->D, c->S);
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
     if (!slow) {
-        {
-            ProfScope ps(c, KC_GMW_PANEL, 32.0 * 32.0 * 32.0 / 3.0, 8.0 * 32.0 * 32.0);
-            srukf_launch_gmw_first(c->stream, n, np, c->p.epsilon, c->G, c->pan[0], c->D, c->S);
-        }
         int pb = 0;
         for (int j0 = 0; j0 + SRUKF_NB < np; j0 += SRUKF_NB, pb ^= 1) {
             const double r2 = np - j0 - 32;
@@ -190,11 +189,12 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             srukf_launch_gmw_step(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb], c->pan[pb ^ 1], c->D, c->S);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
-        srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs);
+        srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs, c->X, frame_tail ? 1 : 0);
     } else {
         ProfScope ps(c, KC_GMW_COL, (double)n * n * n / 3.0, 8.0 * (double)n * n * n / 3.0);
         for (int j = 0; j < n; j++)
             srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+        if (frame_tail) srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     }
 }
 static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev)
@@ -434,7 +434,7 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     if (!c || !P) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs);
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->p.epsilon, nullptr, c->D, c->S);
     HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) { const double v = c->hstage[(size_t)r * np + cc]; P[(size_t)r * n + cc] = v; P[(size_t)cc * n + r] = v; }
@@ -504,7 +504,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     seq_gain(c, c->zcur, c->mcur);
     // visibility is needed on the host only to skip no-op refactors in SEQUENTIAL mode
     if (mode == SRUKF_UPDATE_BATCHED) {
-        seq_refactor(c, 0, d.mp, false, true);
+        seq_refactor(c, 0, d.mp, false, true, false, false);
         int rc = read_fs(c); if (rc) return rc;
         if (c->hfs->clamp_rows > 0) {
             // the reference's theta clamp would have been active: redo this refactor on the exact path
@@ -523,7 +523,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
             if (!matched[k]) continue;                                   // SLAM.cpp:2068
             for (int col = 0; col < 2; col++) {                          // SLAM.cpp:2116
                 const int m = 2 * k + col;
-                seq_refactor(c, m, m + 1, false, true);
+                seq_refactor(c, m, m + 1, false, true, true, false);
                 int rc = read_fs(c); if (rc) return rc;
                 if (c->hfs->clamp_rows > 0) {
                     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
@@ -573,9 +573,7 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
         seq_predict_motion(c, nullptr);
         seq_predict_measurement(c);
         seq_gain(c, nullptr, nullptr);
-        seq_refactor(c, 0, d.mp, false, false);
-        ProfScope ps(c, KC_MISC, 0, 0);
-        srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
+        seq_refactor(c, 0, d.mp, false, false, false, true);
     };
     if (c->use_graph && !c->profiling) {
         // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
@@ -689,7 +687,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
             srukf_launch_gmw_step(st, n, np, j0, epsilon, dG, pan[pb], pan[pb ^ 1], dD, dS);
         hipDeviceSynchronize();
         hipFree(pan[0]); hipFree(pan[1]);
-        srukf_launch_gmw_check(st, n, np, dD, dS, dFs);
+        srukf_launch_gmw_check(st, n, np, dD, dS, dFs, nullptr, 0);
         hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
         if (clamp_hit) *clamp_hit = fs.clamp_rows;
         if (fs.clamp_rows > 0) force_slow = 2;   // same contract as srukf_update: redo on the exact path

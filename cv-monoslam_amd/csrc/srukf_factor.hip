@@ -16,6 +16,10 @@ __device__ __forceinline__ double readlane_d(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+struct GmwPanel;
+__device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int lane, int n, int ld, int j0,
+                                                 GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout);
+
 // one wave: 32x32 output tile at (m0, n0), K range [kb, ke) — (ke - kb) a multiple of 16 —, accumulate.
 // Software-pipelined: the 16 fragment loads of the next group of four k-steps are in flight while the
 // 16 MFMAs of the current group issue (hipcc otherwise waits for each group's loads before its MFMAs).
@@ -134,7 +138,8 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // split-K over the concatenated K range [S rows 0..r0+32) ++ [Ut rows).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
-                                              int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs)
+                                              int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
+                                              double eps, GmwPanel* __restrict__ pan0, double* __restrict__ Dall, double* __restrict__ Sout)
 {
     if (blockIdx.x < blockIdx.y) return;
     __shared__ double red[3][64][17];
@@ -186,6 +191,9 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
         if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
         if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
     }
+    // tile (0,0) is the first diagonal block of the factorisation and has the shortest K range: factor it
+    // here (pan0 != null), hidden behind the longer tiles, instead of a launch of its own
+    if (pan0 && blockIdx.x == 0 && blockIdx.y == 0) gmw_factor_block(acc, eps, lane, d.n, d.np, 0, pan0, Dall, Sout);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -433,10 +441,31 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
 // beta^2 = max(gamma, xi/nu, 1e-15), nu = max(1, sqrt(n^2-1))   (SLAM.cpp:2204-2211, 2264-2285).
 // One workgroup per pivot row.
 __global__ __launch_bounds__(256) void k_gmw_check(int n, int ld, const double* __restrict__ D, const double* __restrict__ S,
-                                                   FrameScalars* __restrict__ fs)
+                                                   FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj)
 {
     __shared__ double red[4];
     const int j = blockIdx.x;
+    if (j == n) {
+        // extra block: per-frame record (x, y, z, theta, P00, P01, P10, P11) = RobotPath.txt columns
+        // (SLAM.cpp:3549-3556), P = S^T S robot x/y block (2404); advances the staged frame counter
+        __shared__ double r3[16 * 3];
+        double v[3] = { 0, 0, 0 };
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const double a = S[(size_t)k * ld + (n - 4)], b = S[(size_t)k * ld + (n - 3)];
+            v[0] += a * a; v[1] += a * b; v[2] += b * b;
+        }
+        block_sum<3>(v, r3);
+        if (threadIdx.x == 0 && do_traj) {
+            double* traj = fs->traj_base;
+            if (traj) {
+                double* t = traj + (size_t)8 * fs->frame;
+                for (int e = 0; e < 4; e++) t[e] = X[n - 4 + e];
+                t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
+            }
+            fs->frame += 1;
+        }
+        return;
+    }
     double mx = 0.0;
     for (int i = j + 1 + threadIdx.x; i < n; i += 256) mx = fmax(mx, fabs(S[(size_t)j * ld + i]));
     mx = wave_max(mx);
@@ -511,9 +540,10 @@ void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S
 {
     hipLaunchKernelGGL(k_pxy, dim3(d.np / 32, d.mp / 32), dim3(256), 0, st, d, DZ, S, Ut);
 }
-void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs)
+void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs,
+                       double eps, void* pan0, double* Dall, double* Sout)
 {
-    hipLaunchKernelGGL(k_syrk, dim3(d.np / 32, d.np / 32), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs);
+    hipLaunchKernelGGL(k_syrk, dim3(d.np / 32, d.np / 32), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, eps, (GmwPanel*)pan0, Dall, Sout);
 }
 // whole fast-path factorisation: first diagonal block, then one launch per panel
 void srukf_launch_gmw_first(hipStream_t st, int n, int ld, double eps, const double* G, void* pan0, double* D, double* Sout)
@@ -528,9 +558,9 @@ void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, do
     hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, eps, G, (const GmwPanel*)cur, (GmwPanel*)nxt, D, Sout);
 }
 int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel); }
-void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs)
+void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj)
 {
-    hipLaunchKernelGGL(k_gmw_check, dim3(n), dim3(256), 0, st, n, ld, D, S, fs);
+    hipLaunchKernelGGL(k_gmw_check, dim3(n + (do_traj ? 1 : 0)), dim3(256), 0, st, n, ld, D, S, fs, X, do_traj);
 }
 void srukf_launch_gmw_col(hipStream_t st, int n, int ld, int j, double eps, const double* G, double* Wf, double* D,
                           unsigned long long* theta_bits, FrameScalars* fs, double* Sout)

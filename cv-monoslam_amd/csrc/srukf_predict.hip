@@ -381,9 +381,10 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     __syncthreads();
     if (sl == 0) dxp[(size_t)blockIdx.y * ld + r] = (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
 }
-__global__ __launch_bounds__(256) void k_gain_dx(KDims d, const double* __restrict__ dxp, double* __restrict__ X)
+__global__ __launch_bounds__(256) void k_gain_dx(KDims d, const double* __restrict__ dxp, double* __restrict__ X, FrameScalars* __restrict__ fs)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }      // gamma / xi accumulators of the k_syrk that follows
     if (r >= d.n) return;
     double acc = 0.0;
 #pragma unroll
@@ -458,10 +459,10 @@ void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* 
 int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
-                       const FrameScalars* fs, double* dxp, double* X)
+                       FrameScalars* fs, double* dxp, double* X)
 {
     hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
-    hipLaunchKernelGGL(k_gain_dx, dim3((d.n + 255) / 256), dim3(256), 0, st, d, dxp, X);
+    hipLaunchKernelGGL(k_gain_dx, dim3((d.n + 255) / 256), dim3(256), 0, st, d, dxp, X, fs);
 }
 int srukf_gain_part_doubles(int np) { return GAIN_SLICES * np; }
 void srukf_launch_traj(hipStream_t st, KDims d, const double* X, const double* S, FrameScalars* fs, double* traj, int advance)
