@@ -213,12 +213,6 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
 //   w = T g, so the whole panel "TRSM" becomes one 32x32 by 32xcols MFMA product.
 struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; double rD[32]; };
 
-#ifdef SRUKF_STAMPS   // diagnostic build only (scripts/mb): cycle stamps of block (0,0) wave 0
-#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); srukf_stamps[i] = t_; } } while (0)
-__device__ unsigned long long srukf_stamps[16];
-#else
-#define STAMP(i)
-#endif
 // Factor a 32x32 diagonal block held in MFMA C-layout registers (one wave):
 //   A[a][b] (a, b in {0,1}):  element (row 16a + lk + 4t, col 16b + lr) in register t of lane (lk, lr).
 // Works on 4-row micro-panels (rows 4s..4s+3 = register t = s&3 of tile row a = s>>2 of EVERY lane):

@@ -10,24 +10,29 @@
 //   restricted to rows n-4..n-1 and the control-noise rows, passSigmaThroughMotionFunction
 //   1476-1532); weighted mean -> X[n-4:n] (1526-1531);
 //   QrAndCholeskyForMotion (1539-1555) in its structured form: the QR matrix
-//   A = wi_sr*(sigma_{i+1}-sigma_0)^T has A[:, :n-4] = (1/sqrt2) [E; -E] S[:n-4,:n-4]... so
-//   R11 = S11 (unchanged), R12[i] = wi_sr/sqrt2 * (dev+_i - dev-_i), and R22 is the R factor of
-//   the (n-4+18) x 4 matrix of residual rows wi_sr/sqrt2 * (dev+_i + dev-_i) (i < n-4) and
-//   wi_sr*dev+-_i (n-4 <= i < Na).  Only the last four columns of S are rewritten: O(n) instead
-//   of the reference's 2n^2(2Na - n/3) flop Householder QR (DESIGN.md "Motion step").
-// One workgroup (1024 threads): L <= 6019 sigma columns, everything else is reductions.
+//   A = wi_sr*(sigma_{i+1}-sigma_0)^T has A[:, :n-4] = (1/sqrt2) [E; -E] S[:n-4,:n-4], so
+//   R11 = S11 (unchanged), R12[i] = wi_sr/sqrt2 * (dev+_i - dev-_i), and R22^T R22 = C^T C with C the
+//   (n+14) x 4 matrix of residual rows wi_sr/sqrt2 * (dev+_i + dev-_i) (i < n-4) and
+//   wi_sr*dev+-_i (n-4 <= i < Na).  R22 = chol(C^T C): a 4x4 Gram matrix from ONE block reduction
+//   (backward stable for P = S^T S, which is what the filter consumes; its rows equal the
+//   Householder R's up to sign).  Only the last four columns of S are rewritten: O(n) instead of
+//   the reference's 2n^2(2Na - n/3) flop Householder QR (DESIGN.md "Motion step").
+// One workgroup of 512 threads, one pass over the sigma directions, ONE block reduction.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_motion(KDims d, KWeights w, srukf_params p,
-                                                 double* __restrict__ X, double* __restrict__ S,
-                                                 double* __restrict__ sigR, double* __restrict__ Cmat,
-                                                 FrameScalars* __restrict__ fs,
-                                                 const double* __restrict__ odo_seq, const double* odo_pair)
+__global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_params p,
+                                                double* __restrict__ X, double* __restrict__ S,
+                                                double* __restrict__ sigR, double* __restrict__ Cmat,
+                                                FrameScalars* __restrict__ fs,
+                                                const double* __restrict__ odo_seq, const double* odo_pair)
 {
-    __shared__ double red[16 * 4];
+    __shared__ double red[16];
     __shared__ double sh[24];
+    __shared__ double part[14][512];
+    __shared__ double part2[14][33];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n = d.n, Na = d.Na, L = d.L, ld = d.np;
 
+    STAMP(0);
     // ---- control (SLAM.cpp:1444-1458) ----
     if (tid == 0) {
         const double* o = odo_pair ? odo_pair : (odo_seq + 3 * fs->frame);
@@ -40,123 +45,143 @@ __global__ __launch_bounds__(1024) void k_motion(KDims d, KWeights w, srukf_para
         sh[4] = p.a3 * trans * trans + p.a4 * rot1 * rot1 + p.a4 * rot2 * rot2;
         sh[5] = p.a1 * rot2 * rot2 + p.a2 * trans * trans;
         for (int q = 0; q < 4; q++) sh[6 + q] = X[n - 4 + q];
+        sh[10] = cos(rot2); sh[11] = sin(rot2);
         for (int q = 0; q < 3; q++) { fs->Ut[q] = sh[q]; fs->Mt[q] = sh[3 + q]; }
         for (int q = 0; q < 4; q++) fs->Xr0[q] = sh[6 + q];
-        fs->gmax_bits = 0ull; fs->ximax_bits = 0ull;
     }
     __syncthreads();
     const double rot1 = sh[0], trans = sh[1], rot2 = sh[2];
     const double xr[4] = { sh[6], sh[7], sh[8], sh[9] };
+    const double crot2 = sh[10], srot2 = sh[11];
 
-    // ---- sigma robot rows through the motion model ----
-    double acc[4] = { 0, 0, 0, 0 };
-    for (int c = tid; c < L; c += nt) {
-        double r[4] = { xr[0], xr[1], xr[2], xr[3] };
-        double q[3] = { 0, 0, 0 };
-        if (c > 0) {
-            const int i = (c - 1) % Na;
-            const double sg = (c <= Na) ? w.gamma : -w.gamma;
-            if (i < n) {
-                // mu + (+-gamma) * S.row(i) restricted to the robot columns (upper triangle only)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int col = n - 4 + e;
-                    const double s = (col >= i) ? S[(size_t)i * ld + col] : 0.0;
-                    r[e] = xr[e] * 1 + s * sg + 0;
-                }
-            } else if (i < n + 3) {
-                q[i - n] = 0.0 * 1 + sh[3 + (i - n)] * sg + 0;   // control-noise sigma rows (sr = blockdiag(S, Mt, Qt))
-            }
-        }
-        const double r1 = rot1 - q[0], tr = trans - q[1], r2 = rot2 - q[2];     // 1492-1494
+    STAMP(1);
+    // ---- one fused pass over the Na sigma directions: each thread takes direction i, reads row i of the
+    //      augmented sqrt matrix once and pushes BOTH sigma points (mu +- gamma*row) through the motion
+    //      model; the deviations from sigma_0 feed R12 and the Gram matrix of the residual rows ----
+    // sigma_0 (centre point through the motion model, no noise): every thread needs it, so every thread computes it
+    double s0[4], c0s, s0s;
+    {
         double sn, cs;
-        sincos(r[3] + r1, &sn, &cs);
-        r[0] += tr * cs;                                                         // 1518-1523
-        r[1] += tr * sn;
-        r[2] += 0.0;
-        r[3] += r1 + r2;
-        double s2, c2;
-        sincos(r[3], &s2, &c2);
-        double* o = sigR + (size_t)c * 8;
-        o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = c2; o[5] = s2; o[6] = 0; o[7] = 0;
-        const double wt = (c == 0) ? w.wm0 : w.wi;
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[e] += wt * r[e];
+        sincos(xr[3] + rot1, &sn, &cs);
+        s0[0] = xr[0] + trans * cs; s0[1] = xr[1] + trans * sn; s0[2] = xr[2] + 0.0; s0[3] = xr[3] + (rot1 + rot2);
+        c0s = cs * crot2 - sn * srot2; s0s = sn * crot2 + cs * srot2;
     }
-    block_sum<4>(acc, red);
-    if (tid < 4) X[n - 4 + tid] = acc[tid];                                      // 1531
-    __threadfence_block();
-    __syncthreads();
-    // rs[e] = sum_c wc_c (sigma_c[e] - X[e]) with the covariance weights (wc0 for the centre): the
-    // constant that k_meas_final needs to re-centre the robot rows of Pxy on the mean h.
-    //   sum_c wc_c sigma_c = mean + (wc0 - wm0) sigma_0,  sum_c wc_c = wc0 + 2 Na wi
-    if (tid < 4) sigR[(size_t)L * 8 + tid] = acc[tid] * (1.0 - (w.wc0 + 2.0 * Na * w.wi)) + (w.wc0 - w.wm0) * sigR[tid];
-
-    // ---- structured QR: R12 rows and the residual matrix C ((n-4)+18 rows x 4), kept in LDS ----
-    extern __shared__ __attribute__((aligned(16))) double Cm[];      // [(n+14)][4]
     const double k2 = w.wi_sr * 0.70710678118654752440;
-    const int m = (n - 4) + 2 * (Na - (n - 4));
-    const double* s0 = sigR;   // sigma_0 robot rows (post-motion)
+    double acc[14];                // [0..3] weighted mean of the robot rows, [4..13] upper triangle of C^T C
+#pragma unroll
+    for (int q = 0; q < 14; q++) acc[q] = 0.0;
+    if (tid == 0) {
+        double* o = sigR;
+        o[0] = s0[0]; o[1] = s0[1]; o[2] = s0[2]; o[3] = s0[3]; o[4] = c0s; o[5] = s0s; o[6] = 0; o[7] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] = w.wm0 * s0[e];
+    }
     for (int i = tid; i < Na; i += nt) {
-        const double* sp = sigR + (size_t)(1 + i) * 8;
-        const double* sm = sigR + (size_t)(1 + Na + i) * 8;
-        double dp[4], dm[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { dp[e] = sp[e] - s0[e]; dm[e] = sm[e] - s0[e]; }
-        if (i < n - 4) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                S[(size_t)i * ld + (n - 4 + e)] = k2 * (dp[e] - dm[e]);
-                Cm[(size_t)i * 4 + e] = k2 * (dp[e] + dm[e]);
-            }
-        } else {
-            const int rp = (n - 4) + 2 * (i - (n - 4));
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                Cm[(size_t)rp * 4 + e] = w.wi_sr * dp[e];
-                Cm[(size_t)(rp + 1) * 4 + e] = w.wi_sr * dm[e];
-            }
+        double srow[4] = { 0, 0, 0, 0 }, mnoise[3] = { 0, 0, 0 };
+        if (i < n) {
+            // S[i][n-4..n-1]: 16-byte aligned (n-4 = 6N is even, ld a multiple of 64); the strictly lower
+            // triangle of S is kept zero, so rows inside the robot block need no masking
+            const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4));
+            const double2 u0 = sp2[0], u1 = sp2[1];
+            srow[0] = u0.x; srow[1] = u0.y; srow[2] = u1.x; srow[3] = u1.y;
+        } else if (i < n + 3) {
+            mnoise[i - n] = sh[3 + (i - n)];                   // control-noise rows (sr = blockdiag(S, Mt, Qt))
         }
+        double dev[2][4];
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) {
+            const double gs = sg ? -w.gamma : w.gamma;
+            double r[4], q[3];
+#pragma unroll
+            for (int e = 0; e < 4; e++) r[e] = xr[e] * 1 + srow[e] * gs + 0;       // generateSigmaPoints, 1159-1160
+#pragma unroll
+            for (int e = 0; e < 3; e++) q[e] = 0.0 * 1 + mnoise[e] * gs + 0;
+            const double r1 = rot1 - q[0], tr = trans - q[1], r2 = rot2 - q[2];     // 1492-1494
+            double sn, cs;
+            sincos(r[3] + r1, &sn, &cs);
+            r[0] += tr * cs;                                                         // 1518-1523
+            r[1] += tr * sn;
+            r[2] += 0.0;
+            r[3] += r1 + r2;
+            // cos/sin of the final heading by angle addition; the rot2-noise columns evaluate it directly
+            double s2, c2;
+            if (q[2] == 0.0) { c2 = cs * crot2 - sn * srot2; s2 = sn * crot2 + cs * srot2; }
+            else sincos(r[3], &s2, &c2);
+            double4* o = reinterpret_cast<double4*>(sigR + (size_t)(1 + sg * Na + i) * 8);
+            o[0] = make_double4(r[0], r[1], r[2], r[3]);
+            o[1] = make_double4(c2, s2, 0.0, 0.0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { acc[e] += w.wi * r[e]; dev[sg][e] = r[e] - s0[e]; }
+        }
+        if (i < n - 4) {
+            double c[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { S[(size_t)i * ld + (n - 4 + e)] = k2 * (dev[0][e] - dev[1][e]); c[e] = k2 * (dev[0][e] + dev[1][e]); }
+            int q = 4;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a; b < 4; b++) acc[q++] += c[a] * c[b];
+        } else {
+            int q = 4;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a; b < 4; b++) acc[q++] += (w.wi_sr * dev[0][a]) * (w.wi_sr * dev[0][b]) + (w.wi_sr * dev[1][a]) * (w.wi_sr * dev[1][b]);
+        }
+    }
+    STAMP(2);
+    // block reduction through LDS only (wave shuffles of 14 doubles cost more LDS-pipeline time than this tree):
+    // [14][512] partials -> 14 x 32 threads sum 16 each -> 14 threads sum 32 each; fixed order => deterministic
+#pragma unroll
+    for (int q = 0; q < 14; q++) part[q][tid] = acc[q];
+    __syncthreads();
+    if (tid < 14 * 32) {
+        const int q = tid >> 5, u = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) t += part[q][u + 32 * e];
+        part2[q][u] = t;
     }
     __syncthreads();
-
-    // ---- Householder QR of C (m x 4), GSL conventions (see oracle/srukf_oracle.c orc_qr_r) ----
-    for (int j = 0; j < 4; j++) {
-        double v1[1] = { 0.0 };
-        for (int r = j + 1 + tid; r < m; r += nt) { const double x = Cm[(size_t)r * 4 + j]; v1[0] += x * x; }
-        block_sum<1>(v1, red);
-        const double xnorm = sqrt(v1[0]);
-        const double alpha = Cm[(size_t)j * 4 + j];
-        double tau = 0.0, beta = alpha;
-        if (xnorm != 0.0) {
-            beta = -(alpha >= 0.0 ? 1.0 : -1.0) * hypot(alpha, xnorm);
-            tau = (beta - alpha) / beta;
-            const double is = 1.0 / (alpha - beta);
-            for (int r = j + 1 + tid; r < m; r += nt) Cm[(size_t)r * 4 + j] *= is;
-        }
-        __syncthreads();
-        if (tid == 0) Cm[(size_t)j * 4 + j] = beta;
-        if (tau != 0.0 && j < 3) {
-            double wj[3] = { 0, 0, 0 };
-            for (int r = j + 1 + tid; r < m; r += nt) {
-                const double v = Cm[(size_t)r * 4 + j];
-                for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cm[(size_t)r * 4 + jj] * v;
-            }
-            block_sum<3>(wj, red);
-            for (int jj = j + 1; jj < 4; jj++) wj[jj - j - 1] += Cm[(size_t)j * 4 + jj];
-            __syncthreads();
-            for (int r = j + 1 + tid; r < m; r += nt) {
-                const double v = Cm[(size_t)r * 4 + j];
-                for (int jj = j + 1; jj < 4; jj++) Cm[(size_t)r * 4 + jj] -= tau * v * wj[jj - j - 1];
-            }
-            if (tid == 0) for (int jj = j + 1; jj < 4; jj++) Cm[(size_t)j * 4 + jj] -= tau * wj[jj - j - 1];
-        }
-        __syncthreads();
+    if (tid < 14) {
+        double t = 0.0;
+        for (int e = 0; e < 32; e++) t += part2[tid][e];
+        red[tid] = t;
     }
-    if (tid < 16) {
-        const int a = tid >> 2, b = tid & 3;
-        S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = (b >= a) ? Cm[(size_t)a * 4 + b] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 14; q++) acc[q] = red[q];
+    STAMP(3);
+    if (tid < 4) {
+        X[n - 4 + tid] = acc[tid];                                               // 1531
+        // rs[e] = sum_c wc_c (sigma_c[e] - X[e]) with the covariance weights (wc0 for the centre): the constant
+        // k_meas_final needs to re-centre the robot rows of Pxy on the mean h.
+        //   sum_c wc_c sigma_c = mean + (wc0 - wm0) sigma_0,  sum_c wc_c = wc0 + 2 Na wi
+        sigR[(size_t)L * 8 + tid] = acc[tid] * (1.0 - (w.wc0 + 2.0 * Na * w.wi)) + (w.wc0 - w.wm0) * s0[tid];
     }
+    STAMP(4);
+    double* g = acc + 4;
+    // ---- R22 = chol(C^T C), upper triangular ----
+    if (tid == 0) {
+        double G4[4][4], R[4][4];
+        int q = 0;
+        for (int a = 0; a < 4; a++) for (int b = a; b < 4; b++) { G4[a][b] = g[q]; G4[b][a] = g[q]; q++; }
+        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) R[a][b] = 0.0;
+        for (int a = 0; a < 4; a++) {
+            double dsum = G4[a][a];
+            for (int k = 0; k < a; k++) dsum -= R[k][a] * R[k][a];
+            const double raa = sqrt(fmax(dsum, 0.0));
+            R[a][a] = raa;
+            for (int b = a + 1; b < 4; b++) {
+                double v = G4[a][b];
+                for (int k = 0; k < a; k++) v -= R[k][a] * R[k][b];
+                R[a][b] = (raa > 0.0) ? v / raa : 0.0;
+            }
+        }
+        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = R[a][b];
+    }
+    STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,10 +464,7 @@ extern "C" {
 void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, double* X, double* S, double* sigR, double* Cmat,
                          FrameScalars* fs, const double* odo_seq, const double* odo_pair)
 {
-    const size_t lds = sizeof(double) * 4 * (size_t)(d.n + 16);
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) { hipFuncSetAttribute((const void*)k_motion, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
-    hipLaunchKernelGGL(k_motion, dim3(1), dim3(1024), lds, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair);
+    hipLaunchKernelGGL(k_motion, dim3(1), dim3(512), 0, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair);
 }
 void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
                           double* Z, double* DZ)

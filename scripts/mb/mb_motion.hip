@@ -1,0 +1,29 @@
+// diagnostic: phases of k_motion (scratch tool)
+#define SRUKF_STAMPS 1
+#include "../../cv-monoslam_amd/csrc/srukf_predict.hip"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+int main()
+{
+    const int N = 200; KDims d; d.N = N; d.n = 6 * N + 4; d.Na = d.n + 5; d.L = 2 * d.Na + 1; d.np = 1216; d.mp = 448;
+    KWeights w; w.wm0 = 1.0 - d.Na / 3.0; w.wc0 = w.wm0; w.wi = (1.0 - w.wc0) / (2 * d.Na); w.wi_sr = sqrt(w.wi); w.gamma = sqrt(d.Na / (1.0 - w.wm0));
+    srukf_params p; srukf_default_params(&p); 
+    std::vector<double> hS((size_t)d.np * d.np, 0.0), hX(d.np, 0.1);
+    for (int r = 0; r < d.n; r++) for (int c = r; c < d.n; c++) hS[(size_t)r * d.np + c] = (r == c) ? 0.02 : 1e-4 / (1 + c - r);
+    double *X, *S, *sigR, *Cmat, *odo; FrameScalars* fs;
+    hipMalloc(&X, 8 * d.np); hipMalloc(&S, 8 * (size_t)d.np * d.np); hipMalloc(&sigR, 8 * ((size_t)d.L * 8 + 8)); hipMalloc(&Cmat, 8 * 4 * (d.np + 64)); hipMalloc(&odo, 8 * 6); hipMalloc(&fs, sizeof(FrameScalars));
+    hipMemcpy(X, hX.data(), 8 * d.np, hipMemcpyHostToDevice); hipMemcpy(S, hS.data(), 8 * (size_t)d.np * d.np, hipMemcpyHostToDevice);
+    double ho[6] = {0, 0, 0, 0.0099, 0.001, 0.1}; hipMemcpy(odo, ho, 48, hipMemcpyHostToDevice); hipMemset(fs, 0, sizeof(FrameScalars));
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(a, st); for (int i = 0; i < 200; i++) srukf_launch_motion(st, d, w, p, X, S, sigR, Cmat, fs, nullptr, odo); hipEventRecord(b, st); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); printf("k_motion: %.2f us/launch\n", ms / 200 * 1000);
+    }
+    unsigned long long hs[32]; hipMemcpyFromSymbol(hs, HIP_SYMBOL(srukf_stamps), sizeof hs);
+    const char* nm[] = {"control (thread 0)", "sigma loop", "block_sum<4>", "rs + C build", "Householder x4"};
+    for (int i = 0; i < 5; i++) printf("%-22s %7llu cycles\n", nm[i], hs[i + 1] - hs[i]);
+    return 0;
+}
+extern "C" int srukf_default_params(srukf_params* p) { memset(p, 0, sizeof *p); p->cam_dx = p->cam_dy = 0.0028; p->cam_cx = 310.1; p->cam_cy = 236.7; p->cam_k1 = 1e-4; p->cam_f = 2.1735; p->image_w = 640; p->image_h = 480; p->a1 = p->a2 = 4e-4; p->a3 = p->a4 = 6e-4; p->sigma_measure = 3; p->epsilon = 1e-13; p->newton_iters = 100; return 0; }
