@@ -331,14 +331,115 @@ __global__ __launch_bounds__(64) void k_gmw_first(int n, int ld, double eps, con
     gmw_factor_block(A, eps, lane, n, ld, 0, out, Dall, Sout);
 }
 
+// Critical-path workgroup of a step: block (0,0) of the trailing square owns the next diagonal block
+// (tile (base, base)).  Its four waves first cooperate on that tile only — each a 16x16 quarter of
+// the panel slab  W = T * G[J][base:base+32)  and of the update — so that wave 0 can start the
+// 32-pivot factorisation as early as possible; waves 1 and 3 then finish the block's other two
+// tiles, (0,1) and (1,1), from a register-resident second slab while wave 0 factors.
+__device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double eps, double* __restrict__ G,
+                                                 const GmwPanel* __restrict__ cur, GmwPanel* __restrict__ nxt,
+                                                 double* __restrict__ Dall, double* __restrict__ Sout,
+                                                 double (*Lr)[80], double (*Wc)[80], double (*Xg)[64][4], int lane, int wv)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    const int base = j0 + 32;
+    const int qa = wv >> 1, qb = wv & 1;                       // this wave's 16x16 quarter
+    // prefetch: the quarter of the diagonal tile this wave updates, and the pivots of the panel rows it produces
+    d4 g;
+#pragma unroll
+    for (int t = 0; t < 4; t++) g[t] = G[(size_t)(base + 16 * qa + lk + 4 * t) * ld + base + 16 * qb + lr];
+    double dr[2][4], sqr[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) { dr[a][t] = cur->rD[16 * a + lk + 4 * t]; sqr[a][t] = cur->sq[16 * a + lk + 4 * t]; }
+    // phase A: quarter (qa, qb) of W = T * G[J][base:base+32): rows jj = 16qa.., columns base + 16qb..
+    {
+        double fa[8], fb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            fa[u] = cur->Tt[(4 * u + lk) * 32 + 16 * qa + lr];
+            fb[u] = G[(size_t)(j0 + 4 * u + lk) * ld + base + 16 * qb + lr];
+        }
+        d4 w = (d4){0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 8; u++) w = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], fb[u], w, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int jj = 16 * qa + lk + 4 * t, cc = 16 * qb + lr;
+            Wc[jj][cc] = w[t];
+            Lr[jj][cc] = w[t] * dr[qa][t];
+            if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + base + cc] = w[t] * sqr[qa][t];
+        }
+    }
+    __syncthreads();
+    // phase B: quarter (qa, qb) of the diagonal tile:  g -= sum_k L[k][16qa + i] W[k][16qb + j]
+#pragma unroll
+    for (int k = 0; k < 32; k += 4)
+        g = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], g, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) Xg[wv][lane][t] = g[t];
+    __syncthreads();
+    if (wv == 0) {
+        // a 16x16 accumulator quarter has the same lane map as the matching tile of the 32x32 C layout
+        d4 A[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) A[a][b][t] = Xg[2 * a + b][lane][t];
+        gmw_factor_block(A, eps, lane, n, ld, base, nxt, Dall, Sout);
+        return;
+    }
+    if (wv == 2 || base + 32 >= ld) return;
+    // waves 1 and 3: second slab W2 = T * G[J][base+32 : base+64) kept in registers (C layout = MFMA operand
+    // layout for the k-step of four consecutive panel rows), then tile (0,1) / (1,1)
+    d4 W2[2][2];
+    zero_acc(W2);
+    tile32_tn<false>(W2, cur->Tt, 32, G + (size_t)j0 * ld, ld, 0, base + 32, 0, 32, lane);
+    const int m0 = (wv == 1) ? base : base + 32, c0 = base + 32;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+#pragma unroll
+    for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int k = 16 * a2 + 4 * t;                     // panel rows k + lk
+            double a0, a1;
+            if (wv == 1) { a0 = -Lr[k + lk][lr]; a1 = -Lr[k + lk][16 + lr]; }                 // rows base..base+32: first slab
+            else { a0 = -(W2[a2][0][t] * dr[a2][t]); a1 = -(W2[a2][1][t] * dr[a2][t]); }      // rows base+32..: L2 = W2 / D
+            const double b0 = W2[a2][0][t], b1 = W2[a2][1][t];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
+                if (wv == 1 && j0 + 16 * a + lk + 4 * t < n)                                   // S rows of the panel, second slab
+                    Sout[(size_t)(j0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = W2[a][b][t] * sqr[a][t];
+            }
+}
+
 // k_gmw_step: one launch per panel J = [j0, j0+32).  Every 64x64 block of the trailing square
 // (base = j0+32):
 //   1. recomputes the panel rows it needs, W[J][slab] = T * G[J][slab]  (MFMA, K = 32), for its
 //      row slab and its column slab, and keeps L = W/D (row slab) and W (column slab) in LDS;
 //   2. updates its tile  G[r][c] -= sum_kk L[kk][r] W[kk][c]  (MFMA from LDS);
 //   3. first block row only: writes the final S rows j0..j0+31 for its column slab;
-//   4. block (0,0), wave 0: its freshly updated tile IS the next diagonal block — factor it and
-//      publish the next panel buffer (visible to the next launch).
+//   4. block (0,0) takes its own route (gmw_step_block00): its tile (0,0) IS the next diagonal block,
+//      which wave 0 factors and publishes as the next panel buffer (visible to the next launch).
 // grid = (T, T), T = ceil((ld - base)/64); blocks strictly below the diagonal exit.
 __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double eps, double* __restrict__ G,
                                                   const GmwPanel* __restrict__ cur, GmwPanel* __restrict__ nxt,
@@ -348,7 +449,9 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
     STAMP(0);
     __shared__ double Lr[32][80];      // stride 80 doubles: lanes l / l+16 land on opposite bank halves
     __shared__ double Wc[32][80];
+    __shared__ double Xg[4][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x == 0 && blockIdx.y == 0) { gmw_step_block00(n, ld, j0, eps, G, cur, nxt, Dall, Sout, Lr, Wc, Xg, lane, wv); return; }
     const int lr = lane & 15, lk = lane >> 4;
     const int base = j0 + 32;
     const int R0 = base + 64 * blockIdx.y, C0 = base + 64 * blockIdx.x;
@@ -425,9 +528,6 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
     }
 
     STAMP(4);
-    // 4. next diagonal block: tile (base, base) of block (0,0), wave 0 — already in C-layout registers
-    if (blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) gmw_factor_block(acc, eps, lane, n, ld, base, nxt, Dall, Sout);
-    STAMP(5);
 }
 
 // k_gmw_check: was the reference's third pivot candidate theta_j^2/beta^2 ever the largest?
