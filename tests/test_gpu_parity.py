@@ -186,7 +186,7 @@ def test_step_api_equals_staged_replay(srukf, synth):
     b = srukf.Filter(20, p); b.set_state(sc["X0"], sc["S0"]); b.stage_sequence(sc["odo"], sc["z"], sc["matched"])
     b.run_frames(0, 6)
     Xa, Sa = a.get_state(); Xb, Sb = b.get_state()
-    assert np.array_equal(Xa, Xb) and np.array_equal(Sa, Sb)       # same kernels, same order: bit-identical
+    assert np.array_equal(Xa, Xb) and np.array_equal(Sa, Sb)       # same kernels, same order: bit-identical (also across graph replay)
 
 
 def test_row_sign_invariance(srukf, synth):
