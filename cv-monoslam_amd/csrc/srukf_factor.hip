@@ -16,6 +16,16 @@ __device__ __forceinline__ double readlane_d(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// 1/x for x >= EPSILON > 0: v_rcp_f64 refined by two Newton steps (error <= 1 ulp).  Five dependent
+// instructions instead of the ~12 of an IEEE division on the 32-pivot chain.
+__device__ __forceinline__ double pivot_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 struct GmwPanel;
 __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int lane, int n, int ld, int j0,
                                                  GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout);
@@ -247,19 +257,19 @@ __device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int 
         const double m22 = readlane_d(st, 32 + 4 * t + 2), m23 = readlane_d(st, 32 + 4 * t + 3);
         const double m33 = readlane_d(st, 48 + 4 * t + 3);
         if (s == 2) STAMP(6);
-        // multipliers use one reciprocal per pivot (1/D by IEEE division, then products): <= 1 ulp from the
-        // reference's C/D quotients, and three divisions instead of six on the pivot chain
-        const double D0 = fmax(eps, fabs(m00)), r0 = 1.0 / D0;
+        // multipliers use one reciprocal per pivot (pivot_rcp, then products): within 2 ulp of the reference's
+        // C/D quotients, and no IEEE division on the pivot chain
+        const double D0 = fmax(eps, fabs(m00)), r0 = pivot_rcp(D0);
         const double l01 = m01 * r0, l02 = m02 * r0, l03 = m03 * r0;
         const double c11 = m11 - l01 * m01, c12 = m12 - l01 * m02, c13 = m13 - l01 * m03;
         double c22 = m22 - l02 * m02, c23 = m23 - l02 * m03, c33 = m33 - l03 * m03;
-        const double D1 = fmax(eps, fabs(c11)), r1 = 1.0 / D1;
+        const double D1 = fmax(eps, fabs(c11)), r1 = pivot_rcp(D1);
         const double l12 = c12 * r1, l13 = c13 * r1;
         c22 -= l12 * c12; c23 -= l12 * c13; c33 -= l13 * c13;
-        const double D2 = fmax(eps, fabs(c22)), r2 = 1.0 / D2;
+        const double D2 = fmax(eps, fabs(c22)), r2 = pivot_rcp(D2);
         const double l23 = c23 * r2;
         c33 -= l23 * c23;
-        const double D3 = fmax(eps, fabs(c33)), r3 = 1.0 / D3;
+        const double D3 = fmax(eps, fabs(c33)), r3 = pivot_rcp(D3);
         if (s == 2) STAMP(7);
         // micro-inverse rows (unit lower triangular): row q = e_q - sum_{q''<q} l[q''][q] row q''
         const double t10 = -l01, t21 = -l12, t32 = -l23;
@@ -353,6 +363,7 @@ __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double e
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int t = 0; t < 4; t++) { dr[a][t] = cur->rD[16 * a + lk + 4 * t]; sqr[a][t] = cur->sq[16 * a + lk + 4 * t]; }
+    STAMP(1);
     // phase A: quarter (qa, qb) of W = T * G[J][base:base+32): rows jj = 16qa.., columns base + 16qb..
     {
         double fa[8], fb[8];
@@ -372,7 +383,9 @@ __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double e
             if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + base + cc] = w[t] * sqr[qa][t];
         }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     // phase B: quarter (qa, qb) of the diagonal tile:  g -= sum_k L[k][16qa + i] W[k][16qb + j]
 #pragma unroll
     for (int k = 0; k < 32; k += 4)
@@ -389,7 +402,9 @@ __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double e
             for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) A[a][b][t] = Xg[2 * a + b][lane][t];
+        STAMP(4);
         gmw_factor_block(A, eps, lane, n, ld, base, nxt, Dall, Sout);
+        STAMP(5);
         return;
     }
     if (wv == 2 || base + 32 >= ld) return;

@@ -31,7 +31,7 @@ int main()
     hipStreamSynchronize(st);
     unsigned long long hs[16];
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(srukf_stamps), sizeof hs);
-    const char* nm[] = { "start->prefetch issued", "slab MFMA + convert + LDS", "barrier", "tile update + store", "factor + outputs" };
+    const char* nm[] = { "start->prefetch issued", "phase A: quarter slab -> LDS", "barrier", "phase B: quarter update + exchange", "factor + outputs" };
     for (int i = 0; i < 5; i++) printf("%-28s %6llu ticks (100 MHz realtime? s_memtime = shader clock)\n", nm[i], hs[i + 1] - hs[i]);
     printf("total in-kernel %llu ticks\n", hs[5] - hs[0]);
     printf("factor: entry->micro-panel 2 start %llu | mp2: readlanes %llu, scalar LDL %llu, strip-apply %llu, trailing %llu | mp3..7 %llu | outputs %llu\n",
