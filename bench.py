@@ -125,7 +125,7 @@ def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local):
         f.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    chunk = 10                                                   # interleave the host-side graph launches
+    chunk = 16                                                   # interleave the host-side graph launches (2 x 8-frame graphs)
     for k0 in range(0, K, chunk):
         for f in fs:
             f.run_frames_async(W + k0, min(chunk, K - k0))

@@ -46,6 +46,7 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
 }
 __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base = traj_base; }
 
+#define SRUKF_GRAPH_FRAMES 8
 static thread_local std::string g_create_error;
 
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_XUPD, KC_SYRK, KC_GMW_PANEL, KC_GMW_TRAIL, KC_GMW_CHECK,
@@ -83,8 +84,8 @@ struct srukf_ctx {
     bool async_pending = false;
     std::string err;
     // one captured frame (BATCHED, staged inputs): replayed by srukf_run_frames_async
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr, graph8 = nullptr;          // one frame / SRUKF_GRAPH_FRAMES frames
+    hipGraphExec_t graph_exec = nullptr, graph8_exec = nullptr;
     bool use_graph = true;
     // profiling
     bool profiling = false;
@@ -294,6 +295,8 @@ int srukf_destroy(srukf_ctx* c)
     prof_collect(c);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->graph) hipGraphDestroy(c->graph);
+    if (c->graph8_exec) hipGraphExecDestroy(c->graph8_exec);
+    if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp };
     for (void* b : bufs) if (b) hipFree(b);
@@ -548,6 +551,8 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
     if (c->odo_seq) { hipFree(c->odo_seq); hipFree(c->z_seq); hipFree(c->m_seq); c->odo_seq = nullptr; c->z_seq = nullptr; c->m_seq = nullptr; }
     if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph8_exec) { hipGraphExecDestroy(c->graph8_exec); c->graph8_exec = nullptr; }
+    if (c->graph8) { hipGraphDestroy(c->graph8); c->graph8 = nullptr; }
     HIPCHK(c, hipMalloc((void**)&c->odo_seq, sizeof(double) * 3 * (F + 1)));
     HIPCHK(c, hipMalloc((void**)&c->z_seq, sizeof(double) * (size_t)F * 2 * N));
     HIPCHK(c, hipMalloc((void**)&c->m_seq, sizeof(int) * (size_t)F * N));
@@ -583,8 +588,16 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
             one_frame();
             HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
             HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+            // and a graph of SRUKF_GRAPH_FRAMES consecutive frames: one host launch per 8 frames keeps the host
+            // ahead of the device when several filters share one host thread
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            for (int q = 0; q < SRUKF_GRAPH_FRAMES; q++) one_frame();
+            HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph8));
+            HIPCHK(c, hipGraphInstantiate(&c->graph8_exec, c->graph8, nullptr, nullptr, 0));
         }
-        for (int f = 0; f < count; f++) HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+        int f = 0;
+        for (; f + SRUKF_GRAPH_FRAMES <= count; f += SRUKF_GRAPH_FRAMES) HIPCHK(c, hipGraphLaunch(c->graph8_exec, c->stream));
+        for (; f < count; f++) HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
     } else {
         for (int f = 0; f < count; f++) one_frame();
     }
