@@ -21,10 +21,10 @@ int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
-void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*);
-void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, double, void*, double*, double*);
+void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int);
+void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, double, void*, double*, double*, const void*, int);
 void srukf_launch_gmw_first(hipStream_t, int, int, double, const double*, void*, double*, double*);
-void srukf_launch_gmw_step(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
+void srukf_launch_gmw_step(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const double*);
 int srukf_gmw_panel_bytes(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
@@ -71,6 +71,8 @@ struct srukf_ctx {
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered)
+    int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
+    int n_syrk_tiles = 0, n_pxy_tiles = 0;
     FrameScalars* fs = nullptr;
     // staged sequence
     int seqF = 0;
@@ -144,6 +146,31 @@ static void prof_collect(srukf_ctx* c)
     c->pev.clear();
 }
 
+// ---- XCD-aware tile order -------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group, MI355X_MICROARCH.md);
+// each XCD has its own 4 MiB L2 and S (11.6 MB at N = 200) does not fit one.  Give every XCD a fixed set of
+// operand panels (tile rows `own`) and walk the other index in the same order on all XCDs, so that an
+// own-panel stays L2-resident and the streamed panel is shared by the tiles that run next to each other.
+//   own(t) = t % 8;  list per XCD: for other = 0.. : for own-tiles of this XCD: (own, other) if valid.
+// The table maps linear workgroup id -> tile; unused slots hold (-1, -1).
+static std::vector<int> build_tile_table(int n_own, int n_other, bool upper, bool own_is_row)
+{
+    std::vector<std::vector<int>> lst(8);
+    for (int x = 0; x < 8; x++)
+        for (int o = 0; o < n_other; o++)
+            for (int w = x; w < n_own; w += 8) {
+                const int r = own_is_row ? w : o, c = own_is_row ? o : w;
+                if (upper && c < r) continue;
+                lst[x].push_back(r); lst[x].push_back(c);
+            }
+    size_t mx = 0;
+    for (auto& l : lst) mx = l.size() / 2 > mx ? l.size() / 2 : mx;
+    std::vector<int> tab(mx * 8 * 2, -1);
+    for (int x = 0; x < 8; x++)
+        for (size_t q = 0; q < lst[x].size() / 2; q++) { tab[(q * 8 + x) * 2] = lst[x][2 * q]; tab[(q * 8 + x) * 2 + 1] = lst[x][2 * q + 1]; }
+    return tab;
+}
+
 // ---- launch sequences --------------------------------------------------------------------------
 static void seq_predict_motion(srukf_ctx* c, const double* odo_pair_dev)
 {
@@ -178,7 +205,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         const double nn = n;
         ProfScope ps(c, KC_SYRK, nn * nn * nn / 3.0 + nn * nn * (ue - ub), 8.0 * (nn * nn + (double)(ue - ub) * nn));
         // the block that owns tile (0,0) also factors it = first diagonal block of the GMW (fast path)
-        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->p.epsilon, slow ? nullptr : c->pan[0], c->D, c->S);
+        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->p.epsilon, slow ? nullptr : c->pan[0], c->D, c->Wf, c->syrk_tiles, c->n_syrk_tiles);
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
     if (!slow) {
@@ -187,7 +214,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             const double r2 = np - j0 - 32;
             // per launch: trailing update 32*r2^2 (upper half, 2 flop) + slab recompute + next diagonal block
             ProfScope ps(c, KC_GMW_TRAIL, 32.0 * r2 * r2 + 2.0 * 32.0 * 32.0 * r2 + 32.0 * 32.0 * 32.0 / 3.0, 8.0 * (r2 * r2 + 2.0 * 32.0 * r2));
-            srukf_launch_gmw_step(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb], c->pan[pb ^ 1], c->D, c->S);
+            srukf_launch_gmw_step(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb], c->pan[pb ^ 1], c->D, c->S, j0 == 0 ? c->Wf : nullptr);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
         srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs, c->X, frame_tail ? 1 : 0);
@@ -204,7 +231,7 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev)
     {
         const double nn = d.n;
         ProfScope ps(c, KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
-        srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut);
+        srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles);
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
@@ -277,6 +304,20 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     ALLOC(c->D, np); ALLOC(c->Wp, 32 * np); ALLOC(c->Lp, 32 * np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
     ALLOC(c->vis, N); ALLOC(c->mcur, N); ALLOC(c->theta, np); ALLOC(c->fs, 1);
     { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
+    {
+        // k_syrk: tile (row r, col c >= r); A panel = S columns of r, B panel = S columns of c.  XCD owns rows.
+        std::vector<int> ts = build_tile_table(d.np / 32, d.np / 32, true, true);
+        // k_pxy: tile (m = measurement tile, n = state tile); XCD owns the S panel (n), DZ panels stream.
+        std::vector<int> tp = build_tile_table(d.np / 32, d.mp / 32, false, false);
+        c->n_syrk_tiles = (int)ts.size() / 2; c->n_pxy_tiles = (int)tp.size() / 2;
+        ALLOC(c->syrk_tiles, ts.size()); ALLOC(c->pxy_tiles, tp.size());
+        // same stream as the zero-fill of ALLOC (a copy on the null stream could be overtaken by it)
+        if (hipMemcpyAsync(c->syrk_tiles, ts.data(), sizeof(int) * ts.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->pxy_tiles, tp.data(), sizeof(int) * tp.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) {
+            g_create_error = "tile table upload failed"; srukf_destroy(c); return SRUKF_ERR_HIP;
+        }
+    }
     c->hstage_bytes = sizeof(double) * (np * np + 4096);
     if (hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars)) != hipSuccess) {
         g_create_error = "hipHostMalloc failed"; srukf_destroy(c); return SRUKF_ERR_NOMEM;
@@ -298,7 +339,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8_exec) hipGraphExecDestroy(c->graph8_exec);
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
-                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp };
+                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles };
     for (void* b : bufs) if (b) hipFree(b);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->hfs) hipHostFree(c->hfs);
@@ -437,7 +478,7 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     if (!c || !P) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->p.epsilon, nullptr, c->D, c->S);
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->p.epsilon, nullptr, c->D, c->S, c->syrk_tiles, c->n_syrk_tiles);
     HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) { const double v = c->hstage[(size_t)r * np + cc]; P[(size_t)r * n + cc] = v; P[(size_t)cc * n + r] = v; }
@@ -697,7 +738,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
         srukf_launch_gmw_first(st, n, np, epsilon, dG, pan[0], dD, dS);
         int pb = 0;
         for (int j0 = 0; j0 + SRUKF_NB < np; j0 += SRUKF_NB, pb ^= 1)
-            srukf_launch_gmw_step(st, n, np, j0, epsilon, dG, pan[pb], pan[pb ^ 1], dD, dS);
+            srukf_launch_gmw_step(st, n, np, j0, epsilon, dG, pan[pb], pan[pb ^ 1], dD, dS, nullptr);
         hipDeviceSynchronize();
         hipFree(pan[0]); hipFree(pan[1]);
         srukf_launch_gmw_check(st, n, np, dD, dS, dFs, nullptr, 0);

@@ -112,15 +112,17 @@ __device__ __forceinline__ void splitk_reduce(d4 (&acc)[2][2], double (*red)[64]
 // = (S^T DZ)^T, i.e. the L rank-1 updates per landmark of calculateOneFeatureCrossCovariance
 // (SLAM.cpp:2028-2037) for ALL landmarks at once; the wi*gamma scale and the robot rows are
 // applied in k_gain.  S upper triangular => K range truncated at r0+32.
-// grid = (np/32, mp/32): one 32x32 tile per workgroup, 4-way split-K.
+// grid = one workgroup per 32x32 tile (XCD-aware order from the tile table), 4-way split-K.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__ DZ, const double* __restrict__ S,
-                                             double* __restrict__ Ut)
+                                             double* __restrict__ Ut, const int2* __restrict__ tiles)
 {
     __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 32;    // c
-    const int n0 = blockIdx.x * 32;    // r
+    const int2 tl = tiles[blockIdx.x];  // XCD-aware tile order (srukf_api.hip build_tile_tables)
+    if (tl.x < 0) return;
+    const int m0 = tl.x * 32;    // c
+    const int n0 = tl.y * 32;    // r
     d4 acc[2][2];
     zero_acc(acc);
     int ke = n0 + 32; if (ke > d.np) ke = d.np;
@@ -144,18 +146,20 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // measurement columns; rows [ub, ue) of Ut select the columns that are downdated — all of them
 // in BATCHED mode, a single one in SEQUENTIAL mode).  Also accumulates gamma = max diag(G) and
 // xi = max(0, max offdiag(G)) for the GMW bound beta^2 (SLAM.cpp:2204-2211).
-// grid = (np/32, np/32): one 32x32 tile per workgroup (tiles below the diagonal exit), 4-way
+// grid = one workgroup per upper-triangle 32x32 tile (XCD-aware order from the tile table), 4-way
 // split-K over the concatenated K range [S rows 0..r0+32) ++ [Ut rows).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
                                               int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
-                                              double eps, GmwPanel* __restrict__ pan0, double* __restrict__ Dall, double* __restrict__ Sout)
+                                              double eps, GmwPanel* __restrict__ pan0, double* __restrict__ Dall, double* __restrict__ Sout,
+                                              const int2* __restrict__ tiles)
 {
-    if (blockIdx.x < blockIdx.y) return;
     __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 32;    // row r
-    const int n0 = blockIdx.x * 32;    // col c
+    const int2 tl = tiles[blockIdx.x];  // upper-triangle tiles only, XCD-aware order
+    if (tl.x < 0) return;
+    const int m0 = tl.x * 32;    // row r
+    const int n0 = tl.y * 32;    // col c
     d4 acc[2][2];
     zero_acc(acc);
     int ke = m0 + 32; if (ke > d.np) ke = d.np;          // S[k][r] = 0 for k > r
@@ -202,8 +206,10 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
         if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
     }
     // tile (0,0) is the first diagonal block of the factorisation and has the shortest K range: factor it
-    // here (pan0 != null), hidden behind the longer tiles, instead of a launch of its own
-    if (pan0 && blockIdx.x == 0 && blockIdx.y == 0) gmw_factor_block(acc, eps, lane, d.n, d.np, 0, pan0, Dall, Sout);
+    // here (pan0 != null), hidden behind the longer tiles, instead of a launch of its own.  Its S rows go to
+    // the scratch matrix Sout (NOT the live S, which other tiles of this launch are still reading); the first
+    // k_gmw_step copies them over.
+    if (pan0 && m0 == 0 && n0 == 0) gmw_factor_block(acc, eps, lane, d.n, d.np, 0, pan0, Dall, Sout);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,7 +464,7 @@ __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double e
 // grid = (T, T), T = ceil((ld - base)/64); blocks strictly below the diagonal exit.
 __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double eps, double* __restrict__ G,
                                                   const GmwPanel* __restrict__ cur, GmwPanel* __restrict__ nxt,
-                                                  double* __restrict__ Dall, double* __restrict__ Sout)
+                                                  double* __restrict__ Dall, double* __restrict__ Sout, const double* __restrict__ Sfirst)
 {
     if (blockIdx.x < blockIdx.y) return;
     STAMP(0);
@@ -466,6 +472,13 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double 
     __shared__ double Wc[32][80];
     __shared__ double Xg[4][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (Sfirst && blockIdx.x == 0 && blockIdx.y == 0) {
+        // first step: bring the diagonal block of S rows 0..31 (factored inside k_syrk into scratch) into S
+        for (int e = tid; e < 1024; e += 256) {
+            const int r = e >> 5, c = e & 31;
+            if (c >= r && c < n) Sout[(size_t)r * ld + c] = Sfirst[(size_t)r * ld + c];
+        }
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0) { gmw_step_block00(n, ld, j0, eps, G, cur, nxt, Dall, Sout, Lr, Wc, Xg, lane, wv); return; }
     const int lr = lane & 15, lk = lane >> 4;
     const int base = j0 + 32;
@@ -645,26 +658,27 @@ __global__ __launch_bounds__(256) void k_gmw_stats(int n, int ld, const double* 
 }
 
 extern "C" {
-void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S, double* Ut)
+void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S, double* Ut, const void* tiles, int ntiles)
 {
-    hipLaunchKernelGGL(k_pxy, dim3(d.np / 32, d.mp / 32), dim3(256), 0, st, d, DZ, S, Ut);
+    hipLaunchKernelGGL(k_pxy, dim3(ntiles), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles);
 }
 void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs,
-                       double eps, void* pan0, double* Dall, double* Sout)
+                       double eps, void* pan0, double* Dall, double* Sout, const void* tiles, int ntiles)
 {
-    hipLaunchKernelGGL(k_syrk, dim3(d.np / 32, d.np / 32), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, eps, (GmwPanel*)pan0, Dall, Sout);
+    hipLaunchKernelGGL(k_syrk, dim3(ntiles), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, eps, (GmwPanel*)pan0, Dall, Sout, (const int2*)tiles);
 }
 // whole fast-path factorisation: first diagonal block, then one launch per panel
 void srukf_launch_gmw_first(hipStream_t st, int n, int ld, double eps, const double* G, void* pan0, double* D, double* Sout)
 {
     hipLaunchKernelGGL(k_gmw_first, dim3(1), dim3(64), 0, st, n, ld, eps, G, (GmwPanel*)pan0, D, Sout);
 }
-void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)
+void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout,
+                           const double* Sfirst)
 {
     const int rem = ld - j0 - 32;
     if (rem <= 0) return;
     const int T = (rem + 63) / 64;
-    hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, eps, G, (const GmwPanel*)cur, (GmwPanel*)nxt, D, Sout);
+    hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, eps, G, (const GmwPanel*)cur, (GmwPanel*)nxt, D, Sout, Sfirst);
 }
 int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel); }
 void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj)
