@@ -8,6 +8,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "srukf_device.h"
 
 extern "C" {
@@ -153,7 +155,7 @@ static void prof_collect(srukf_ctx* c)
 // own-panel stays L2-resident and the streamed panel is shared by the tiles that run next to each other.
 //   own(t) = t % 8;  list per XCD: for other = 0.. : for own-tiles of this XCD: (own, other) if valid.
 // The table maps linear workgroup id -> tile; unused slots hold (-1, -1).
-static std::vector<int> build_tile_table(int n_own, int n_other, bool upper, bool own_is_row)
+static std::vector<int> build_tile_table(int n_own, int n_other, bool upper, bool own_is_row, int k_index /* 0: K grows with tile.x, 1: with tile.y */)
 {
     std::vector<std::vector<int>> lst(8);
     for (int x = 0; x < 8; x++)
@@ -163,6 +165,17 @@ static std::vector<int> build_tile_table(int n_own, int n_other, bool upper, boo
                 if (upper && c < r) continue;
                 lst[x].push_back(r); lst[x].push_back(c);
             }
+    {
+        // longest K first (S is upper triangular, so the K range grows with the state tile index): the long tiles
+        // must not be the last ones dispatched
+        for (auto& l : lst) {
+            std::vector<std::pair<int, int>> t;
+            for (size_t q = 0; q < l.size() / 2; q++) t.push_back({ l[2 * q], l[2 * q + 1] });
+            std::stable_sort(t.begin(), t.end(), [k_index](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+                return k_index ? a.second > b.second : a.first > b.first; });
+            for (size_t q = 0; q < t.size(); q++) { l[2 * q] = t[q].first; l[2 * q + 1] = t[q].second; }
+        }
+    }
     size_t mx = 0;
     for (auto& l : lst) mx = l.size() / 2 > mx ? l.size() / 2 : mx;
     std::vector<int> tab(mx * 8 * 2, -1);
@@ -306,9 +319,9 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
     {
         // k_syrk: tile (row r, col c >= r); A panel = S columns of r, B panel = S columns of c.  XCD owns rows.
-        std::vector<int> ts = build_tile_table(d.np / 32, d.np / 32, true, true);
+        std::vector<int> ts = build_tile_table(d.np / 32, d.np / 32, true, true, 0);
         // k_pxy: tile (m = measurement tile, n = state tile); XCD owns the S panel (n), DZ panels stream.
-        std::vector<int> tp = build_tile_table(d.np / 32, d.mp / 32, false, false);
+        std::vector<int> tp = build_tile_table(d.np / 32, d.mp / 32, false, false, 1);
         c->n_syrk_tiles = (int)ts.size() / 2; c->n_pxy_tiles = (int)tp.size() / 2;
         ALLOC(c->syrk_tiles, ts.size()); ALLOC(c->pxy_tiles, tp.size());
         // same stream as the zero-fill of ALLOC (a copy on the null stream could be overtaken by it)
