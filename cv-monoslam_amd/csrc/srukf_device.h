@@ -139,8 +139,10 @@ __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, 
 #ifdef SRUKF_STAMPS
 __device__ unsigned long long srukf_stamps[32];
 #define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); srukf_stamps[i] = t_; } } while (0)
+#define STAMPW(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); srukf_stamps[i] = t_; } } while (0)
 #else
 #define STAMP(i)
+#define STAMPW(i)
 #endif
 
 // ---- launch prototypes (host side, implemented in the .hip files) ---------------------------

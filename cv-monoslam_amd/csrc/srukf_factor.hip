@@ -8,27 +8,11 @@
 //   B: lane l holds B_op[k = l>>4][j = l&15]  -> B[k0 + (l>>4)][n0 + (l&15)]
 //   D: reg t of lane l is D[row = (l>>4) + 4t][col = l&15]
 #include "srukf_device.h"
-
-__device__ __forceinline__ double readlane_d(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// 1/x for x >= EPSILON > 0: v_rcp_f64 refined by two Newton steps (error <= 1 ulp).  Five dependent
-// instructions instead of the ~12 of an IEEE division on the 32-pivot chain.
-__device__ __forceinline__ double pivot_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
+#include "srukf_gmw_cols.h"
 
 struct GmwPanel;
-__device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int lane, int n, int ld, int j0,
-                                                 GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout);
+__device__ __forceinline__ void gmw_cols_factor_wg(const GmwColsLds& w, int wv, int lane, double eps, int n, int ld, int j0,
+                                                   GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout);
 
 // one wave: 32x32 output tile at (m0, n0), K range [kb, ke) — (ke - kb) a multiple of 16 —, accumulate.
 // Software-pipelined: the 16 fragment loads of the next group of four k-steps are in flight while the
@@ -184,32 +168,40 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
         }
     }
     splitk_reduce(acc, red, wv, lane);
-    if (wv != 0) return;
-    const int lr = lane & 15, lk = lane >> 4;
-    double gmax = 0.0, xmax = 0.0;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
-                const double v = acc[a][b][t];
-                G[(size_t)r * d.np + c] = v;
-                if (r < d.n && c < d.n) {
-                    if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v);
-                }
-            }
-    gmax = wave_max(gmax); xmax = wave_max(xmax);
-    if (lane == 0) {
-        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
-        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
-    }
     // tile (0,0) is the first diagonal block of the factorisation and has the shortest K range: factor it
     // here (pan0 != null), hidden behind the longer tiles, instead of a launch of its own.  Its S rows go to
     // the scratch matrix Sout (NOT the live S, which other tiles of this launch are still reading); the first
     // k_gmw_step copies them over.
-    if (pan0 && m0 == 0 && n0 == 0) gmw_factor_block(acc, eps, lane, d.n, d.np, 0, pan0, Dall, Sout);
+    const bool fac = pan0 && m0 == 0 && n0 == 0;           // workgroup-uniform
+    if (wv != 0 && !fac) return;
+    const GmwColsLds ws = gmw_cols_carve(&red[0][0][0]);   // the split-K scratch is free once wave 0 has summed it
+    if (wv == 0) {
+        const int lr = lane & 15, lk = lane >> 4;
+        double gmax = 0.0, xmax = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
+                    const double v = acc[a][b][t];
+                    G[(size_t)r * d.np + c] = v;
+                    if (fac) ws.Xm[16 * a + lk + 4 * t][16 * b + lr] = v;
+                    if (r < d.n && c < d.n) {
+                        if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v);
+                    }
+                }
+        if (fac && lane < 32) ws.Dv[lane] = 0.0;
+        gmax = wave_max(gmax); xmax = wave_max(xmax);
+        if (lane == 0) {
+            if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+            if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
+        }
+    }
+    if (!fac) return;
+    __syncthreads();
+    gmw_cols_factor_wg(ws, wv, lane, eps, d.n, d.np, 0, pan0, Dall, Sout);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,133 +221,42 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
 //   w = T g, so the whole panel "TRSM" becomes one 32x32 by 32xcols MFMA product.
 struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; double rD[32]; };
 
-// Factor a 32x32 diagonal block held in MFMA C-layout registers (one wave):
-//   A[a][b] (a, b in {0,1}):  element (row 16a + lk + 4t, col 16b + lr) in register t of lane (lk, lr).
-// Works on 4-row micro-panels (rows 4s..4s+3 = register t = s&3 of tile row a = s>>2 of EVERY lane):
-//   1. the 4x4 diagonal micro-block is read with v_readlane and factored on wave-uniform values
-//      (the reference's recurrence: L = C/D, C -= L*C; D = max(EPSILON, |C_jj|));
-//   2. the within-strip elimination  W[q] = in[q] - sum_{q''<q} L[q''][q] W[q'']  is one MFMA per
-//      column tile with the 4x4 unit-triangular micro-inverse as the A operand;
-//   3. rows below the strip get the rank-4 update  C[r][c] -= L[k][r] W[k][c]  by MFMA — the strip
-//      registers are, as they stand, valid A (k = lk, i = lr) and B (k = lk, j = lr) operands.
-// The same operations applied to identity columns (I[a][b]) give T = (I + M^T)^{-1} for the panel.
-// Out: next panel buffer (Tt, D, sqrt D), pivots D, and the diagonal-block part of S rows j0..j0+31.
-__device__ __forceinline__ void gmw_factor_block(d4 (&A)[2][2], double eps, int lane, int n, int ld, int j0,
-                                                 GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout)
+// Factor a 32x32 diagonal block that sits in LDS (ws.Xm, with ws.Dv zeroed and a workgroup barrier behind it).
+// All four waves of the workgroup call this: wave 0 runs the pivot chain, wave 2 follows it with T = L^{-1}, waves
+// 1 and 3 write the outputs (srukf_gmw_cols.h).  No barrier inside; each wave returns when its part is done.
+// Out: next panel buffer (Tt, D, sqrt(D)/D, 1/D), pivots D, and the diagonal-block part of S rows j0..j0+31.
+__device__ __forceinline__ void gmw_cols_factor_wg(const GmwColsLds& w, int wv, int lane, double eps, int n, int ld, int j0,
+                                                   GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout)
 {
-    const int lr = lane & 15, lk = lane >> 4;
-    d4 I[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) I[a][b][t] = (a == b && lk + 4 * t == lr) ? 1.0 : 0.0;
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        const int a = s >> 2, t = s & 3;
-        if (s == 2) STAMP(11);
-        if (s == 3) STAMP(9);
-        // 1. 4x4 diagonal micro-block: element (4s+q, 4s+q') sits in lane 16q + 4t + q' of A[a][a][t]
-        const double st = A[a][a][t];
-        const double m00 = readlane_d(st, 0 + 4 * t + 0), m01 = readlane_d(st, 0 + 4 * t + 1), m02 = readlane_d(st, 0 + 4 * t + 2), m03 = readlane_d(st, 0 + 4 * t + 3);
-        const double m11 = readlane_d(st, 16 + 4 * t + 1), m12 = readlane_d(st, 16 + 4 * t + 2), m13 = readlane_d(st, 16 + 4 * t + 3);
-        const double m22 = readlane_d(st, 32 + 4 * t + 2), m23 = readlane_d(st, 32 + 4 * t + 3);
-        const double m33 = readlane_d(st, 48 + 4 * t + 3);
-        if (s == 2) STAMP(6);
-        // multipliers use one reciprocal per pivot (pivot_rcp, then products): within 2 ulp of the reference's
-        // C/D quotients, and no IEEE division on the pivot chain
-        const double D0 = fmax(eps, fabs(m00)), r0 = pivot_rcp(D0);
-        const double l01 = m01 * r0, l02 = m02 * r0, l03 = m03 * r0;
-        const double c11 = m11 - l01 * m01, c12 = m12 - l01 * m02, c13 = m13 - l01 * m03;
-        double c22 = m22 - l02 * m02, c23 = m23 - l02 * m03, c33 = m33 - l03 * m03;
-        const double D1 = fmax(eps, fabs(c11)), r1 = pivot_rcp(D1);
-        const double l12 = c12 * r1, l13 = c13 * r1;
-        c22 -= l12 * c12; c23 -= l12 * c13; c33 -= l13 * c13;
-        const double D2 = fmax(eps, fabs(c22)), r2 = pivot_rcp(D2);
-        const double l23 = c23 * r2;
-        c33 -= l23 * c23;
-        const double D3 = fmax(eps, fabs(c33)), r3 = pivot_rcp(D3);
-        if (s == 2) STAMP(7);
-        // micro-inverse rows (unit lower triangular): row q = e_q - sum_{q''<q} l[q''][q] row q''
-        const double t10 = -l01, t21 = -l12, t32 = -l23;
-        const double t20 = -l02 - l12 * t10;
-        const double t31 = -l13 - l23 * t21;
-        const double t30 = -l03 - l13 * t10 - l23 * t20;
-        // 2. strip apply: D = (Tm - I) * strip + tile  (the tile's strip rows come through the C operand, so
-        //    nothing has to be zeroed).  A operand lane (lk = k, lr = i): (Tm - I)[i - 4t][k] for i in [4t, 4t+4)
-        const int qi = lr - 4 * t;
-        double aop = 0.0;
-        if (qi >= 1 && qi < 4) {
-            const double w1 = (lk == 0) ? t10 : 0.0;
-            const double w2 = (lk == 0) ? t20 : ((lk == 1) ? t21 : 0.0);
-            const double w3 = (lk == 0) ? t30 : ((lk == 1) ? t31 : ((lk == 2) ? t32 : 0.0));
-            aop = (qi == 1) ? w1 : ((qi == 2) ? w2 : w3);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            if (b >= a) A[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, A[a][b][t], A[a][b], 0, 0, 0);   // upper tiles only
-            if (b <= a) I[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, I[a][b][t], I[a][b], 0, 0, 0);   // columns <= current rows only
-        }
-        if (s == 2) STAMP(8);
-        const double Dsel = (lk == 0) ? D0 : ((lk == 1) ? D1 : ((lk == 2) ? D2 : D3));
-        const double rsel = (lk == 0) ? r0 : ((lk == 1) ? r1 : ((lk == 2) ? r2 : r3));
-        // 3. rank-4 update of the rows below the strip
-#pragma unroll
-        for (int ap = 0; ap < 2; ap++) {
-            if (ap < a) continue;
-            if (16 * ap + 15 <= 4 * s + 3) continue;       // no rows of this tile below the strip
-            // multipliers L[k][r] = W[k][r] / D_k for r = 16ap + lr > 4s+3 (rows already final keep their values)
-            const double wkr = A[a][ap][t];
-            const double lop = (16 * ap + lr > 4 * s + 3) ? -(wkr * rsel) : 0.0;
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                if (b >= ap) A[ap][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, A[a][b][t], A[ap][b], 0, 0, 0);
-                if (b <= a) I[ap][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, I[a][b][t], I[ap][b], 0, 0, 0);
-            }
-        }
-        // 4. rows 4s..4s+3 are final: write their outputs now, in the shadow of the MFMAs just issued
-        {
-            const int r = 4 * s + lk;
-            const double sq = sqrt(Dsel), isq = sq * rsel;
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const int c = 16 * b + lr;
-                if (b >= a) {
-                    if (c == r) { out->D[r] = Dsel; out->sq[r] = isq; out->rD[r] = rsel; Dall[j0 + r] = Dsel; }
-                    if (c >= r && j0 + r < n && j0 + c < n) Sout[(size_t)(j0 + r) * ld + j0 + c] = (c == r) ? sq : isq * A[a][b][t];
-                }
-                if (b <= a) out->Tt[c * 32 + r] = I[a][b][t];            // Tt[kk = c][jj = r] = T[r][c]; entries with c > r stay 0
-            }
-        }
-    }
-    STAMP(10);
+    if (wv == 0) gmw_cols_pivot_wave(w, eps, lane);
+    else if (wv == 2) gmw_cols_t_wave(w, lane, out->Tt);
+    else gmw_cols_out_wave(w, wv == 1 ? 0 : 1, lane, n, ld, j0, out->D, out->sq, out->rD, Dall, Sout);
 }
 
-// k_gmw_first: factor the first diagonal block (j0 = 0).  One wave.
-__global__ __launch_bounds__(64) void k_gmw_first(int n, int ld, double eps, const double* __restrict__ G, GmwPanel* __restrict__ out,
-                                                  double* __restrict__ Dall, double* __restrict__ Sout)
+// k_gmw_first: factor the first diagonal block (j0 = 0) on its own (standalone srukf_gmw_host path; the filter
+// gets this block from k_syrk).  One workgroup.
+__global__ __launch_bounds__(256) void k_gmw_first(int n, int ld, double eps, const double* __restrict__ G, GmwPanel* __restrict__ out,
+                                                   double* __restrict__ Dall, double* __restrict__ Sout)
 {
-    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
-    d4 A[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) A[a][b][t] = G[(size_t)(16 * a + lk + 4 * t) * ld + 16 * b + lr];
-    gmw_factor_block(A, eps, lane, n, ld, 0, out, Dall, Sout);
+    __shared__ double region[GMW_XM_DOUBLES + GMW_LM_DOUBLES + 32];
+    const GmwColsLds ws = gmw_cols_carve(region);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 1024; e += 256) ws.Xm[e >> 5][e & 31] = G[(size_t)(e >> 5) * ld + (e & 31)];
+    if (tid < 32) ws.Dv[tid] = 0.0;
+    __syncthreads();
+    gmw_cols_factor_wg(ws, tid >> 6, tid & 63, eps, n, ld, 0, out, Dall, Sout);
 }
 
 // Critical-path workgroup of a step: block (0,0) of the trailing square owns the next diagonal block
 // (tile (base, base)).  Its four waves first cooperate on that tile only — each a 16x16 quarter of
 // the panel slab  W = T * G[J][base:base+32)  and of the update — so that wave 0 can start the
-// 32-pivot factorisation as early as possible; waves 1 and 3 then finish the block's other two
-// tiles, (0,1) and (1,1), from a register-resident second slab while wave 0 factors.
+// 32-pivot chain as early as possible (gmw_cols_factor_wg: wave 2 follows with T); waves 1 and 3 first
+// finish the block's other two tiles, (0,1) and (1,1), from a register-resident second slab, then write
+// the outputs of the factored block as its rows appear.
 __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double eps, double* __restrict__ G,
                                                  const GmwPanel* __restrict__ cur, GmwPanel* __restrict__ nxt,
                                                  double* __restrict__ Dall, double* __restrict__ Sout,
-                                                 double (*Lr)[80], double (*Wc)[80], double (*Xg)[64][4], int lane, int wv)
+                                                 double (*Lr)[80], double (*Wc)[80], double* Xg, double* Dv, int lane, int wv)
 {
     const int lr = lane & 15, lk = lane >> 4;
     const int base = j0 + 32;
@@ -396,24 +297,23 @@ __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double e
 #pragma unroll
     for (int k = 0; k < 32; k += 4)
         g = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], g, 0, 0, 0);
+    // the updated diagonal block goes to LDS in plain row-major form (Xg), the layout the column factor reads;
+    // Wc is dead after this barrier and becomes the factor's row-of-L buffer
+    GmwColsLds ws;
+    ws.Xm = (double (*)[32])Xg; ws.Lm = &Wc[0][0]; ws.Dv = Dv;
 #pragma unroll
-    for (int t = 0; t < 4; t++) Xg[wv][lane][t] = g[t];
+    for (int t = 0; t < 4; t++) ws.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = g[t];
     __syncthreads();
-    if (wv == 0) {
-        // a 16x16 accumulator quarter has the same lane map as the matching tile of the 32x32 C layout
-        d4 A[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) A[a][b][t] = Xg[2 * a + b][lane][t];
-        STAMP(4);
-        gmw_factor_block(A, eps, lane, n, ld, base, nxt, Dall, Sout);
+    STAMP(4);
+    if (wv == 0 || wv == 2) {
+        gmw_cols_factor_wg(ws, wv, lane, eps, n, ld, base, nxt, Dall, Sout);
         STAMP(5);
         return;
     }
-    if (wv == 2 || base + 32 >= ld) return;
+    if (base + 32 >= ld) {                                     // last panel: no second slab
+        gmw_cols_factor_wg(ws, wv, lane, eps, n, ld, base, nxt, Dall, Sout);
+        return;
+    }
     // waves 1 and 3: second slab W2 = T * G[J][base+32 : base+64) kept in registers (C layout = MFMA operand
     // layout for the k-step of four consecutive panel rows), then tile (0,1) / (1,1)
     d4 W2[2][2];
@@ -451,6 +351,7 @@ __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double e
                 if (wv == 1 && j0 + 16 * a + lk + 4 * t < n)                                   // S rows of the panel, second slab
                     Sout[(size_t)(j0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = W2[a][b][t] * sqr[a][t];
             }
+    gmw_cols_factor_wg(ws, wv, lane, eps, n, ld, base, nxt, Dall, Sout);                       // output duty
 }
 
 // k_gmw_step: one launch per panel J = [j0, j0+32).  Every 64x64 block of the trailing square
@@ -462,24 +363,31 @@ __device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double e
 //   4. block (0,0) takes its own route (gmw_step_block00): its tile (0,0) IS the next diagonal block,
 //      which wave 0 factors and publishes as the next panel buffer (visible to the next launch).
 // grid = (T, T), T = ceil((ld - base)/64); blocks strictly below the diagonal exit.
-__global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, double eps, double* __restrict__ G,
-                                                  const GmwPanel* __restrict__ cur, GmwPanel* __restrict__ nxt,
-                                                  double* __restrict__ Dall, double* __restrict__ Sout, const double* __restrict__ Sfirst)
+// (argument order: everything the critical-path workgroup needs before its first global load sits in the first
+//  14 dwords, the part of the kernarg segment that -amdgpu-kernarg-preload-count hands over in SGPRs)
+__global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, int first, double* __restrict__ G,
+                                                  const GmwPanel* __restrict__ cur, double* __restrict__ Sout, GmwPanel* __restrict__ nxt,
+                                                  double* __restrict__ Dall, double eps, const double* __restrict__ Sfirst)
 {
     if (blockIdx.x < blockIdx.y) return;
     STAMP(0);
     __shared__ double Lr[32][80];      // stride 80 doubles: lanes l / l+16 land on opposite bank halves
     __shared__ double Wc[32][80];
-    __shared__ double Xg[4][64][4];
+    __shared__ double Xg[GMW_XM_DOUBLES];
+    __shared__ double Dv[32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (Sfirst && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (first && blockIdx.x == 0 && blockIdx.y == 0) {
         // first step: bring the diagonal block of S rows 0..31 (factored inside k_syrk into scratch) into S
         for (int e = tid; e < 1024; e += 256) {
             const int r = e >> 5, c = e & 31;
             if (c >= r && c < n) Sout[(size_t)r * ld + c] = Sfirst[(size_t)r * ld + c];
         }
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0) { gmw_step_block00(n, ld, j0, eps, G, cur, nxt, Dall, Sout, Lr, Wc, Xg, lane, wv); return; }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid < 32) Dv[tid] = 0.0;                           // "row published" flags of the column factor (two barriers ahead of their first use)
+        gmw_step_block00(n, ld, j0, eps, G, cur, nxt, Dall, Sout, Lr, Wc, Xg, Dv, lane, wv);
+        return;
+    }
     const int lr = lane & 15, lk = lane >> 4;
     const int base = j0 + 32;
     const int R0 = base + 64 * blockIdx.y, C0 = base + 64 * blockIdx.x;
@@ -670,7 +578,7 @@ void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* U
 // whole fast-path factorisation: first diagonal block, then one launch per panel
 void srukf_launch_gmw_first(hipStream_t st, int n, int ld, double eps, const double* G, void* pan0, double* D, double* Sout)
 {
-    hipLaunchKernelGGL(k_gmw_first, dim3(1), dim3(64), 0, st, n, ld, eps, G, (GmwPanel*)pan0, D, Sout);
+    hipLaunchKernelGGL(k_gmw_first, dim3(1), dim3(256), 0, st, n, ld, eps, G, (GmwPanel*)pan0, D, Sout);
 }
 void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout,
                            const double* Sfirst)
@@ -678,7 +586,7 @@ void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, do
     const int rem = ld - j0 - 32;
     if (rem <= 0) return;
     const int T = (rem + 63) / 64;
-    hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, eps, G, (const GmwPanel*)cur, (GmwPanel*)nxt, D, Sout, Sfirst);
+    hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, Sfirst ? 1 : 0, G, (const GmwPanel*)cur, Sout, (GmwPanel*)nxt, D, eps, Sfirst);
 }
 int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel); }
 void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj)

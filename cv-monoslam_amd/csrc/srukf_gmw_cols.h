@@ -1,0 +1,250 @@
+// srukf_gmw_cols.h — the 32-pivot chain of the GMW factorisation (one 32x32 diagonal block) in
+// COLUMN layout on the vector ALU.  gfx950 only.
+//
+// Why not MFMA here: on MI355X the FP64 matrix pipe has the same peak as the FP64 vector pipe (one
+// v_mfma_f64_16x16x4 = 1024 FMAs in 64 cycles = one v_fma_f64 per 4 cycles), and a dependent MFMA
+// costs 64-92 cycles against 4.8 for a dependent v_fma_f64 (scripts/mb/mb_lat.hip).  The pivot chain
+// is latency bound, so it runs as plain FMAs; what made a VALU version slow before — two v_readlane
+// per multiplier — is replaced by DPP row_newbcast operands, one instruction per row update:
+//
+//   lane c16 of EVERY 16-lane DPP row holds columns c16 (P[r] = C[r][c16], r < 16) and 16 + c16
+//   (Q[r] = C[r][16 + c16], r < 32) of the block — row_newbcast only reaches the own DPP row.
+//   pivot j:  xp,xq = P[j], Q[j]                      the pivot row entries of this lane's two columns
+//             d   = xp|xq[lane j & 15]  (v_mov_b64_dpp row_newbcast),  D = max(eps, |d|),  rc = 1/D
+//             ntp,ntq = -xp * rc, -xq * rc             = -L[j][c]
+//             P[r] += xp[lane r] * ntp, Q[r] += (xp|xq)[lane r & 15] * ntq   for r > j   (v_fmac_f64_dpp)
+//   i.e. C[r][c] -= C[j][r] * C[j][c] / D_j, the reference's recurrence (SLAM.cpp:2246-2262) with
+//   D_j = max(EPSILON, |C_jj|) (the theta clamp is verified afterwards by k_gmw_check).
+//
+// The pivot wave publishes row j of -L (and D_j, which doubles as the "row j ready" flag) in LDS as
+// soon as it exists.  A second wave follows one pivot behind and builds T = (I + M^T)^{-1} = L^{-1}
+// (column c' per lane, multipliers as uniform LDS reads), so the panel "TRSM" of the next step stays
+// an MFMA product.  After a barrier every wave of the workgroup helps to write S rows / D outputs.
+#pragma once
+#include "srukf_device.h"
+
+struct GmwPanel;
+
+template <int N> __device__ __forceinline__ void fmac_bcast16(double& acc, double src, double nt)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(nt), "n"(N));
+}
+// the s_nop covers the "VALU writes VGPR -> DPP reads it" hazard (2 wait states), which the compiler
+// cannot see inside inline asm; src is produced right before this instruction on the pivot chain
+template <int N> __device__ __forceinline__ double mov_bcast16(double src)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(N));
+    return r;
+}
+
+// ---- LDS workspace ---------------------------------------------------------------------------
+// Xm: the block to factor (row-major, upper triangle valid).
+// Lm: row J of -L as published by the pivot wave, one 528-byte strip per lane c16 (conflict-free for
+//     128-bit accesses): strip[2J] = -L[J][c16], strip[2J+1] = -L[J][16 + c16].
+// Dv: D_J; zero before the factorisation starts, D_J > 0 afterwards — doubles as the "row J published" flag.
+#define GMW_LM_STRIDE 66                       // doubles per lane strip
+#define GMW_XM_DOUBLES 1024
+#define GMW_LM_DOUBLES (16 * GMW_LM_STRIDE)
+struct GmwColsLds {                            // pointers, so that a kernel can alias LDS arrays it no longer needs
+    double (*Xm)[32];
+    double* Lm;
+    double* Dv;
+};
+// carve the three arrays out of one LDS region of >= GMW_XM_DOUBLES + GMW_LM_DOUBLES + 32 doubles
+__device__ __forceinline__ GmwColsLds gmw_cols_carve(double* region)
+{
+    GmwColsLds w;
+    w.Xm = (double (*)[32])region; w.Lm = region + GMW_XM_DOUBLES; w.Dv = region + GMW_XM_DOUBLES + GMW_LM_DOUBLES;
+    return w;
+}
+__device__ __forceinline__ double gmw_lm(const double* Lm, int j, int c) { return Lm[(c & 15) * GMW_LM_STRIDE + 2 * j + (c >> 4)]; }
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef volatile __attribute__((address_space(3))) double lds_vdouble;
+typedef volatile __attribute__((address_space(3))) d2 lds_vd2;
+__device__ __forceinline__ unsigned lds_off(const volatile void* p)
+{
+    return (unsigned)(__UINTPTR_TYPE__)(const volatile __attribute__((address_space(3))) void*)p;
+}
+// Publishing stores: asm volatile statements keep their order, and LDS executes one wave's accesses in
+// issue order, so "row, then D" needs no s_waitcnt on the pivot chain.
+template <int OFF> __device__ __forceinline__ void lds_publish(unsigned off, double v)
+{
+    asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(off), "v"(v), "n"(OFF) : "memory");
+}
+template <int O0, int O1> __device__ __forceinline__ void lds_publish2(unsigned off, double v0, double v1)
+{
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(off), "v"(v0), "v"(v1), "n"(O0), "n"(O1) : "memory");
+}
+
+__device__ __forceinline__ double gmw_pivot_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// rows R..RE-1 of one register set: acc[r] += src[lane r & 15 of this DPP row] * nt
+template <int R, int RE, int NA> struct GmwRowUpd {
+    static __device__ __forceinline__ void run(double (&acc)[NA], double src, double nt)
+    {
+        if constexpr (R < RE) {
+            fmac_bcast16<(R & 15)>(acc[R], src, nt);
+            GmwRowUpd<R + 1, RE, NA>::run(acc, src, nt);
+        }
+    }
+};
+
+// Pivot J.  Every DPP row of 16 lanes holds the whole block: lane c16 owns column c16 (P[r], rows 0..15 — the
+// lower-left 16x16 quarter is never needed) and column 16 + c16 (Q[r], rows 0..31), so the pivot row is
+// available to row_newbcast in every DPP row without any cross-row traffic.
+template <int J> struct GmwPivot {
+    // lm: LDS offset of this lane's Lm strip, dv: LDS offset of Dv[0]
+    static __device__ __forceinline__ void run(double (&P)[16], double (&Q)[32], double eps, unsigned lm, unsigned dv)
+    {
+        if constexpr (J < 32) {
+            const double xq = Q[J];
+            double xp = 0.0;
+            if constexpr (J < 16) xp = P[J];
+            const double d = mov_bcast16<(J & 15)>(J < 16 ? xp : xq);
+            double D;
+            asm("v_max_f64 %0, %1, |%2|" : "=v"(D) : "v"(eps), "v"(d));     // NaN-proof: max(eps, NaN) = eps
+            const double nrc = -gmw_pivot_rcp(D);
+            const double ntq = xq * nrc;
+            double ntp = 0.0;
+            if constexpr (J < 16) {
+                ntp = xp * nrc;
+                lds_publish2<2 * J, 2 * J + 1>(lm, ntp, ntq);       // row J of -L (entries c <= J are not used)
+            } else {
+                lds_publish<16 * J + 8>(lm, ntq);
+            }
+            lds_publish<J * 8>(dv, D);
+            if constexpr (J < 16) {
+                GmwRowUpd<J + 1, 16, 16>::run(P, xp, ntp);
+                GmwRowUpd<J + 1, 16, 32>::run(Q, xp, ntq);
+                GmwRowUpd<16, 32, 32>::run(Q, xq, ntq);
+            } else {
+                GmwRowUpd<J + 1, 32, 32>::run(Q, xq, ntq);
+            }
+            GmwPivot<J + 1>::run(P, Q, eps, lm, dv);
+        }
+    }
+};
+
+// Pivot wave.
+__device__ __forceinline__ void gmw_cols_pivot_wave(const GmwColsLds& w, double eps, int lane)
+{
+    const int c = lane & 15;
+    double P[16], Q[32];
+#pragma unroll
+    for (int r = 0; r < 16; r++) P[r] = w.Xm[r][c];
+#pragma unroll
+    for (int r = 0; r < 32; r++) Q[r] = w.Xm[r][16 + c];
+    GmwPivot<0>::run(P, Q, eps, lds_off(&w.Lm[c * GMW_LM_STRIDE]), lds_off(w.Dv));
+}
+
+// ---- follower waves ----------------------------------------------------------------------------
+// Both followers consume the published rows in groups (8, 8, 8, 4, rest): one wave-uniform poll per group on
+// the D of its last row, then ordinary LDS loads, so the compiler pipelines them; a follower that polled on
+// every row would pay an LDS round trip per pivot and fall behind the pivot wave.
+#define GMW_POLL_LIMIT (1 << 22)               // a stuck pivot wave must never hang the GPU: give up (k_gmw_check then flags the frame)
+__device__ __forceinline__ void gmw_wait_row(unsigned dv, int j)
+{
+    int spins = 0;
+    double f;
+    // (explicit ds_read: a volatile C++ load would make the compiler drain all outstanding global stores first)
+    // (the s_sleep keeps three polling waves from crowding the pivot wave's LDS traffic)
+    do { asm volatile("s_sleep 1\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(dv + j * 8) : "memory"); }
+    while (__builtin_amdgcn_readfirstlane(__double2hiint(f)) <= 0 && spins++ < GMW_POLL_LIMIT);
+    asm volatile("" ::: "memory");             // nothing below may be read before the flag
+}
+
+// T[r][c'] -= L[J][r] T[J][c'] for r > J, J = J0..J1-1.  a/b = row J of -L (columns lane&15 / 16 + lane&15, i.e.
+// replicated into every DPP row).
+template <int J, int J1> struct GmwTStep {
+    static __device__ __forceinline__ void run(double (&t)[32], const d2 (&ab)[8], int)
+    {
+        if constexpr (J < J1) {
+            const double tj = t[J];
+            if constexpr (J < 15) GmwRowUpd<J + 1, 16, 32>::run(t, ab[J & 7][0], tj);
+            GmwRowUpd<(J < 15 ? 16 : J + 1), 32, 32>::run(t, ab[J & 7][1], tj);
+            GmwTStep<J + 1, J1>::run(t, ab, 0);
+        }
+    }
+};
+template <int J0, int J1> __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane, double* __restrict__ Tt)
+{
+    gmw_wait_row(dv, J1 - 1);
+    d2 ab[8];
+    const d2* strip = (const d2*)&w.Lm[(lane & 15) * GMW_LM_STRIDE];
+#pragma unroll
+    for (int j = J0; j < J1; j++) ab[j & 7] = strip[j];
+    GmwTStep<J0, J1>::run(t, ab, 0);
+#pragma unroll
+    for (int r = J0 + 1; r < 32; r++) asm volatile("" : "+v"(t[r]));   // keep the FMAs in this group (no sinking past the next poll)
+    // rows <= J1 of T are final now: store them while the pivot wave works on the next group
+    if (lane < 32) {
+#pragma unroll
+        for (int r = (J0 == 0 ? 0 : J0 + 1); r <= (J1 == 31 ? 31 : J1); r++) Tt[lane * 32 + r] = t[r];
+    }
+}
+
+// Follower wave 1: T = L^{-1}, column c' = lane & 31 per lane, written as Tt[kk = c'][jj] = T[jj][kk].
+__device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt)
+{
+    const int c = lane & 31;
+    const unsigned dv = lds_off(w.Dv);
+    double t[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) t[r] = (r == c) ? 1.0 : 0.0;
+    gmw_t_group<0, 8>(t, w, dv, lane, Tt);
+    gmw_t_group<8, 16>(t, w, dv, lane, Tt);
+    gmw_t_group<16, 24>(t, w, dv, lane, Tt);
+    gmw_t_group<24, 28>(t, w, dv, lane, Tt);
+    gmw_t_group<28, 31>(t, w, dv, lane, Tt);
+}
+
+// Follower wave 2: outputs of rows J0..J1-1 — S rows j0+J (diagonal-block part), pivots, per-row scales of the
+// panel buffer.  Lane l handles row J0 + (l >> 3) (when the group has 8 rows) and four columns.
+template <int J0, int J1> __device__ __forceinline__ void gmw_out_group(const GmwColsLds& w, unsigned dv, int lane, int n, int ld, int j0,
+                                                                        double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
+                                                                        double* __restrict__ Dall, double* __restrict__ Sout)
+{
+    gmw_wait_row(dv, J1 - 1);
+    const int j = J0 + (lane >> 3), c0 = (lane & 7) * 4;
+    if (j >= J1) return;
+    const double D = w.Dv[j];
+    double l[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) l[q] = gmw_lm(w.Lm, j, c0 + q);          // unconditional: all four LDS reads in flight together
+    const double sq = sqrt(D);
+    if ((lane & 7) == 0) {
+        const double rc = gmw_pivot_rcp(D);
+        pD[j] = D; psq[j] = sq * rc; prD[j] = rc; Dall[j0 + j] = D;
+    }
+    // the whole 32-byte chunk is stored: zeros below the diagonal and in the padding rows / columns are what S holds there anyway
+    d4 v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int c = c0 + q;
+        v[q] = (c > j && j0 + c < n && j0 + j < n) ? -(l[q] * sq) : ((c == j && j0 + j < n) ? sq : 0.0);
+    }
+    *(d4*)&Sout[(size_t)(j0 + j) * ld + j0 + c0] = v;
+}
+// Two output waves (which = 0 / 1) take alternate groups, so the last group starts the moment its rows exist.
+__device__ __forceinline__ void gmw_cols_out_wave(const GmwColsLds& w, int which, int lane, int n, int ld, int j0,
+                                                  double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
+                                                  double* __restrict__ Dall, double* __restrict__ Sout)
+{
+    const unsigned dv = lds_off(w.Dv);
+    if (which == 0) {
+        gmw_out_group<0, 8>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
+        gmw_out_group<16, 24>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
+        gmw_out_group<28, 32>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
+    } else {
+        gmw_out_group<8, 16>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
+        gmw_out_group<24, 28>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
+    }
+}
