@@ -27,6 +27,7 @@ void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*,
 void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, double, void*, double*, double*, const void*, int);
 void srukf_launch_gmw_first(hipStream_t, int, int, double, const double*, void*, double*, double*);
 void srukf_launch_gmw_step(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const double*);
+void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
 int srukf_gmw_panel_bytes(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
@@ -217,17 +218,18 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     {
         const double nn = n;
         ProfScope ps(c, KC_SYRK, nn * nn * nn / 3.0 + nn * nn * (ue - ub), 8.0 * (nn * nn + (double)(ue - ub) * nn));
-        // the block that owns tile (0,0) also factors it = first diagonal block of the GMW (fast path)
-        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->p.epsilon, slow ? nullptr : c->pan[0], c->D, c->Wf, c->syrk_tiles, c->n_syrk_tiles);
+        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->p.epsilon, nullptr, c->D, c->Wf, c->syrk_tiles, c->n_syrk_tiles);
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
     if (!slow) {
+        // 64-row panels: j0 = -64 factors the first 64x64 region, then one launch per panel
         int pb = 0;
-        for (int j0 = 0; j0 + SRUKF_NB < np; j0 += SRUKF_NB, pb ^= 1) {
-            const double r2 = np - j0 - 32;
-            // per launch: trailing update 32*r2^2 (upper half, 2 flop) + slab recompute + next diagonal block
-            ProfScope ps(c, KC_GMW_TRAIL, 32.0 * r2 * r2 + 2.0 * 32.0 * 32.0 * r2 + 32.0 * 32.0 * 32.0 / 3.0, 8.0 * (r2 * r2 + 2.0 * 32.0 * r2));
-            srukf_launch_gmw_step(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb], c->pan[pb ^ 1], c->D, c->S, j0 == 0 ? c->Wf : nullptr);
+        for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1) {
+            const double r2 = np - j0 - 64;
+            // per launch: trailing update 64*r2^2 (upper half, 2 flop) + three-stage slab recompute + next 64x64 diagonal region
+            ProfScope ps(c, KC_GMW_TRAIL, j0 < 0 ? 64.0 * 64.0 * 64.0 / 3.0 : 64.0 * r2 * r2 + 3.0 * 2.0 * 32.0 * 32.0 * r2 + 64.0 * 64.0 * 64.0 / 3.0,
+                         8.0 * (r2 * r2 + 2.0 * 64.0 * r2));
+            srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb ^ 1], c->pan[pb], c->D, c->S);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
         srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs, c->X, frame_tail ? 1 : 0);
@@ -748,10 +750,9 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
     if (!force_slow) {
         void* pan[2];
         hipMalloc(&pan[0], srukf_gmw_panel_bytes()); hipMalloc(&pan[1], srukf_gmw_panel_bytes());
-        srukf_launch_gmw_first(st, n, np, epsilon, dG, pan[0], dD, dS);
         int pb = 0;
-        for (int j0 = 0; j0 + SRUKF_NB < np; j0 += SRUKF_NB, pb ^= 1)
-            srukf_launch_gmw_step(st, n, np, j0, epsilon, dG, pan[pb], pan[pb ^ 1], dD, dS, nullptr);
+        for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
+            srukf_launch_gmw_step64(st, n, np, j0, epsilon, dG, pan[pb ^ 1], pan[pb], dD, dS);
         hipDeviceSynchronize();
         hipFree(pan[0]); hipFree(pan[1]);
         srukf_launch_gmw_check(st, n, np, dD, dS, dFs, nullptr, 0);

@@ -466,6 +466,362 @@ __global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, int fir
     STAMP(4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 64-row panels: one launch per TWO 32-row sub-panels.
+// Every launch pays ~2.5 us of dispatch gap plus ~1.5 us of kernarg / first-load latency before any
+// arithmetic starts, and the factorisation is one long dependent chain of launches; with 32-row
+// panels that overhead was as large as the work.  Here the critical-path workgroup factors both
+// 32x32 diagonal blocks of the NEXT 64-row panel inside one launch, and the trailing update runs
+// with K = 64 (G is read and written half as often).
+//
+// Panel buffer: sub-panel 1 = rows j0..j0+31, sub-panel 2 = rows j0+32..j0+63.
+//   Tt1, Tt2 : Tt[kk][jj] = T[jj][kk], T = L^{-1} of the sub-panel's diagonal block (as GmwPanel)
+//   E        : E[k][r] = L[k][32 + r] = W1d[k][r] / D_k, the multipliers that couple sub-panel 2 to the
+//              pivots of sub-panel 1
+//   W1 = T1 G1;   G2' = G2 - E^T W1;   W2 = T2 G2'        (three K = 32 MFMA stages per column slab,
+//   register resident: a C-layout accumulator tile is a valid B operand of the next stage)
+// ------------------------------------------------------------------------------------------------
+struct GmwPanel64 { double Tt1[1024]; double Tt2[1024]; double E[1024]; double D[64]; double sq[64]; double rD[64]; };
+
+// acc[a][b] (+)= sum_k A[k][16a + i] * B[k][16b + j],  k < 32:  A from a 32x32 K-major global array (row stride 32),
+// B from a C-layout register tile (rows = k).  All 16 A fragments are requested before the first MFMA.
+template <bool NEG>
+__device__ __forceinline__ void stage32_regB(d4 (&acc)[2][2], const double* __restrict__ A, const d4 (&B)[2][2], int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    double fa0[8], fa1[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { fa0[u] = A[(4 * u + lk) * 32 + lr]; fa1[u] = A[(4 * u + lk) * 32 + 16 + lr]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int a2 = u >> 2, t = u & 3;                      // k = 16 a2 + 4 t + lk
+        const double a0 = NEG ? -fa0[u] : fa0[u], a1 = NEG ? -fa1[u] : fa1[u];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, B[a2][0][t], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, B[a2][1][t], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, B[a2][0][t], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, B[a2][1][t], acc[1][1], 0, 0, 0);
+    }
+}
+
+#define G64_LS 80              // LDS row stride of the slabs (doubles): lanes l / l+16 land on opposite bank halves
+
+// Critical-path workgroup of a 64-row step: owns the next panel's 64x64 diagonal region R = [base, base+64),
+// tiles (0,0), (0,1), (1,1).
+//   A   Tt1 | E | Tt2 are staged through LDS once (each wave needs all three); each wave then runs the
+//       three-stage slab for 16 of R's 64 columns -> LDS (W and L = W/D)
+//   B   quarters of tile (0,0) with K = 64 -> Xm;  factor 1: wave 0 pivots; wave 2 first writes the panel's S rows
+//       for R's columns from the LDS slab, then follows with T1'; waves 1 / 3 update tiles (0,1) / (1,1) with
+//       K = 64, park them in LDS, then write factor 1's outputs
+//   C   W1d = T1' X01 (quarters), E' = W1d / D';  X11 -= E'^T W1d (quarters) -> Xm;  factor 2 (waves 1 / 3 first
+//       write E' and the (0,1) tile of S, then factor 2's outputs)
+// Global stores cost ~85 cycles of issue each on this path, so the pivot wave never stores to global memory.
+// first != 0: there is no current panel (R is the first 64 rows): phase A and the K = 64 updates are skipped.
+__device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int first, double eps, double* __restrict__ G,
+                                                   const GmwPanel64* __restrict__ cur, GmwPanel64* __restrict__ nxt,
+                                                   double* __restrict__ Dall, double* __restrict__ Sout,
+                                                   double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg,
+                                                   double* xreg, double* lsq, double* lrc, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int base = j0 + 64;
+    const int qa = wv >> 1, qb = wv & 1;
+    const GmwColsLds ws = gmw_cols_carve(facreg);
+    double (*X01)[32] = (double (*)[32])xreg;                  // tiles (0,1) / (1,1) after the K = 64 update
+    double (*X11)[32] = (double (*)[32])(xreg + 1024);
+    double* Tl = xreg + 2048;                                  // T1' [kk][33]
+    double* PT = xreg;                                         // phase A only: Tt1 | E | Tt2, element (row, col) at row*32 + (col ^ 16*(row&1))
+    if (tid < 32) ws.Dv[tid] = 0.0;
+    // prefetch: this wave's quarter of tile (0,0), its share of the panel matrices, its panel rows
+    d4 g;
+#pragma unroll
+    for (int t = 0; t < 4; t++) g[t] = G[(size_t)(base + 16 * qa + lk + 4 * t) * ld + base + 16 * qb + lr];
+    const int cw = base + 16 * wv;
+    const int ro = (wv == 1) ? 0 : 32;                         // waves 1 / 3: tile rows base + ro .., columns base + 32 ..
+    d4 acc[2][2];
+    zero_acc(acc);
+    if (!first) {
+        d4 pt[3], X2[2];
+        double fb[8], dr[4][4];
+        pt[0] = *(const d4*)&cur->Tt1[4 * tid]; pt[1] = *(const d4*)&cur->E[4 * tid]; pt[2] = *(const d4*)&cur->Tt2[4 * tid];
+#pragma unroll
+        for (int u = 0; u < 8; u++) fb[u] = G[(size_t)(j0 + 4 * u + lk) * ld + cw + lr];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) X2[a][t] = G[(size_t)(j0 + 32 + 16 * a + lk + 4 * t) * ld + cw + lr];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) dr[q][t] = cur->rD[16 * q + lk + 4 * t];     // 1/D of rows 16 q + lk + 4 t
+        STAMP(1);
+        {
+            const int row = tid >> 3, c4 = ((tid & 7) * 4) ^ (16 * (row & 1));
+#pragma unroll
+            for (int m = 0; m < 3; m++) *(d4*)&PT[m * 1024 + row * 32 + c4] = pt[m];
+        }
+        __syncthreads();
+        if (wv & 1) {                                          // requested now, needed after phase B
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = G[(size_t)(base + ro + 16 * a + lk + 4 * t) * ld + base + 32 + 16 * b + lr];
+        }
+        // ---- A: slab for columns cw .. cw+15; A operand (k = 4u + lk, column 16a + lr) of matrix m from LDS ----
+        d4 W1[2] = { (d4){0, 0, 0, 0}, (d4){0, 0, 0, 0} }, W2[2] = { (d4){0, 0, 0, 0}, (d4){0, 0, 0, 0} };
+        const int sw = 16 * (lk & 1);                          // (4u + lk) & 1 == lk & 1
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double* rowp = &PT[(4 * u + lk) * 32];
+            W1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr ^ sw], fb[u], W1[0], 0, 0, 0);
+            W1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[(16 + lr) ^ sw], fb[u], W1[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double* rowp = &PT[1024 + (4 * u + lk) * 32];
+            X2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rowp[lr ^ sw], W1[u >> 2][u & 3], X2[0], 0, 0, 0);
+            X2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rowp[(16 + lr) ^ sw], W1[u >> 2][u & 3], X2[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double* rowp = &PT[2048 + (4 * u + lk) * 32];
+            W2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr ^ sw], X2[u >> 2][u & 3], W2[0], 0, 0, 0);
+            W2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[(16 + lr) ^ sw], X2[u >> 2][u & 3], W2[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int jj = 16 * a + lk + 4 * t, cc = 16 * wv + lr;
+                Wc[jj][cc] = W1[a][t];       Lr[jj][cc] = W1[a][t] * dr[a][t];
+                Wc[32 + jj][cc] = W2[a][t];  Lr[32 + jj][cc] = W2[a][t] * dr[2 + a][t];
+            }
+    } else {
+        STAMP(1);
+        if (wv & 1) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = G[(size_t)(base + ro + 16 * a + lk + 4 * t) * ld + base + 32 + 16 * b + lr];
+        }
+    }
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
+    // ---- B: quarter (qa, qb) of tile (0,0), K = 64 ----
+    if (!first) {
+#pragma unroll
+        for (int k = 0; k < 64; k += 4)
+            g = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], g, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) ws.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = g[t];
+    __syncthreads();
+    STAMP(4);
+    // ---- factor 1 (+ panel S rows, tiles (0,1), (1,1)) ----
+    if (wv == 0) gmw_cols_pivot_wave(ws, eps, lane);
+    else if (wv == 2) {
+        if (!first) {
+            // S rows j0..j0+63 of the panel, columns base..base+63 (rows / columns >= n carry zeros: G is zero there)
+            const int c4 = lr * 4;
+#pragma unroll 4
+            for (int i = 0; i < 16; i++) {
+                const int row = 4 * i + lk;
+                const double sq = cur->sq[row];
+                d4 w = *(const d4*)&Wc[row][c4];
+                w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
+                *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
+            }
+        }
+        gmw_cols_t_wave(ws, lane, nxt->Tt1, Tl);
+    } else {
+        if (!first) {
+#pragma unroll 4
+            for (int k = 0; k < 64; k += 4) {
+                const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
+                const double b0 = Wc[k + lk][32 + lr], b1 = Wc[k + lk][48 + lr];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        double (*X)[32] = (wv == 1) ? X01 : X11;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) X[16 * a + lk + 4 * t][16 * b + lr] = acc[a][b][t];
+        gmw_cols_out_wave(ws, wv == 1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, lsq, lrc);
+    }
+    STAMP(5);
+    __syncthreads();
+    STAMP(6);
+    // ---- C1: quarter (qa, qb) of W1d = T1' X01 and of E' = W1d / D' -> LDS (the slabs are dead by now) ----
+    {
+        d4 wq = (d4){0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            wq = __builtin_amdgcn_mfma_f64_16x16x4f64(Tl[(4 * u + lk) * 33 + 16 * qa + lr], X01[4 * u + lk][16 * qb + lr], wq, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int k = 16 * qa + lk + 4 * t, cc = 16 * qb + lr;
+            Wc[k][cc] = wq[t];                                 // Wd
+            Lr[k][cc] = wq[t] * lrc[k];                        // Ld = E'
+        }
+    }
+    __syncthreads();
+    // ---- C2: quarter of X11 -= E'^T W1d -> Xm; reset the row flags ----
+    {
+        d4 x;
+#pragma unroll
+        for (int t = 0; t < 4; t++) x[t] = X11[16 * qa + lk + 4 * t][16 * qb + lr];
+#pragma unroll
+        for (int k = 0; k < 32; k += 4)
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], x, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) ws.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = x[t];
+        if (tid < 32) ws.Dv[tid] = 0.0;
+    }
+    __syncthreads();
+    STAMP(7);
+    // ---- factor 2 ----
+    if (wv == 0) gmw_cols_pivot_wave(ws, eps, lane);
+    else if (wv == 2) gmw_cols_t_wave(ws, lane, nxt->Tt2);
+    else {
+        const int c4 = (lane & 7) * 4;
+        if (wv == 1) {                                         // E' for the next launch
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = 8 * i + (lane >> 3);
+                *(d4*)&nxt->E[row * 32 + c4] = *(const d4*)&Lr[row][c4];
+            }
+        } else {                                               // S rows base..base+31, columns base+32..base+63
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = 8 * i + (lane >> 3);
+                const double sq = (base + row < n) ? lsq[row] : 0.0;
+                d4 w = *(const d4*)&Wc[row][c4];
+                w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
+                *(d4*)&Sout[(size_t)(base + row) * ld + base + 32 + c4] = w;
+            }
+        }
+        gmw_cols_out_wave(ws, wv == 1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout);
+    }
+    STAMP(8);
+}
+
+// k_gmw_step64: one launch per 64-row panel JJ = [j0, j0+64)  (j0 = -64, first = 1: only the first region is factored).
+// Every 64x64 block of the trailing square (base = j0+64):
+//   1. recomputes the panel rows it needs for its row slab and its column slab by the three MFMA stages
+//      above (one 32-column half slab per wave, register resident) and keeps L = W/D and W in LDS;
+//   2. updates its tile  G[r][c] -= sum_{kk<64} L[kk][r] W[kk][c];
+//   3. first block row only: writes the final S rows j0..j0+63 for its column slab;
+//   4. block (0,0) takes its own route (gmw_step64_block00).
+// grid = (T, T), T = (ld - base)/64; blocks strictly below the diagonal exit.
+__global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int first, double* __restrict__ G,
+                                                    const GmwPanel64* __restrict__ cur, double* __restrict__ Sout, GmwPanel64* __restrict__ nxt,
+                                                    double* __restrict__ Dall, double eps)
+{
+    if (blockIdx.x < blockIdx.y) return;
+    STAMP(0);
+    __shared__ double Lr[64][G64_LS];
+    __shared__ double Wc[64][G64_LS];
+    __shared__ double facreg[GMW_XM_DOUBLES + GMW_LM_DOUBLES + 32];
+    __shared__ double xreg[1024 + 1024 + 32 * 33];            // block (0,0): staged panel matrices, then X01 | X11 | T1'
+    __shared__ double lsq[32];
+    __shared__ double lrc[32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        gmw_step64_block00(n, ld, j0, first, eps, G, cur, nxt, Dall, Sout, Lr, Wc, facreg, xreg, lsq, lrc, tid);
+        return;
+    }
+    const int lr = lane & 15, lk = lane >> 4;
+    const int base = j0 + 64;
+    const int R0 = base + 64 * blockIdx.y, C0 = base + 64 * blockIdx.x;
+    const bool diagblk = blockIdx.x == blockIdx.y;
+    const int m0 = R0 + 32 * (wv >> 1), c0 = C0 + 32 * (wv & 1);
+    const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
+    d4 acc[2][2];
+    zero_acc(acc);
+    if (live) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+    }
+    // 1. half slab of this wave: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
+    {
+        const int which = wv >> 1, half = wv & 1;
+        const int n0 = (which ? C0 : R0) + 32 * half;
+        if (n0 < ld && !(diagblk && which == 1)) {
+            d4 X2[2][2], W1[2][2], W2[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) X2[a][b][t] = G[(size_t)(j0 + 32 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr];
+            double dr[4][4], sqr[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) { dr[q][t] = cur->rD[16 * q + lk + 4 * t]; sqr[q][t] = cur->sq[16 * q + lk + 4 * t]; }
+            zero_acc(W1);
+            tile32_tn<false>(W1, cur->Tt1, 32, G + (size_t)j0 * ld, ld, 0, n0, 0, 32, lane);
+            stage32_regB<true>(X2, cur->E, W1, lane);
+            zero_acc(W2);
+            stage32_regB<false>(W2, cur->Tt2, X2, lane);
+            const bool write_s = (blockIdx.y == 0) && (which == 1 || diagblk);
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
+                        const double w1 = W1[a][b][t], w2 = W2[a][b][t];
+                        if (which == 0) {
+                            Lr[jj][cc] = w1 * dr[a][t]; Lr[32 + jj][cc] = w2 * dr[2 + a][t];
+                            if (diagblk) { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
+                        } else { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
+                        if (write_s) {
+                            if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = w1 * sqr[a][t];
+                            if (j0 + 32 + jj < n) Sout[(size_t)(j0 + 32 + jj) * ld + n0 + 16 * b + lr] = w2 * sqr[2 + a][t];
+                        }
+                    }
+        }
+    }
+    __syncthreads();
+    // 2. tile update from LDS fragments, K = 64
+    if (live) {
+        const int ro = m0 - R0, co = c0 - C0;
+#pragma unroll 4
+        for (int k = 0; k < 64; k += 4) {
+            const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
+            const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
+    }
+}
+
 // k_gmw_check: was the reference's third pivot candidate theta_j^2/beta^2 ever the largest?
 // theta_j = max_{i>j} |C[i][j]| = sqrt(D_j) * max_{i>j} |S[j][i]|  (S[j][i] = C[i][j]/sqrt(D_j)),
 // beta^2 = max(gamma, xi/nu, 1e-15), nu = max(1, sqrt(n^2-1))   (SLAM.cpp:2204-2211, 2264-2285).
@@ -588,7 +944,15 @@ void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, do
     const int T = (rem + 63) / 64;
     hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, Sfirst ? 1 : 0, G, (const GmwPanel*)cur, Sout, (GmwPanel*)nxt, D, eps, Sfirst);
 }
-int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel); }
+// 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
+void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)
+{
+    const int rem = ld - j0 - 64;
+    if (rem <= 0) return;
+    const int T = (j0 < 0) ? 1 : rem / 64;
+    hipLaunchKernelGGL(k_gmw_step64, dim3(T, T), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, G, (const GmwPanel64*)cur, Sout, (GmwPanel64*)nxt, D, eps);
+}
+int srukf_gmw_panel_bytes(void) { return (int)(sizeof(GmwPanel64) > sizeof(GmwPanel) ? sizeof(GmwPanel64) : sizeof(GmwPanel)); }
 void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj)
 {
     hipLaunchKernelGGL(k_gmw_check, dim3(n + (do_traj ? 1 : 0)), dim3(256), 0, st, n, ld, D, S, fs, X, do_traj);

@@ -174,7 +174,8 @@ template <int J, int J1> struct GmwTStep {
         }
     }
 };
-template <int J0, int J1> __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane, double* __restrict__ Tt)
+template <int J0, int J1> __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane, double* __restrict__ Tt,
+                                                                      double* Tl)
 {
     gmw_wait_row(dv, J1 - 1);
     d2 ab[8];
@@ -188,29 +189,34 @@ template <int J0, int J1> __device__ __forceinline__ void gmw_t_group(double (&t
     if (lane < 32) {
 #pragma unroll
         for (int r = (J0 == 0 ? 0 : J0 + 1); r <= (J1 == 31 ? 31 : J1); r++) Tt[lane * 32 + r] = t[r];
+        if (Tl) {                                                       // workgroup-local copy, row stride 33 (conflict-free)
+#pragma unroll
+            for (int r = (J0 == 0 ? 0 : J0 + 1); r <= (J1 == 31 ? 31 : J1); r++) Tl[lane * 33 + r] = t[r];
+        }
     }
 }
 
-// Follower wave 1: T = L^{-1}, column c' = lane & 31 per lane, written as Tt[kk = c'][jj] = T[jj][kk].
-__device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt)
+// Follower wave 1: T = L^{-1}, column c' = lane & 31 per lane, written as Tt[kk = c'][jj] = T[jj][kk] (and, if Tl is
+// not null, to the LDS array Tl[kk][33]).
+__device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt, double* Tl = nullptr)
 {
     const int c = lane & 31;
     const unsigned dv = lds_off(w.Dv);
     double t[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) t[r] = (r == c) ? 1.0 : 0.0;
-    gmw_t_group<0, 8>(t, w, dv, lane, Tt);
-    gmw_t_group<8, 16>(t, w, dv, lane, Tt);
-    gmw_t_group<16, 24>(t, w, dv, lane, Tt);
-    gmw_t_group<24, 28>(t, w, dv, lane, Tt);
-    gmw_t_group<28, 31>(t, w, dv, lane, Tt);
+    gmw_t_group<0, 8>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<8, 16>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<16, 24>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<24, 28>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<28, 31>(t, w, dv, lane, Tt, Tl);
 }
 
 // Follower wave 2: outputs of rows J0..J1-1 — S rows j0+J (diagonal-block part), pivots, per-row scales of the
 // panel buffer.  Lane l handles row J0 + (l >> 3) (when the group has 8 rows) and four columns.
 template <int J0, int J1> __device__ __forceinline__ void gmw_out_group(const GmwColsLds& w, unsigned dv, int lane, int n, int ld, int j0,
                                                                         double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
-                                                                        double* __restrict__ Dall, double* __restrict__ Sout)
+                                                                        double* __restrict__ Dall, double* __restrict__ Sout, double* lsq, double* lrc)
 {
     gmw_wait_row(dv, J1 - 1);
     const int j = J0 + (lane >> 3), c0 = (lane & 7) * 4;
@@ -223,6 +229,7 @@ template <int J0, int J1> __device__ __forceinline__ void gmw_out_group(const Gm
     if ((lane & 7) == 0) {
         const double rc = gmw_pivot_rcp(D);
         pD[j] = D; psq[j] = sq * rc; prD[j] = rc; Dall[j0 + j] = D;
+        if (lsq) { lsq[j] = sq * rc; lrc[j] = rc; }                    // workgroup-local copies
     }
     // the whole 32-byte chunk is stored: zeros below the diagonal and in the padding rows / columns are what S holds there anyway
     d4 v;
@@ -236,15 +243,15 @@ template <int J0, int J1> __device__ __forceinline__ void gmw_out_group(const Gm
 // Two output waves (which = 0 / 1) take alternate groups, so the last group starts the moment its rows exist.
 __device__ __forceinline__ void gmw_cols_out_wave(const GmwColsLds& w, int which, int lane, int n, int ld, int j0,
                                                   double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
-                                                  double* __restrict__ Dall, double* __restrict__ Sout)
+                                                  double* __restrict__ Dall, double* __restrict__ Sout, double* lsq = nullptr, double* lrc = nullptr)
 {
     const unsigned dv = lds_off(w.Dv);
     if (which == 0) {
-        gmw_out_group<0, 8>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
-        gmw_out_group<16, 24>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
-        gmw_out_group<28, 32>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
+        gmw_out_group<0, 8>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<16, 24>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<28, 32>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     } else {
-        gmw_out_group<8, 16>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
-        gmw_out_group<24, 28>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout);
+        gmw_out_group<8, 16>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<24, 28>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     }
 }

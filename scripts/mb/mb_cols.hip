@@ -7,17 +7,18 @@
 __device__ __forceinline__ unsigned long long now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
 __global__ __launch_bounds__(256) void k(const double* G, int ld, double eps, double* Tt, double* pD, double* psq, double* prD, double* Dall, double* S, unsigned long long* ts)
 {
-    __shared__ GmwColsLds w;
+    __shared__ double region[GMW_XM_DOUBLES + GMW_LM_DOUBLES + 32];
+    const GmwColsLds w = gmw_cols_carve(region);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int e = tid; e < 1024; e += 256) w.Xm[e >> 5][e & 31] = G[(size_t)(e >> 5) * ld + (e & 31)];
     if (tid < 32) w.Dv[tid] = 0.0;
     __syncthreads();
     unsigned long long t0 = now();
     if (tid == 64) srukf_stamps[19] = t0;
-    if (wv == 0) { gmw_cols_pivot_wave(&w, eps, lane); ts[0] = now() - t0; }
-    else if (wv == 2) { gmw_cols_t_wave(&w, lane, Tt); ts[1] = now() - t0; }
-    else if (wv == 1) { gmw_cols_out_wave(&w, 0, lane, 32, ld, 0, pD, psq, prD, Dall, S); if (lane == 0) ts[2] = now() - t0; }
-    else { gmw_cols_out_wave(&w, 1, lane, 32, ld, 0, pD, psq, prD, Dall, S); }
+    if (wv == 0) { gmw_cols_pivot_wave(w, eps, lane); ts[0] = now() - t0; }
+    else if (wv == 2) { gmw_cols_t_wave(w, lane, Tt); ts[1] = now() - t0; }
+    else if (wv == 1) { gmw_cols_out_wave(w, 0, lane, 32, ld, 0, pD, psq, prD, Dall, S); if (lane == 0) ts[2] = now() - t0; }
+    else { gmw_cols_out_wave(w, 1, lane, 32, ld, 0, pD, psq, prD, Dall, S); }
 }
 int main()
 {
