@@ -511,26 +511,27 @@ __device__ __forceinline__ void stage32_regB(d4 (&acc)[2][2], const double* __re
 //       three-stage slab for 16 of R's 64 columns -> LDS (W and L = W/D)
 //   B   quarters of tile (0,0) with K = 64 -> Xm;  factor 1: wave 0 pivots; wave 2 first writes the panel's S rows
 //       for R's columns from the LDS slab, then follows with T1'; waves 1 / 3 update tiles (0,1) / (1,1) with
-//       K = 64, park them in LDS, then write factor 1's outputs
-//   C   W1d = T1' X01 (quarters), E' = W1d / D';  X11 -= E'^T W1d (quarters) -> Xm;  factor 2 (waves 1 / 3 first
-//       write E' and the (0,1) tile of S, then factor 2's outputs)
+//       K = 64 and park them in LDS
+//   C   W1d = T1' X01 (quarters), E' = W1d / D';  X11 -= E'^T W1d (quarters) -> Xm;  factor 2, in its own LDS
+//       workspace: waves 1 / 3 first write E', the (0,1) tile of S and factor 1's outputs, then factor 2's outputs
 // Global stores cost ~85 cycles of issue each on this path, so the pivot wave never stores to global memory.
 // first != 0: there is no current panel (R is the first 64 rows): phase A and the K = 64 updates are skipped.
 __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int first, double eps, double* __restrict__ G,
                                                    const GmwPanel64* __restrict__ cur, GmwPanel64* __restrict__ nxt,
                                                    double* __restrict__ Dall, double* __restrict__ Sout,
                                                    double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg,
-                                                   double* xreg, double* lsq, double* lrc, int tid)
+                                                   double* xreg, int tid)
 {
     const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int base = j0 + 64;
     const int qa = wv >> 1, qb = wv & 1;
-    const GmwColsLds ws = gmw_cols_carve(facreg);
+    // two factor workspaces: factor 1's rows stay readable while factor 2 runs, so its outputs can be written then
+    const GmwColsLds ws = gmw_cols_carve(facreg), ws2 = gmw_cols_carve(facreg + GMW_FAC_DOUBLES);
     double (*X01)[32] = (double (*)[32])xreg;                  // tiles (0,1) / (1,1) after the K = 64 update
     double (*X11)[32] = (double (*)[32])(xreg + 1024);
     double* Tl = xreg + 2048;                                  // T1' [kk][33]
     double* PT = xreg;                                         // phase A only: Tt1 | E | Tt2, element (row, col) at row*32 + (col ^ 16*(row&1))
-    if (tid < 32) ws.Dv[tid] = 0.0;
+    if (tid < 32) { ws.Dv[tid] = 0.0; ws2.Dv[tid] = 0.0; }
     // prefetch: this wave's quarter of tile (0,0), its share of the panel matrices, its panel rows
     d4 g;
 #pragma unroll
@@ -656,7 +657,6 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
             for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) X[16 * a + lk + 4 * t][16 * b + lr] = acc[a][b][t];
-        gmw_cols_out_wave(ws, wv == 1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, lsq, lrc);
     }
     STAMP(5);
     __syncthreads();
@@ -671,7 +671,7 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
         for (int t = 0; t < 4; t++) {
             const int k = 16 * qa + lk + 4 * t, cc = 16 * qb + lr;
             Wc[k][cc] = wq[t];                                 // Wd
-            Lr[k][cc] = wq[t] * lrc[k];                        // Ld = E'
+            Lr[k][cc] = wq[t] * gmw_pivot_rcp(ws.Dv[k]);       // Ld = E'
         }
     }
     __syncthreads();
@@ -684,14 +684,13 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
         for (int k = 0; k < 32; k += 4)
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], x, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 4; t++) ws.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = x[t];
-        if (tid < 32) ws.Dv[tid] = 0.0;
+        for (int t = 0; t < 4; t++) ws2.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = x[t];
     }
     __syncthreads();
     STAMP(7);
     // ---- factor 2 ----
-    if (wv == 0) gmw_cols_pivot_wave(ws, eps, lane);
-    else if (wv == 2) gmw_cols_t_wave(ws, lane, nxt->Tt2);
+    if (wv == 0) gmw_cols_pivot_wave(ws2, eps, lane);
+    else if (wv == 2) gmw_cols_t_wave(ws2, lane, nxt->Tt2);
     else {
         const int c4 = (lane & 7) * 4;
         if (wv == 1) {                                         // E' for the next launch
@@ -704,13 +703,15 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int row = 8 * i + (lane >> 3);
-                const double sq = (base + row < n) ? lsq[row] : 0.0;
+                const double Dr = ws.Dv[row];
+                const double sq = (base + row < n) ? sqrt(Dr) * gmw_pivot_rcp(Dr) : 0.0;
                 d4 w = *(const d4*)&Wc[row][c4];
                 w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
                 *(d4*)&Sout[(size_t)(base + row) * ld + base + 32 + c4] = w;
             }
         }
-        gmw_cols_out_wave(ws, wv == 1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout);
+        gmw_cols_out_wave(ws, wv == 1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout);             // factor 1 (all rows published long ago)
+        gmw_cols_out_wave(ws2, wv == 1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout);
     }
     STAMP(8);
 }
@@ -731,13 +732,11 @@ __global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int f
     STAMP(0);
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
-    __shared__ double facreg[GMW_XM_DOUBLES + GMW_LM_DOUBLES + 32];
+    __shared__ double facreg[2 * GMW_FAC_DOUBLES];           // block (0,0): one column-factor workspace per sub-panel
     __shared__ double xreg[1024 + 1024 + 32 * 33];            // block (0,0): staged panel matrices, then X01 | X11 | T1'
-    __shared__ double lsq[32];
-    __shared__ double lrc[32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        gmw_step64_block00(n, ld, j0, first, eps, G, cur, nxt, Dall, Sout, Lr, Wc, facreg, xreg, lsq, lrc, tid);
+        gmw_step64_block00(n, ld, j0, first, eps, G, cur, nxt, Dall, Sout, Lr, Wc, facreg, xreg, tid);
         return;
     }
     const int lr = lane & 15, lk = lane >> 4;

@@ -46,6 +46,7 @@ template <int N> __device__ __forceinline__ double mov_bcast16(double src)
 #define GMW_LM_STRIDE 66                       // doubles per lane strip
 #define GMW_XM_DOUBLES 1024
 #define GMW_LM_DOUBLES (16 * GMW_LM_STRIDE)
+#define GMW_FAC_DOUBLES (GMW_XM_DOUBLES + GMW_LM_DOUBLES + 32)
 struct GmwColsLds {                            // pointers, so that a kernel can alias LDS arrays it no longer needs
     double (*Xm)[32];
     double* Lm;
