@@ -24,9 +24,7 @@ void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameSc
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int);
-void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, double, void*, double*, double*, const void*, int);
-void srukf_launch_gmw_first(hipStream_t, int, int, double, const double*, void*, double*, double*);
-void srukf_launch_gmw_step(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const double*);
+void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int);
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
 int srukf_gmw_panel_bytes(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
@@ -55,7 +53,7 @@ static thread_local std::string g_create_error;
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_XUPD, KC_SYRK, KC_GMW_PANEL, KC_GMW_TRAIL, KC_GMW_CHECK,
               KC_GMW_COL, KC_MISC, KC_COUNT };
 static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_state_update", "k_syrk",
-                                             "k_gmw_first(standalone)", "k_gmw_step", "k_gmw_check", "k_gmw_col", "misc" };
+                                             "(unused)", "k_gmw_step64", "k_gmw_check", "k_gmw_col", "misc" };
 
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
@@ -218,7 +216,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     {
         const double nn = n;
         ProfScope ps(c, KC_SYRK, nn * nn * nn / 3.0 + nn * nn * (ue - ub), 8.0 * (nn * nn + (double)(ue - ub) * nn));
-        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->p.epsilon, nullptr, c->D, c->Wf, c->syrk_tiles, c->n_syrk_tiles);
+        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles);
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
     if (!slow) {
@@ -493,7 +491,7 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     if (!c || !P) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->p.epsilon, nullptr, c->D, c->S, c->syrk_tiles, c->n_syrk_tiles);
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles);
     HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) { const double v = c->hstage[(size_t)r * np + cc]; P[(size_t)r * n + cc] = v; P[(size_t)cc * n + r] = v; }

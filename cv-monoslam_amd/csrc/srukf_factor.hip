@@ -10,10 +10,6 @@
 #include "srukf_device.h"
 #include "srukf_gmw_cols.h"
 
-struct GmwPanel;
-__device__ __forceinline__ void gmw_cols_factor_wg(const GmwColsLds& w, int wv, int lane, double eps, int n, int ld, int j0,
-                                                   GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout);
-
 // one wave: 32x32 output tile at (m0, n0), K range [kb, ke) — (ke - kb) a multiple of 16 —, accumulate.
 // Software-pipelined: the 16 fragment loads of the next group of four k-steps are in flight while the
 // 16 MFMAs of the current group issue (hipcc otherwise waits for each group's loads before its MFMAs).
@@ -135,7 +131,6 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
                                               int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
-                                              double eps, GmwPanel* __restrict__ pan0, double* __restrict__ Dall, double* __restrict__ Sout,
                                               const int2* __restrict__ tiles)
 {
     __shared__ double red[3][64][17];
@@ -168,314 +163,54 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
         }
     }
     splitk_reduce(acc, red, wv, lane);
-    // tile (0,0) is the first diagonal block of the factorisation and has the shortest K range: factor it
-    // here (pan0 != null), hidden behind the longer tiles, instead of a launch of its own.  Its S rows go to
-    // the scratch matrix Sout (NOT the live S, which other tiles of this launch are still reading); the first
-    // k_gmw_step copies them over.
-    const bool fac = pan0 && m0 == 0 && n0 == 0;           // workgroup-uniform
-    if (wv != 0 && !fac) return;
-    const GmwColsLds ws = gmw_cols_carve(&red[0][0][0]);   // the split-K scratch is free once wave 0 has summed it
-    if (wv == 0) {
-        const int lr = lane & 15, lk = lane >> 4;
-        double gmax = 0.0, xmax = 0.0;
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
-                    const double v = acc[a][b][t];
-                    G[(size_t)r * d.np + c] = v;
-                    if (fac) ws.Xm[16 * a + lk + 4 * t][16 * b + lr] = v;
-                    if (r < d.n && c < d.n) {
-                        if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v);
-                    }
-                }
-        if (fac && lane < 32) ws.Dv[lane] = 0.0;
-        gmax = wave_max(gmax); xmax = wave_max(xmax);
-        if (lane == 0) {
-            if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
-            if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
-        }
-    }
-    if (!fac) return;
-    __syncthreads();
-    gmw_cols_factor_wg(ws, wv, lane, eps, d.n, d.np, 0, pan0, Dall, Sout);
-}
-
-// ------------------------------------------------------------------------------------------------
-// GMW modified Cholesky (modifiedCholeskyDecomposition, SLAM.cpp:2197-2327), blocked,
-// right-looking, one launch per 32-row panel.
-// Storage: W[j][i] = C[i][j] (the reference's column j below the diagonal is our row j right of
-// the diagonal), so the final S[j][i] = sqrt(D_j) * L[i][j] = sqrt(D_j) * (W[j][i] / D_j) is a
-// row scaling of W.  Fast path pivots with D_j = max(EPSILON, |C_jj|); the third candidate
-// theta_j^2 / beta^2 (2279-2285) is evaluated afterwards from the row maxima theta_j collected
-// here (k_gmw_check) — if it never wins, the result equals the reference algorithm's exactly;
-// if it does, the caller reruns the frame on the column-by-column path (k_gmw_col_*).
-// ------------------------------------------------------------------------------------------------
-
-// Panel buffer handed from one step to the next (double-buffered in HBM).
-//   Tt[kk][jj] = T[jj][kk],  T = (I + M^T)^{-1},  M[kk][jj] = L[kk][jj] = W[kk][jj]/D_kk (kk < jj):
-//   the forward substitution  w[jj] = g[jj] - sum_{kk<jj} L[kk][jj] w[kk]  of a panel column is
-//   w = T g, so the whole panel "TRSM" becomes one 32x32 by 32xcols MFMA product.
-struct GmwPanel { double Tt[32 * 32]; double D[32]; double sq[32]; double rD[32]; };
-
-// Factor a 32x32 diagonal block that sits in LDS (ws.Xm, with ws.Dv zeroed and a workgroup barrier behind it).
-// All four waves of the workgroup call this: wave 0 runs the pivot chain, wave 2 follows it with T = L^{-1}, waves
-// 1 and 3 write the outputs (srukf_gmw_cols.h).  No barrier inside; each wave returns when its part is done.
-// Out: next panel buffer (Tt, D, sqrt(D)/D, 1/D), pivots D, and the diagonal-block part of S rows j0..j0+31.
-__device__ __forceinline__ void gmw_cols_factor_wg(const GmwColsLds& w, int wv, int lane, double eps, int n, int ld, int j0,
-                                                   GmwPanel* __restrict__ out, double* __restrict__ Dall, double* __restrict__ Sout)
-{
-    if (wv == 0) gmw_cols_pivot_wave(w, eps, lane);
-    else if (wv == 2) gmw_cols_t_wave(w, lane, out->Tt);
-    else gmw_cols_out_wave(w, wv == 1 ? 0 : 1, lane, n, ld, j0, out->D, out->sq, out->rD, Dall, Sout);
-}
-
-// k_gmw_first: factor the first diagonal block (j0 = 0) on its own (standalone srukf_gmw_host path; the filter
-// gets this block from k_syrk).  One workgroup.
-__global__ __launch_bounds__(256) void k_gmw_first(int n, int ld, double eps, const double* __restrict__ G, GmwPanel* __restrict__ out,
-                                                   double* __restrict__ Dall, double* __restrict__ Sout)
-{
-    __shared__ double region[GMW_XM_DOUBLES + GMW_LM_DOUBLES + 32];
-    const GmwColsLds ws = gmw_cols_carve(region);
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 1024; e += 256) ws.Xm[e >> 5][e & 31] = G[(size_t)(e >> 5) * ld + (e & 31)];
-    if (tid < 32) ws.Dv[tid] = 0.0;
-    __syncthreads();
-    gmw_cols_factor_wg(ws, tid >> 6, tid & 63, eps, n, ld, 0, out, Dall, Sout);
-}
-
-// Critical-path workgroup of a step: block (0,0) of the trailing square owns the next diagonal block
-// (tile (base, base)).  Its four waves first cooperate on that tile only — each a 16x16 quarter of
-// the panel slab  W = T * G[J][base:base+32)  and of the update — so that wave 0 can start the
-// 32-pivot chain as early as possible (gmw_cols_factor_wg: wave 2 follows with T); waves 1 and 3 first
-// finish the block's other two tiles, (0,1) and (1,1), from a register-resident second slab, then write
-// the outputs of the factored block as its rows appear.
-__device__ __forceinline__ void gmw_step_block00(int n, int ld, int j0, double eps, double* __restrict__ G,
-                                                 const GmwPanel* __restrict__ cur, GmwPanel* __restrict__ nxt,
-                                                 double* __restrict__ Dall, double* __restrict__ Sout,
-                                                 double (*Lr)[80], double (*Wc)[80], double* Xg, double* Dv, int lane, int wv)
-{
+    if (wv != 0) return;
     const int lr = lane & 15, lk = lane >> 4;
-    const int base = j0 + 32;
-    const int qa = wv >> 1, qb = wv & 1;                       // this wave's 16x16 quarter
-    // prefetch: the quarter of the diagonal tile this wave updates, and the pivots of the panel rows it produces
-    d4 g;
-#pragma unroll
-    for (int t = 0; t < 4; t++) g[t] = G[(size_t)(base + 16 * qa + lk + 4 * t) * ld + base + 16 * qb + lr];
-    double dr[2][4], sqr[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) { dr[a][t] = cur->rD[16 * a + lk + 4 * t]; sqr[a][t] = cur->sq[16 * a + lk + 4 * t]; }
-    STAMP(1);
-    // phase A: quarter (qa, qb) of W = T * G[J][base:base+32): rows jj = 16qa.., columns base + 16qb..
-    {
-        double fa[8], fb[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            fa[u] = cur->Tt[(4 * u + lk) * 32 + 16 * qa + lr];
-            fb[u] = G[(size_t)(j0 + 4 * u + lk) * ld + base + 16 * qb + lr];
-        }
-        d4 w = (d4){0, 0, 0, 0};
-#pragma unroll
-        for (int u = 0; u < 8; u++) w = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], fb[u], w, 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int jj = 16 * qa + lk + 4 * t, cc = 16 * qb + lr;
-            Wc[jj][cc] = w[t];
-            Lr[jj][cc] = w[t] * dr[qa][t];
-            if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + base + cc] = w[t] * sqr[qa][t];
-        }
-    }
-    STAMP(2);
-    __syncthreads();
-    STAMP(3);
-    // phase B: quarter (qa, qb) of the diagonal tile:  g -= sum_k L[k][16qa + i] W[k][16qb + j]
-#pragma unroll
-    for (int k = 0; k < 32; k += 4)
-        g = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], g, 0, 0, 0);
-    // the updated diagonal block goes to LDS in plain row-major form (Xg), the layout the column factor reads;
-    // Wc is dead after this barrier and becomes the factor's row-of-L buffer
-    GmwColsLds ws;
-    ws.Xm = (double (*)[32])Xg; ws.Lm = &Wc[0][0]; ws.Dv = Dv;
-#pragma unroll
-    for (int t = 0; t < 4; t++) ws.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = g[t];
-    __syncthreads();
-    STAMP(4);
-    if (wv == 0 || wv == 2) {
-        gmw_cols_factor_wg(ws, wv, lane, eps, n, ld, base, nxt, Dall, Sout);
-        STAMP(5);
-        return;
-    }
-    if (base + 32 >= ld) {                                     // last panel: no second slab
-        gmw_cols_factor_wg(ws, wv, lane, eps, n, ld, base, nxt, Dall, Sout);
-        return;
-    }
-    // waves 1 and 3: second slab W2 = T * G[J][base+32 : base+64) kept in registers (C layout = MFMA operand
-    // layout for the k-step of four consecutive panel rows), then tile (0,1) / (1,1)
-    d4 W2[2][2];
-    zero_acc(W2);
-    tile32_tn<false>(W2, cur->Tt, 32, G + (size_t)j0 * ld, ld, 0, base + 32, 0, 32, lane);
-    const int m0 = (wv == 1) ? base : base + 32, c0 = base + 32;
-    d4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
-#pragma unroll
-    for (int a2 = 0; a2 < 2; a2++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int k = 16 * a2 + 4 * t;                     // panel rows k + lk
-            double a0, a1;
-            if (wv == 1) { a0 = -Lr[k + lk][lr]; a1 = -Lr[k + lk][16 + lr]; }                 // rows base..base+32: first slab
-            else { a0 = -(W2[a2][0][t] * dr[a2][t]); a1 = -(W2[a2][1][t] * dr[a2][t]); }      // rows base+32..: L2 = W2 / D
-            const double b0 = W2[a2][0][t], b1 = W2[a2][1][t];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
+    double gmax = 0.0, xmax = 0.0;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
-                if (wv == 1 && j0 + 16 * a + lk + 4 * t < n)                                   // S rows of the panel, second slab
-                    Sout[(size_t)(j0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = W2[a][b][t] * sqr[a][t];
+                const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
+                const double v = acc[a][b][t];
+                G[(size_t)r * d.np + c] = v;
+                if (r < d.n && c < d.n) {
+                    if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v);
+                }
             }
-    gmw_cols_factor_wg(ws, wv, lane, eps, n, ld, base, nxt, Dall, Sout);                       // output duty
-}
-
-// k_gmw_step: one launch per panel J = [j0, j0+32).  Every 64x64 block of the trailing square
-// (base = j0+32):
-//   1. recomputes the panel rows it needs, W[J][slab] = T * G[J][slab]  (MFMA, K = 32), for its
-//      row slab and its column slab, and keeps L = W/D (row slab) and W (column slab) in LDS;
-//   2. updates its tile  G[r][c] -= sum_kk L[kk][r] W[kk][c]  (MFMA from LDS);
-//   3. first block row only: writes the final S rows j0..j0+31 for its column slab;
-//   4. block (0,0) takes its own route (gmw_step_block00): its tile (0,0) IS the next diagonal block,
-//      which wave 0 factors and publishes as the next panel buffer (visible to the next launch).
-// grid = (T, T), T = ceil((ld - base)/64); blocks strictly below the diagonal exit.
-// (argument order: everything the critical-path workgroup needs before its first global load sits in the first
-//  14 dwords, the part of the kernarg segment that -amdgpu-kernarg-preload-count hands over in SGPRs)
-__global__ __launch_bounds__(256) void k_gmw_step(int n, int ld, int j0, int first, double* __restrict__ G,
-                                                  const GmwPanel* __restrict__ cur, double* __restrict__ Sout, GmwPanel* __restrict__ nxt,
-                                                  double* __restrict__ Dall, double eps, const double* __restrict__ Sfirst)
-{
-    if (blockIdx.x < blockIdx.y) return;
-    STAMP(0);
-    __shared__ double Lr[32][80];      // stride 80 doubles: lanes l / l+16 land on opposite bank halves
-    __shared__ double Wc[32][80];
-    __shared__ double Xg[GMW_XM_DOUBLES];
-    __shared__ double Dv[32];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (first && blockIdx.x == 0 && blockIdx.y == 0) {
-        // first step: bring the diagonal block of S rows 0..31 (factored inside k_syrk into scratch) into S
-        for (int e = tid; e < 1024; e += 256) {
-            const int r = e >> 5, c = e & 31;
-            if (c >= r && c < n) Sout[(size_t)r * ld + c] = Sfirst[(size_t)r * ld + c];
-        }
+    gmax = wave_max(gmax); xmax = wave_max(xmax);
+    if (lane == 0) {
+        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < 32) Dv[tid] = 0.0;                           // "row published" flags of the column factor (two barriers ahead of their first use)
-        gmw_step_block00(n, ld, j0, eps, G, cur, nxt, Dall, Sout, Lr, Wc, Xg, Dv, lane, wv);
-        return;
-    }
-    const int lr = lane & 15, lk = lane >> 4;
-    const int base = j0 + 32;
-    const int R0 = base + 64 * blockIdx.y, C0 = base + 64 * blockIdx.x;
-    const bool diagblk = blockIdx.x == blockIdx.y;
-
-    // issue every global read this wave needs up front: its output tile (for step 2) and the
-    // pivots of its eight panel rows; their latency hides behind the slab MFMAs
-    const int m0 = R0 + 32 * (wv >> 1), c0 = C0 + 32 * (wv & 1);
-    const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
-    d4 acc[2][2];
-    zero_acc(acc);
-    if (live) {
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
-    }
-    double dr[2][4], sqr[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int t = 0; t < 4; t++) { dr[a][t] = cur->rD[16 * a + lk + 4 * t]; sqr[a][t] = cur->sq[16 * a + lk + 4 * t]; }   // 1/D_j, sqrt(D_j)/D_j
-
-    STAMP(1);
-    // 1. panel slabs by MFMA: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
-    {
-        const int which = wv >> 1, half = wv & 1;
-        const int n0 = (which ? C0 : R0) + 32 * half;
-        if (n0 < ld && !(diagblk && which == 1)) {
-            d4 sl[2][2];
-            zero_acc(sl);
-            tile32_tn<false>(sl, cur->Tt, 32, G + (size_t)j0 * ld, ld, 0, n0, 0, 32, lane);
-            const bool write_s = (blockIdx.y == 0) && (which == 1 || diagblk);
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
-                        const double w = sl[a][b][t];
-                        if (which == 0) { Lr[jj][cc] = w * dr[a][t]; if (diagblk) Wc[jj][cc] = w; }   // L = W * (1/D)
-                        else Wc[jj][cc] = w;
-                        if (write_s && j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = w * sqr[a][t];   // S = W / sqrt(D)
-                    }
-        }
-    }
-    STAMP(2);
-    __syncthreads();
-    STAMP(3);
-
-    // 2. tile update from LDS fragments
-    if (live) {
-        const int ro = m0 - R0, co = c0 - C0;
-#pragma unroll
-        for (int k = 0; k < 32; k += 4) {
-            const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
-            const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
-    }
-
-    STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64-row panels: one launch per TWO 32-row sub-panels.
-// Every launch pays ~2.5 us of dispatch gap plus ~1.5 us of kernarg / first-load latency before any
+// GMW modified Cholesky (modifiedCholeskyDecomposition, SLAM.cpp:2197-2327), blocked, right-looking.
+// Storage: W[j][i] = C[i][j] (the reference's column j below the diagonal is our row j right of
+// the diagonal), so the final S[j][i] = sqrt(D_j) * L[i][j] = sqrt(D_j) * (W[j][i] / D_j) is a
+// row scaling of W.  Fast path pivots with D_j = max(EPSILON, |C_jj|); the third candidate
+// theta_j^2 / beta^2 (2279-2285) is evaluated afterwards from the row maxima theta_j collected
+// here (k_gmw_check) — if it never wins, the result equals the reference algorithm's exactly;
+// if it does, the caller reruns the frame on the column-by-column path (k_gmw_col_*).
+//
+// A 32x32 diagonal block is factored by srukf_gmw_cols.h (pivot chain on the vector ALU).  For the
+// panel rows right of it, with M[kk][jj] = L[kk][jj] = W[kk][jj]/D_kk (kk < jj) and
+// T = (I + M^T)^{-1} = L^{-1}, the forward substitution  w[jj] = g[jj] - sum_{kk<jj} L[kk][jj] w[kk]
+// of a panel column is  w = T g,  so the panel "TRSM" is an MFMA product with Tt[kk][jj] = T[jj][kk].
+// ------------------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------------------
+// 64-row panels: one launch per TWO 32-row sub-panels.  (One launch per 32-row panel was the first
+// design: 37 launches, 2154 frames/s at N = 200.)  Every launch pays ~2.5 us of dispatch gap plus ~1.5 us of kernarg / first-load latency before any
 // arithmetic starts, and the factorisation is one long dependent chain of launches; with 32-row
 // panels that overhead was as large as the work.  Here the critical-path workgroup factors both
 // 32x32 diagonal blocks of the NEXT 64-row panel inside one launch, and the trailing update runs
 // with K = 64 (G is read and written half as often).
 //
 // Panel buffer: sub-panel 1 = rows j0..j0+31, sub-panel 2 = rows j0+32..j0+63.
-//   Tt1, Tt2 : Tt[kk][jj] = T[jj][kk], T = L^{-1} of the sub-panel's diagonal block (as GmwPanel)
+//   Tt1, Tt2 : Tt[kk][jj] = T[jj][kk], T = L^{-1} of the sub-panel's diagonal block
 //   E        : E[k][r] = L[k][32 + r] = W1d[k][r] / D_k, the multipliers that couple sub-panel 2 to the
 //              pivots of sub-panel 1
 //   W1 = T1 G1;   G2' = G2 - E^T W1;   W2 = T2 G2'        (three K = 32 MFMA stages per column slab,
@@ -926,22 +661,9 @@ void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S
     hipLaunchKernelGGL(k_pxy, dim3(ntiles), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles);
 }
 void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs,
-                       double eps, void* pan0, double* Dall, double* Sout, const void* tiles, int ntiles)
+                       const void* tiles, int ntiles)
 {
-    hipLaunchKernelGGL(k_syrk, dim3(ntiles), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, eps, (GmwPanel*)pan0, Dall, Sout, (const int2*)tiles);
-}
-// whole fast-path factorisation: first diagonal block, then one launch per panel
-void srukf_launch_gmw_first(hipStream_t st, int n, int ld, double eps, const double* G, void* pan0, double* D, double* Sout)
-{
-    hipLaunchKernelGGL(k_gmw_first, dim3(1), dim3(256), 0, st, n, ld, eps, G, (GmwPanel*)pan0, D, Sout);
-}
-void srukf_launch_gmw_step(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout,
-                           const double* Sfirst)
-{
-    const int rem = ld - j0 - 32;
-    if (rem <= 0) return;
-    const int T = (rem + 63) / 64;
-    hipLaunchKernelGGL(k_gmw_step, dim3(T, T), dim3(256), 0, st, n, ld, j0, Sfirst ? 1 : 0, G, (const GmwPanel*)cur, Sout, (GmwPanel*)nxt, D, eps, Sfirst);
+    hipLaunchKernelGGL(k_syrk, dim3(ntiles), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles);
 }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
 void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)
@@ -951,7 +673,7 @@ void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, 
     const int T = (j0 < 0) ? 1 : rem / 64;
     hipLaunchKernelGGL(k_gmw_step64, dim3(T, T), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, G, (const GmwPanel64*)cur, Sout, (GmwPanel64*)nxt, D, eps);
 }
-int srukf_gmw_panel_bytes(void) { return (int)(sizeof(GmwPanel64) > sizeof(GmwPanel) ? sizeof(GmwPanel64) : sizeof(GmwPanel)); }
+int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel64); }
 void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj)
 {
     hipLaunchKernelGGL(k_gmw_check, dim3(n + (do_traj ? 1 : 0)), dim3(256), 0, st, n, ld, D, S, fs, X, do_traj);
