@@ -244,9 +244,9 @@ __device__ __forceinline__ void stage32_regB(d4 (&acc)[2][2], const double* __re
 // tiles (0,0), (0,1), (1,1).
 //   A   Tt1 | E | Tt2 are staged through LDS once (each wave needs all three); each wave then runs the
 //       three-stage slab for 16 of R's 64 columns -> LDS (W and L = W/D)
-//   B   quarters of tile (0,0) with K = 64 -> Xm;  factor 1: wave 0 pivots; wave 2 first writes the panel's S rows
-//       for R's columns from the LDS slab, then follows with T1'; waves 1 / 3 update tiles (0,1) / (1,1) with
-//       K = 64 and park them in LDS
+//   B   quarters of tile (0,0) with K = 64 -> Xm;  factor 1: wave 0 pivots, wave 2 follows with T1'; waves 1 / 3
+//       update tiles (0,1) / (1,1) with K = 64, park them in LDS, and write the panel's S rows for R's columns
+//       from the LDS slab
 //   C   W1d = T1' X01 (quarters), E' = W1d / D';  X11 -= E'^T W1d (quarters) -> Xm;  factor 2, in its own LDS
 //       workspace: waves 1 / 3 first write E', the (0,1) tile of S and factor 1's outputs, then factor 2's outputs
 // Global stores cost ~85 cycles of issue each on this path, so the pivot wave never stores to global memory.
@@ -359,23 +359,10 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
     STAMP(4);
     // ---- factor 1 (+ panel S rows, tiles (0,1), (1,1)) ----
     if (wv == 0) gmw_cols_pivot_wave(ws, eps, lane);
-    else if (wv == 2) {
+    else if (wv == 2) { gmw_cols_t_wave<false>(ws, lane, nxt->Tt1, Tl); STAMPW(13); }
+    else {
         if (!first) {
-            // S rows j0..j0+63 of the panel, columns base..base+63 (rows / columns >= n carry zeros: G is zero there)
-            const int c4 = lr * 4;
-#pragma unroll 4
-            for (int i = 0; i < 16; i++) {
-                const int row = 4 * i + lk;
-                const double sq = cur->sq[row];
-                d4 w = *(const d4*)&Wc[row][c4];
-                w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
-                *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
-            }
-        }
-        gmw_cols_t_wave(ws, lane, nxt->Tt1, Tl);
-    } else {
-        if (!first) {
-#pragma unroll 4
+#pragma unroll
             for (int k = 0; k < 64; k += 4) {
                 const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
                 const double b0 = Wc[k + lk][32 + lr], b1 = Wc[k + lk][48 + lr];
@@ -392,6 +379,20 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
             for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) X[16 * a + lk + 4 * t][16 * b + lr] = acc[a][b][t];
+        if (!first) {
+            // S rows of the panel for R's columns, from the LDS slab: wave 1 rows j0..j0+31, wave 3 rows j0+32..j0+63
+            // (rows / columns >= n carry zeros: G is zero there)
+            const int c4 = lr * 4;
+#pragma unroll 4
+            for (int i = 0; i < 8; i++) {
+                const int row = ro + 4 * i + lk;
+                const double sq = cur->sq[row];
+                d4 w = *(const d4*)&Wc[row][c4];
+                w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
+                *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
+            }
+        }
+        STAMPW(11 + wv);
     }
     STAMP(5);
     __syncthreads();
@@ -425,15 +426,16 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
     STAMP(7);
     // ---- factor 2 ----
     if (wv == 0) gmw_cols_pivot_wave(ws2, eps, lane);
-    else if (wv == 2) gmw_cols_t_wave(ws2, lane, nxt->Tt2);
+    else if (wv == 2) gmw_cols_t_wave<true>(ws2, lane, nxt->Tt2, xreg);          // X01 / X11 are dead: staging buffer
     else {
         const int c4 = (lane & 7) * 4;
-        if (wv == 1) {                                         // E' for the next launch
+        if (wv == 1) {                                         // E' and T1' for the next launch
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int row = 8 * i + (lane >> 3);
                 *(d4*)&nxt->E[row * 32 + c4] = *(const d4*)&Lr[row][c4];
             }
+            gmw_copy_t(Tl, nxt->Tt1, lane);
         } else {                                               // S rows base..base+31, columns base+32..base+63
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int f
     // 2. tile update from LDS fragments, K = 64
     if (live) {
         const int ro = m0 - R0, co = c0 - C0;
-#pragma unroll 4
+#pragma unroll
         for (int k = 0; k < 64; k += 4) {
             const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
             const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];

@@ -156,9 +156,10 @@ __device__ __forceinline__ void gmw_wait_row(unsigned dv, int j)
     int spins = 0;
     double f;
     // (explicit ds_read: a volatile C++ load would make the compiler drain all outstanding global stores first)
-    // (the s_sleep keeps three polling waves from crowding the pivot wave's LDS traffic)
-    do { asm volatile("s_sleep 1\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(dv + j * 8) : "memory"); }
-    while (__builtin_amdgcn_readfirstlane(__double2hiint(f)) <= 0 && spins++ < GMW_POLL_LIMIT);
+    // (the s_sleep of the retries keeps three polling waves from crowding the pivot wave's LDS traffic)
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(dv + j * 8) : "memory");
+    while (__builtin_amdgcn_readfirstlane(__double2hiint(f)) <= 0 && spins++ < GMW_POLL_LIMIT)
+        asm volatile("s_sleep 1\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(dv + j * 8) : "memory");
     asm volatile("" ::: "memory");             // nothing below may be read before the flag
 }
 
@@ -175,8 +176,8 @@ template <int J, int J1> struct GmwTStep {
         }
     }
 };
-template <int J0, int J1> __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane, double* __restrict__ Tt,
-                                                                      double* Tl)
+template <int J0, int J1, bool GLOBAL> __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane,
+                                                                                   double* __restrict__ Tt, double* Tl)
 {
     gmw_wait_row(dv, J1 - 1);
     d2 ab[8];
@@ -186,31 +187,52 @@ template <int J0, int J1> __device__ __forceinline__ void gmw_t_group(double (&t
     GmwTStep<J0, J1>::run(t, ab, 0);
 #pragma unroll
     for (int r = J0 + 1; r < 32; r++) asm volatile("" : "+v"(t[r]));   // keep the FMAs in this group (no sinking past the next poll)
-    // rows <= J1 of T are final now: store them while the pivot wave works on the next group
+    // rows < J1 of T are final now (row 31 after the last group): publish rows [J0, J1') while the pivot wave works on
+    // the next group.  Column per lane is the wrong shape for a global store (32 lanes x 8 B, 256 B apart: ~85 cycles
+    // of issue per row), so the rows go to the LDS copy Tl[kk][33] first and come back transposed: one 128-bit store
+    // per lane for the whole group.
+    constexpr int R0 = J0, R1 = (J1 == 31) ? 32 : J1, NR = R1 - R0;     // 8 or 4 rows
     if (lane < 32) {
 #pragma unroll
-        for (int r = (J0 == 0 ? 0 : J0 + 1); r <= (J1 == 31 ? 31 : J1); r++) Tt[lane * 32 + r] = t[r];
-        if (Tl) {                                                       // workgroup-local copy, row stride 33 (conflict-free)
-#pragma unroll
-            for (int r = (J0 == 0 ? 0 : J0 + 1); r <= (J1 == 31 ? 31 : J1); r++) Tl[lane * 33 + r] = t[r];
+        for (int r = R0; r < R1; r++) Tl[lane * 33 + r] = t[r];
+    }
+    if constexpr (GLOBAL) {
+        const int kk = (NR == 8) ? (lane >> 1) : lane, jj = R0 + ((NR == 8) ? 4 * (lane & 1) : 0);
+        if (NR == 8 || lane < 32) {
+            const double* src = &Tl[kk * 33 + jj];
+            d4 v = { src[0], src[1], src[2], src[3] };
+            *(d4*)&Tt[kk * 32 + jj] = v;
         }
     }
 }
 
-// Follower wave 1: T = L^{-1}, column c' = lane & 31 per lane, written as Tt[kk = c'][jj] = T[jj][kk] (and, if Tl is
-// not null, to the LDS array Tl[kk][33]).
-__device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt, double* Tl = nullptr)
+// Follower wave 1: T = L^{-1}, column c' = lane & 31 per lane, into the LDS array Tl[kk][33] = T[jj][kk] (32 x 33 doubles)
+// and, if GLOBAL, through it to Tt[kk*32 + jj] in global memory (otherwise gmw_copy_t does that later).
+template <bool GLOBAL>
+__device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt, double* Tl)
 {
     const int c = lane & 31;
     const unsigned dv = lds_off(w.Dv);
     double t[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) t[r] = (r == c) ? 1.0 : 0.0;
-    gmw_t_group<0, 8>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<8, 16>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<16, 24>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<24, 28>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<28, 31>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<0, 4, GLOBAL>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<4, 8, GLOBAL>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<8, 16, GLOBAL>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<16, 24, GLOBAL>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<24, 28, GLOBAL>(t, w, dv, lane, Tt, Tl);
+    gmw_t_group<28, 31, GLOBAL>(t, w, dv, lane, Tt, Tl);
+}
+// Tl[kk][33] -> Tt[kk*32 + jj], one wave, coalesced 128-bit stores
+__device__ __forceinline__ void gmw_copy_t(const double* Tl, double* __restrict__ Tt, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int kk = 8 * i + (lane >> 3), jj = (lane & 7) * 4;
+        const double* src = &Tl[kk * 33 + jj];
+        d4 v = { src[0], src[1], src[2], src[3] };
+        *(d4*)&Tt[kk * 32 + jj] = v;
+    }
 }
 
 // Follower wave 2: outputs of rows J0..J1-1 — S rows j0+J (diagonal-block part), pivots, per-row scales of the

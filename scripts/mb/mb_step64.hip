@@ -30,6 +30,7 @@ int main()
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(srukf_stamps), sizeof hs);
     const char* nm[] = { "start->prefetch issued", "A: 3-stage slab -> LDS", "barrier", "B: quarter K=64 + exchange", "factor 1 (wave 0)", "barrier (waits for waves 1-3)", "C1 + C2", "factor 2 (wave 0)" };
     for (int i = 0; i < 8; i++) printf("%-32s %6llu ticks\n", nm[i], hs[i + 1] - hs[i]);
+    printf("after barrier B: wave 0 done %llu, wave 1 done %llu, wave 2 (T1) done %llu, wave 3 done %llu\n", hs[5] - hs[4], hs[12] - hs[4], hs[13] - hs[4], hs[14] - hs[4]);
     printf("total in-kernel %llu ticks\n", hs[8] - hs[0]);
     return 0;
 }
