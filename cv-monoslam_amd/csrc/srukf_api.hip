@@ -23,8 +23,8 @@ int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
-void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int);
-void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int);
+void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int, KWeights, MeasArgs);
+void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*);
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
 int srukf_gmw_panel_bytes(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
@@ -42,6 +42,7 @@ __global__ void k_refactor_reset(int np, unsigned long long* theta_bits, FrameSc
 __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
 {
     fs->frame = frame;
+    fs->stat_count = 0;
     fs->traj_base = nullptr;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; }
 }
@@ -71,6 +72,7 @@ struct srukf_ctx {
     double *zcur = nullptr, *odocur = nullptr, *small = nullptr, *mpart = nullptr, *dxp = nullptr;
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
+    bool dx_pending = false;               // k_gain left slice partials of dX that the next k_syrk must add to X
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered)
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
     int n_syrk_tiles = 0, n_pxy_tiles = 0;
@@ -190,14 +192,15 @@ static void seq_predict_motion(srukf_ctx* c, const double* odo_pair_dev)
     ProfScope ps(c, KC_MOTION, 60.0 * d.L, 8.0 * (4.0 * d.n + 8.0 * d.L + 4.0 * d.n));
     srukf_launch_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->fs, c->odo_seq, odo_pair_dev);
 }
-static void seq_predict_measurement(srukf_ctx* c)
+// fused_stats: the statistics ride on the k_pxy launch of seq_gain (replay path, no host in between)
+static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
 {
     const KDims& d = c->d;
     {
         ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N));
         srukf_launch_project(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Z, c->DZ);
     }
-    {
+    if (!fused_stats) {
         ProfScope ps(c, KC_STATS, 30.0 * d.L * d.N, 8.0 * 3.0 * d.L * 2 * d.N);
         srukf_launch_meas_stats(c->stream, d, c->w, c->X, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR);
     }
@@ -216,7 +219,8 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     {
         const double nn = n;
         ProfScope ps(c, KC_SYRK, nn * nn * nn / 3.0 + nn * nn * (ue - ub), 8.0 * (nn * nn + (double)(ue - ub) * nn));
-        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles);
+        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X);
+        c->dx_pending = false;
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
     if (!slow) {
@@ -238,17 +242,20 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         if (frame_tail) srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     }
 }
-static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev)
+static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats)
 {
     const KDims& d = c->d;
     {
         const double nn = d.n;
         ProfScope ps(c, KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
-        srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles);
+        MeasArgs ms = {};
+        if (fused_stats) ms = MeasArgs{ c->X, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32 };
+        srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
         srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X);
+        c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
 }
 
@@ -491,7 +498,7 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     if (!c || !P) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles);
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X);
     HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) { const double v = c->hstage[(size_t)r * np + cc]; P[(size_t)r * n + cc] = v; P[(size_t)cc * n + r] = v; }
@@ -518,7 +525,7 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     if (c->phase < 1) { c->err = "predict_measurement before predict_motion"; return SRUKF_ERR_SEQUENCE; }
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->d.N;
-    seq_predict_measurement(c);
+    seq_predict_measurement(c, false);
     double* hs = c->hstage;
     HIPCHK(c, hipMemcpyAsync(hs, c->h, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs + 2 * N, c->Si, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
@@ -558,7 +565,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     HIPCHK(c, hipMemcpyAsync(c->zcur, hs, sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->mcur, hm, sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
-    seq_gain(c, c->zcur, c->mcur);
+    seq_gain(c, c->zcur, c->mcur, false);
     // visibility is needed on the host only to skip no-op refactors in SEQUENTIAL mode
     if (mode == SRUKF_UPDATE_BATCHED) {
         seq_refactor(c, 0, d.mp, false, true, false, false);
@@ -630,8 +637,8 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, traj);
     auto one_frame = [&]() {
         seq_predict_motion(c, nullptr);
-        seq_predict_measurement(c);
-        seq_gain(c, nullptr, nullptr);
+        seq_predict_measurement(c, true);
+        seq_gain(c, nullptr, nullptr, true);
         seq_refactor(c, 0, d.mp, false, false, false, true);
     };
     if (c->use_graph && !c->profiling) {

@@ -40,7 +40,7 @@ struct FrameScalars {
     int clamp_rows;            // rows where the GMW theta clamp would have been active
     int clamp_first;           // first such row
     int frame;                 // frame counter for staged sequences
-    int pad_;
+    int stat_count;            // measurement-statistics slices finished in the current k_pxy launch (last one runs the final pass)
     double* traj_base;         // device trajectory buffer of the current replay (row = absolute frame), or null
 };
 
@@ -134,6 +134,25 @@ __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, 
     ox = vis ? vx : 0.0;
     oy = vis ? vy : 0.0;
 }
+
+// ---- state update X += sum of the k_gain slice partials (fixed order): 256 state rows per workgroup ----
+#define GAIN_SLICES 8
+__device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job)
+{
+    const int r = job * 256 + threadIdx.x;
+    if (r >= n) return;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < GAIN_SLICES; u++) acc += dxp[(size_t)u * np + r];
+    X[r] += acc;
+}
+
+// measurement-statistics work attached to a k_pxy launch (replay path): Z == null -> none
+struct MeasArgs {
+    const double* X; const double* sigR; const double* Z; double* part;
+    double* h; double* Si; int* vis; double* PxyR;
+    FrameScalars* fs; int gx;                                  // gx = (N + 31) / 32 landmark groups
+};
 
 // ---- optional cycle stamps (diagnostic builds under scripts/mb only; compiled out of the product) ----
 #ifdef SRUKF_STAMPS

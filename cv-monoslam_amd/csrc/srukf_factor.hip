@@ -9,6 +9,7 @@
 //   D: reg t of lane l is D[row = (l>>4) + 4t][col = l&15]
 #include "srukf_device.h"
 #include "srukf_gmw_cols.h"
+#include "srukf_meas.h"
 
 // one wave: 32x32 output tile at (m0, n0), K range [kb, ke) — (ke - kb) a multiple of 16 —, accumulate.
 // Software-pipelined: the 16 fragment loads of the next group of four k-steps are in flight while the
@@ -94,12 +95,33 @@ __device__ __forceinline__ void splitk_reduce(d4 (&acc)[2][2], double (*red)[64]
 // applied in k_gain.  S upper triangular => K range truncated at r0+32.
 // grid = one workgroup per 32x32 tile (XCD-aware order from the tile table), 4-way split-K.
 // ------------------------------------------------------------------------------------------------
+// In the replay path the measurement statistics of the same frame ride along: the first workgroups of the
+// grid run the MEAS_SLICES x gx partial-sum jobs, and the one that finishes last (device-scope counter)
+// reduces the slices into h, Si, visible, PxyR — two launches fewer on the per-frame chain.
 __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__ DZ, const double* __restrict__ S,
-                                             double* __restrict__ Ut, const int2* __restrict__ tiles)
+                                             double* __restrict__ Ut, const int2* __restrict__ tiles, int ntiles, KWeights w, MeasArgs ms)
 {
-    __shared__ double red[3][64][17];
+    __shared__ double shm[MEAS_SM_DOUBLES];                    // >= 3*64*17: split-K scratch or statistics scratch
+    const int nstat = ms.Z ? MEAS_SLICES * ms.gx : 0;         // statistics jobs first: they start with the launch, the tiles fill in behind
+    if ((int)blockIdx.x < nstat) {
+        const int job = blockIdx.x;
+        meas_partial_job<true>(d, w, ms.X, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm);
+        __shared__ int last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's device-scope stores have landed ...
+        __syncthreads();                                       // ... and so have the whole workgroup's, before the count
+        if (threadIdx.x == 0) {
+            const int done = __hip_atomic_fetch_add(&ms.fs->stat_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (done == ms.gx * MEAS_SLICES - 1);
+            if (last) __hip_atomic_store(&ms.fs->stat_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next frame
+        }
+        __syncthreads();
+        if (!last) return;
+        for (int k = threadIdx.x; k < d.N; k += 256) meas_final_one<true>(d, w, ms.X, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, k);
+        return;
+    }
+    double (*red)[64][17] = (double (*)[64][17])shm;
+    const int2 tl = tiles[blockIdx.x - nstat];  // XCD-aware tile order (srukf_api.hip build_tile_tables)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int2 tl = tiles[blockIdx.x];  // XCD-aware tile order (srukf_api.hip build_tile_tables)
     if (tl.x < 0) return;
     const int m0 = tl.x * 32;    // c
     const int n0 = tl.y * 32;    // r
@@ -131,8 +153,10 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
                                               int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
-                                              const int2* __restrict__ tiles)
+                                              const int2* __restrict__ tiles, int ntiles, const double* __restrict__ dxp, double* __restrict__ X)
 {
+    // workgroups past the tile list: the state update X += sum_k K_k (z_k - h_k) left over by k_gain
+    if ((int)blockIdx.x >= ntiles) { srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles); return; }
     __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int2 tl = tiles[blockIdx.x];  // upper-triangle tiles only, XCD-aware order
@@ -658,14 +682,18 @@ __global__ __launch_bounds__(256) void k_gmw_stats(int n, int ld, const double* 
 }
 
 extern "C" {
-void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S, double* Ut, const void* tiles, int ntiles)
+// ms.Z != null: MEAS_SLICES * ms.gx extra workgroups compute the measurement statistics of the frame
+void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S, double* Ut, const void* tiles, int ntiles, KWeights w, MeasArgs ms)
 {
-    hipLaunchKernelGGL(k_pxy, dim3(ntiles), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles);
+    const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
+    hipLaunchKernelGGL(k_pxy, dim3(ntiles + extra), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles, ntiles, w, ms);
 }
+// dxp != null: (n + 255)/256 extra workgroups apply the pending state update
 void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs,
-                       const void* tiles, int ntiles)
+                       const void* tiles, int ntiles, const double* dxp, double* X)
 {
-    hipLaunchKernelGGL(k_syrk, dim3(ntiles), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles);
+    const int extra = dxp ? (d.n + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X);
 }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
 void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)

@@ -1,0 +1,119 @@
+// srukf_meas.h — measurement statistics jobs (device functions shared by the stand-alone kernels
+// k_meas_partial / k_meas_final and by the extra workgroups of the k_pxy launch).  See srukf_predict.hip
+// for the definition of the 13 sums.
+#pragma once
+#include "srukf_device.h"
+
+#define MEAS_SLICES 16
+#define MEAS_NS 13
+#define MEAS_SM_DOUBLES (8 * 32 * MEAS_NS)
+// one workgroup: 32 landmarks (bx) x one of MEAS_SLICES row slices (by); smem: MEAS_SM_DOUBLES doubles of LDS
+template <bool COHERENT>
+__device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights& w, const double* __restrict__ X,
+                                                 const double* __restrict__ sigR, const double* __restrict__ Z,
+                                                 double* __restrict__ part /* [MEAS_SLICES][MEAS_NS][mp/2] */, int bx, int by, double* smem)
+{
+    double (*sm)[32][MEAS_NS] = (double (*)[32][MEAS_NS])smem;
+    const int lx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int k = bx * 32 + lx;
+    const int kk = (k < d.N) ? k : 0;
+    const int L = d.L, mp = d.mp, n = d.n;
+    const int rows = (L + MEAS_SLICES - 1) / MEAS_SLICES;
+    const int c_beg = by * rows, c_end = min(L, c_beg + rows);
+    const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * kk);
+    double xr[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) xr[e] = X[n - 4 + e];
+    double s[MEAS_NS];
+#pragma unroll
+    for (int q = 0; q < MEAS_NS; q++) s[q] = 0.0;
+    for (int c = c_beg + sl; c < c_end; c += 8) {
+        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
+        const double* r = sigR + (size_t)c * 8;
+        const double dx = z.x - z0.x, dy = z.y - z0.y;
+        const double wt = (c == 0) ? w.wc0 : w.wi;
+        s[0] += dx; s[1] += dy;
+        const double a = w.wi_sr * dx, b = w.wi_sr * dy;
+        s[2] += a * a; s[3] += a * b; s[4] += b * b;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); s[5 + e] += dr * dx; s[9 + e] += dr * dy; }
+    }
+#pragma unroll
+    for (int q = 0; q < MEAS_NS; q++) sm[sl][lx][q] = s[q];
+    __syncthreads();
+    const int half = mp / 2;
+    for (int e = threadIdx.x; e < 32 * MEAS_NS; e += 256) {
+        const int q = e / 32, l2 = e % 32;
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) t += sm[u][l2][q];
+        const int k2 = bx * 32 + l2;
+        if (k2 < d.N) {
+            double* dst = &part[((size_t)by * MEAS_NS + q) * half + k2];
+            // COHERENT: device-scope store (write-through, sc1) so that the last workgroup of the same launch can read it
+            // without a release fence — a fence would write back the whole L2, where the k_pxy tiles are writing Ut
+            if (COHERENT) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = t;
+        }
+    }
+}
+
+// landmark k: reduce the slices, finish h, Si, visible, PxyR
+template <bool COHERENT>
+__device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w, const double* __restrict__ X, const double* __restrict__ sigR,
+                                               const double* __restrict__ Z, const double* __restrict__ part,
+                                               double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
+                                               double* __restrict__ PxyR, int k)
+{
+    const int mp = d.mp, half = mp / 2, n = d.n;
+    double t[MEAS_NS];
+#pragma unroll
+    for (int q = 0; q < MEAS_NS; q++) {
+        double acc = 0.0;
+        for (int u = 0; u < MEAS_SLICES; u++) {
+            const double* src = &part[((size_t)u * MEAS_NS + q) * half + k];
+            acc += COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+        }
+        t[q] = acc;
+    }
+    const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * k);
+    // h = wm0*Z0 + wi*sum_{c>=1} Z_c = Z0*(wm0 + 2Na*wi) + wi*sum (Z_c - Z0)      (SLAM.cpp:1678-1681)
+    const double wsum = w.wm0 + 2.0 * d.Na * w.wi;
+    const double hx = wsum * z0.x + w.wi * t[0], hy = wsum * z0.y + w.wi * t[1];
+    // robot rows of Pxy: sum_c w_c (r_c - xr)(Z_c - h) = sum_c w_c (r_c - xr)(Z_c - Z0) - (h - Z0) * sum_c w_c (r_c - xr)
+    double rs[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) rs[e] = sigR[(size_t)d.L * 8 + e];      // sum_c w_c (r_c - xr), from k_motion
+    const bool v = (hx != 0.0) && (hy != 0.0);
+    h[2 * k] = hx; h[2 * k + 1] = hy;
+    vis[k] = v ? 1 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        PxyR[(size_t)e * mp + 2 * k]     = t[5 + e] - (hx - z0.x) * rs[e];
+        PxyR[(size_t)e * mp + 2 * k + 1] = t[9 + e] - (hy - z0.y) * rs[e];
+    }
+    // Householder R of the 2Na x 2 matrix [a b] (GSL: beta = -sign(alpha) hypot(alpha, xnorm); tau = 0 if xnorm == 0)
+    const double2 z1 = *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * k);
+    const double2 z2 = *reinterpret_cast<const double2*>(Z + (size_t)2 * mp + 2 * k);
+    const double a0 = w.wi_sr * (z1.x - z0.x), b0 = w.wi_sr * (z1.y - z0.y);
+    const double a1 = w.wi_sr * (z2.x - z0.x), b1 = w.wi_sr * (z2.y - z0.y);
+    const double saa = t[2], sab = t[3], sbb = t[4];
+    const double xn2 = fmax(saa - a0 * a0, 0.0);
+    double R00 = a0, R01 = b0, tau = 0.0, wv = 0.0, inv_s = 0.0;
+    if (xn2 > 0.0) {
+        const double beta = -(a0 >= 0.0 ? 1.0 : -1.0) * sqrt(saa);
+        tau = (beta - a0) / beta;
+        inv_s = 1.0 / (a0 - beta);
+        wv = b0 + (sab - a0 * b0) * inv_s;              // w = B_0 + sum_{r>=1} B_r v_r
+        R00 = beta;
+        R01 = b0 - tau * wv;
+    }
+    // second column: b' = H1 b; |b'[1:]|^2 = |b|^2 - R01^2 (H1 orthogonal); R11 = -sign(b'_1) |b'[1:]|,
+    // or b'_1 itself when the rest of the sub-column is zero
+    const double bp1 = b1 - tau * (a1 * inv_s) * wv;
+    const double nrm2 = fmax(sbb - R01 * R01, 0.0);
+    const double rest2 = nrm2 - bp1 * bp1;
+    double R11 = bp1;
+    if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(nrm2);
+    Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;
+}
+

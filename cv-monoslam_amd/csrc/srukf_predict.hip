@@ -2,6 +2,7 @@
 // projection of every sigma point, measurement statistics (h, Si, robot rows of Pxy).
 // gfx950 only.  See srukf_device.h for the HBM layout.
 #include "srukf_device.h"
+#include "srukf_meas.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_motion: predictMotion numeric tail (SLAM.cpp:1430-1465) fused:
@@ -249,126 +250,39 @@ __global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_para
 // per-slice partial sums (fixed order => run-to-run deterministic).  k_meas_final reduces the slices
 // and finishes h, Si (GSL Householder sign rule), visible, PxyR.
 // ------------------------------------------------------------------------------------------------
-#define MEAS_SLICES 16
-#define MEAS_NS 13
 __global__ __launch_bounds__(256) void k_meas_partial(KDims d, KWeights w, const double* __restrict__ X,
-                                                      const double* __restrict__ sigR, const double* __restrict__ Z,
-                                                      double* __restrict__ part /* [MEAS_SLICES][MEAS_NS][mp/2] */)
+                                                      const double* __restrict__ sigR, const double* __restrict__ Z, double* __restrict__ part)
 {
-    __shared__ double sm[8][32][MEAS_NS];
-    const int lx = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int k = blockIdx.x * 32 + lx;
-    const int kk = (k < d.N) ? k : 0;
-    const int L = d.L, mp = d.mp, n = d.n;
-    const int rows = (L + MEAS_SLICES - 1) / MEAS_SLICES;
-    const int c_beg = blockIdx.y * rows, c_end = min(L, c_beg + rows);
-    const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * kk);
-    double xr[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) xr[e] = X[n - 4 + e];
-    double s[MEAS_NS];
-#pragma unroll
-    for (int q = 0; q < MEAS_NS; q++) s[q] = 0.0;
-    for (int c = c_beg + sl; c < c_end; c += 8) {
-        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
-        const double* r = sigR + (size_t)c * 8;
-        const double dx = z.x - z0.x, dy = z.y - z0.y;
-        const double wt = (c == 0) ? w.wc0 : w.wi;
-        s[0] += dx; s[1] += dy;
-        const double a = w.wi_sr * dx, b = w.wi_sr * dy;
-        s[2] += a * a; s[3] += a * b; s[4] += b * b;
-#pragma unroll
-        for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); s[5 + e] += dr * dx; s[9 + e] += dr * dy; }
-    }
-#pragma unroll
-    for (int q = 0; q < MEAS_NS; q++) sm[sl][lx][q] = s[q];
-    __syncthreads();
-    const int half = mp / 2;
-    for (int e = threadIdx.x; e < 32 * MEAS_NS; e += 256) {
-        const int q = e / 32, l2 = e % 32;
-        double t = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; u++) t += sm[u][l2][q];
-        const int k2 = blockIdx.x * 32 + l2;
-        if (k2 < d.N) part[((size_t)blockIdx.y * MEAS_NS + q) * half + k2] = t;
-    }
+    __shared__ double sm[MEAS_SM_DOUBLES];
+    meas_partial_job<false>(d, w, X, sigR, Z, part, blockIdx.x, blockIdx.y, sm);
 }
-
 __global__ __launch_bounds__(256) void k_meas_final(KDims d, KWeights w, const double* __restrict__ X, const double* __restrict__ sigR,
                                                     const double* __restrict__ Z, const double* __restrict__ part,
                                                     double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
                                                     double* __restrict__ PxyR)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= d.N) return;
-    const int mp = d.mp, half = mp / 2, n = d.n;
-    double t[MEAS_NS];
-#pragma unroll
-    for (int q = 0; q < MEAS_NS; q++) {
-        double acc = 0.0;
-        for (int u = 0; u < MEAS_SLICES; u++) acc += part[((size_t)u * MEAS_NS + q) * half + k];
-        t[q] = acc;
-    }
-    const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * k);
-    // h = wm0*Z0 + wi*sum_{c>=1} Z_c = Z0*(wm0 + 2Na*wi) + wi*sum (Z_c - Z0)      (SLAM.cpp:1678-1681)
-    const double wsum = w.wm0 + 2.0 * d.Na * w.wi;
-    const double hx = wsum * z0.x + w.wi * t[0], hy = wsum * z0.y + w.wi * t[1];
-    // robot rows of Pxy: sum_c w_c (r_c - xr)(Z_c - h) = sum_c w_c (r_c - xr)(Z_c - Z0) - (h - Z0) * sum_c w_c (r_c - xr)
-    double rs[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) rs[e] = sigR[(size_t)d.L * 8 + e];      // sum_c w_c (r_c - xr), from k_motion
-    const bool v = (hx != 0.0) && (hy != 0.0);
-    h[2 * k] = hx; h[2 * k + 1] = hy;
-    vis[k] = v ? 1 : 0;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        PxyR[(size_t)e * mp + 2 * k]     = t[5 + e] - (hx - z0.x) * rs[e];
-        PxyR[(size_t)e * mp + 2 * k + 1] = t[9 + e] - (hy - z0.y) * rs[e];
-    }
-    // Householder R of the 2Na x 2 matrix [a b] (GSL: beta = -sign(alpha) hypot(alpha, xnorm); tau = 0 if xnorm == 0)
-    const double2 z1 = *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * k);
-    const double2 z2 = *reinterpret_cast<const double2*>(Z + (size_t)2 * mp + 2 * k);
-    const double a0 = w.wi_sr * (z1.x - z0.x), b0 = w.wi_sr * (z1.y - z0.y);
-    const double a1 = w.wi_sr * (z2.x - z0.x), b1 = w.wi_sr * (z2.y - z0.y);
-    const double saa = t[2], sab = t[3], sbb = t[4];
-    const double xn2 = fmax(saa - a0 * a0, 0.0);
-    double R00 = a0, R01 = b0, tau = 0.0, wv = 0.0, inv_s = 0.0;
-    if (xn2 > 0.0) {
-        const double beta = -(a0 >= 0.0 ? 1.0 : -1.0) * sqrt(saa);
-        tau = (beta - a0) / beta;
-        inv_s = 1.0 / (a0 - beta);
-        wv = b0 + (sab - a0 * b0) * inv_s;              // w = B_0 + sum_{r>=1} B_r v_r
-        R00 = beta;
-        R01 = b0 - tau * wv;
-    }
-    // second column: b' = H1 b; |b'[1:]|^2 = |b|^2 - R01^2 (H1 orthogonal); R11 = -sign(b'_1) |b'[1:]|,
-    // or b'_1 itself when the rest of the sub-column is zero
-    const double bp1 = b1 - tau * (a1 * inv_s) * wv;
-    const double nrm2 = fmax(sbb - R01 * R01, 0.0);
-    const double rest2 = nrm2 - bp1 * bp1;
-    double R11 = bp1;
-    if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(nrm2);
-    Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;
+    if (k < d.N) meas_final_one<false>(d, w, X, sigR, Z, part, h, Si, vis, PxyR, k);
 }
-
 // ------------------------------------------------------------------------------------------------
 // k_gain: KalmanUpdate gains for all landmarks + state update (SLAM.cpp:2070-2080):
 //   sii = Si^{-1} (OpenCV closed-form 2x2 inverse), U = Ki*Si^T = Pxy*sii, y = sii^T (z - h),
 //   X += sum_k Ki (z - h) = sum_k U_k y_k.
 // In : Ut rows 2k, 2k+1 hold S^T DZ for r < n-4 (k_pxy; scaled here by wi*gamma), PxyR rows n-4..n-1.
 // Out: Ut rows become U^T (zero for unmatched / invisible landmarks); per-slice partial dX.
-// grid = (np/64, GAIN_SLICES): block = 64 state rows x 4 sub-slices of one landmark slice; k_gain_dx
-// adds the slice partials to X in fixed order (deterministic).
+// grid = (np/64, GAIN_SLICES): block = 64 state rows x 4 sub-slices of one landmark slice; the k_syrk
+// launch that follows adds the slice partials to X in fixed order (deterministic) in a few extra
+// workgroups (srukf_gain_dx_job).  Block (0,0) also clears the gamma / xi accumulators of that k_syrk.
 // ------------------------------------------------------------------------------------------------
-#define GAIN_SLICES 8
 __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               double* __restrict__ Ut, const double* __restrict__ PxyR,
                                               const double* __restrict__ Si, const int* __restrict__ vis,
                                               const double* __restrict__ h, const double* __restrict__ z_seq,
                                               const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
-                                              const FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */)
+                                              FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */)
 {
     __shared__ double red[4][64];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
     const int rl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + rl;
     const int n = d.n, ld = d.np, mp = d.mp, N = d.N;
@@ -406,17 +320,6 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     __syncthreads();
     if (sl == 0) dxp[(size_t)blockIdx.y * ld + r] = (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
 }
-__global__ __launch_bounds__(256) void k_gain_dx(KDims d, const double* __restrict__ dxp, double* __restrict__ X, FrameScalars* __restrict__ fs)
-{
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }      // gamma / xi accumulators of the k_syrk that follows
-    if (r >= d.n) return;
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < GAIN_SLICES; u++) acc += dxp[(size_t)u * d.np + r];
-    X[r] += acc;
-}
-
 // k_traj: per-frame record (x, y, z, theta, P00, P01, P10, P11) of the robot = RobotPath.txt
 // columns (SLAM.cpp:3549-3556) with P = S^T S restricted to the robot x/y block (2404); also
 // advances the staged-sequence frame counter.  One workgroup.
@@ -484,7 +387,6 @@ void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const do
                        FrameScalars* fs, double* dxp, double* X)
 {
     hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
-    hipLaunchKernelGGL(k_gain_dx, dim3((d.n + 255) / 256), dim3(256), 0, st, d, dxp, X, fs);
 }
 int srukf_gain_part_doubles(int np) { return GAIN_SLICES * np; }
 void srukf_launch_traj(hipStream_t st, KDims d, const double* X, const double* S, FrameScalars* fs, double* traj, int advance)
