@@ -176,15 +176,32 @@ template <int J, int J1> struct GmwTStep {
         }
     }
 };
-template <int J0, int J1, bool GLOBAL> __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane,
-                                                                                   double* __restrict__ Tt, double* Tl)
+// Flag and rows of group [J0, J1) as read (speculatively) while the previous group was being processed: valid if f > 0
+// (the flag is read BEFORE the rows, and LDS executes a wave's reads in order).
+struct GmwTPre { double f; d2 ab[8]; };
+template <int J0, int J1> __device__ __forceinline__ void gmw_t_prefetch(GmwTPre& p, const GmwColsLds& w, int lane)
 {
-    gmw_wait_row(dv, J1 - 1);
-    d2 ab[8];
+    asm volatile("" ::: "memory");
+    p.f = w.Dv[J1 - 1];
+    asm volatile("" ::: "memory");             // the compiler must not hoist a row read above the flag read
     const d2* strip = (const d2*)&w.Lm[(lane & 15) * GMW_LM_STRIDE];
 #pragma unroll
-    for (int j = J0; j < J1; j++) ab[j & 7] = strip[j];
-    GmwTStep<J0, J1>::run(t, ab, 0);
+    for (int j = J0; j < J1; j++) p.ab[j & 7] = strip[j];
+    asm volatile("" ::: "memory");
+}
+// Group [J0, J1); [N0, N1) is the group after it (N1 == N0: none), read ahead into nxt before this group's FMAs so that a
+// follower that has fallen behind pays no LDS round trip per group.
+template <int J0, int J1, int N0, int N1, bool GLOBAL>
+__device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane,
+                                            double* __restrict__ Tt, double* Tl, GmwTPre& cur, GmwTPre& nxt)
+{
+    // not published yet when we looked: read flag + rows again (one LDS round trip per attempt, bounded)
+    for (int spins = 0; __builtin_amdgcn_readfirstlane(__double2hiint(cur.f)) <= 0 && spins < GMW_POLL_LIMIT; spins++) {
+        if (spins) __builtin_amdgcn_s_sleep(1);
+        gmw_t_prefetch<J0, J1>(cur, w, lane);
+    }
+    if constexpr (N1 > N0) gmw_t_prefetch<N0, N1>(nxt, w, lane);
+    GmwTStep<J0, J1>::run(t, cur.ab, 0);
 #pragma unroll
     for (int r = J0 + 1; r < 32; r++) asm volatile("" : "+v"(t[r]));   // keep the FMAs in this group (no sinking past the next poll)
     // rows < J1 of T are final now (row 31 after the last group): publish rows [J0, J1') while the pivot wave works on
@@ -216,12 +233,14 @@ __device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, d
     double t[32];
 #pragma unroll
     for (int r = 0; r < 32; r++) t[r] = (r == c) ? 1.0 : 0.0;
-    gmw_t_group<0, 4, GLOBAL>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<4, 8, GLOBAL>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<8, 16, GLOBAL>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<16, 24, GLOBAL>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<24, 28, GLOBAL>(t, w, dv, lane, Tt, Tl);
-    gmw_t_group<28, 31, GLOBAL>(t, w, dv, lane, Tt, Tl);
+    GmwTPre pa, pb;
+    pa.f = 0.0;                                                         // nothing read ahead for the first group
+    gmw_t_group<0, 4, 4, 8, GLOBAL>(t, w, dv, lane, Tt, Tl, pa, pb);
+    gmw_t_group<4, 8, 8, 16, GLOBAL>(t, w, dv, lane, Tt, Tl, pb, pa);
+    gmw_t_group<8, 16, 16, 24, GLOBAL>(t, w, dv, lane, Tt, Tl, pa, pb);
+    gmw_t_group<16, 24, 24, 28, GLOBAL>(t, w, dv, lane, Tt, Tl, pb, pa);
+    gmw_t_group<24, 28, 28, 31, GLOBAL>(t, w, dv, lane, Tt, Tl, pa, pb);
+    gmw_t_group<28, 31, 0, 0, GLOBAL>(t, w, dv, lane, Tt, Tl, pb, pa);
 }
 // Tl[kk][33] -> Tt[kk*32 + jj], one wave, coalesced 128-bit stores
 __device__ __forceinline__ void gmw_copy_t(const double* Tl, double* __restrict__ Tt, int lane)
