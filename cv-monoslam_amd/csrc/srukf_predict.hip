@@ -34,6 +34,21 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
     const int n = d.n, Na = d.Na, L = d.L, ld = d.np;
 
     STAMP(0);
+    // the S rows of this thread's directions are requested before the control block: their round trip then overlaps
+    // thread 0's dependent chain  frame counter -> odometry pair  instead of following it
+    constexpr int MAXIT = 4;                                   // the first 4 * 512 directions; the rest load in the loop
+    double2 pre[MAXIT][2];
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+        const int i = tid + it * 512;
+        pre[it][0] = make_double2(0.0, 0.0); pre[it][1] = make_double2(0.0, 0.0);
+        if (i < n) {
+            // S[i][n-4..n-1]: 16-byte aligned (n-4 = 6N is even, ld a multiple of 64); the strictly lower
+            // triangle of S is kept zero, so rows inside the robot block need no masking
+            const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4));
+            pre[it][0] = sp2[0]; pre[it][1] = sp2[1];
+        }
+    }
     // ---- control (SLAM.cpp:1444-1458) ----
     if (tid == 0) {
         const double* o = odo_pair ? odo_pair : (odo_seq + 3 * fs->frame);
@@ -77,13 +92,9 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[e] = w.wm0 * s0[e];
     }
-    for (int i = tid; i < Na; i += nt) {
+    auto direction = [&](const int i, const double2 u0, const double2 u1) {
         double srow[4] = { 0, 0, 0, 0 }, mnoise[3] = { 0, 0, 0 };
         if (i < n) {
-            // S[i][n-4..n-1]: 16-byte aligned (n-4 = 6N is even, ld a multiple of 64); the strictly lower
-            // triangle of S is kept zero, so rows inside the robot block need no masking
-            const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4));
-            const double2 u0 = sp2[0], u1 = sp2[1];
             srow[0] = u0.x; srow[1] = u0.y; srow[2] = u1.x; srow[3] = u1.y;
         } else if (i < n + 3) {
             mnoise[i - n] = sh[3 + (i - n)];                   // control-noise rows (sr = blockdiag(S, Mt, Qt))
@@ -130,6 +141,16 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
 #pragma unroll
                 for (int b = a; b < 4; b++) acc[q++] += (w.wi_sr * dev[0][a]) * (w.wi_sr * dev[0][b]) + (w.wi_sr * dev[1][a]) * (w.wi_sr * dev[1][b]);
         }
+    };
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+        const int i = tid + it * 512;
+        if (i < Na) direction(i, pre[it][0], pre[it][1]);
+    }
+    for (int i = tid + MAXIT * 512; i < Na; i += 512) {         // more than 2048 directions (N > 339): plain loads
+        double2 u0 = make_double2(0.0, 0.0), u1 = u0;
+        if (i < n) { const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4)); u0 = sp2[0]; u1 = sp2[1]; }
+        direction(i, u0, u1);
     }
     STAMP(2);
     // block reduction through LDS only (wave shuffles of 14 doubles cost more LDS-pipeline time than this tree):
