@@ -48,6 +48,30 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
 }
 __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base = traj_base; }
 
+// ---- NEED_REORDER helpers (GSLCholeskyUpdate, SLAM.cpp:2122-2138) -------------------------------
+// dst = P^T src P on the upper triangle of a symmetric matrix stored upper: dst[a][b] = src[ip[a]][ip[b]] (a <= b),
+// ip[a] = the row r of the source with perm[r] = a.  forward = 0 swaps the roles (dst[r][c] = src[perm[r]][perm[c]]).
+// Entries outside the upper n x n part are zeroed.
+__global__ __launch_bounds__(256) void k_sym_permute(int n, int ld, const double* __restrict__ src, double* __restrict__ dst,
+                                                     const int* __restrict__ map)
+{
+    const int a = blockIdx.x;
+    for (int b = threadIdx.x; b < ld; b += 256) {
+        double v = 0.0;
+        if (a < n && b < n && b >= a) {
+            const int r = map[a], c = map[b];
+            v = (r <= c) ? src[(size_t)r * ld + c] : src[(size_t)c * ld + r];
+        }
+        dst[(size_t)a * ld + b] = v;
+    }
+}
+// "bottom rows zero" of CholeskyDecompositionWithPivoting (SLAM.cpp:2161, 2176): rows >= rank of the disordered factor
+__global__ __launch_bounds__(256) void k_zero_rows(int ld, int r0, double* __restrict__ A)
+{
+    const int r = r0 + blockIdx.x;
+    for (int b = threadIdx.x; b < ld; b += 256) A[(size_t)r * ld + b] = 0.0;
+}
+
 #define SRUKF_GRAPH_FRAMES 8
 static thread_local std::string g_create_error;
 
@@ -73,6 +97,11 @@ struct srukf_ctx {
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
     bool dx_pending = false;               // k_gain left slice partials of dX that the next k_syrk must add to X
+    // NEED_REORDER (frames that follow a landmark addition): K_new = m_nFilters, permutation between the normal and the
+    // disordered layout (getPermutationMatrix, SLAM.cpp:1303-1334), disordered factor
+    int K_new = 0;
+    int *perm = nullptr, *iperm = nullptr;
+    double* Sdis = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered)
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
     int n_syrk_tiles = 0, n_pxy_tiles = 0;
@@ -242,6 +271,57 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         if (frame_tail) srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     }
 }
+// Blocked fast path (or, slow = true, the exact column path) on an arbitrary matrix buffer: Gbuf (upper triangle,
+// destroyed) -> upper-triangular factor rows in Sout (whose lower triangle must already be zero).
+static void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow)
+{
+    const int np = c->d.np, n = c->d.n;
+    if (!slow) {
+        int pb = 0;
+        for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
+            srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, Gbuf, c->pan[pb ^ 1], c->pan[pb], c->D, Sout);
+        srukf_launch_gmw_check(c->stream, n, np, c->D, Sout, c->fs, c->X, 0);
+    } else {
+        hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 0);
+        for (int j = 0; j < n; j++) srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, Gbuf, c->Wf, c->D, c->theta, c->fs, Sout);
+    }
+}
+static int read_fs(srukf_ctx* c);
+// GSLCholeskyUpdate with FLAG_NEED_REORDER (SLAM.cpp:2122-2138) for the columns [ub, ue) of U:
+//   dst = S^T S - U U^T;  dst_dis = Pi^T dst Pi  (disordered layout: the rank-deficient new-anchor block last);
+//   S_dis = [R11 R12; 0 0],  R11 = gmw(dst_dis[0:r, 0:r]),  R12 = R11^{-T} dst_dis[0:r, r:n]   (2158-2179, r = n - 3 K_new);
+//   S = R factor of QR(Pi S_dis Pi^T).
+// [R11 R12] is what the right-looking GMW leaves in its first r rows whatever stands in the lower right block, so the
+// full factorisation runs and rows >= r are zeroed.  R^T R = Pi (S_dis^T S_dis) Pi^T, so the QR is a second
+// SYRK + permutation + GMW (P = S^T S is what the filter consumes; row signs of R are a convention).
+static int refactor_reorder(srukf_ctx* c, int ub, int ue)
+{
+    const KDims& d = c->d;
+    const int np = d.np, n = d.n, r = n - 3 * c->K_new;
+    const size_t bytes = sizeof(double) * (size_t)np * np;
+    if (!c->Sdis) { if (hipMalloc((void**)&c->Sdis, bytes) != hipSuccess) { c->err = "out of device memory (NEED_REORDER buffer)"; return SRUKF_ERR_NOMEM; } }
+    hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
+    srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X);
+    c->dx_pending = false;
+    for (int stage = 0; stage < 2; stage++) {
+        double* out = stage == 0 ? c->Sdis : c->S;
+        if (stage == 1) {
+            hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
+            srukf_launch_syrk(c->stream, d, c->Sdis, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X);
+        }
+        for (int slow = 0; slow < 2; slow++) {
+            hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
+            hipLaunchKernelGGL(k_sym_permute, dim3(np), dim3(256), 0, c->stream, n, np, c->G, c->Gbak, stage == 0 ? c->iperm : c->perm);
+            if (stage == 0) HIPCHK(c, hipMemsetAsync(c->Sdis, 0, bytes, c->stream));
+            run_gmw(c, c->Gbak, out, slow != 0);
+            if (stage == 0 && r < np) hipLaunchKernelGGL(k_zero_rows, dim3(np - r), dim3(256), 0, c->stream, np, r, c->Sdis);
+            if (slow) break;
+            int rc = read_fs(c); if (rc) return rc;
+            if (c->hfs->clamp_rows == 0) break;        // the theta clamp never won: the blocked result is the reference's
+        }
+    }
+    return SRUKF_OK;
+}
 static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats)
 {
     const KDims& d = c->d;
@@ -359,7 +439,8 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8_exec) hipGraphExecDestroy(c->graph8_exec);
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
-                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles };
+                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles,
+                     c->perm, c->iperm, c->Sdis };
     for (void* b : bufs) if (b) hipFree(b);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->hfs) hipHostFree(c->hfs);
@@ -550,7 +631,8 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
 {
     if (!c || !z || !matched) return SRUKF_ERR_BAD_ARG;
     if (c->phase < 2) { c->err = "update before predict_measurement"; return SRUKF_ERR_SEQUENCE; }
-    if (reorder != SRUKF_NEEDNOT_REORDER) { c->err = "NEED_REORDER (rank-aware pivoted path, SLAM.cpp:2122-2138) is not built yet"; return SRUKF_ERR_UNSUPPORTED; }
+    if (reorder != SRUKF_NEEDNOT_REORDER && reorder != SRUKF_NEED_REORDER) return SRUKF_ERR_BAD_ARG;
+    if (reorder == SRUKF_NEED_REORDER && c->K_new <= 0) { c->err = "NEED_REORDER without srukf_set_new_landmarks (m_nFilters = 0)"; return SRUKF_ERR_SEQUENCE; }
     if (mode != SRUKF_UPDATE_SEQUENTIAL && mode != SRUKF_UPDATE_BATCHED) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const KDims& d = c->d;
@@ -567,7 +649,15 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
     seq_gain(c, c->zcur, c->mcur, false);
     // visibility is needed on the host only to skip no-op refactors in SEQUENTIAL mode
-    if (mode == SRUKF_UPDATE_BATCHED) {
+    if (reorder == SRUKF_NEED_REORDER) {
+        if (mode == SRUKF_UPDATE_BATCHED) { int rc = refactor_reorder(c, 0, d.mp); if (rc) return rc; }
+        else {
+            for (int k = 0; k < N; k++) {
+                if (!matched[k]) continue;                               // SLAM.cpp:2068
+                for (int col = 0; col < 2; col++) { int rc = refactor_reorder(c, 2 * k + col, 2 * k + col + 1); if (rc) return rc; }
+            }
+        }
+    } else if (mode == SRUKF_UPDATE_BATCHED) {
         seq_refactor(c, 0, d.mp, false, true, false, false);
         int rc = read_fs(c); if (rc) return rc;
         if (c->hfs->clamp_rows > 0) {
@@ -601,6 +691,30 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    return SRUKF_OK;
+}
+
+int srukf_set_new_landmarks(srukf_ctx* c, int K_new)
+{
+    if (!c || K_new < 0) return SRUKF_ERR_BAD_ARG;
+    const int n = c->d.n;
+    if (6 * K_new > n - 4) { c->err = "K_new larger than the map"; return SRUKF_ERR_DIM_MISMATCH; }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->K_new = K_new;
+    if (K_new == 0) return SRUKF_OK;
+    // getPermutationMatrix, SLAM.cpp:1303-1334: X_normal[r] = X_disordered[perm[r]]
+    std::vector<int> perm(n), iperm(n);
+    const int dimOld = n - 6 * K_new;
+    for (int i = 0; i < dimOld - 4; i++) perm[i] = i;
+    for (int e = 0; e < 4; e++) perm[n - 4 + e] = dimOld - 4 + e;
+    for (int id = 0; id < K_new; id++) {
+        for (int e = 0; e < 3; e++) perm[dimOld - 4 + 6 * id + e] = dimOld + 3 * K_new + 3 * id + e;
+        for (int e = 0; e < 3; e++) perm[dimOld - 4 + 6 * id + 3 + e] = dimOld + 3 * id + e;
+    }
+    for (int r2 = 0; r2 < n; r2++) iperm[perm[r2]] = r2;
+    if (!c->perm) { HIPCHK(c, hipMalloc((void**)&c->perm, sizeof(int) * c->d.np)); HIPCHK(c, hipMalloc((void**)&c->iperm, sizeof(int) * c->d.np)); }
+    HIPCHK(c, hipMemcpy(c->perm, perm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->iperm, iperm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     return SRUKF_OK;
 }
 

@@ -58,7 +58,7 @@ void CSLAM::resetAllParameters()
     initializeParameters();
 }
 
-bool CSLAM::setMap(int N, const double* X, const double* S, const double* px)
+bool CSLAM::setMap(int N, const double* X, const double* S, const double* px, int n_added)
 {
     if (ctx_) { srukf_destroy(ctx_); ctx_ = nullptr; }
     if (!check(srukf_create(&ctx_, N, &m_params, device_, nullptr))) return false;
@@ -68,7 +68,8 @@ bool CSLAM::setMap(int N, const double* X, const double* S, const double* px)
     map.assign(N, PointsMap());
     for (int k = 0; k < N; k++) { map[k].ID = k + 1; if (px) { map[k].initPixel.x = px[2 * k]; map[k].initPixel.y = px[2 * k + 1]; } }
     m_nMapFeatures = N;
-    m_nAddings = 0;          // steady state: FLAG_4_NEEDNOT_REORDER (SLAM.cpp:2083-2090)
+    m_nAddings = n_added;    // 0 = steady state: FLAG_4_NEEDNOT_REORDER (SLAM.cpp:2083-2090)
+    if (n_added > 0 && !check(srukf_set_new_landmarks(ctx_, n_added))) return false;                           // m_nFilters, 758-766
     refreshMirrors();
     return true;
 }

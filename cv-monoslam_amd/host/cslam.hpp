@@ -73,7 +73,9 @@ public:
     // ---- map set-up (the reference builds it inside addFeatures -> integrateFeaturesInformation,
     //      SLAM.cpp:552-562, 818-1018; landmark augmentation on the device is a "next" row, so the
     //      host supplies the augmented state) ------------------------------------------------
-    bool setMap(int n_landmarks, const double* X, const double* S, const double* init_pixels /*2N or null*/);
+    //      n_added = m_nFilters: the last n_added landmarks are new; the next KalmanUpdate then takes the
+    //      FLAG_4_NEED_REORDER path (SLAM.cpp:2083-2090), as the reference does after integrateFeaturesInformation
+    bool setMap(int n_landmarks, const double* X, const double* S, const double* init_pixels /*2N or null*/, int n_added = 0);
 
     // the reference's loadPictures()+dataAssociation() slot (SLAM.cpp:95-97)
     std::function<void(CSLAM&)> dataAssociation;

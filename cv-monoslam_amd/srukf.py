@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -96,6 +96,7 @@ def load_library():
     L.srukf_predict_motion.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_predict_measurement.argtypes = [C.c_void_p, _dp, _dp, _ip]
     L.srukf_update.argtypes = [C.c_void_p, _dp, _ip, C.c_int, C.c_int]
+    L.srukf_set_new_landmarks.argtypes = [C.c_void_p, C.c_int]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.srukf_run_frames_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.srukf_run_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
@@ -209,6 +210,10 @@ class Filter:
         z, m = _c(z), _c(matched, np.int32)
         assert z.shape == (2 * self.N,) and m.shape == (self.N,)
         self._chk(self._lib.srukf_update(self._h, _d(z), _i(m), reorder, mode))
+
+    def set_new_landmarks(self, K_new):
+        """m_nFilters: the last K_new landmarks of the map were just added (NEED_REORDER updates use it)."""
+        self._chk(self._lib.srukf_set_new_landmarks(self._h, int(K_new)))
 
     def stage_sequence(self, odo, z, matched):
         odo, z, m = _c(odo), _c(z), _c(matched, np.int32)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRUKF_ABI_VERSION 1
+#define SRUKF_ABI_VERSION 2
 
 typedef enum srukf_status {
     SRUKF_OK                =  0,
@@ -121,9 +121,17 @@ int  srukf_predict_measurement(srukf_ctx* ctx, double* h, double* Si, int* visib
 
 /* KalmanUpdate (SLAM.cpp:2048-2104): z[2N] matched pixels (PointsMap::matchLocation),
  * matched[N] (PointsMap::isMatching).  reorder = SRUKF_NEEDNOT_REORDER for steady state;
- * SRUKF_NEED_REORDER (the frame right after landmarks were added) is not built yet and
- * returns SRUKF_ERR_UNSUPPORTED. */
+ * SRUKF_NEED_REORDER on the frames that follow a landmark addition (the reference passes
+ * `m_nAddings != 0 ? NEED_REORDER : NEEDNOT_REORDER`, SLAM.cpp:2084-2090): the rank-aware path
+ * GSLCholeskyUpdate 2122-2138 + CholeskyDecompositionWithPivoting 2158-2179 with
+ * m_covRank = n - 3*K_new; K_new must have been set with srukf_set_new_landmarks
+ * (SRUKF_ERR_SEQUENCE otherwise). */
 int  srukf_update(srukf_ctx* ctx, const double* z, const int* matched, int reorder, int mode);
+
+/* m_nFilters (SLAM.cpp:826-830, 2126-2131): the number of landmarks added by the last augmentation, i.e. the LAST
+ * K_new landmarks of the map.  Defines the permutation of getPermutationMatrix (SLAM.cpp:1303-1334) and the rank
+ * n - 3*K_new used by SRUKF_NEED_REORDER updates.  0 clears it. */
+int  srukf_set_new_landmarks(srukf_ctx* ctx, int K_new);
 
 /* ---- benchmark seam: whole frames with inputs pre-staged in HBM --------------------------- */
 

@@ -215,14 +215,52 @@ def test_error_behaviour(srukf, synth):
     assert e.value.rc == -5
     f.predict_motion(sc["odo"][0], sc["odo"][1]); f.predict_measurement()
     with pytest.raises(srukf.SrukfError) as e:
-        f.update(sc["z"][0], sc["matched"][0], reorder=srukf.NEED_REORDER)
-    assert e.value.rc == -6
+        f.update(sc["z"][0], sc["matched"][0], reorder=srukf.NEED_REORDER)   # no srukf_set_new_landmarks before
+    assert e.value.rc == -5
+    with pytest.raises(srukf.SrukfError) as e:
+        f.set_new_landmarks(5)                                   # more new landmarks than the map has
+    assert e.value.rc == -2
     with pytest.raises(srukf.SrukfError) as e:
         f.run_frames(0, 1)                                      # nothing staged
     assert e.value.rc == -2
     f.reset()
     X, S = f.get_state()
     assert np.array_equal(X, np.zeros(28)) and S[-1, -1] == 0.02 and S[-2, -2] == 0.005
+
+
+@pytest.mark.parametrize("N,K", [(8, 8), (12, 3), (40, 5)])
+def test_need_reorder_matches_oracle(srukf, oracle, synth, N, K):
+    """Frames that follow a landmark addition (GSLCholeskyUpdate NEED_REORDER, SLAM.cpp:2122-2138, with
+    CholeskyDecompositionWithPivoting 2158-2179): the last K landmarks are new, rank = n - 3K.  The reference runs
+    this path column by column (SEQUENTIAL); the device's BATCHED variant must agree with it as well."""
+    p = synth.scene_params()
+    sc = synth.make_scene(N, 3, seed=11, p=p)               # S0 from the reference's joint initialisation: rank deficient
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    o.predict_motion(sc["odo"][0], sc["odo"][1]); o.predict_measurement()
+    res = {}
+    for mode in (srukf.UPDATE_SEQUENTIAL, srukf.UPDATE_BATCHED):
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.set_new_landmarks(K)
+        f.predict_motion(sc["odo"][0], sc["odo"][1]); f.predict_measurement()
+        f.update(sc["z"][0], sc["matched"][0], reorder=srukf.NEED_REORDER, mode=mode)
+        res[mode] = f.get_state()
+    o.update(sc["z"][0], sc["matched"][0], reorder=oracle.Oracle.NEED_REORDER, k_new=K, mode=oracle.Oracle.SEQUENTIAL)
+    Xo, So = o.get_state()
+    Po = So.T @ So
+    for mode, (X, S) in res.items():
+        assert np.all(np.tril(S, -1) == 0.0)
+        np.testing.assert_allclose(X, Xo, atol=1e-9)
+        np.testing.assert_allclose(S.T @ S, Po, atol=1e-10)
+    # one more steady-state frame on top of the reordered factor stays in step with the oracle
+    f = srukf.Filter(N, p); f.set_state(*res[srukf.UPDATE_SEQUENTIAL])
+    f.predict_motion(sc["odo"][1], sc["odo"][2]); f.predict_measurement(); f.update(sc["z"][1], sc["matched"][1])
+    o.predict_motion(sc["odo"][1], sc["odo"][2]); o.predict_measurement(); o.update(sc["z"][1], sc["matched"][1], mode=oracle.Oracle.BATCHED)
+    # (the 3K null directions of the new anchors are pivoted with EPSILON by both sides, from factors that differ by
+    #  rounding noise there, and the reference algorithm divides that noise by 1e-13 — SURVEY 0.5; the frame is only
+    #  held to the north star's pose tolerance of 1e-6)
+    X, S = f.get_state(); Xo, So = o.get_state()
+    np.testing.assert_allclose(X[-4:], Xo[-4:], atol=1e-6)
+    np.testing.assert_allclose((S.T @ S)[-4:, -4:], (So.T @ So)[-4:, -4:], atol=1e-8)
+    np.testing.assert_allclose(X, Xo, atol=1e-4)
 
 
 def test_full_size_properties_n200(srukf, synth):
