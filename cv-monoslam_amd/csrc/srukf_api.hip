@@ -30,6 +30,10 @@ int srukf_gmw_panel_bytes(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
+void srukf_launch_aug_map(hipStream_t, srukf_params, int, int, int, int, double, const double*, const double*, const double*, double*);
+void srukf_launch_aug_x(hipStream_t, int, int, int, double, double, const double*, const double*, const int*, double*, double*, int, int);
+void srukf_launch_aug_build(hipStream_t, int, int, int, int, double, double, const double*, const double*, const double*, double*, int, int, int);
+void srukf_launch_gram(hipStream_t, int, int, const double*, double*);
 }
 
 // resets the per-refactor accumulators (theta row maxima, gamma/xi)
@@ -369,7 +373,7 @@ static int alloc_zero(srukf_ctx* c, void** p, size_t bytes)
 
 int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void* stream)
 {
-    if (!out || !p || N < 1) { g_create_error = "bad argument"; return SRUKF_ERR_BAD_ARG; }
+    if (!out || !p || N < 0) { g_create_error = "bad argument"; return SRUKF_ERR_BAD_ARG; }      // N = 0: the robot block only (SLAM.cpp:226-231), until landmarks are added
     if (p->noise_type != 0) { g_create_error = "noise_type != 0 draws random numbers (SLAM.cpp:1505-1516) and is not built"; return SRUKF_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -395,14 +399,14 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     }
     KDims& d = c->d;
     d.N = N; d.n = 6 * N + 4; d.Na = d.n + 5; d.L = 2 * d.Na + 1;
-    d.np = round_up(d.n, SRUKF_PAD); d.mp = round_up(2 * N, SRUKF_PAD);
+    d.np = round_up(d.n, SRUKF_PAD); d.mp = round_up(2 * N > 0 ? 2 * N : 1, SRUKF_PAD);
     host_weights(d.Na, c->p, c->w);
     const size_t np = d.np, mp = d.mp;
     ALLOC(c->X, np); ALLOC(c->S, np * np); ALLOC(c->G, np * np); ALLOC(c->Gbak, np * np); ALLOC(c->Wf, np * np);
     ALLOC(c->sigR, (size_t)d.L * 8 + 8); ALLOC(c->mpart, srukf_meas_part_doubles(d.mp)); ALLOC(c->dxp, srukf_gain_part_doubles(d.np)); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
-    ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)N); ALLOC(c->PxyR, 4 * mp); ALLOC(c->y, mp);
+    ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)(N > 0 ? N : 1)); ALLOC(c->PxyR, 4 * mp); ALLOC(c->y, mp);
     ALLOC(c->D, np); ALLOC(c->Wp, 32 * np); ALLOC(c->Lp, 32 * np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
-    ALLOC(c->vis, N); ALLOC(c->mcur, N); ALLOC(c->theta, np); ALLOC(c->fs, 1);
+    ALLOC(c->vis, N > 0 ? N : 1); ALLOC(c->mcur, N > 0 ? N : 1); ALLOC(c->theta, np); ALLOC(c->fs, 1);
     { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
     {
         // k_syrk: tile (row r, col c >= r); A panel = S columns of r, B panel = S columns of c.  XCD owns rows.
@@ -606,6 +610,7 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     if (c->phase < 1) { c->err = "predict_measurement before predict_motion"; return SRUKF_ERR_SEQUENCE; }
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->d.N;
+    if (N == 0) { c->phase = 2; return SRUKF_OK; }                       // empty map: nothing to predict
     seq_predict_measurement(c, false);
     double* hs = c->hstage;
     HIPCHK(c, hipMemcpyAsync(hs, c->h, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, c->stream));
@@ -716,6 +721,74 @@ int srukf_set_new_landmarks(srukf_ctx* c, int K_new)
     HIPCHK(c, hipMemcpy(c->perm, perm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->iperm, iperm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     return SRUKF_OK;
+}
+
+// integrateFeaturesInformation, numeric part (SLAM.cpp:826-871): K new landmarks at the distorted pixels uv[K][2] are
+// appended to the map (normal order: before the robot block).  The context is rebuilt for N + K landmarks in place
+// (the handle stays valid; staged sequences and captured graphs are dropped) and K_new = K is armed for the
+// FLAG_4_NEED_REORDER update that follows (SLAM.cpp:2083-2090).  See srukf_augment.hip.
+int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
+{
+    if (!c || K < 1 || !uv) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int dim = c->d.n, ld = c->d.np;
+    const int Na = dim + 3 * K, L = 2 * Na + 1, dimn = dim + 6 * K;                          // 827-828
+    srukf_ctx* c2 = nullptr;
+    int rc = srukf_create(&c2, c->d.N + K, &c->p, c->device, c->stream);
+    if (rc) { c->err = std::string("add_landmarks: ") + g_create_error; return rc; }
+    const int ldn = c2->d.np, rows_p = round_up(2 * Na, 16);
+    KWeights wa; host_weights(Na, c->p, wa);                                                 // 867
+    std::vector<int> perm(dimn);
+    {   // getPermutationMatrix, 1303-1334 (dim = new dimension)
+        const int dimOld = dimn - 6 * K;
+        for (int i = 0; i < dimOld - 4; i++) perm[i] = i;
+        for (int e = 0; e < 4; e++) perm[dimn - 4 + e] = dimOld - 4 + e;
+        for (int id = 0; id < K; id++) {
+            for (int e = 0; e < 3; e++) perm[dimOld - 4 + 6 * id + e] = dimOld + 3 * K + 3 * id + e;
+            for (int e = 0; e < 3; e++) perm[dimOld - 4 + 6 * id + 3 + e] = dimOld + 3 * id + e;
+        }
+    }
+    double *d_uv = nullptr, *d_ang = nullptr, *d_A = nullptr, *d_mu = nullptr; int* d_perm = nullptr;
+    auto cleanup = [&]() { for (void* b : { (void*)d_uv, (void*)d_ang, (void*)d_A, (void*)d_mu, (void*)d_perm }) if (b) hipFree(b); };
+    if (hipMalloc((void**)&d_uv, sizeof(double) * 2 * K) != hipSuccess || hipMalloc((void**)&d_ang, sizeof(double) * (size_t)L * 3 * K) != hipSuccess ||
+        hipMalloc((void**)&d_A, sizeof(double) * (size_t)rows_p * ldn) != hipSuccess || hipMalloc((void**)&d_mu, sizeof(double) * 3 * K) != hipSuccess ||
+        hipMalloc((void**)&d_perm, sizeof(int) * dimn) != hipSuccess) {
+        cleanup(); srukf_destroy(c2); c->err = "add_landmarks: out of device memory"; return SRUKF_ERR_NOMEM;
+    }
+    hipMemcpyAsync(d_uv, uv, sizeof(double) * 2 * K, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * dimn, hipMemcpyHostToDevice, c->stream);
+    hipStreamSynchronize(c->stream);                                                         // uv / perm are pageable host memory
+    srukf_launch_aug_map(c->stream, c->p, dim, ld, K, Na, wa.gamma, c->X, c->S, d_uv, d_ang);
+    srukf_launch_aug_x(c->stream, dim, K, Na, wa.wm0, wa.wi, c->X, d_ang, d_perm, d_mu, c2->X, dimn, ldn);
+    srukf_launch_aug_build(c->stream, dim, ld, K, Na, wa.gamma, wa.wi_sr, c->X, c->S, d_ang, d_A, rows_p, dimn, ldn);
+    srukf_launch_gram(c->stream, rows_p, ldn, d_A, c2->G);                                   // A^T A, disordered layout
+    for (int slow = 0; slow < 2; slow++) {
+        hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c2->fs, 0, 1);
+        hipLaunchKernelGGL(k_refactor_reset, dim3((ldn + 255) / 256), dim3(256), 0, c->stream, ldn, c2->theta, c2->fs, 1);
+        hipLaunchKernelGGL(k_sym_permute, dim3(ldn), dim3(256), 0, c->stream, dimn, ldn, c2->G, c2->Gbak, d_perm);      // Pi (A^T A) Pi^T
+        srukf_launch_gmw_stats(c->stream, dimn, ldn, c2->Gbak, c2->fs);
+        if (slow) hipMemsetAsync(c2->S, 0, sizeof(double) * (size_t)ldn * ldn, c->stream);
+        run_gmw(c2, c2->Gbak, c2->S, slow != 0);
+        if (slow) break;
+        rc = read_fs(c2);
+        if (rc) { c->err = c2->err; cleanup(); srukf_destroy(c2); return rc; }
+        if (c2->hfs->clamp_rows == 0) break;
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("add_landmarks: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
+    // the handle keeps its identity: swap the guts, keep the stream ownership, the profile and the error slot
+    const bool own = c->own_stream;
+    std::swap(*c, *c2);
+    c->own_stream = own; c2->own_stream = false;
+    c->profiling = c2->profiling; c->use_graph = c2->use_graph;
+    memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
+    memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
+    c2->profiling = false; c2->pev.clear();
+    srukf_destroy(c2);
+    c->phase = 0;
+    return srukf_set_new_landmarks(c, K);
 }
 
 int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z, const int* matched)

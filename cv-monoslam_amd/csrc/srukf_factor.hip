@@ -8,84 +8,9 @@
 //   B: lane l holds B_op[k = l>>4][j = l&15]  -> B[k0 + (l>>4)][n0 + (l&15)]
 //   D: reg t of lane l is D[row = (l>>4) + 4t][col = l&15]
 #include "srukf_device.h"
+#include "srukf_tiles.h"
 #include "srukf_gmw_cols.h"
 #include "srukf_meas.h"
-
-// one wave: 32x32 output tile at (m0, n0), K range [kb, ke) — (ke - kb) a multiple of 16 —, accumulate.
-// Software-pipelined: the 16 fragment loads of the next group of four k-steps are in flight while the
-// 16 MFMAs of the current group issue (hipcc otherwise waits for each group's loads before its MFMAs).
-template <bool NEG>
-__device__ __forceinline__ void tile32_tn(d4 (&acc)[2][2], const double* __restrict__ A, int lda,
-                                          const double* __restrict__ B, int ldb, int m0, int n0, int kb, int ke, int lane)
-{
-    const int lr = lane & 15, lk = lane >> 4;
-    const double* pa = A + (size_t)(kb + lk) * lda + m0 + lr;
-    const double* pb = B + (size_t)(kb + lk) * ldb + n0 + lr;
-    const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
-    const int ng = (ke - kb) >> 4;
-    if (ng <= 0) return;
-    double ca0[4], ca1[4], cb0[4], cb1[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { ca0[u] = pa[0]; ca1[u] = pa[16]; cb0[u] = pb[0]; cb1[u] = pb[16]; pa += sa; pb += sb; }
-    for (int g = 0; g + 1 < ng; g++) {
-        double na0[4], na1[4], nb0[4], nb1[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { na0[u] = pa[0]; na1[u] = pa[16]; nb0[u] = pb[0]; nb1[u] = pb[16]; pa += sa; pb += sb; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const double a0 = NEG ? -ca0[u] : ca0[u], a1 = NEG ? -ca1[u] : ca1[u];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb0[u], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb1[u], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb0[u], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb1[u], acc[1][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) { ca0[u] = na0[u]; ca1[u] = na1[u]; cb0[u] = nb0[u]; cb1[u] = nb1[u]; }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const double a0 = NEG ? -ca0[u] : ca0[u], a1 = NEG ? -ca1[u] : ca1[u];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb0[u], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, cb1[u], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb0[u], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, cb1[u], acc[1][1], 0, 0, 0);
-    }
-}
-
-__device__ __forceinline__ void zero_acc(d4 (&acc)[2][2])
-{
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = (d4){0, 0, 0, 0};
-}
-
-// Split-K helper: the four waves of a workgroup share ONE 32x32 output tile, each contracting a
-// quarter of the K range (in groups of 16); partial tiles are summed through LDS in fixed wave
-// order (deterministic) and wave 0 owns the result.  Balances the triangular K ranges (S is upper
-// triangular, so K grows with the tile's row index) and quadruples the waves in flight.
-__device__ __forceinline__ void splitk_reduce(d4 (&acc)[2][2], double (*red)[64][17], int wv, int lane)
-{
-    if (wv > 0) {
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) red[wv - 1][lane][(a * 2 + b) * 4 + t] = acc[a][b][t];
-    }
-    __syncthreads();
-    if (wv == 0) {
-#pragma unroll
-        for (int u = 0; u < 3; u++)
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) acc[a][b][t] += red[u][lane][(a * 2 + b) * 4 + t];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_pxy: landmark rows of all cross covariances in one contraction

@@ -74,6 +74,23 @@ bool CSLAM::setMap(int N, const double* X, const double* S, const double* px, in
     return true;
 }
 
+bool CSLAM::integrateFeaturesInformation(int K, const double* kp)
+{
+    if (K <= 0) { m_nAddings = 0; return true; }                                                                // SLAM.cpp:820-821
+    if (!ctx_) {                                                                                                // frame 1: robot block only (221-231)
+        if (!check(srukf_create(&ctx_, 0, &m_params, device_, nullptr))) return false;
+        m_nMapFeatures = 0; map.clear();
+    }
+    if (!check(srukf_add_landmarks(ctx_, K, kp))) return false;
+    const int N = m_nMapFeatures + K, n = 6 * N + 4;
+    m_X_k.create(n, 1); m_S_k.create(n, n); m_P_k.create(n, n);
+    for (int k = 0; k < K; k++) { PointsMap pm; pm.ID = m_nMapFeatures + k + 1; pm.initPixel.x = kp[2 * k]; pm.initPixel.y = kp[2 * k + 1]; map.push_back(pm); }
+    m_nMapFeatures = N;                                                                                         // 766
+    m_nAddings = K;                                                                                             // 758-765 (m_nFilters = m_nAddings = counter)
+    refreshMirrors();
+    return true;
+}
+
 // SLAM.cpp:462-496 + 363-450: "%d : %*lf %lf %lf %lf" lines, first sample is the origin, samples
 // closer than MIN_STEP in both x and y are skipped, turns above MIN_STEP_THETA flag a redirection.
 bool CSLAM::loadOdometryData(const std::string& path)

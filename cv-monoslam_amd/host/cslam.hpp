@@ -76,6 +76,10 @@ public:
     //      n_added = m_nFilters: the last n_added landmarks are new; the next KalmanUpdate then takes the
     //      FLAG_4_NEED_REORDER path (SLAM.cpp:2083-2090), as the reference does after integrateFeaturesInformation
     bool setMap(int n_landmarks, const double* X, const double* S, const double* init_pixels /*2N or null*/, int n_added = 0);
+    // integrateFeaturesInformation (SLAM.cpp:818-871) for K key points the host detected (m_keyPoints[i].pt, distorted
+    // pixels): joint initialisation on the device, the map and the mirrors grow by K, m_nFilters = m_nAddings = K so that
+    // the next KalmanUpdate runs FLAG_4_NEED_REORDER.  Works from the empty map of initializeParameters (frame 1).
+    bool integrateFeaturesInformation(int K, const double* keyPoints /*2K*/);
 
     // the reference's loadPictures()+dataAssociation() slot (SLAM.cpp:95-97)
     std::function<void(CSLAM&)> dataAssociation;

@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -97,6 +97,7 @@ def load_library():
     L.srukf_predict_measurement.argtypes = [C.c_void_p, _dp, _dp, _ip]
     L.srukf_update.argtypes = [C.c_void_p, _dp, _ip, C.c_int, C.c_int]
     L.srukf_set_new_landmarks.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_add_landmarks.argtypes = [C.c_void_p, C.c_int, _dp]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.srukf_run_frames_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.srukf_run_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
@@ -143,6 +144,9 @@ class Filter:
             msg = self._lib.srukf_last_error(None)
             self._h = None
             raise SrukfError(rc, msg.decode() if msg else "")
+        self._refresh_dims()
+
+    def _refresh_dims(self):
         N, n, Na, L = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self._lib.srukf_dims(self._h, C.byref(N), C.byref(n), C.byref(Na), C.byref(L))
         self.N, self.n, self.Na, self.L = N.value, n.value, Na.value, L.value
@@ -214,6 +218,12 @@ class Filter:
     def set_new_landmarks(self, K_new):
         """m_nFilters: the last K_new landmarks of the map were just added (NEED_REORDER updates use it)."""
         self._chk(self._lib.srukf_set_new_landmarks(self._h, int(K_new)))
+
+    def add_landmarks(self, uv):
+        """Joint initialisation of K new landmarks at distorted pixels uv[K][2]; the filter grows to N + K."""
+        uv = _c(uv).reshape(-1, 2)
+        self._chk(self._lib.srukf_add_landmarks(self._h, uv.shape[0], _d(uv)))
+        self._refresh_dims()
 
     def stage_sequence(self, odo, z, matched):
         odo, z, m = _c(odo), _c(z), _c(matched, np.int32)

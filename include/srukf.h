@@ -80,7 +80,7 @@ int  srukf_abi_version(void);
  * CSLAM::initializeParameters (SLAM.cpp:158-343). */
 int  srukf_default_params(srukf_params* p);
 
-/* Create a filter for N landmarks (n = 6N+4) on HIP device `device`.
+/* Create a filter for N >= 0 landmarks (n = 6N+4) on HIP device `device`.
  * `stream` is an existing hipStream_t to launch on (so a host can time with its own events) or
  * NULL to let the context create one.  Replaces CSLAM::CSLAM + the allocation side of
  * initializeParameters (SLAM.cpp:21-57, 226-239).  Initial state: robot X=0, S=diag(sigma_x,
@@ -132,6 +132,14 @@ int  srukf_update(srukf_ctx* ctx, const double* z, const int* matched, int reord
  * K_new landmarks of the map.  Defines the permutation of getPermutationMatrix (SLAM.cpp:1303-1334) and the rank
  * n - 3*K_new used by SRUKF_NEED_REORDER updates.  0 clears it. */
 int  srukf_set_new_landmarks(srukf_ctx* ctx, int K_new);
+
+/* integrateFeaturesInformation, numeric part (SLAM.cpp:826-871, with passSigmaThroughMapingFunction 1177-1250,
+ * QrAndCholeskyForInitilization 1260-1300, getPermutationMatrix 1303-1334): K new landmarks first seen at the
+ * distorted pixels uv[K][2] (m_keyPoints[i].pt) are joint-initialised and appended to the map (inverse depth rho0,
+ * sigma_rho; pixel noise sigma_measure).  The context grows to N + K landmarks in place — the handle stays valid,
+ * staged sequences are dropped — and K_new = K is armed for the SRUKF_NEED_REORDER update that follows.  A context
+ * created with N = 0 holds the robot block only (initializeParameters 221-231) and is the reference's frame-1 state. */
+int  srukf_add_landmarks(srukf_ctx* ctx, int K, const double* uv);
 
 /* ---- benchmark seam: whole frames with inputs pre-staged in HBM --------------------------- */
 

@@ -263,6 +263,58 @@ def test_need_reorder_matches_oracle(srukf, oracle, synth, N, K):
     np.testing.assert_allclose(X, Xo, atol=1e-4)
 
 
+@pytest.mark.parametrize("K", [1, 2, 8, 40])
+def test_add_landmarks_from_empty_map(srukf, oracle, synth, K):
+    """Frame-1 joint initialisation (integrateFeaturesInformation, SLAM.cpp:826-871) from the reference's initial
+    4x4 state, against the oracle (golden G4 covers K = 1, 2, 8 of the same routine)."""
+    p = synth.scene_params()
+    rng = np.random.default_rng(5 + K)
+    uv = np.column_stack([rng.uniform(60, 580, K), rng.uniform(60, 420, K)])
+    f = srukf.Filter(0, p)
+    X4, S4 = f.get_state()
+    assert X4.shape == (4,) and np.array_equal(np.diag(S4), [p["sigma_x"], p["sigma_y"], p["sigma_z"], p["sigma_theta"]])
+    Xo, So = oracle.joint_init(p, X4, S4, uv)
+    f.add_landmarks(uv)
+    assert (f.N, f.n) == (K, 6 * K + 4)
+    X, S = f.get_state()
+    assert np.all(np.tril(S, -1) == 0.0)
+    np.testing.assert_allclose(X, Xo, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(S.T @ S, So.T @ So, rtol=0, atol=1e-12)
+    assert np.linalg.matrix_rank(S.T @ S, tol=1e-9) == 4 + 3 * K          # the K anchors are copies of the camera position
+
+
+def test_add_landmarks_then_need_reorder_frame(srukf, oracle, synth):
+    """Augmentation of an existing map in the middle of a run, then the frame the reference runs right after it:
+    predictMotion, predictMeasurement, KalmanUpdate with FLAG_4_NEED_REORDER."""
+    p = synth.scene_params()
+    N0, K = 10, 4
+    sc = synth.make_scene(N0 + K, 3, seed=21, p=p)
+    sc0 = synth.make_scene(N0, 3, seed=22, p=p)
+    f = srukf.Filter(N0, p); f.set_state(sc0["X0"], sc0["S0"])
+    o = oracle.Oracle(N0, p); o.set_state(sc0["X0"], sc0["S0"])
+    f.predict_motion(sc0["odo"][0], sc0["odo"][1]); f.predict_measurement(); f.update(sc0["z"][0], sc0["matched"][0])
+    o.predict_motion(sc0["odo"][0], sc0["odo"][1]); o.predict_measurement(); o.update(sc0["z"][0], sc0["matched"][0], mode=oracle.Oracle.BATCHED)
+    rng = np.random.default_rng(3)
+    uv = np.column_stack([rng.uniform(60, 580, K), rng.uniform(60, 420, K)])
+    Xf, Sf = f.get_state()
+    Xo, So = oracle.joint_init(p, Xf, Sf, uv)                   # same input state on both sides: isolates the augmentation
+    f.add_landmarks(uv)
+    X, S = f.get_state()
+    np.testing.assert_allclose(X, Xo, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(S.T @ S, So.T @ So, rtol=0, atol=1e-11)
+    # the following frame: all N0 + K landmarks matched at their predicted pixels + noise, NEED_REORDER with K_new = K
+    o2 = oracle.Oracle(N0 + K, p); o2.set_state(X, S)
+    f.predict_motion(sc0["odo"][1], sc0["odo"][2]); h, Si, vis = f.predict_measurement()
+    o2.predict_motion(sc0["odo"][1], sc0["odo"][2]); ho, Sio, viso = o2.predict_measurement()
+    np.testing.assert_allclose(h, ho, atol=1e-8)
+    z = h + rng.normal(0, 0.5, h.shape); m = np.asarray(vis, dtype=np.int32)
+    f.update(z, m, reorder=srukf.NEED_REORDER, mode=srukf.UPDATE_SEQUENTIAL)
+    o2.update(z, m, reorder=oracle.Oracle.NEED_REORDER, k_new=K, mode=oracle.Oracle.SEQUENTIAL)
+    X2, S2 = f.get_state(); Xo2, So2 = o2.get_state()
+    np.testing.assert_allclose(X2, Xo2, atol=1e-8)
+    np.testing.assert_allclose(S2.T @ S2, So2.T @ So2, atol=1e-9)
+
+
 def test_full_size_properties_n200(srukf, synth):
     """BASELINE config 3 (N = 200, n = 1204): no oracle at this size inside a unit test; check
     size-independent properties of the device results."""

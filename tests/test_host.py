@@ -55,7 +55,7 @@ def test_bad_arguments(pkg):
     assert lib.srukf_default_params(None) == -1
     h = C.c_void_p()
     p = pkg.srukf.Params.from_dict(pkg.synth.scene_params())
-    assert lib.srukf_create(C.byref(h), 0, C.byref(p), 0, None) == -1
+    assert lib.srukf_create(C.byref(h), -1, C.byref(p), 0, None) == -1      # N = 0 is legal: the robot block only
     p.noise_type = 1
     assert lib.srukf_create(C.byref(h), 4, C.byref(p), 0, None) == -6            # random-noise models unsupported
     assert lib.srukf_destroy(None) == 0
