@@ -56,7 +56,8 @@ __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base 
 // dst = P^T src P on the upper triangle of a symmetric matrix stored upper: dst[a][b] = src[ip[a]][ip[b]] (a <= b),
 // ip[a] = the row r of the source with perm[r] = a.  forward = 0 swaps the roles (dst[r][c] = src[perm[r]][perm[c]]).
 // Entries outside the upper n x n part are zeroed.
-__global__ __launch_bounds__(256) void k_sym_permute(int n, int ld, const double* __restrict__ src, double* __restrict__ dst,
+// The same kernel compacts a covariance when landmarks leave the state (map skips their indices, lds > ld).
+__global__ __launch_bounds__(256) void k_sym_permute(int n, int ld, const double* __restrict__ src, int lds, double* __restrict__ dst,
                                                      const int* __restrict__ map)
 {
     const int a = blockIdx.x;
@@ -64,10 +65,15 @@ __global__ __launch_bounds__(256) void k_sym_permute(int n, int ld, const double
         double v = 0.0;
         if (a < n && b < n && b >= a) {
             const int r = map[a], c = map[b];
-            v = (r <= c) ? src[(size_t)r * ld + c] : src[(size_t)c * ld + r];
+            v = (r <= c) ? src[(size_t)r * lds + c] : src[(size_t)c * lds + r];
         }
         dst[(size_t)a * ld + b] = v;
     }
+}
+__global__ __launch_bounds__(256) void k_gather(int n, int ld, const double* __restrict__ src, double* __restrict__ dst, const int* __restrict__ map)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < ld) dst[a] = (a < n) ? src[map[a]] : 0.0;
 }
 // "bottom rows zero" of CholeskyDecompositionWithPivoting (SLAM.cpp:2161, 2176): rows >= rank of the disordered factor
 __global__ __launch_bounds__(256) void k_zero_rows(int ld, int r0, double* __restrict__ A)
@@ -315,7 +321,7 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
         }
         for (int slow = 0; slow < 2; slow++) {
             hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
-            hipLaunchKernelGGL(k_sym_permute, dim3(np), dim3(256), 0, c->stream, n, np, c->G, c->Gbak, stage == 0 ? c->iperm : c->perm);
+            hipLaunchKernelGGL(k_sym_permute, dim3(np), dim3(256), 0, c->stream, n, np, c->G, np, c->Gbak, stage == 0 ? c->iperm : c->perm);
             if (stage == 0) HIPCHK(c, hipMemsetAsync(c->Sdis, 0, bytes, c->stream));
             run_gmw(c, c->Gbak, out, slow != 0);
             if (stage == 0 && r < np) hipLaunchKernelGGL(k_zero_rows, dim3(np - r), dim3(256), 0, c->stream, np, r, c->Sdis);
@@ -723,6 +729,7 @@ int srukf_set_new_landmarks(srukf_ctx* c, int K_new)
     return SRUKF_OK;
 }
 
+static void adopt_context(srukf_ctx* c, srukf_ctx* c2);
 // integrateFeaturesInformation, numeric part (SLAM.cpp:826-871): K new landmarks at the distorted pixels uv[K][2] are
 // appended to the map (normal order: before the robot block).  The context is rebuilt for N + K landmarks in place
 // (the handle stays valid; staged sequences and captured graphs are dropped) and K_new = K is armed for the
@@ -766,7 +773,7 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     for (int slow = 0; slow < 2; slow++) {
         hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c2->fs, 0, 1);
         hipLaunchKernelGGL(k_refactor_reset, dim3((ldn + 255) / 256), dim3(256), 0, c->stream, ldn, c2->theta, c2->fs, 1);
-        hipLaunchKernelGGL(k_sym_permute, dim3(ldn), dim3(256), 0, c->stream, dimn, ldn, c2->G, c2->Gbak, d_perm);      // Pi (A^T A) Pi^T
+        hipLaunchKernelGGL(k_sym_permute, dim3(ldn), dim3(256), 0, c->stream, dimn, ldn, c2->G, ldn, c2->Gbak, d_perm);      // Pi (A^T A) Pi^T
         srukf_launch_gmw_stats(c->stream, dimn, ldn, c2->Gbak, c2->fs);
         if (slow) hipMemsetAsync(c2->S, 0, sizeof(double) * (size_t)ldn * ldn, c->stream);
         run_gmw(c2, c2->Gbak, c2->S, slow != 0);
@@ -778,7 +785,14 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     hipError_t e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("add_landmarks: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
-    // the handle keeps its identity: swap the guts, keep the stream ownership, the profile and the error slot
+    adopt_context(c, c2);
+    return srukf_set_new_landmarks(c, K);
+}
+
+// the handle keeps its identity when the map changes size: swap the guts of a freshly built context in, keep the
+// stream ownership and the profile, destroy the old buffers
+static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
+{
     const bool own = c->own_stream;
     std::swap(*c, *c2);
     c->own_stream = own; c2->own_stream = false;
@@ -788,7 +802,50 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     c2->profiling = false; c2->pev.clear();
     srukf_destroy(c2);
     c->phase = 0;
-    return srukf_set_new_landmarks(c, K);
+}
+
+// deleteOneFeature, numeric part (SLAM.cpp:2637-2668): landmark id (0-based, state order) leaves the state.  The
+// reference drops its 6 rows and columns from S and folds the 6 removed rows V back in with six
+// S <- gmw(S^T S + v v^T); the sum of those is the remaining block of P = S^T S, so the device takes S^T S
+// (k_syrk), compacts it and factors it once (the batched form of the six updates, as in srukf_update).
+int srukf_delete_landmark(srukf_ctx* c, int id)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    const int N = c->d.N, n = c->d.n, np = c->d.np;
+    if (id < 0 || id >= N) { c->err = "delete_landmark: no such landmark"; return SRUKF_ERR_BAD_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    srukf_ctx* c2 = nullptr;
+    int rc = srukf_create(&c2, N - 1, &c->p, c->device, c->stream);
+    if (rc) { c->err = std::string("delete_landmark: ") + g_create_error; return rc; }
+    const int nn = n - 6, ldn = c2->d.np;
+    std::vector<int> map(nn);
+    for (int a = 0; a < nn; a++) map[a] = a < 6 * id ? a : a + 6;
+    int* d_map = nullptr;
+    if (hipMalloc((void**)&d_map, sizeof(int) * nn) != hipSuccess) { srukf_destroy(c2); c->err = "delete_landmark: out of device memory"; return SRUKF_ERR_NOMEM; }
+    hipMemcpy(d_map, map.data(), sizeof(int) * nn, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X);   // P = S^T S
+    hipLaunchKernelGGL(k_gather, dim3((ldn + 255) / 256), dim3(256), 0, c->stream, nn, ldn, c->X, c2->X, d_map);
+    for (int slow = 0; slow < 2; slow++) {
+        hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c2->fs, 0, 1);
+        hipLaunchKernelGGL(k_refactor_reset, dim3((ldn + 255) / 256), dim3(256), 0, c->stream, ldn, c2->theta, c2->fs, 1);
+        hipLaunchKernelGGL(k_sym_permute, dim3(ldn), dim3(256), 0, c->stream, nn, ldn, c->G, np, c2->Gbak, d_map);
+        srukf_launch_gmw_stats(c->stream, nn, ldn, c2->Gbak, c2->fs);
+        hipMemsetAsync(c2->S, 0, sizeof(double) * (size_t)ldn * ldn, c->stream);
+        run_gmw(c2, c2->Gbak, c2->S, slow != 0);
+        if (slow) break;
+        rc = read_fs(c2);
+        if (rc) { c->err = c2->err; hipFree(d_map); srukf_destroy(c2); return rc; }
+        if (c2->hfs->clamp_rows == 0) break;
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d_map);
+    if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("delete_landmark: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
+    // m_nFilters-- when one of the landmarks added last is the one that goes (SLAM.cpp:2468-2492)
+    const int k_new = c->K_new > 0 ? (id >= N - c->K_new ? c->K_new - 1 : c->K_new) : 0;
+    adopt_context(c, c2);
+    return srukf_set_new_landmarks(c, k_new);
 }
 
 int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z, const int* matched)

@@ -91,6 +91,19 @@ bool CSLAM::integrateFeaturesInformation(int K, const double* kp)
     return true;
 }
 
+bool CSLAM::deleteOneFeature(int id)
+{
+    if (!ctx_ || id < 0 || id >= m_nMapFeatures) { lastError = "deleteOneFeature: no such landmark"; return false; }
+    if (!check(srukf_delete_landmark(ctx_, id))) return false;                                                  // 2643-2668
+    map.erase(map.begin() + id);                                                                                // 2670-2705
+    m_nMapFeatures--;                                                                                           // 2664
+    if (m_nAddings > 0 && id >= m_nMapFeatures + 1 - m_nAddings) m_nAddings--;                                  // 2468-2492
+    const int n = 6 * m_nMapFeatures + 4;
+    m_X_k.create(n, 1); m_S_k.create(n, n); m_P_k.create(n, n);
+    refreshMirrors();
+    return true;
+}
+
 // SLAM.cpp:462-496 + 363-450: "%d : %*lf %lf %lf %lf" lines, first sample is the origin, samples
 // closer than MIN_STEP in both x and y are skipped, turns above MIN_STEP_THETA flag a redirection.
 bool CSLAM::loadOdometryData(const std::string& path)

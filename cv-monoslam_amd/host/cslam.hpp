@@ -80,6 +80,8 @@ public:
     // pixels): joint initialisation on the device, the map and the mirrors grow by K, m_nFilters = m_nAddings = K so that
     // the next KalmanUpdate runs FLAG_4_NEED_REORDER.  Works from the empty map of initializeParameters (frame 1).
     bool integrateFeaturesInformation(int K, const double* keyPoints /*2K*/);
+    // deleteOneFeature (SLAM.cpp:2637-2706): the id-th landmark of the state (0-based) leaves the filter and the map
+    bool deleteOneFeature(int id);
 
     // the reference's loadPictures()+dataAssociation() slot (SLAM.cpp:95-97)
     std::function<void(CSLAM&)> dataAssociation;

@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -98,6 +98,7 @@ def load_library():
     L.srukf_update.argtypes = [C.c_void_p, _dp, _ip, C.c_int, C.c_int]
     L.srukf_set_new_landmarks.argtypes = [C.c_void_p, C.c_int]
     L.srukf_add_landmarks.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.srukf_delete_landmark.argtypes = [C.c_void_p, C.c_int]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.srukf_run_frames_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.srukf_run_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
@@ -223,6 +224,11 @@ class Filter:
         """Joint initialisation of K new landmarks at distorted pixels uv[K][2]; the filter grows to N + K."""
         uv = _c(uv).reshape(-1, 2)
         self._chk(self._lib.srukf_add_landmarks(self._h, uv.shape[0], _d(uv)))
+        self._refresh_dims()
+
+    def delete_landmark(self, idx):
+        """deleteOneFeature: landmark idx (0-based state order) leaves the map; the filter shrinks to N - 1."""
+        self._chk(self._lib.srukf_delete_landmark(self._h, int(idx)))
         self._refresh_dims()
 
     def stage_sequence(self, odo, z, matched):

@@ -141,6 +141,12 @@ int  srukf_set_new_landmarks(srukf_ctx* ctx, int K_new);
  * created with N = 0 holds the robot block only (initializeParameters 221-231) and is the reference's frame-1 state. */
 int  srukf_add_landmarks(srukf_ctx* ctx, int K, const double* uv);
 
+/* deleteOneFeature, numeric part (SLAM.cpp:2637-2668): landmark `id` (0-based position in the state) leaves the map:
+ * X and S lose its 6 entries / rows / columns and the removed rows are folded back in (GSLCholeskyUpdate with
+ * FLAG_4_UPDATING), i.e. S becomes the factor of the remaining block of P = S^T S.  The context shrinks to N - 1
+ * landmarks in place. */
+int  srukf_delete_landmark(srukf_ctx* ctx, int id);
+
 /* ---- benchmark seam: whole frames with inputs pre-staged in HBM --------------------------- */
 
 /* Stage F frames of inputs on the device: odo[(F+1)*3] odometry poses (frame f uses f, f+1),

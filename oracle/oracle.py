@@ -77,6 +77,7 @@ def lib():
         L.orc_project.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
         L.orc_sample_parameter.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp]
         L.orc_joint_init.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]
+        L.orc_delete_feature.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, C.c_int, _dp, _dp]
         L.orc_sigma_ptr.restype = _dp
         L.orc_sigma_ptr.argtypes = [C.c_void_p]
         L.orc_Z_ptr.restype = _dp
@@ -206,6 +207,17 @@ def sample_parameter(Na, weight_type=0, alpha=1e-3, beta=2.0):
     out = np.zeros(7)
     lib().orc_sample_parameter(Na, weight_type, alpha, beta, _d(out))
     return dict(zip(["wm0", "wc0", "wi", "wi_sr", "gamma", "wm0_sr", "wc0_sr"], out))
+
+
+def delete_feature(params, X, S, idx):
+    """deleteOneFeature, numeric part: (X_new, S_new) without landmark idx (0-based state order)."""
+    p = Params.from_dict(params)
+    X, S = _c(X), _c(S)
+    dim = X.shape[0]
+    Xn, Sn = np.zeros(dim - 6), np.zeros((dim - 6, dim - 6))
+    rc = lib().orc_delete_feature(C.byref(p), dim, _d(X), _d(S), int(idx), _d(Xn), _d(Sn))
+    assert rc == 0
+    return Xn, Sn
 
 
 def joint_init(params, X, S, uv):

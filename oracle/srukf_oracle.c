@@ -732,6 +732,38 @@ ORC_API int orc_joint_init(const srukf_params *p, int dim, const double *X, cons
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* deleteOneFeature, numeric part (SLAM.cpp:2637-2663): landmark `id` (0-based, state order) leaves
+ * the state: X loses its 6 entries, S loses its 6 rows and columns, and the 6 removed rows (without
+ * the removed columns), V (6 x (dim-6)), are folded back in by GSLCholeskyUpdate(V^T,
+ * FLAG_4_UPDATING, FLAG_4_NEEDNOT_REORDER): one  S <- gmw(S^T S + u u^T)  per row u of V.
+ * In: X (dim), S (dim x dim).  Out: X_new (dim-6), S_new ((dim-6) x (dim-6)).                     */
+ORC_API int orc_delete_feature(const srukf_params *p, int dim, const double *X, const double *S, int id,
+                               double *X_new, double *S_new)
+{
+    int N = (dim - 4) / 6, dn = dim - 6;
+    if (id < 0 || id >= N) return SRUKF_ERR_BAD_ARG;
+    orc_state *st = orc_create(N - 1 > 0 ? N - 1 : 1, p);
+    if (!st) return SRUKF_ERR_NOMEM;
+    /* orc_create sized the state for max(N-1,1) landmarks; the update below only needs n = dn */
+    st->N = N - 1; st->n = dn;
+    double *V = (double *)malloc(sizeof(double) * 6 * (size_t)dn);
+    double *P = (double *)malloc(sizeof(double) * (size_t)dn * dn);
+    int lo = 6 * id, hi = 6 * (id + 1);
+    for (int r = 0, a = 0; r < dim; r++) {                                          /* 2645-2661 */
+        if (r >= lo && r < hi) continue;
+        X_new[a] = X[r];
+        for (int c = 0, b = 0; c < dim; c++) { if (c >= lo && c < hi) continue; st->S[(size_t)a * dn + b] = S[(size_t)r * dim + c]; b++; }
+        a++;
+    }
+    for (int q = 0; q < 6; q++)
+        for (int c = 0, b = 0; c < dim; c++) { if (c >= lo && c < hi) continue; V[(size_t)q * dn + b] = S[(size_t)(lo + q) * dim + c]; b++; }
+    for (int q = 0; q < 6; q++) cholesky_update_col(st, V + (size_t)q * dn, +1, SRUKF_NEEDNOT_REORDER, 0, P);   /* 2667-2668, 2116-2154 */
+    memcpy(S_new, st->S, sizeof(double) * (size_t)dn * dn);
+    free(V); free(P); orc_destroy(st);
+    return SRUKF_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Whole-sequence driver used by the trajectory tests and by bench.py's cpu_baseline leg:
  * runs F frames  predictMotion -> predictMeasurement -> KalmanUpdate  (CSLAM::SLAM,
  * SLAM.cpp:87-112, minus image I/O, association and display) and records per frame

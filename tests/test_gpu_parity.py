@@ -315,6 +315,36 @@ def test_add_landmarks_then_need_reorder_frame(srukf, oracle, synth):
     np.testing.assert_allclose(S2.T @ S2, So2.T @ So2, atol=1e-9)
 
 
+@pytest.mark.parametrize("N,idx", [(6, 0), (6, 3), (6, 5), (1, 0), (30, 11)])
+def test_delete_landmark_matches_oracle(srukf, oracle, synth, N, idx):
+    """deleteOneFeature (SLAM.cpp:2637-2668): compaction of X, S and the six rank-1 UPDATES with the removed rows."""
+    p = synth.scene_params()
+    sc = synth.make_scene(N, 2, seed=31 + N, p=p)
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    f.predict_motion(sc["odo"][0], sc["odo"][1]); f.predict_measurement(); f.update(sc["z"][0], sc["matched"][0])
+    X, S = f.get_state()
+    Xo, So = oracle.delete_feature(p, X, S, idx)
+    P = S.T @ S
+    keep = np.r_[0:6 * idx, 6 * idx + 6:6 * N + 4]
+    f.delete_landmark(idx)
+    assert (f.N, f.n) == (N - 1, 6 * (N - 1) + 4)
+    Xd, Sd = f.get_state()
+    assert np.all(np.tril(Sd, -1) == 0.0)
+    np.testing.assert_array_equal(Xd, X[keep])
+    np.testing.assert_allclose(Sd.T @ Sd, P[np.ix_(keep, keep)], rtol=0, atol=1e-13)     # marginal of the remaining states
+    np.testing.assert_allclose(Sd.T @ Sd, So.T @ So, rtol=0, atol=1e-11)                 # the reference's six sequential updates
+    np.testing.assert_array_equal(Xd, Xo)
+    if N > 1:                                                   # and the filter keeps running on the smaller map
+        sel = np.r_[0:idx, idx + 1:N]
+        z, m = sc["z"][1].reshape(N, 2)[sel].ravel(), sc["matched"][1][sel]
+        o = oracle.Oracle(N - 1, p); o.set_state(Xd, Sd)
+        f.predict_motion(sc["odo"][1], sc["odo"][2]); f.predict_measurement(); f.update(z, m)
+        o.predict_motion(sc["odo"][1], sc["odo"][2]); o.predict_measurement(); o.update(z, m, mode=oracle.Oracle.BATCHED)
+        X2, S2 = f.get_state(); Xo2, So2 = o.get_state()
+        np.testing.assert_allclose(X2, Xo2, atol=1e-9)
+        np.testing.assert_allclose(S2.T @ S2, So2.T @ So2, atol=1e-10)
+
+
 def test_full_size_properties_n200(srukf, synth):
     """BASELINE config 3 (N = 200, n = 1204): no oracle at this size inside a unit test; check
     size-independent properties of the device results."""
