@@ -207,3 +207,16 @@ def test_default_gain_structure_diverges_with_large_process_noise(oracle, synth)
     o.set_state(sc["X0"], sc["S0"])
     o.run_frames(sc["odo"], sc["z"], sc["matched"], 1)
     assert o.clamp_stats()["theta"] > 0
+
+
+def test_delete_feature_is_the_marginal(oracle, synth):
+    """deleteOneFeature (SLAM.cpp:2637-2668): the six rank-1 updates with the removed rows rebuild exactly the
+    remaining block of P = S^T S (numpy cross-check of the oracle restatement)."""
+    p = synth.scene_params()
+    for N, idx in ((5, 0), (5, 2), (5, 4), (1, 0)):
+        sc = synth.make_scene(N, 1, seed=40 + N, p=p, init="fullrank")
+        X, S = sc["X0"], sc["S0"]
+        Xn, Sn = oracle.delete_feature(p, X, S, idx)
+        keep = np.r_[0:6 * idx, 6 * idx + 6:6 * N + 4]
+        assert np.array_equal(Xn, X[keep]) and np.all(np.tril(Sn, -1) == 0.0)
+        np.testing.assert_allclose(Sn.T @ Sn, (S.T @ S)[np.ix_(keep, keep)], rtol=0, atol=1e-14)
