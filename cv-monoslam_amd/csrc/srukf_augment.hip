@@ -78,9 +78,7 @@ __global__ __launch_bounds__(256) void k_aug_x(int dim, int K, int Na, double wm
                                                const double* __restrict__ ang, const int* __restrict__ perm,
                                                double* __restrict__ mu_ang, double* __restrict__ Xn, int dimn, int ldn)
 {
-    __shared__ double mu[256];
     const int L = 2 * Na + 1;
-    // K <= 85 new landmarks per call fit one workgroup's mean pass; larger K loops
     for (int j0 = 0; j0 < 3 * K; j0 += 256) {
         const int j = j0 + threadIdx.x;
         if (j < 3 * K) {
@@ -89,8 +87,7 @@ __global__ __launch_bounds__(256) void k_aug_x(int dim, int K, int Na, double wm
             mu_ang[j] = m;
         }
     }
-    __syncthreads();
-    __threadfence_block();
+    __syncthreads();                                           // mu_ang (global) written above is read below by other threads
     for (int r = threadIdx.x; r < ldn; r += 256) {
         double v = 0.0;
         if (r < dimn) {
@@ -101,7 +98,6 @@ __global__ __launch_bounds__(256) void k_aug_x(int dim, int K, int Na, double wm
         }
         Xn[r] = v;
     }
-    (void)mu;
 }
 
 // k_aug_build: the QR matrix of QrAndCholeskyForInitilization (1268-1275), rows_p x ldn, row i = sigma column i+1,
