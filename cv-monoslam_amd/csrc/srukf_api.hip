@@ -82,6 +82,24 @@ __global__ __launch_bounds__(256) void k_zero_rows(int ld, int r0, double* __res
     for (int b = threadIdx.x; b < ld; b += 256) A[(size_t)r * ld + b] = 0.0;
 }
 
+// SRUKF_STORAGE_F32 (BASELINE configs[4]: fp32 filter state, fp64 arithmetic): the state that lives from frame to frame
+// is X32 / S32; the fp64 working copies are rounded to the stored values at the end of every refactorisation, so the
+// next frame computes from exactly what fp32 storage holds.  One workgroup per row of S (+ one for X).
+__global__ __launch_bounds__(256) void k_quantize(int n, int ld, double* __restrict__ S, double* __restrict__ X,
+                                                  float* __restrict__ S32, float* __restrict__ X32)
+{
+    const int r = blockIdx.x;
+    if (r == n) {
+        for (int c = threadIdx.x; c < n; c += 256) { const float f = (float)X[c]; X32[c] = f; X[c] = (double)f; }
+        return;
+    }
+    for (int c = r + threadIdx.x; c < n; c += 256) {
+        const float f = (float)S[(size_t)r * ld + c];
+        S32[(size_t)r * ld + c] = f;
+        S[(size_t)r * ld + c] = (double)f;
+    }
+}
+
 #define SRUKF_GRAPH_FRAMES 8
 static thread_local std::string g_create_error;
 
@@ -110,6 +128,8 @@ struct srukf_ctx {
     // NEED_REORDER (frames that follow a landmark addition): K_new = m_nFilters, permutation between the normal and the
     // disordered layout (getPermutationMatrix, SLAM.cpp:1303-1334), disordered factor
     int K_new = 0;
+    int storage = SRUKF_STORAGE_F64;       // SRUKF_STORAGE_F32: X32 / S32 hold the inter-frame state
+    float *S32 = nullptr, *X32 = nullptr;
     int *perm = nullptr, *iperm = nullptr;
     double* Sdis = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered)
@@ -225,6 +245,11 @@ static std::vector<int> build_tile_table(int n_own, int n_other, bool upper, boo
 }
 
 // ---- launch sequences --------------------------------------------------------------------------
+static void quantize_state(srukf_ctx* c)
+{
+    if (c->storage == SRUKF_STORAGE_F32)
+        hipLaunchKernelGGL(k_quantize, dim3(c->d.n + 1), dim3(256), 0, c->stream, c->d.n, c->d.np, c->S, c->X, c->S32, c->X32);
+}
 static void seq_predict_motion(srukf_ctx* c, const double* odo_pair_dev)
 {
     const KDims& d = c->d;
@@ -272,12 +297,14 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
                          8.0 * (r2 * r2 + 2.0 * 64.0 * r2));
             srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb ^ 1], c->pan[pb], c->D, c->S);
         }
+        quantize_state(c);
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
         srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs, c->X, frame_tail ? 1 : 0);
     } else {
         ProfScope ps(c, KC_GMW_COL, (double)n * n * n / 3.0, 8.0 * (double)n * n * n / 3.0);
         for (int j = 0; j < n; j++)
             srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+        quantize_state(c);
         if (frame_tail) srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     }
 }
@@ -330,6 +357,7 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
             if (c->hfs->clamp_rows == 0) break;        // the theta clamp never won: the blocked result is the reference's
         }
     }
+    quantize_state(c);
     return SRUKF_OK;
 }
 static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats)
@@ -450,7 +478,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles,
-                     c->perm, c->iperm, c->Sdis };
+                     c->perm, c->iperm, c->Sdis, c->S32, c->X32 };
     for (void* b : bufs) if (b) hipFree(b);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->hfs) hipHostFree(c->hfs);
@@ -498,6 +526,7 @@ int srukf_set_state(srukf_ctx* c, const double* X, const double* S)
     memset(hs, 0, sizeof(double) * np);
     memcpy(hs, X, sizeof(double) * n);
     HIPCHK(c, hipMemcpyAsync(c->X, hs, sizeof(double) * np, hipMemcpyHostToDevice, c->stream));
+    quantize_state(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase = 0;
     return SRUKF_OK;
@@ -531,6 +560,7 @@ int srukf_set_state_device(srukf_ctx* c, const double* dX, const double* dS, int
     HIPCHK(c, hipMemcpy2DAsync(c->S, sizeof(double) * np, dS, sizeof(double) * S_ld, sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->X, 0, sizeof(double) * np, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->X, dX, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    quantize_state(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase = 0;
     return SRUKF_OK;
@@ -678,6 +708,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
             HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
             ProfScope ps(c, KC_GMW_COL, 0, 0);
             for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+            quantize_state(c);
         }
     } else {
         std::vector<int> visible(N);
@@ -695,6 +726,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
                     hipLaunchKernelGGL(k_refactor_reset, dim3((d.np + 255) / 256), dim3(256), 0, c->stream, d.np, c->theta, c->fs, 0);
                     HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
                     for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+                    quantize_state(c);
                     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
                 }
             }
@@ -702,6 +734,42 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    return SRUKF_OK;
+}
+
+static void drop_graphs(srukf_ctx* c)
+{
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph8_exec) { hipGraphExecDestroy(c->graph8_exec); c->graph8_exec = nullptr; }
+    if (c->graph8) { hipGraphDestroy(c->graph8); c->graph8 = nullptr; }
+}
+int srukf_set_storage(srukf_ctx* c, int storage)
+{
+    if (!c || (storage != SRUKF_STORAGE_F64 && storage != SRUKF_STORAGE_F32)) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (storage == SRUKF_STORAGE_F32 && !c->S32) {
+        const size_t np = c->d.np;
+        HIPCHK(c, hipMalloc((void**)&c->S32, sizeof(float) * np * np));
+        HIPCHK(c, hipMalloc((void**)&c->X32, sizeof(float) * np));
+        HIPCHK(c, hipMemsetAsync(c->S32, 0, sizeof(float) * np * np, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->X32, 0, sizeof(float) * np, c->stream));
+    }
+    if (storage != c->storage) drop_graphs(c);             // the captured frames do or do not contain the rounding pass
+    c->storage = storage;
+    quantize_state(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SRUKF_OK;
+}
+int srukf_get_state_f32(srukf_ctx* c, float* X, float* S)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    if (c->storage != SRUKF_STORAGE_F32) { c->err = "get_state_f32: the context stores fp64 (srukf_set_storage)"; return SRUKF_ERR_SEQUENCE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->d.n; const size_t np = c->d.np;
+    if (X) HIPCHK(c, hipMemcpy(X, c->X32, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (S) HIPCHK(c, hipMemcpy2D(S, sizeof(float) * n, c->S32, sizeof(float) * np, sizeof(float) * n, n, hipMemcpyDeviceToHost));
     return SRUKF_OK;
 }
 
@@ -785,7 +853,9 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     hipError_t e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("add_landmarks: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
+    const int storage = c->storage;
     adopt_context(c, c2);
+    rc = srukf_set_storage(c, storage); if (rc) return rc;
     return srukf_set_new_landmarks(c, K);
 }
 
@@ -844,7 +914,9 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("delete_landmark: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
     // m_nFilters-- when one of the landmarks added last is the one that goes (SLAM.cpp:2468-2492)
     const int k_new = c->K_new > 0 ? (id >= N - c->K_new ? c->K_new - 1 : c->K_new) : 0;
+    const int storage = c->storage;
     adopt_context(c, c2);
+    rc = srukf_set_storage(c, storage); if (rc) return rc;
     return srukf_set_new_landmarks(c, k_new);
 }
 

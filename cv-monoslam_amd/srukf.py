@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_get_state_f32", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -32,6 +32,7 @@ STATUS = {0: "SRUKF_OK", -1: "SRUKF_ERR_BAD_ARG", -2: "SRUKF_ERR_DIM_MISMATCH", 
           -4: "SRUKF_ERR_NO_DEVICE", -5: "SRUKF_ERR_SEQUENCE", -6: "SRUKF_ERR_UNSUPPORTED",
           -7: "SRUKF_ERR_CLAMP_PENDING", -8: "SRUKF_ERR_NOMEM"}
 
+STORAGE_F64, STORAGE_F32 = 0, 1
 UPDATE_SEQUENTIAL, UPDATE_BATCHED = 0, 1
 NEED_REORDER, NEEDNOT_REORDER = 0, 1
 
@@ -99,6 +100,8 @@ def load_library():
     L.srukf_set_new_landmarks.argtypes = [C.c_void_p, C.c_int]
     L.srukf_add_landmarks.argtypes = [C.c_void_p, C.c_int, _dp]
     L.srukf_delete_landmark.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_set_storage.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_get_state_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.srukf_run_frames_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.srukf_run_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
@@ -225,6 +228,16 @@ class Filter:
         uv = _c(uv).reshape(-1, 2)
         self._chk(self._lib.srukf_add_landmarks(self._h, uv.shape[0], _d(uv)))
         self._refresh_dims()
+
+    def set_storage(self, storage):
+        """STORAGE_F64 (default) or STORAGE_F32: precision of the state kept between frames."""
+        self._chk(self._lib.srukf_set_storage(self._h, int(storage)))
+
+    def get_state_f32(self):
+        X, S = np.zeros(self.n, dtype=np.float32), np.zeros((self.n, self.n), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        self._chk(self._lib.srukf_get_state_f32(self._h, X.ctypes.data_as(fp), S.ctypes.data_as(fp)))
+        return X, S
 
     def delete_landmark(self, idx):
         """deleteOneFeature: landmark idx (0-based state order) leaves the map; the filter shrinks to N - 1."""

@@ -72,6 +72,11 @@ typedef enum srukf_update_mode { SRUKF_UPDATE_SEQUENTIAL = 0, SRUKF_UPDATE_BATCH
 /* SLAM.cpp:36-37 FLAG_4_NEED_REORDER(0) / FLAG_4_NEEDNOT_REORDER(1) */
 typedef enum srukf_reorder { SRUKF_NEED_REORDER = 0, SRUKF_NEEDNOT_REORDER = 1 } srukf_reorder;
 
+/* Precision of the filter state that lives from frame to frame (arithmetic is fp64 in both).  F32 is BASELINE
+ * configs[4] ("500 landmarks fp32 SRUKF ..., tolerance study"): X and S are kept as float and every frame computes
+ * from exactly those rounded values. */
+typedef enum srukf_storage { SRUKF_STORAGE_F64 = 0, SRUKF_STORAGE_F32 = 1 } srukf_storage;
+
 typedef struct srukf_ctx srukf_ctx;   /* opaque; owns all device buffers + pinned staging */
 
 int  srukf_abi_version(void);
@@ -140,6 +145,12 @@ int  srukf_set_new_landmarks(srukf_ctx* ctx, int K_new);
  * staged sequences are dropped — and K_new = K is armed for the SRUKF_NEED_REORDER update that follows.  A context
  * created with N = 0 holds the robot block only (initializeParameters 221-231) and is the reference's frame-1 state. */
 int  srukf_add_landmarks(srukf_ctx* ctx, int K, const double* uv);
+
+/* Select the storage precision (default SRUKF_STORAGE_F64).  With SRUKF_STORAGE_F32 the state is rounded to float at
+ * the end of every refactorisation (and by srukf_set_state); srukf_get_state returns those values widened to double,
+ * srukf_get_state_f32 the float arrays themselves (X[n], S[n*n] row-major). */
+int  srukf_set_storage(srukf_ctx* ctx, int storage);
+int  srukf_get_state_f32(srukf_ctx* ctx, float* X, float* S);
 
 /* deleteOneFeature, numeric part (SLAM.cpp:2637-2668): landmark `id` (0-based position in the state) leaves the map:
  * X and S lose its 6 entries / rows / columns and the removed rows are folded back in (GSLCholeskyUpdate with

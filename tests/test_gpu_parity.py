@@ -345,6 +345,37 @@ def test_delete_landmark_matches_oracle(srukf, oracle, synth, N, idx):
         np.testing.assert_allclose(S2.T @ S2, So2.T @ So2, atol=1e-10)
 
 
+def test_f32_storage_tolerance_study(srukf, oracle, synth):
+    """BASELINE configs[4] as a parity case: fp32 filter state (X32, S32), fp64 arithmetic.  Every frame starts from
+    exactly the float-rounded state; the trajectory is held against the fp64 oracle with the error an fp32 state
+    implies (eps_f32 ~ 6e-8 relative per frame), the fp64 run of the same sequence stays at 1e-9."""
+    p = synth.scene_params()
+    N, F = 20, 30
+    sc = synth.make_scene(N, F, seed=3, p=p)
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    to = o.run_frames(sc["odo"], sc["z"], sc["matched"], mode=oracle.Oracle.BATCHED)
+    err = {}
+    for storage in (srukf.STORAGE_F64, srukf.STORAGE_F32):
+        f = srukf.Filter(N, p); f.set_storage(storage); f.set_state(sc["X0"], sc["S0"])
+        f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        t = f.run_frames(0, F)
+        err[storage] = np.sqrt(np.mean((t[:, :2] - to[:, :2]) ** 2, axis=1))      # pose error per frame
+        if storage == srukf.STORAGE_F32:
+            X, S = f.get_state(); X32, S32 = f.get_state_f32()
+            assert np.array_equal(X, X32.astype(np.float64)) and np.array_equal(np.triu(S), np.triu(S32).astype(np.float64))
+            assert np.all(np.tril(S, -1) == 0.0)
+    assert err[srukf.STORAGE_F64].max() < 1e-9
+    assert 1e-12 < err[srukf.STORAGE_F32].max() < 1e-4          # visibly fp32, far inside the filter's own sigma (cm)
+    # step-wise API under fp32 storage takes the same rounding points as the replay
+    f = srukf.Filter(N, p); f.set_storage(srukf.STORAGE_F32); f.set_state(sc["X0"], sc["S0"])
+    for k in range(3):
+        f.predict_motion(sc["odo"][k], sc["odo"][k + 1]); f.predict_measurement(); f.update(sc["z"][k], sc["matched"][k])
+    g = srukf.Filter(N, p); g.set_storage(srukf.STORAGE_F32); g.set_state(sc["X0"], sc["S0"])
+    g.stage_sequence(sc["odo"], sc["z"], sc["matched"]); g.run_frames(0, 3)
+    np.testing.assert_array_equal(f.get_state()[0], g.get_state()[0])
+    np.testing.assert_array_equal(f.get_state()[1], g.get_state()[1])
+
+
 def test_full_size_properties_n200(srukf, synth):
     """BASELINE config 3 (N = 200, n = 1204): no oracle at this size inside a unit test; check
     size-independent properties of the device results."""
