@@ -30,6 +30,7 @@ int srukf_gmw_panel_bytes(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
+void srukf_launch_landmarks_cartesian(hipStream_t, KDims, const double*, const double*, double*, double*);
 void srukf_launch_aug_map(hipStream_t, srukf_params, int, int, int, int, double, const double*, const double*, const double*, double*);
 void srukf_launch_aug_x(hipStream_t, int, int, int, double, double, const double*, const double*, const int*, double*, double*, int, int);
 void srukf_launch_aug_build(hipStream_t, int, int, int, int, double, double, const double*, const double*, const double*, double*, int, int, int);
@@ -610,6 +611,23 @@ int srukf_get_landmark_block(srukf_ctx* c, int k, double X6[6], double P66[36])
         memcpy(X6, c->hstage + 64, sizeof(double) * 6);
     }
     if (P66) return block_cov(c, 6 * k, 6, P66);
+    return SRUKF_OK;
+}
+
+int srukf_get_landmarks_cartesian(srukf_ctx* c, double* xyz, double* cov)
+{
+    if (!c || (!xyz && !cov)) return SRUKF_ERR_BAD_ARG;
+    const int N = c->d.N;
+    if (N == 0) return SRUKF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // Z is scratch between frames (written by k_project before anything reads it): 12 N doubles for the results
+    double* dx = c->Z; double* dc = c->Z + 3 * (size_t)N;
+    srukf_launch_landmarks_cartesian(c->stream, c->d, c->X, c->S, dx, dc);
+    HIPCHK(c, hipMemcpyAsync(c->hstage, dx, sizeof(double) * 12 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (xyz) memcpy(xyz, c->hstage, sizeof(double) * 3 * (size_t)N);
+    if (cov) memcpy(cov, c->hstage + 3 * (size_t)N, sizeof(double) * 9 * (size_t)N);
     return SRUKF_OK;
 }
 

@@ -383,8 +383,52 @@ __global__ __launch_bounds__(256) void k_block_cov(KDims d, const double* __rest
         }
 }
 
+// k_landmarks_cartesian: getFeatureCartesianInformation (SLAM.cpp:2721-2751) for ALL landmarks in one launch — the
+// per-paint loop of OpenGlDisplay.cpp:449-583 reads xyz and the 3x3 Cartesian covariance of every landmark, which the
+// reference takes from m_P_k = S^T S (a 2 n^3 gemm per frame, 2404).  One workgroup per landmark: the 6x6 block of P
+// (21 column dot products over the rows k <= 6 id + 5), then cov = J P66 J^T with J = [I3 | d(xyz)/d(theta, phi, rho)].
+__global__ __launch_bounds__(256) void k_landmarks_cartesian(KDims d, const double* __restrict__ X, const double* __restrict__ S,
+                                                             double* __restrict__ xyz, double* __restrict__ cov)
+{
+    __shared__ double red[16 * 21];
+    const int id = blockIdx.x, off = 6 * id, ld = d.np;
+    double v[21];
+#pragma unroll
+    for (int q = 0; q < 21; q++) v[q] = 0.0;
+    for (int k = threadIdx.x; k < off + 6; k += 256) {          // S upper triangular: rows below the block do not contribute
+        double s[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) s[e] = (off + e >= k) ? S[(size_t)k * ld + off + e] : 0.0;
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) v[q++] += s[a] * s[b];
+    }
+    block_sum<21>(v, red);
+    if (threadIdx.x != 0) return;
+    double P[6][6];
+    { int q = 0; for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { P[a][b] = v[q]; P[b][a] = v[q]; q++; } }
+    const double xi = X[off], yi = X[off + 1], zi = X[off + 2], th = X[off + 3], ph = X[off + 4], rho = X[off + 5];
+    double sth, cth, sph, cph;
+    sincos(th, &sth, &cth); sincos(ph, &sph, &cph);
+    xyz[3 * id + 0] = xi + cph * sth / rho;                                                      // 2738-2740
+    xyz[3 * id + 1] = yi - sph / rho;
+    xyz[3 * id + 2] = zi + cph * cth / rho;
+    double J[3][6] = { { 1, 0, 0,  cph * cth / rho, -sph * sth / rho, -cph * sth / (rho * rho) },   // 2742-2747
+                       { 0, 1, 0,  0.0,             -cph / rho,        sph / (rho * rho) },
+                       { 0, 0, 1, -cph * sth / rho, -sph * cth / rho, -cph * cth / (rho * rho) } };
+    double JP[3][6];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 6; b++) { double t = 0.0; for (int k = 0; k < 6; k++) t += J[a][k] * P[k][b]; JP[a][b] = t; }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { double t = 0.0; for (int k = 0; k < 6; k++) t += JP[a][k] * J[b][k]; cov[9 * id + 3 * a + b] = t; }   // 2749
+}
+
 // ---- host-callable launchers -------------------------------------------------------------------
 extern "C" {
+void srukf_launch_landmarks_cartesian(hipStream_t st, KDims d, const double* X, const double* S, double* xyz, double* cov)
+{
+    hipLaunchKernelGGL(k_landmarks_cartesian, dim3(d.N), dim3(256), 0, st, d, X, S, xyz, cov);
+}
 void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, double* X, double* S, double* sigR, double* Cmat,
                          FrameScalars* fs, const double* odo_seq, const double* odo_pair)
 {

@@ -104,6 +104,107 @@ bool CSLAM::deleteOneFeature(int id)
     return true;
 }
 
+// ---- display accessors -----------------------------------------------------------------------------------------
+bool CSLAM::updateFeaturesInformation()
+{
+    const int N = m_nMapFeatures;
+    if (!ctx_ || N == 0) return true;
+    std::vector<double> xyz(3 * (size_t)N), cov(9 * (size_t)N);
+    if (!check(srukf_get_landmarks_cartesian(ctx_, xyz.data(), cov.data()))) return false;
+    Mat c; c.create(3, 3);
+    for (int k = 0; k < N; k++) {
+        map[k].xyz.x = xyz[3 * k]; map[k].xyz.y = xyz[3 * k + 1]; map[k].xyz.z = xyz[3 * k + 2];
+        for (int e = 0; e < 9; e++) { map[k].cov[e] = cov[9 * (size_t)k + e]; c.data[e] = map[k].cov[e]; }
+        get3DdisplayInformation(map[k].axis, map[k].sigma, c);                                                 // 2575
+    }
+    return true;
+}
+
+void CSLAM::getFeatureCartesianInformation(Point3d& xyz, Mat& sr, Mat& cov, const int& id) const
+{
+    xyz = map[id].xyz;
+    cov.create(3, 3);
+    for (int e = 0; e < 9; e++) cov.data[e] = map[id].cov[e];
+    sr.create(0, 0);
+    if (fullCovariance && m_S_k.rows >= 6 * id + 6) {
+        sr.create(6, 6);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) sr.at(a, b) = m_S_k.at(6 * id + a, 6 * id + b);
+    }
+}
+
+void CSLAM::get3DdisplayInformation(Quaternion& axis, Point3d& sigma, const Mat& matrix) const
+{
+    Mat values, vectors;
+    calculateEigenvaluesAndEigenvectors(matrix, values, vectors);
+    matrix2Quaternion(axis, vectors);
+    sigma.x = sqrt(values.at(0, 0)); sigma.y = sqrt(values.at(1, 1)); sigma.z = sqrt(values.at(2, 2));       // 1-sigma semi-axes
+}
+
+// Classical Jacobi method for a real symmetric matrix: repeatedly annihilate the off-diagonal element of largest
+// magnitude with a plane rotation A <- R^T A R, accumulating V <- V R.  On return the diagonal of `eigenvalues` holds
+// the eigenvalues (in the positions the rotations left them, not sorted) and column j of `eigenvectors` is the
+// eigenvector of eigenvalues(j, j).  Stops when every off-diagonal magnitude is below EPSILON (false after 30 n^2 sweeps).
+bool CSLAM::calculateEigenvaluesAndEigenvectors(Mat src, Mat& eigenvalues, Mat& eigenvectors) const
+{
+    const int n = src.rows;
+    eigenvalues = src;
+    eigenvectors.create(n, n);
+    for (int i = 0; i < n; i++) eigenvectors.at(i, i) = 1.0;
+    Mat& A = eigenvalues; Mat& V = eigenvectors;
+    for (int it = 0; it <= 30 * n * n; it++) {
+        int p = -1, q = -1; double big = 0.0;
+        for (int i = 1; i < n; i++) for (int j = 0; j < i; j++) if (fabs(A.at(i, j)) > big) { big = fabs(A.at(i, j)); p = i; q = j; }
+        if (big < m_params.epsilon) return true;
+        // rotation angle phi with tan(2 phi) = 2 a_pq / (a_qq - a_pp), written through omega = sin(2 phi) so that the
+        // half-angle formulas need no atan
+        const double x = -A.at(p, q), y = 0.5 * (A.at(q, q) - A.at(p, p));
+        double omega = x / sqrt(x * x + y * y);
+        if (y < 0.0) omega = -omega;
+        const double sn = omega / sqrt(2.0 * (1.0 + sqrt(1.0 - omega * omega)));
+        const double cn = sqrt(1.0 - sn * sn);
+        const double app = A.at(p, p), aqq = A.at(q, q), apq = A.at(p, q);
+        A.at(p, p) = app * cn * cn + aqq * sn * sn + apq * omega;
+        A.at(q, q) = app * sn * sn + aqq * cn * cn - apq * omega;
+        A.at(p, q) = 0.0; A.at(q, p) = 0.0;
+        for (int j = 0; j < n; j++) if (j != p && j != q) {
+            const double ap = A.at(p, j), aq = A.at(q, j);
+            A.at(p, j) = ap * cn + aq * sn; A.at(q, j) = -ap * sn + aq * cn;
+        }
+        for (int i = 0; i < n; i++) if (i != p && i != q) {
+            const double ap = A.at(i, p), aq = A.at(i, q);
+            A.at(i, p) = ap * cn + aq * sn; A.at(i, q) = -ap * sn + aq * cn;
+        }
+        for (int i = 0; i < n; i++) {
+            const double vp = V.at(i, p), vq = V.at(i, q);
+            V.at(i, p) = vp * cn + vq * sn; V.at(i, q) = -vp * sn + vq * cn;
+        }
+    }
+    return false;
+}
+
+// rotation matrix -> unit quaternion (r, x, y, z), branching on the largest of trace / diagonal entries so that the
+// square root argument stays away from zero; element pairing as in the reference (SLAM.cpp:2902-2948)
+void CSLAM::matrix2Quaternion(Quaternion& qn, const Mat& m) const
+{
+    const double m11 = m.at(0, 0), m12 = m.at(0, 1), m13 = m.at(0, 2);
+    const double m21 = m.at(1, 0), m22 = m.at(1, 1), m23 = m.at(1, 2);
+    const double m31 = m.at(2, 0), m32 = m.at(2, 1), m33 = m.at(2, 2);
+    const double tr = m11 + m22 + m33;
+    if (tr > 0.0) {
+        const double t = 0.5 / sqrt(tr + 1);
+        qn.r = 0.25 / t; qn.x = (m23 - m32) * t; qn.y = (m31 - m13) * t; qn.z = (m12 - m21) * t;
+    } else if (m11 > m22 && m11 > m33) {
+        const double t = 2.0 * sqrt(1.0 + m11 - m22 - m33);
+        qn.r = (m32 - m23) / t; qn.x = 0.25 * t; qn.y = (m12 + m21) / t; qn.z = (m13 + m31) / t;
+    } else if (m22 > m33) {
+        const double t = 2.0 * sqrt(1.0 + m22 - m11 - m33);
+        qn.r = (m13 - m31) / t; qn.x = (m12 + m21) / t; qn.y = 0.25 * t; qn.z = (m23 + m32) / t;
+    } else {
+        const double t = 2.0 * sqrt(1.0 + m33 - m11 - m22);
+        qn.r = (m21 - m12) / t; qn.x = (m13 + m31) / t; qn.y = (m23 + m32) / t; qn.z = 0.25 * t;
+    }
+}
+
 // SLAM.cpp:462-496 + 363-450: "%d : %*lf %lf %lf %lf" lines, first sample is the origin, samples
 // closer than MIN_STEP in both x and y are skipped, turns above MIN_STEP_THETA flag a redirection.
 bool CSLAM::loadOdometryData(const std::string& path)

@@ -31,6 +31,7 @@ struct Mat {
 
 struct Point2d { double x = 0, y = 0; };
 struct Point3d { double x = 0, y = 0, z = 0; };
+struct Quaternion { double r = 1, x = 0, y = 0, z = 0; };      // SLAM.h:39-45
 
 // SLAM.h:47-70 (numeric fields only)
 struct PointsMap {
@@ -43,7 +44,10 @@ struct PointsMap {
     Point2d matchLocation;
     double  Si[4] = {0, 0, 0, 0};     // 2x2 upper-triangular sqrt innovation covariance
     Point2d initPixel;
-    Point3d xyz;
+    Point3d xyz;                      // Cartesian mean                                  (SLAM.h:64)
+    Quaternion axis;                  // orientation of the 1-sigma ellipsoid            (SLAM.h:66)
+    Point3d sigma;                    // its semi-axes = sqrt of the eigenvalues of cov  (SLAM.h:67)
+    double  cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // Cartesian 3x3 covariance
 };
 
 // SLAM.h:85-92
@@ -82,6 +86,19 @@ public:
     bool integrateFeaturesInformation(int K, const double* keyPoints /*2K*/);
     // deleteOneFeature (SLAM.cpp:2637-2706): the id-th landmark of the state (0-based) leaves the filter and the map
     bool deleteOneFeature(int id);
+
+    // ---- display accessors (what OpenGlDisplay.cpp:449-583 reads per paint) ------------------------------
+    // updateFeaturesInformation's numeric part (SLAM.cpp:2566-2580): xyz, axis, sigma of every landmark of `map`, from
+    // ONE device call (srukf_get_landmarks_cartesian) instead of a pass over the n x n m_P_k per landmark
+    bool updateFeaturesInformation();
+    // getFeatureCartesianInformation (2721-2751): xyz and cov (3x3) of landmark id from the last refresh; sr (the 6x6
+    // diagonal block of m_S_k) only when fullCovariance mirrors are on, otherwise left empty
+    void getFeatureCartesianInformation(Point3d& xyz, Mat& sr, Mat& cov, const int& id) const;
+    // get3DdisplayInformation (2791-2802), calculateEigenvaluesAndEigenvectors (2816-2891: classical Jacobi rotations,
+    // largest off-diagonal pivot, eigenvalues left on the diagonal in place), matrix2Quaternion (2902-2948)
+    void get3DdisplayInformation(Quaternion& axis, Point3d& sigma, const Mat& matrix) const;
+    bool calculateEigenvaluesAndEigenvectors(Mat src, Mat& eigenvalues, Mat& eigenvectors) const;
+    void matrix2Quaternion(Quaternion& quaternion, const Mat& matrix) const;
 
     // the reference's loadPictures()+dataAssociation() slot (SLAM.cpp:95-97)
     std::function<void(CSLAM&)> dataAssociation;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 #include "cslam.hpp"
 
@@ -52,6 +53,18 @@ int main(int argc, char** argv)
     FILE* o = fopen(argv[4], "wb");
     fwrite(traj.data(), 8, traj.size(), o);
     fclose(o);
+    // what the OpenGL view reads per paint (OpenGlDisplay.cpp:449-583): xyz, cov, ellipsoid axes of every landmark
+    if (!SLAM.updateFeaturesInformation()) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+    {
+        std::string fn = std::string(argv[4]) + ".features";
+        FILE* ff = fopen(fn.c_str(), "wb");
+        for (const monoslam::PointsMap& pm : SLAM.map) {
+            const double rec[19] = { pm.xyz.x, pm.xyz.y, pm.xyz.z, pm.cov[0], pm.cov[1], pm.cov[2], pm.cov[3], pm.cov[4], pm.cov[5], pm.cov[6], pm.cov[7], pm.cov[8],
+                                     pm.axis.r, pm.axis.x, pm.axis.y, pm.axis.z, pm.sigma.x, pm.sigma.y, pm.sigma.z };
+            fwrite(rec, 8, 19, ff);
+        }
+        fclose(ff);
+    }
     printf("frames %d  landmarks %d  predicts %d  matches %d  total %.3f s\n", F, SLAM.m_nMapFeatures, SLAM.m_nPredicts, SLAM.m_nMatches, SLAM.m_totalTime);
     return 0;
 }

@@ -22,7 +22,7 @@ _INT_FIELDS = ["weight_type", "noise_type", "newton_iters", "reserved_"]
 EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
-    "srukf_get_landmark_block", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
+    "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
     "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_get_state_f32", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
@@ -94,6 +94,7 @@ def load_library():
     L.srukf_get_robot.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_get_landmark_block.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     L.srukf_get_covariance.argtypes = [C.c_void_p, _dp]
+    L.srukf_get_landmarks_cartesian.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_predict_motion.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_predict_measurement.argtypes = [C.c_void_p, _dp, _dp, _ip]
     L.srukf_update.argtypes = [C.c_void_p, _dp, _ip, C.c_int, C.c_int]
@@ -228,6 +229,12 @@ class Filter:
         uv = _c(uv).reshape(-1, 2)
         self._chk(self._lib.srukf_add_landmarks(self._h, uv.shape[0], _d(uv)))
         self._refresh_dims()
+
+    def get_landmarks_cartesian(self):
+        """(xyz[N,3], cov[N,3,3]) of every landmark: getFeatureCartesianInformation batched on the device."""
+        xyz, cov = np.zeros((self.N, 3)), np.zeros((self.N, 3, 3))
+        self._chk(self._lib.srukf_get_landmarks_cartesian(self._h, _d(xyz), _d(cov)))
+        return xyz, cov
 
     def set_storage(self, storage):
         """STORAGE_F64 (default) or STORAGE_F32: precision of the state kept between frames."""

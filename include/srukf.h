@@ -110,6 +110,11 @@ int  srukf_get_state_device(srukf_ctx* ctx, double* dX, double* dS, int S_ld);
 int  srukf_get_robot(srukf_ctx* ctx, double pose4[4], double P4[16]);
 /* Landmark k: its 6 state rows and the 6x6 diagonal block of P (SLAM.cpp:2427-2432, 2748). */
 int  srukf_get_landmark_block(srukf_ctx* ctx, int k, double X6[6], double P66[36]);
+/* getFeatureCartesianInformation (SLAM.cpp:2721-2751) for every landmark at once: xyz[3N] = anchor + m(theta, phi)/rho,
+ * cov[9N] = J P66 J^T (row-major 3x3 each) with P66 the landmark's block of P = S^T S.  What the OpenGL view reads on
+ * every paint (OpenGlDisplay.cpp:449-583) without ever forming the n x n P.  Either pointer may be NULL. */
+int  srukf_get_landmarks_cartesian(srukf_ctx* ctx, double* xyz, double* cov);
+
 /* Full covariance m_P_k = S^T S (SLAM.cpp:2404), n*n row-major, for hosts that want it. */
 int  srukf_get_covariance(srukf_ctx* ctx, double* P);
 

@@ -53,3 +53,25 @@ def test_cslam_facade_replay_matches_golden(tmp_path, golden, synth, mode):
     np.testing.assert_allclose(rp[:, 1:3], sc["odo"][1:F + 1, :2], atol=1e-6)
     np.testing.assert_allclose(rp[:, 3:5], traj[:, :2], atol=1e-6)
     assert f"frames {F}  landmarks 20  predicts 20  matches 20" in out.stdout
+    # display accessors (getFeatureCartesianInformation / get3DdisplayInformation for every landmark of the map)
+    feat = np.fromfile(f"{tmp}/traj.bin.features").reshape(20, 19)
+    import __graft_entry__ as ge
+    srukf = ge.load_package().srukf
+    flt = srukf.Filter(20, p); flt.set_state(sc["X0"], sc["S0"])
+    for k in range(F):
+        flt.predict_motion(sc["odo"][k], sc["odo"][k + 1]); flt.predict_measurement()
+        flt.update(sc["z"][k], sc["matched"][k], mode=srukf.UPDATE_BATCHED if mode == "batched" else srukf.UPDATE_SEQUENTIAL)
+    X, S = flt.get_state(); P = S.T @ S
+    for k in range(20):
+        xi, yi, zi, th, ph, rho = X[6 * k:6 * k + 6]
+        xyz = np.array([xi + np.cos(ph) * np.sin(th) / rho, yi - np.sin(ph) / rho, zi + np.cos(ph) * np.cos(th) / rho])
+        J = np.zeros((3, 6)); J[:, :3] = np.eye(3)
+        J[:, 3:] = [[np.cos(ph) * np.cos(th) / rho, -np.sin(ph) * np.sin(th) / rho, -np.cos(ph) * np.sin(th) / rho ** 2],
+                    [0.0, -np.cos(ph) / rho, np.sin(ph) / rho ** 2],
+                    [-np.cos(ph) * np.sin(th) / rho, -np.sin(ph) * np.cos(th) / rho, -np.cos(ph) * np.cos(th) / rho ** 2]]
+        cov = J @ P[6 * k:6 * k + 6, 6 * k:6 * k + 6] @ J.T
+        np.testing.assert_allclose(feat[k, :3], xyz, atol=1e-9)
+        np.testing.assert_allclose(feat[k, 3:12].reshape(3, 3), cov, rtol=1e-9, atol=1e-9 * np.abs(cov).max())
+        lam = np.linalg.eigvalsh(feat[k, 3:12].reshape(3, 3))
+        np.testing.assert_allclose(np.sort(feat[k, 16:19] ** 2), np.maximum(lam, 0.0), rtol=1e-6, atol=1e-9 * lam.max())   # Jacobi stops at |offdiag| < EPSILON
+        assert np.all(np.isfinite(feat[k, 12:16]))

@@ -345,6 +345,28 @@ def test_delete_landmark_matches_oracle(srukf, oracle, synth, N, idx):
         np.testing.assert_allclose(S2.T @ S2, So2.T @ So2, atol=1e-10)
 
 
+def test_landmarks_cartesian_accessor(srukf, synth):
+    """getFeatureCartesianInformation (SLAM.cpp:2721-2751) for all landmarks in one launch, against numpy on P = S^T S."""
+    p = synth.scene_params()
+    N = 30
+    sc = synth.make_scene(N, 2, seed=9, p=p)
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    f.predict_motion(sc["odo"][0], sc["odo"][1]); f.predict_measurement(); f.update(sc["z"][0], sc["matched"][0])
+    X, S = f.get_state(); P = S.T @ S
+    xyz, cov = f.get_landmarks_cartesian()
+    for k in range(N):
+        xi, yi, zi, th, ph, rho = X[6 * k:6 * k + 6]
+        np.testing.assert_allclose(xyz[k], [xi + np.cos(ph) * np.sin(th) / rho, yi - np.sin(ph) / rho, zi + np.cos(ph) * np.cos(th) / rho], rtol=1e-14, atol=1e-14)
+        J = np.zeros((3, 6)); J[:, :3] = np.eye(3)
+        J[:, 3:] = [[np.cos(ph) * np.cos(th) / rho, -np.sin(ph) * np.sin(th) / rho, -np.cos(ph) * np.sin(th) / rho ** 2],
+                    [0.0, -np.cos(ph) / rho, np.sin(ph) / rho ** 2],
+                    [-np.cos(ph) * np.sin(th) / rho, -np.sin(ph) * np.cos(th) / rho, -np.cos(ph) * np.cos(th) / rho ** 2]]
+        ref = J @ P[6 * k:6 * k + 6, 6 * k:6 * k + 6] @ J.T
+        np.testing.assert_allclose(cov[k], ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+        Xk, Pk = f.get_landmark_block(k)
+        np.testing.assert_allclose(Pk, P[6 * k:6 * k + 6, 6 * k:6 * k + 6], rtol=1e-12, atol=1e-18)
+
+
 def test_f32_storage_tolerance_study(srukf, oracle, synth):
     """BASELINE configs[4] as a parity case: fp32 filter state (X32, S32), fp64 arithmetic.  Every frame starts from
     exactly the float-rounded state; the trajectory is held against the fp64 oracle with the error an fp32 state
