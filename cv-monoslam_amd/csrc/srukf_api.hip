@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void k_quantize(int n, int ld, double* __restr
 #define SRUKF_GRAPH_FRAMES 8
 static thread_local std::string g_create_error;
 
-enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_XUPD, KC_SYRK, KC_GMW_PANEL, KC_GMW_TRAIL, KC_GMW_CHECK,
+enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_SYRK, KC_GMW_TRAIL, KC_GMW_CHECK,
               KC_GMW_COL, KC_MISC, KC_COUNT };
-static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_state_update", "k_syrk",
-                                             "(unused)", "k_gmw_step64", "k_gmw_check", "k_gmw_col", "misc" };
+static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_syrk",
+                                             "k_gmw_step64", "k_gmw_check", "k_gmw_col", "misc" };
 
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
@@ -121,7 +121,7 @@ struct srukf_ctx {
     // HBM buffers
     double *X = nullptr, *S = nullptr, *G = nullptr, *Gbak = nullptr, *Wf = nullptr;
     double *sigR = nullptr, *Cmat = nullptr, *Z = nullptr, *DZ = nullptr, *Ut = nullptr;
-    double *h = nullptr, *Si = nullptr, *PxyR = nullptr, *y = nullptr, *D = nullptr, *Wp = nullptr, *Lp = nullptr;
+    double *h = nullptr, *Si = nullptr, *PxyR = nullptr, *D = nullptr;
     double *zcur = nullptr, *odocur = nullptr, *small = nullptr, *mpart = nullptr, *dxp = nullptr;
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
@@ -271,7 +271,7 @@ static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
     }
 }
 // one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path.
-// need_reset: the gamma/xi accumulators were not just cleared by k_gain_dx (SEQUENTIAL mode, fallbacks).
+// need_reset: the gamma/xi accumulators were not just cleared by k_gain (SEQUENTIAL mode, fallbacks).
 // frame_tail: the check kernel also records the trajectory row and advances the staged frame counter.
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
 {
@@ -439,8 +439,8 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     const size_t np = d.np, mp = d.mp;
     ALLOC(c->X, np); ALLOC(c->S, np * np); ALLOC(c->G, np * np); ALLOC(c->Gbak, np * np); ALLOC(c->Wf, np * np);
     ALLOC(c->sigR, (size_t)d.L * 8 + 8); ALLOC(c->mpart, srukf_meas_part_doubles(d.mp)); ALLOC(c->dxp, srukf_gain_part_doubles(d.np)); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
-    ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)(N > 0 ? N : 1)); ALLOC(c->PxyR, 4 * mp); ALLOC(c->y, mp);
-    ALLOC(c->D, np); ALLOC(c->Wp, 32 * np); ALLOC(c->Lp, 32 * np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
+    ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)(N > 0 ? N : 1)); ALLOC(c->PxyR, 4 * mp);
+    ALLOC(c->D, np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
     ALLOC(c->vis, N > 0 ? N : 1); ALLOC(c->mcur, N > 0 ? N : 1); ALLOC(c->theta, np); ALLOC(c->fs, 1);
     { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
     {
@@ -477,7 +477,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph) hipGraphDestroy(c->graph);
     if (c->graph8_exec) hipGraphExecDestroy(c->graph8_exec);
     if (c->graph8) hipGraphDestroy(c->graph8);
-    void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->y, c->D, c->Wp, c->Lp,
+    void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles,
                      c->perm, c->iperm, c->Sdis, c->S32, c->X32 };
     for (void* b : bufs) if (b) hipFree(b);
