@@ -35,6 +35,12 @@ void srukf_launch_aug_map(hipStream_t, srukf_params, int, int, int, int, double,
 void srukf_launch_aug_x(hipStream_t, int, int, int, double, double, const double*, const double*, const int*, double*, double*, int, int);
 void srukf_launch_aug_build(hipStream_t, int, int, int, int, double, double, const double*, const double*, const double*, double*, int, int, int);
 void srukf_launch_gram(hipStream_t, int, int, const double*, double*);
+void srukf_launch_warp_patch(hipStream_t, KDims, srukf_params, const double*, const double*, const double*, const double*, const double*, const double*,
+                             const unsigned char*, const int*, unsigned char*);
+void srukf_launch_associate(hipStream_t, KDims, srukf_params, const unsigned char*, const double*, const double*, const int*, const int*,
+                            const unsigned char*, double*, int*, double*);
+int srukf_app_patch_stride(void);
+int srukf_app_tmpl_stride(void);
 }
 
 // resets the per-refactor accumulators (theta row maxima, gamma/xi)
@@ -129,6 +135,10 @@ struct srukf_ctx {
     // NEED_REORDER (frames that follow a landmark addition): K_new = m_nFilters, permutation between the normal and the
     // disordered layout (getPermutationMatrix, SLAM.cpp:1303-1334), disordered factor
     int K_new = 0;
+    // data association (srukf_assoc.hip): per-landmark appearance records, allocated on first use
+    unsigned char *app_patch = nullptr, *app_tmpl = nullptr, *d_image = nullptr;
+    double *appR = nullptr, *appT = nullptr, *appPx = nullptr, *corr = nullptr;
+    int* has_app = nullptr;
     int storage = SRUKF_STORAGE_F64;       // SRUKF_STORAGE_F32: X32 / S32 hold the inter-frame state
     float *S32 = nullptr, *X32 = nullptr;
     int *perm = nullptr, *iperm = nullptr;
@@ -479,7 +489,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles,
-                     c->perm, c->iperm, c->Sdis, c->S32, c->X32 };
+                     c->perm, c->iperm, c->Sdis, c->S32, c->X32, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) hipFree(b);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->hfs) hipHostFree(c->hfs);
@@ -816,6 +826,93 @@ int srukf_set_new_landmarks(srukf_ctx* c, int K_new)
 }
 
 static void adopt_context(srukf_ctx* c, srukf_ctx* c2);
+// ---- data association ------------------------------------------------------------------------------
+static int ensure_appearance(srukf_ctx* c)
+{
+    if (c->app_patch) return SRUKF_OK;
+    const size_t N = c->d.N > 0 ? c->d.N : 1;
+    const size_t img = (size_t)c->p.image_w * c->p.image_h;
+    HIPCHK(c, hipMalloc((void**)&c->app_patch, N * srukf_app_patch_stride()));
+    HIPCHK(c, hipMalloc((void**)&c->app_tmpl, N * srukf_app_tmpl_stride()));
+    HIPCHK(c, hipMalloc((void**)&c->d_image, img));
+    HIPCHK(c, hipMalloc((void**)&c->appR, sizeof(double) * 9 * N));
+    HIPCHK(c, hipMalloc((void**)&c->appT, sizeof(double) * 3 * N));
+    HIPCHK(c, hipMalloc((void**)&c->appPx, sizeof(double) * 2 * N));
+    HIPCHK(c, hipMalloc((void**)&c->corr, sizeof(double) * N));
+    HIPCHK(c, hipMalloc((void**)&c->has_app, sizeof(int) * N));
+    HIPCHK(c, hipMemsetAsync(c->app_patch, 0, N * srukf_app_patch_stride(), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->app_tmpl, 0, N * srukf_app_tmpl_stride(), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->has_app, 0, sizeof(int) * N, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SRUKF_OK;
+}
+// the appearance record of landmark `from` of `a` becomes the one of landmark `to` of `b` (map changes)
+static void copy_appearance(srukf_ctx* a, int from, srukf_ctx* b, int to)
+{
+    const size_t ps = srukf_app_patch_stride(), ts = srukf_app_tmpl_stride();
+    hipMemcpyAsync(b->app_patch + to * ps, a->app_patch + from * ps, ps, hipMemcpyDeviceToDevice, b->stream);
+    hipMemcpyAsync(b->app_tmpl + to * ts, a->app_tmpl + from * ts, ts, hipMemcpyDeviceToDevice, b->stream);
+    hipMemcpyAsync(b->appR + 9 * to, a->appR + 9 * from, sizeof(double) * 9, hipMemcpyDeviceToDevice, b->stream);
+    hipMemcpyAsync(b->appT + 3 * to, a->appT + 3 * from, sizeof(double) * 3, hipMemcpyDeviceToDevice, b->stream);
+    hipMemcpyAsync(b->appPx + 2 * to, a->appPx + 2 * from, sizeof(double) * 2, hipMemcpyDeviceToDevice, b->stream);
+    hipMemcpyAsync(b->has_app + to, a->has_app + from, sizeof(int), hipMemcpyDeviceToDevice, b->stream);
+}
+// PointsMap::initPatch / initRotation / initTrans / initPixel as set at creation (SLAM.cpp:920-925): patch = the
+// (2 HP_INIT + 1)^2 = 21 x 21 gray window image(Rect(round(u) - 10, round(v) - 10, 21, 21)), row-major as cv::Mat;
+// R = Rwc (3x3 row-major), t = camera position, px = the distorted pixel.  matchPatch is zeroed (926).
+int srukf_set_landmark_appearance(srukf_ctx* c, int k, const unsigned char* patch, const double R[9], const double t[3], const double px[2])
+{
+    if (!c || !patch || !R || !t || !px || k < 0 || k >= c->d.N) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_appearance(c); if (rc) return rc;
+    const size_t ps = srukf_app_patch_stride(), ts = srukf_app_tmpl_stride();
+    const int one = 1;
+    HIPCHK(c, hipMemcpy(c->app_patch + k * ps, patch, 441, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->app_tmpl + k * ts, 0, ts));
+    HIPCHK(c, hipMemcpy(c->appR + 9 * k, R, sizeof(double) * 9, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->appT + 3 * k, t, sizeof(double) * 3, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->appPx + 2 * k, px, sizeof(double) * 2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->has_app + k, &one, sizeof(int), hipMemcpyHostToDevice));
+    return SRUKF_OK;
+}
+int srukf_get_match_patch(srukf_ctx* c, int k, unsigned char* out)
+{
+    if (!c || !out || k < 0 || k >= c->d.N) return SRUKF_ERR_BAD_ARG;
+    if (!c->app_tmpl) { c->err = "get_match_patch: no appearance records"; return SRUKF_ERR_SEQUENCE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->app_tmpl + (size_t)k * srukf_app_tmpl_stride(), 289, hipMemcpyDeviceToHost));
+    return SRUKF_OK;
+}
+// wrapPatch + dataAssociation (SLAM.cpp:1803-2009) between srukf_predict_measurement and srukf_update: gray = the
+// image_h x image_w frame (row-major uchar).  Out (host, any may be NULL): z[2N] = matchLocation, matched[N] =
+// isMatching, corr[N] = best normalised cross correlation.  Landmarks without an appearance record never match.
+int srukf_associate(srukf_ctx* c, const unsigned char* gray, double* z, int* matched, double* corr)
+{
+    if (!c || !gray) return SRUKF_ERR_BAD_ARG;
+    if (c->phase < 2) { c->err = "associate before predict_measurement"; return SRUKF_ERR_SEQUENCE; }
+    const int N = c->d.N;
+    if (N == 0) return SRUKF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_appearance(c); if (rc) return rc;
+    const size_t img = (size_t)c->p.image_w * c->p.image_h;
+    HIPCHK(c, hipMemcpyAsync(c->d_image, gray, img, hipMemcpyHostToDevice, c->stream));
+    double* dxyz = c->Z; double* dcov = c->Z + 3 * (size_t)N;            // Z is free between predict_measurement and the next frame
+    srukf_launch_landmarks_cartesian(c->stream, c->d, c->X, c->S, dxyz, dcov);                              // PointsMap::xyz (2574)
+    srukf_launch_warp_patch(c->stream, c->d, c->p, c->X, dxyz, c->h, c->appR, c->appT, c->appPx, c->app_patch, c->has_app, c->app_tmpl);
+    srukf_launch_associate(c->stream, c->d, c->p, c->d_image, c->h, c->Si, c->vis, c->has_app, c->app_tmpl, c->zcur, c->mcur, c->corr);
+    double* hs = c->hstage;
+    HIPCHK(c, hipMemcpyAsync(hs, c->zcur, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + 2 * N, c->corr, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + 3 * N, c->mcur, sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (z) memcpy(z, hs, sizeof(double) * 2 * N);
+    if (corr) memcpy(corr, hs + 2 * N, sizeof(double) * N);
+    if (matched) memcpy(matched, hs + 3 * N, sizeof(int) * N);
+    return SRUKF_OK;
+}
+
 // integrateFeaturesInformation, numeric part (SLAM.cpp:826-871): K new landmarks at the distorted pixels uv[K][2] are
 // appended to the map (normal order: before the robot block).  The context is rebuilt for N + K landmarks in place
 // (the handle stays valid; staged sequences and captured graphs are dropped) and K_new = K is armed for the
@@ -871,6 +968,12 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     hipError_t e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("add_landmarks: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
+    if (c->app_patch) {                                      // the old landmarks keep their appearance records
+        rc = ensure_appearance(c2);
+        if (rc) { c->err = c2->err; srukf_destroy(c2); return rc; }
+        for (int k = 0; k < c->d.N; k++) copy_appearance(c, k, c2, k);
+        hipStreamSynchronize(c->stream);
+    }
     const int storage = c->storage;
     adopt_context(c, c2);
     rc = srukf_set_storage(c, storage); if (rc) return rc;
@@ -932,6 +1035,12 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("delete_landmark: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
     // m_nFilters-- when one of the landmarks added last is the one that goes (SLAM.cpp:2468-2492)
     const int k_new = c->K_new > 0 ? (id >= N - c->K_new ? c->K_new - 1 : c->K_new) : 0;
+    if (c->app_patch) {
+        rc = ensure_appearance(c2);
+        if (rc) { c->err = c2->err; srukf_destroy(c2); return rc; }
+        for (int k = 0, a = 0; k < N; k++) if (k != id) copy_appearance(c, k, c2, a++);
+        hipStreamSynchronize(c->stream);
+    }
     const int storage = c->storage;
     adopt_context(c, c2);
     rc = srukf_set_storage(c, storage); if (rc) return rc;

@@ -104,6 +104,28 @@ bool CSLAM::deleteOneFeature(int id)
     return true;
 }
 
+// ---- data association on the device ------------------------------------------------------------------------------
+bool CSLAM::setFeatureAppearance(int id, const unsigned char* patch, const double R[9], const double t[3], const double px[2])
+{
+    if (!ctx_ || id < 0 || id >= m_nMapFeatures) { lastError = "setFeatureAppearance: no such landmark"; return false; }
+    map[id].initPixel.x = px[0]; map[id].initPixel.y = px[1];
+    return check(srukf_set_landmark_appearance(ctx_, id, patch, R, t, px));
+}
+
+bool CSLAM::dataAssociationOnDevice(const unsigned char* gray)
+{
+    const int N = m_nMapFeatures;
+    if (!ctx_ || N == 0) return true;
+    std::vector<double> z(2 * (size_t)N); std::vector<int> m(N);
+    if (!check(srukf_associate(ctx_, gray, z.data(), m.data(), nullptr))) return false;
+    m_nMatches = 0;
+    for (int k = 0; k < N; k++) {                                                                               // 1989-2000
+        map[k].isMatching = m[k] != 0;
+        if (m[k]) { map[k].matchLocation.x = z[2 * k]; map[k].matchLocation.y = z[2 * k + 1]; m_nMatches++; }
+    }
+    return true;
+}
+
 // ---- display accessors -----------------------------------------------------------------------------------------
 bool CSLAM::updateFeaturesInformation()
 {

@@ -87,6 +87,15 @@ public:
     // deleteOneFeature (SLAM.cpp:2637-2706): the id-th landmark of the state (0-based) leaves the filter and the map
     bool deleteOneFeature(int id);
 
+    // ---- data association on the device ----------------------------------------------------------------
+    // the appearance fields of PointsMap the reference fills at creation (SLAM.cpp:920-925): initPatch = the 21 x 21 gray
+    // window around cvRound(initPixel) (row-major), initRotation = Rwc, initTrans = camera position
+    bool setFeatureAppearance(int id, const unsigned char* initPatch, const double initRotation[9], const double initTrans[3], const double initPixel[2]);
+    // wrapPatch() + dataAssociation() (SLAM.cpp:1803-2009) for the current gray frame (image_h x image_w uchar): fills
+    // isMatching / matchLocation / nMatchTimes of every map entry and m_nMatches.  Install it as the association step:
+    //   SLAM.dataAssociation = [&](monoslam::CSLAM& s) { s.dataAssociationOnDevice(grabGrayFrame()); };
+    bool dataAssociationOnDevice(const unsigned char* gray);
+
     // ---- display accessors (what OpenGlDisplay.cpp:449-583 reads per paint) ------------------------------
     // updateFeaturesInformation's numeric part (SLAM.cpp:2566-2580): xyz, axis, sigma of every landmark of `map`, from
     // ONE device call (srukf_get_landmarks_cartesian) instead of a pass over the n x n m_P_k per landmark

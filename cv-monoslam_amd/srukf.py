@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_get_state_f32", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -101,6 +101,10 @@ def load_library():
     L.srukf_set_new_landmarks.argtypes = [C.c_void_p, C.c_int]
     L.srukf_add_landmarks.argtypes = [C.c_void_p, C.c_int, _dp]
     L.srukf_delete_landmark.argtypes = [C.c_void_p, C.c_int]
+    _bp = C.POINTER(C.c_ubyte)
+    L.srukf_set_landmark_appearance.argtypes = [C.c_void_p, C.c_int, _bp, _dp, _dp, _dp]
+    L.srukf_associate.argtypes = [C.c_void_p, _bp, _dp, _ip, _dp]
+    L.srukf_get_match_patch.argtypes = [C.c_void_p, C.c_int, _bp]
     L.srukf_set_storage.argtypes = [C.c_void_p, C.c_int]
     L.srukf_get_state_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
@@ -235,6 +239,24 @@ class Filter:
         xyz, cov = np.zeros((self.N, 3)), np.zeros((self.N, 3, 3))
         self._chk(self._lib.srukf_get_landmarks_cartesian(self._h, _d(xyz), _d(cov)))
         return xyz, cov
+
+    def set_landmark_appearance(self, k, patch, R, t, px):
+        """PointsMap::initPatch (21x21 uint8), initRotation (3x3), initTrans (3), initPixel (2) of landmark k."""
+        patch = np.ascontiguousarray(patch, dtype=np.uint8); assert patch.shape == (21, 21)
+        self._chk(self._lib.srukf_set_landmark_appearance(self._h, int(k), patch.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                                          _d(_c(R).reshape(9)), _d(_c(t).reshape(3)), _d(_c(px).reshape(2))))
+
+    def associate(self, gray):
+        """wrapPatch + dataAssociation on the device; returns (z[2N], matched[N], corr[N])."""
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        z, m, cr = np.zeros(2 * self.N), np.zeros(self.N, dtype=np.int32), np.zeros(self.N)
+        self._chk(self._lib.srukf_associate(self._h, gray.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(z), _i(m), _d(cr)))
+        return z, m, cr
+
+    def get_match_patch(self, k):
+        out = np.zeros((17, 17), dtype=np.uint8)
+        self._chk(self._lib.srukf_get_match_patch(self._h, int(k), out.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return out
 
     def set_storage(self, storage):
         """STORAGE_F64 (default) or STORAGE_F32: precision of the state kept between frames."""

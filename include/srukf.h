@@ -151,6 +151,22 @@ int  srukf_set_new_landmarks(srukf_ctx* ctx, int K_new);
  * created with N = 0 holds the robot block only (initializeParameters 221-231) and is the reference's frame-1 state. */
 int  srukf_add_landmarks(srukf_ctx* ctx, int K, const double* uv);
 
+/* ---- data association on the device (wrapPatch 1803-1906, dataAssociation 1915-2009, calculateCrossCorrelation
+ * 3141-3166) ----
+ * srukf_set_landmark_appearance: the PointsMap fields set when landmark k was created (SLAM.cpp:920-925): patch =
+ *   initPatch, the 21 x 21 gray window image(Rect(cvRound(u) - 10, cvRound(v) - 10, 21, 21)) row-major; R = initRotation
+ *   (Rwc, 3x3 row-major); t = initTrans (camera position); px = initPixel (distorted).  Records follow their landmark
+ *   through srukf_add_landmarks / srukf_delete_landmark.
+ * srukf_associate: between srukf_predict_measurement and srukf_update.  gray = the image_h x image_w frame (uchar,
+ *   row-major).  Warps every init patch to the current pose (matchPatch, persistent as in the reference) and searches
+ *   the chi-square gated window around the predicted pixel for the best normalised cross correlation; a landmark
+ *   matches when it exceeds THRESHOLD_MATCH_PATCH = 0.8.  Out (host, any may be NULL): z[2N] matchLocation,
+ *   matched[N] isMatching, corr[N] the best correlation.
+ * srukf_get_match_patch: the 17 x 17 matchPatch of landmark k (row-major, 289 bytes). */
+int  srukf_set_landmark_appearance(srukf_ctx* ctx, int k, const unsigned char* patch, const double R[9], const double t[3], const double px[2]);
+int  srukf_associate(srukf_ctx* ctx, const unsigned char* gray, double* z, int* matched, double* corr);
+int  srukf_get_match_patch(srukf_ctx* ctx, int k, unsigned char* out);
+
 /* Select the storage precision (default SRUKF_STORAGE_F64).  With SRUKF_STORAGE_F32 the state is rounded to float at
  * the end of every refactorisation (and by srukf_set_state); srukf_get_state returns those values widened to double,
  * srukf_get_state_f32 the float arrays themselves (X[n], S[n*n] row-major). */

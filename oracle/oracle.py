@@ -78,6 +78,10 @@ def lib():
         L.orc_sample_parameter.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp]
         L.orc_joint_init.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]
         L.orc_delete_feature.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+        _bp = C.POINTER(C.c_ubyte)
+        L.orc_warp_patch.argtypes = [C.POINTER(Params), _dp, _dp, _dp, _dp, _dp, _dp, _bp, _bp]
+        L.orc_warp_patch.restype = None
+        L.orc_associate_one.argtypes = [C.POINTER(Params), _bp, _dp, _dp, _bp, _dp, _dp]
         L.orc_sigma_ptr.restype = _dp
         L.orc_sigma_ptr.argtypes = [C.c_void_p]
         L.orc_Z_ptr.restype = _dp
@@ -207,6 +211,27 @@ def sample_parameter(Na, weight_type=0, alpha=1e-3, beta=2.0):
     out = np.zeros(7)
     lib().orc_sample_parameter(Na, weight_type, alpha, beta, _d(out))
     return dict(zip(["wm0", "wc0", "wi", "wi_sr", "gamma", "wm0_sr", "wc0_sr"], out))
+
+
+def warp_patch(params, robot, initR, initT, initPixel, xyz, predict, initPatch, matchPatch):
+    """wrapPatch for one landmark; returns the new 17x17 matchPatch (the input one is not modified)."""
+    p = Params.from_dict(params)
+    ip = np.ascontiguousarray(initPatch, dtype=np.uint8); assert ip.shape == (21, 21)
+    mp = np.array(matchPatch, dtype=np.uint8, copy=True, order="C"); assert mp.shape == (17, 17)
+    bp = C.POINTER(C.c_ubyte)
+    lib().orc_warp_patch(C.byref(p), _d(_c(robot)), _d(_c(initR).reshape(9)), _d(_c(initT)), _d(_c(initPixel)), _d(_c(xyz)), _d(_c(predict)),
+                         ip.ctypes.data_as(bp), mp.ctypes.data_as(bp))
+    return mp
+
+
+def associate_one(params, image, predict, Si, matchPatch):
+    """dataAssociation for one visible landmark; returns (matched, best correlation, match location[2])."""
+    p = Params.from_dict(params)
+    img = np.ascontiguousarray(image, dtype=np.uint8); mp = np.ascontiguousarray(matchPatch, dtype=np.uint8)
+    bp = C.POINTER(C.c_ubyte)
+    best, loc = np.zeros(1), np.zeros(2)
+    ok = lib().orc_associate_one(C.byref(p), img.ctypes.data_as(bp), _d(_c(predict)), _d(_c(Si).reshape(4)), mp.ctypes.data_as(bp), _d(best), _d(loc))
+    return bool(ok), float(best[0]), loc
 
 
 def delete_feature(params, X, S, idx):

@@ -764,6 +764,166 @@ ORC_API int orc_delete_feature(const srukf_params *p, int dim, const double *X, 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Data association: wrapPatch (SLAM.cpp:1803-1906), dataAssociation (1915-2009),
+ * calculateCrossCorrelation (3141-3166).  Constants HP_INIT_W = HP_INIT_H = 10, HP_MATCH_W =
+ * HP_MATCH_H = 8 (SLAM.cpp:41-44), chi2inv(0.95, 2) = 5.99146454710798 (54),
+ * THRESHOLD_MATCH_PATCH = 0.8 (184).
+ * Un-vendored dependency: the 4x4 cv::Mat::inv() of wrapPatch (OpenCV 2.4.3, LU with partial
+ * pivoting); restated as Gauss-Jordan with partial pivoting.  3x3 / 2x2 inverses are OpenCV's
+ * closed forms (inv3 / inv2 above).                                                           */
+#define ORC_HP_INIT 10
+#define ORC_HP_MATCH 8
+static int inv4(const double a[16], double out[16])
+{
+    double m[4][8];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { m[r][c] = a[4 * r + c]; m[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; c++) {
+        int piv = c; double big = fabs(m[c][c]);
+        for (int r = c + 1; r < 4; r++) if (fabs(m[r][c]) > big) { big = fabs(m[r][c]); piv = r; }
+        if (big == 0.0) return 0;
+        if (piv != c) for (int k = 0; k < 8; k++) { double t = m[c][k]; m[c][k] = m[piv][k]; m[piv][k] = t; }
+        double d = 1.0 / m[c][c];
+        for (int k = 0; k < 8; k++) m[c][k] *= d;
+        for (int r = 0; r < 4; r++) if (r != c) { double f = m[r][c]; if (f != 0.0) for (int k = 0; k < 8; k++) m[r][k] -= f * m[c][k]; }
+    }
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[4 * r + c] = m[r][4 + c];
+    return 1;
+}
+static void mat4mul(const double a[16], const double b[16], double o[16])
+{
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { double t = 0; for (int k = 0; k < 4; k++) t += a[4 * r + k] * b[4 * k + c]; o[4 * r + c] = t; }
+}
+static void mat3mul(const double a[9], const double b[9], double o[9])
+{
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double t = 0; for (int k = 0; k < 3; k++) t += a[3 * r + k] * b[3 * k + c]; o[3 * r + c] = t; }
+}
+/* wrapPatch for ONE landmark.  robot = (x, y, z, theta) = X[dim-4..dim-1]; initR (3x3), initT (3),
+ * initPixel (2): the PointsMap fields set at creation (SLAM.cpp:920-925); xyz: current Cartesian
+ * mean (PointsMap::xyz); predict: predictLocation; initPatch[21][21] (uchar, cv::Mat rows);
+ * matchPatch[17][17] in/out — pixels whose warp falls outside the init patch KEEP their old value. */
+ORC_API void orc_warp_patch(const srukf_params *p, const double robot[4], const double initR[9], const double initT[3],
+                            const double initPixel[2], const double xyz[3], const double predict[2],
+                            const unsigned char *initPatch, unsigned char *matchPatch)
+{
+    orc_state tmp; memset(&tmp, 0, sizeof tmp); tmp.newton_early_exit = 1;
+    const double f1 = p->cam_f / p->cam_dx, f2 = p->cam_f / p->cam_dy;
+    double Rwc[9]; transfer_matrix(Rwc, robot[3]);                                  /* 1806-1807 */
+    double C0W[16] = { 0 }, C1W[16] = { 0 };                                        /* 1821-1827 */
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) { C0W[4 * r + c] = initR[3 * r + c] + 0; C1W[4 * r + c] = Rwc[3 * r + c] + 0; }
+        C0W[4 * r + 3] = initR[3 * r] * initT[0] + initR[3 * r + 1] * initT[1] + initR[3 * r + 2] * initT[2] + 0;
+        C1W[4 * r + 3] = Rwc[3 * r] * robot[0] + Rwc[3 * r + 1] * robot[1] + Rwc[3 * r + 2] * robot[2] + 0;
+    }
+    C0W[15] = 1; C1W[15] = 1;
+    double C0Wi[16], C1C0[16];
+    inv4(C0W, C0Wi);
+    mat4mul(C0Wi, C1W, C1C0);                                                       /* 1829 */
+    double R[9], r3[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[3 * r + c] = C1C0[4 * r + c]; r3[r] = C1C0[4 * r + 3]; }
+    double n0[3] = { initPixel[0] - p->cam_cx, initPixel[1] - p->cam_cy, -f1 };     /* 1833 */
+    double t0[4] = { predict[0] - p->cam_cx, predict[1] - p->cam_cy, -f1, 1 };      /* 1834-1835 */
+    double t1[4];
+    for (int r = 0; r < 4; r++) t1[r] = C1C0[4 * r] * t0[0] + C1C0[4 * r + 1] * t0[1] + C1C0[4 * r + 2] * t0[2] + C1C0[4 * r + 3] * t0[3];
+    for (int r = 0; r < 4; r++) t1[r] /= t1[3];   /* 1837: the division runs over the elements in order, element 3 last */
+    double n1[3] = { t1[0], t1[1], t1[2] };
+    double nn = sqrt(n0[0] * n0[0] + n0[1] * n0[1] + n0[2] * n0[2]);
+    for (int r = 0; r < 3; r++) n0[r] /= nn;                                        /* 1839 */
+    nn = sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+    for (int r = 0; r < 3; r++) n1[r] /= nn;                                        /* 1840 */
+    double n[3] = { n0[0] + n1[0], n0[1] + n1[1], n0[2] + n1[2] };                  /* 1841 */
+    nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (int r = 0; r < 3; r++) n[r] /= nn;                                         /* 1842 */
+    double w4[4] = { xyz[0], xyz[1], xyz[2], 1 }, c0[4];                            /* 1844-1847 */
+    for (int r = 0; r < 4; r++) c0[r] = C0Wi[4 * r] * w4[0] + C0Wi[4 * r + 1] * w4[1] + C0Wi[4 * r + 2] * w4[2] + C0Wi[4 * r + 3] * w4[3];
+    for (int r = 0; r < 4; r++) c0[r] /= c0[3];
+    double d = ((-1) * n[0]) * c0[0] + ((-1) * n[1]) * c0[1] + ((-1) * n[2]) * c0[2];   /* 1848-1849 */
+    /* H = K (R - r n^T / d) K^{-1}                                                     1855, 1876 */
+    double K[9] = { f1, 0, p->cam_cx, 0, f2, p->cam_cy, 0, 0, 1 }, Ki[9], M[9], KM[9], H[9], Hi[9];
+    inv3(K, Ki);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[3 * r + c] = R[3 * r + c] - (r3[r] * n[c]) / d;
+    mat3mul(K, M, KM); mat3mul(KM, Ki, H);
+    double uu_x, uu_y;
+    undistort_rw(p, initPixel[0], initPixel[1], &uu_x, &uu_y);                       /* 1852 */
+    inv3(H, Hi);                                                                    /* 1856 */
+    double q[3] = { Hi[0] * uu_x + Hi[1] * uu_y + Hi[2] * 1, Hi[3] * uu_x + Hi[4] * uu_y + Hi[5] * 1, Hi[6] * uu_x + Hi[7] * uu_y + Hi[8] * 1 };
+    q[0] /= q[2]; q[1] /= q[2];                                                     /* 1857 */
+    double uv_x, uv_y;
+    distort_rw(&tmp, p, q[0], q[1], &uv_x, &uv_y);                                   /* 1861 */
+    for (int i = 0; i < 2 * ORC_HP_MATCH + 1; i++)                                  /* 1865 */
+        for (int j = 0; j < 2 * ORC_HP_MATCH + 1; j++) {
+            double ax = uv_x - ORC_HP_MATCH + i, ay = uv_y - ORC_HP_MATCH + j;      /* 1869-1870 */
+            double bx, by;
+            undistort_rw(p, ax, ay, &bx, &by);                                       /* 1871 */
+            double t[3] = { H[0] * bx + H[1] * by + H[2] * 1, H[3] * bx + H[4] * by + H[5] * 1, H[6] * bx + H[7] * by + H[8] * 1 };   /* 1874 */
+            t[0] /= t[2]; t[1] /= t[2];                                             /* 1875 */
+            double cx1, cy1;
+            distort_rw(&tmp, p, t[0], t[1], &cx1, &cy1);                             /* 1879 */
+            cx1 -= (initPixel[0] - ORC_HP_INIT - 1);                                /* 1881 */
+            cy1 -= (initPixel[1] - ORC_HP_INIT - 1);                                /* 1882 */
+            int lx = (int)floor(cx1), ly = (int)floor(cy1), rx = (int)ceil(cx1), ry = (int)ceil(cy1);   /* 1884-1887 */
+            if (lx >= 0 && rx < 2 * ORC_HP_INIT && ly >= 0 && ry < 2 * ORC_HP_INIT) {   /* 1889 */
+                double rate_lx = rx - cx1, rate_ly = ry - cy1, rate_rx = 1.0 - rate_lx, rate_ry = 1.0 - rate_ly;
+                const int PW = 2 * ORC_HP_INIT + 1;
+                unsigned char ll = initPatch[lx * PW + ly], lr = initPatch[lx * PW + ry];       /* at<uchar>(row = x index, col = y index) */
+                unsigned char rl = initPatch[rx * PW + ly], rr = initPatch[rx * PW + ry];
+                matchPatch[i * (2 * ORC_HP_MATCH + 1) + j] =
+                    (unsigned char)(ll * rate_lx * rate_ly + lr * rate_lx * rate_ry + rl * rate_rx * rate_ly + rr * rate_rx * rate_ry);   /* 1899-1900 */
+            }
+        }
+}
+
+/* calculateCrossCorrelation, SLAM.cpp:3141-3166: roi = 17x17 window of the gray image (row stride `stride`). */
+static double cross_correlation(const unsigned char *roi, int stride, const unsigned char *patch)
+{
+    const int PW = 2 * ORC_HP_MATCH + 1, NP = PW * PW;
+    double s1 = 0, s2 = 0;
+    for (int r = 0; r < PW; r++) for (int c = 0; c < PW; c++) { s1 += roi[r * stride + c]; s2 += patch[r * PW + c]; }
+    double a1 = s1 / NP, a2 = s2 / NP, q1 = 0, q2 = 0, dot = 0;
+    for (int r = 0; r < PW; r++) for (int c = 0; c < PW; c++) {
+        double v1 = roi[r * stride + c] - a1, v2 = patch[r * PW + c] - a2;
+        q1 += v1 * v1; q2 += v2 * v2; dot += v1 * v2;
+    }
+    double std1 = sqrt(q1), std2 = sqrt(q2);
+    if (std1 == 0 || std2 == 0) return 0;
+    return dot / std1 / std2;
+}
+/* dataAssociation for ONE visible landmark, SLAM.cpp:1947-2001.  image: H x W uchar, row-major.
+ * Returns 1 and match[2] if the best correlation exceeds THRESHOLD_MATCH_PATCH; *best = maxVal.  */
+ORC_API int orc_associate_one(const srukf_params *p, const unsigned char *image, const double predict[2], const double Si[4],
+                              const unsigned char *matchPatch, double *best, double match[2])
+{
+    const int W = p->image_w, H = p->image_h;
+    const double px = predict[0], py = predict[1];
+    double pi[4] = { Si[0] * Si[0] + Si[2] * Si[2], Si[0] * Si[1] + Si[2] * Si[3], Si[1] * Si[0] + Si[3] * Si[2], Si[1] * Si[1] + Si[3] * Si[3] };   /* 1951: Si^T Si */
+    double pinv[4]; inv2(pi, pinv);
+    int half_x = (int)ceil(2 * Si[0]), half_y = (int)ceil(2 * Si[3]);               /* 1953-1954 */
+    half_x = ORC_HP_INIT < (ORC_HP_MATCH > half_x ? ORC_HP_MATCH : half_x) ? ORC_HP_INIT : (ORC_HP_MATCH > half_x ? ORC_HP_MATCH : half_x);   /* 1955 */
+    half_y = ORC_HP_INIT < (ORC_HP_MATCH > half_y ? ORC_HP_MATCH : half_y) ? ORC_HP_INIT : (ORC_HP_MATCH > half_y ? ORC_HP_MATCH : half_y);
+    double maxVal = 0.0; int mi = 0, mj = 0;                                        /* minMaxLoc over a zero-initialised matrix: first maximum in row-major order */
+    int found = 0;
+    for (int j = (int)py - half_y; j <= (int)py + half_y; j++) {                     /* row-major scan of `correlation` = j outer */
+        for (int i = (int)px - half_x; i <= (int)px + half_x; i++) {
+            double c = 0.0;
+            if (!(i < ORC_HP_MATCH || i > W - ORC_HP_MATCH - 1) && !(j < ORC_HP_MATCH || j > H - ORC_HP_MATCH - 1)) {   /* 1962, 1969 */
+                double ex = i - px, ey = j - py;
+                double pii = (ex * pinv[0] + ey * pinv[2]) * ex + (ex * pinv[1] + ey * pinv[3]) * ey;   /* 1975 */
+                if (pii < 5.99146454710798)                                          /* 1977 */
+                    c = cross_correlation(image + (size_t)(j - ORC_HP_MATCH) * W + (i - ORC_HP_MATCH), W, matchPatch);   /* 1979-1981 */
+            }
+            if (!found || c > maxVal) { if (!found) { maxVal = c; mi = i; mj = j; found = 1; } else { maxVal = c; mi = i; mj = j; } }
+        }
+    }
+    if (maxVal < 0.0) maxVal = maxVal;                                              /* (maxVal initialised to 0.0 at 1986 is overwritten by minMaxLoc) */
+    *best = maxVal;
+    if (maxVal > 0.8) {                                                             /* 1989 */
+        match[0] = (mi - ((int)px - half_x)) - half_x + px;                          /* 1991: maxLoc.x - half_x + px */
+        match[1] = (mj - ((int)py - half_y)) - half_y + py;
+        return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Whole-sequence driver used by the trajectory tests and by bench.py's cpu_baseline leg:
  * runs F frames  predictMotion -> predictMeasurement -> KalmanUpdate  (CSLAM::SLAM,
  * SLAM.cpp:87-112, minus image I/O, association and display) and records per frame

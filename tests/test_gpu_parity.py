@@ -345,6 +345,94 @@ def test_delete_landmark_matches_oracle(srukf, oracle, synth, N, idx):
         np.testing.assert_allclose(S2.T @ S2, So2.T @ So2, atol=1e-10)
 
 
+def _texture(rng, h=480, w=640):
+    t = rng.uniform(0, 255, (h, w))
+    k = 5
+    c = np.cumsum(np.cumsum(np.pad(t, ((k, k), (k, k)), mode="wrap"), axis=0), axis=1)
+    t = (c[2 * k:, 2 * k:] - c[:-2 * k, 2 * k:] - c[2 * k:, :-2 * k] + c[:-2 * k, :-2 * k]) / (2 * k) ** 2
+    t = (t - t.min()) / (t.max() - t.min()) * 255
+    return t.astype(np.uint8)
+
+
+def test_data_association_matches_oracle(srukf, oracle, synth):
+    """wrapPatch + dataAssociation on the device (srukf_associate) against the oracle's restatement, landmark by
+    landmark, on a synthetic textured frame: the landmarks were 'created' at the first pose from texture T, the
+    current frame is T shifted by a few pixels and the robot has moved, so the warp is a real homography."""
+    p = synth.scene_params()
+    N = 24
+    sc = synth.make_scene(N, 3, seed=13, p=p)
+    rng = np.random.default_rng(2)
+    T = _texture(rng)
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    pose0 = sc["X0"][-4:].copy()
+    R0 = np.array([[np.cos(pose0[3]), -np.sin(pose0[3]), 0], [np.sin(pose0[3]), np.cos(pose0[3]), 0], [0, 0, 1.0]])
+    f.predict_motion(sc["odo"][0], sc["odo"][1]); h0, _, _ = f.predict_measurement(); f.update(sc["z"][0], sc["matched"][0])
+    f.predict_motion(sc["odo"][1], sc["odo"][2]); h, Si, vis = f.predict_measurement()
+    shift = (2, -1)                                              # (dx, dy) of the scene content between creation and now
+    frame = np.roll(T, (shift[1], shift[0]), axis=(0, 1))
+    init_px, patches = [], []
+    for k in range(N):
+        ipx = h.reshape(N, 2)[k] - np.array(shift) + rng.uniform(-1.5, 1.5, 2)   # where the landmark was first seen
+        cu, cv = int(round(ipx[0])), int(round(ipx[1]))
+        if not (20 <= cu < 620 and 20 <= cv < 460):
+            ipx = np.array([320.0, 240.0]); cu, cv = 320, 240
+        patch = T[cv - 10:cv + 11, cu - 10:cu + 11].copy()
+        init_px.append(ipx); patches.append(patch)
+        if k != 5:                                               # landmark 5 never gets an appearance record: must not match
+            f.set_landmark_appearance(k, patch, R0, pose0[:3], ipx)
+    X, S = f.get_state()
+    xyz, _ = f.get_landmarks_cartesian()
+    z, m, cr = f.associate(frame)
+    assert m[5] == 0 and cr[5] == 0.0
+    agree, n_vis = 0, 0
+    for k in range(N):
+        if k == 5 or not vis[k]:
+            assert m[k] == 0
+            continue
+        n_vis += 1
+        mp_o = oracle.warp_patch(p, X[-4:], R0, pose0[:3], init_px[k], xyz[k], h.reshape(N, 2)[k], patches[k], np.zeros((17, 17), dtype=np.uint8))
+        mp_d = f.get_match_patch(k)
+        dpx = np.abs(mp_o.astype(int) - mp_d.astype(int))
+        assert dpx.max() <= 1 or (dpx > 1).mean() < 0.02         # truncating uchar casts of values a rounding error apart
+        ok, best, loc = oracle.associate_one(p, frame, h.reshape(N, 2)[k], Si.reshape(N, 4)[k], mp_d)   # same template: isolates the search
+        assert abs(best - cr[k]) < 1e-9
+        assert bool(m[k]) == ok
+        if ok:
+            np.testing.assert_allclose(z[2 * k:2 * k + 2], loc, atol=1e-9)
+            agree += 1
+    assert n_vis >= N // 2
+    # (the frame above is a pure shift of T while the robot has turned since "creation", so few templates correlate;
+    #  what is checked there is device == oracle.)  Now landmarks created at the CURRENT pose: the warp is the identity
+    #  view and every visible landmark must be found where its patch content sits in the frame.
+    pose = X[-4:]
+    Rc = np.array([[np.cos(pose[3]), -np.sin(pose[3]), 0], [np.sin(pose[3]), np.cos(pose[3]), 0], [0, 0, 1.0]])
+    for k in range(N):
+        f.set_landmark_appearance(k, patches[k], Rc, pose[:3], init_px[k])
+    z, m, cr = f.associate(frame)
+    found = 0
+    for k in range(N):
+        if not vis[k] or np.array_equal(init_px[k], [320.0, 240.0]):
+            continue
+        ok, best, loc = oracle.associate_one(p, frame, h.reshape(N, 2)[k], Si.reshape(N, 4)[k], f.get_match_patch(k))
+        assert bool(m[k]) == ok and abs(best - cr[k]) < 1e-9
+        if m[k]:
+            np.testing.assert_allclose(z[2 * k:2 * k + 2], loc, atol=1e-9)
+            true = np.round(init_px[k]) + np.array(shift)         # where the centre of the init patch is in this frame
+            hk = h.reshape(N, 2)[k]
+            peak = z[2 * k:2 * k + 2] - (hk - np.trunc(hk))         # 1991: maxLoc - half + px carries the fraction of px
+            # (the template is cut one pixel off-centre: matchPatch[i][j] <- initPatch[i + 3][j + 3], 1881-1882 subtract
+            #  initPixel - HP_INIT - 1, so the reported location is the patch centre + (1, 1) — the reference's own offset)
+            assert np.abs(peak - (true + 1)).max() <= 1.0 and cr[k] > 0.8
+            found += 1
+    assert found >= n_vis // 2
+    # a second call keeps (does not re-zero) the templates, and the matches can be fed to the update
+    z2, m2, cr2 = f.associate(frame)
+    np.testing.assert_array_equal(m2, m); np.testing.assert_allclose(cr2, cr, atol=1e-12)
+    f.update(z, m)
+    Xn, Sn = f.get_state()
+    assert np.all(np.isfinite(Xn)) and np.all(np.isfinite(Sn))
+
+
 def test_landmarks_cartesian_accessor(srukf, synth):
     """getFeatureCartesianInformation (SLAM.cpp:2721-2751) for all landmarks in one launch, against numpy on P = S^T S."""
     p = synth.scene_params()

@@ -220,3 +220,63 @@ def test_delete_feature_is_the_marginal(oracle, synth):
         keep = np.r_[0:6 * idx, 6 * idx + 6:6 * N + 4]
         assert np.array_equal(Xn, X[keep]) and np.all(np.tril(Sn, -1) == 0.0)
         np.testing.assert_allclose(Sn.T @ Sn, (S.T @ S)[np.ix_(keep, keep)], rtol=0, atol=1e-14)
+
+
+def _texture(rng, h=480, w=640):
+    """smooth random gray texture (box-filtered noise) so that correlation peaks are well defined"""
+    t = rng.uniform(0, 255, (h, w))
+    k = 5
+    c = np.cumsum(np.cumsum(np.pad(t, ((k, k), (k, k)), mode="wrap"), axis=0), axis=1)
+    t = (c[2 * k:, 2 * k:] - c[:-2 * k, 2 * k:] - c[2 * k:, :-2 * k] + c[:-2 * k, :-2 * k]) / (2 * k) ** 2
+    t = (t - t.min()) / (t.max() - t.min()) * 255
+    return t.astype(np.uint8)
+
+
+def test_association_oracle_against_numpy(oracle, synth):
+    """calculateCrossCorrelation / dataAssociation (SLAM.cpp:1915-2009, 3141-3166) restated in the oracle, pinned on
+    numpy: the best normalised cross correlation inside the chi-square gate, first maximum in row-major order."""
+    p = synth.scene_params()
+    rng = np.random.default_rng(0)
+    img = _texture(rng)
+    for trial in range(6):
+        u, v = rng.uniform(40, 600), rng.uniform(40, 440)
+        true = (int(u) + rng.integers(-3, 4), int(v) + rng.integers(-3, 4))
+        tmpl = img[true[1] - 8:true[1] + 9, true[0] - 8:true[0] + 9].copy()          # rows = y, like the image ROI
+        Si = np.array([[rng.uniform(2.5, 4.0), rng.uniform(-0.5, 0.5)], [0.0, rng.uniform(2.5, 4.0)]])
+        ok, best, loc = oracle.associate_one(p, img, [u, v], Si, tmpl)
+        # numpy restatement
+        pi = Si.T @ Si; pinv = np.linalg.inv(pi)
+        hx = min(10, max(8, int(np.ceil(2 * Si[0, 0])))); hy = min(10, max(8, int(np.ceil(2 * Si[1, 1]))))
+        bestn, locn = 0.0, None
+        for j in range(int(v) - hy, int(v) + hy + 1):
+            for i in range(int(u) - hx, int(u) + hx + 1):
+                e = np.array([i - u, j - v])
+                if e @ pinv @ e < 5.99146454710798:
+                    roi = img[j - 8:j + 9, i - 8:i + 9].astype(np.float64); a = roi - roi.mean(); b = tmpl - tmpl.astype(np.float64).mean()
+                    c = float((a * b).sum() / np.sqrt((a * a).sum()) / np.sqrt((b * b).sum()))
+                    if c > bestn: bestn, locn = c, (i - int(u) + u, j - int(v) + v)
+        assert ok and abs(best - bestn) < 1e-12 and best > 0.999
+        np.testing.assert_allclose(loc, locn, atol=1e-12)
+        assert (round(loc[0] - (u - int(u))), round(loc[1] - (v - int(v)))) == true   # found where the template was cut
+
+
+def test_warp_patch_identity_view(oracle, synth):
+    """wrapPatch (SLAM.cpp:1803-1906) from the very pose and pixel the landmark was created at reproduces the centre
+    of the init patch (x/y transposed as the reference indexes it; the truncating uchar cast may lose one grey level)."""
+    p = synth.scene_params()
+    rng = np.random.default_rng(1)
+    img = _texture(rng)
+    robot = np.array([0.3, -0.2, 0.0, 0.4])
+    R = np.array([[np.cos(robot[3]), -np.sin(robot[3]), 0], [np.sin(robot[3]), np.cos(robot[3]), 0], [0, 0, 1.0]])
+    for trial in range(4):
+        px = np.array([rng.uniform(60, 580), rng.uniform(60, 420)])
+        cu, cv = int(round(px[0])), int(round(px[1]))
+        patch = img[cv - 10:cv + 11, cu - 10:cu + 11].copy()
+        xyz = np.array([1.0, 0.5, 3.0])
+        out = oracle.warp_patch(p, robot, R, robot[:3], px, xyz, px, patch, np.zeros((17, 17), dtype=np.uint8))
+        ref = patch[3:20, 3:20]                                   # matchPatch[i][j] <- initPatch.at(i + 3, j + 3)
+        # index 16 maps to 19 + rounding noise: when the noise is positive, ceil gives 20 and the reference's bound
+        # `right < 2*HP_INIT` (1889) leaves the pixel untouched — only rows / columns 0..15 are certain to be written
+        assert np.abs(out[:16, :16].astype(int) - ref[:16, :16].astype(int)).max() <= 1
+        edge = np.abs(out.astype(int) - ref.astype(int)) > 1
+        assert np.all(out[edge] == 0)
