@@ -169,21 +169,48 @@ struct GmwPanel64 { double Tt1[1024]; double Tt2[1024]; double E[1024]; double D
 
 // acc[a][b] (+)= sum_k A[k][16a + i] * B[k][16b + j],  k < 32:  A from a 32x32 K-major global array (row stride 32),
 // B from a C-layout register tile (rows = k).  All 16 A fragments are requested before the first MFMA.
-template <bool NEG>
+// TRI: A = Tt of a unit lower triangular T (A[k][j] = 0 for k > j): output rows 0..15 only see k < 16.
+template <bool NEG, bool TRI>
 __device__ __forceinline__ void stage32_regB(d4 (&acc)[2][2], const double* __restrict__ A, const d4 (&B)[2][2], int lane)
 {
     const int lr = lane & 15, lk = lane >> 4;
     double fa0[8], fa1[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { fa0[u] = A[(4 * u + lk) * 32 + lr]; fa1[u] = A[(4 * u + lk) * 32 + 16 + lr]; }
+    for (int u = 0; u < 8; u++) { if (!TRI || u < 4) fa0[u] = A[(4 * u + lk) * 32 + lr]; fa1[u] = A[(4 * u + lk) * 32 + 16 + lr]; }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int a2 = u >> 2, t = u & 3;                      // k = 16 a2 + 4 t + lk
-        const double a0 = NEG ? -fa0[u] : fa0[u], a1 = NEG ? -fa1[u] : fa1[u];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, B[a2][0][t], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, B[a2][1][t], acc[0][1], 0, 0, 0);
+        const double a1 = NEG ? -fa1[u] : fa1[u];
+        if (!TRI || u < 4) {
+            const double a0 = NEG ? -fa0[u] : fa0[u];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, B[a2][0][t], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, B[a2][1][t], acc[0][1], 0, 0, 0);
+        }
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, B[a2][0][t], acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, B[a2][1][t], acc[1][1], 0, 0, 0);
+    }
+}
+
+// first stage of a slab, W1 = T1 G1: A = Tt1 (global, row stride 32, triangular as above), B = 32 rows of G from
+// row pointer Bp (row stride ldb), columns n0 .. n0+31.  All fragments are requested before the first MFMA.
+__device__ __forceinline__ void stage32_tri_globalB(d4 (&acc)[2][2], const double* __restrict__ A, const double* __restrict__ Bp, int ldb, int n0, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    double fa0[4], fa1[8], fb0[8], fb1[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (u < 4) fa0[u] = A[(4 * u + lk) * 32 + lr];
+        fa1[u] = A[(4 * u + lk) * 32 + 16 + lr];
+        fb0[u] = Bp[(size_t)(4 * u + lk) * ldb + n0 + lr]; fb1[u] = Bp[(size_t)(4 * u + lk) * ldb + n0 + 16 + lr];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (u < 4) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[u], fb0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[u], fb1[u], acc[0][1], 0, 0, 0);
+        }
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[u], fb0[u], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[u], fb1[u], acc[1][1], 0, 0, 0);
     }
 }
 
@@ -259,7 +286,7 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const double* rowp = &PT[(4 * u + lk) * 32];
-            W1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr ^ sw], fb[u], W1[0], 0, 0, 0);
+            if (u < 4) W1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr ^ sw], fb[u], W1[0], 0, 0, 0);   // Tt[k][j] = 0 for k > j
             W1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[(16 + lr) ^ sw], fb[u], W1[1], 0, 0, 0);
         }
 #pragma unroll
@@ -271,7 +298,7 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const double* rowp = &PT[2048 + (4 * u + lk) * 32];
-            W2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr ^ sw], X2[u >> 2][u & 3], W2[0], 0, 0, 0);
+            if (u < 4) W2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr ^ sw], X2[u >> 2][u & 3], W2[0], 0, 0, 0);
             W2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[(16 + lr) ^ sw], X2[u >> 2][u & 3], W2[1], 0, 0, 0);
         }
 #pragma unroll
@@ -460,10 +487,10 @@ __global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int f
 #pragma unroll
                 for (int t = 0; t < 4; t++) { dr[q][t] = cur->rD[16 * q + lk + 4 * t]; sqr[q][t] = cur->sq[16 * q + lk + 4 * t]; }
             zero_acc(W1);
-            tile32_tn<false>(W1, cur->Tt1, 32, G + (size_t)j0 * ld, ld, 0, n0, 0, 32, lane);
-            stage32_regB<true>(X2, cur->E, W1, lane);
+            stage32_tri_globalB(W1, cur->Tt1, G + (size_t)j0 * ld, ld, n0, lane);
+            stage32_regB<true, false>(X2, cur->E, W1, lane);
             zero_acc(W2);
-            stage32_regB<false>(W2, cur->Tt2, X2, lane);
+            stage32_regB<false, true>(W2, cur->Tt2, X2, lane);
             const bool write_s = (blockIdx.y == 0) && (which == 1 || diagblk);
 #pragma unroll
             for (int a = 0; a < 2; a++)

@@ -509,3 +509,33 @@ def test_full_size_properties_n200(srukf, synth):
     # landmark anchors never move relative to each other by more than the clamp allows (null space kept)
     anchors = X[:-4].reshape(N, 6)[:, :3]
     assert np.abs(anchors - anchors[0]).max() < 1e-3
+
+
+def test_full_size_tolerance_study_n500(srukf, synth):
+    """BASELINE configs[4] at full size (N = 500, n = 3004): fp32 state storage against the fp64 run of the same
+    sequence (no oracle at this size inside a unit test), plus the size-independent properties of both."""
+    p = synth.scene_params()
+    N, F = 500, 4
+    sc = synth.make_scene(N, F, seed=0, p=p)
+    traj, state = {}, {}
+    for storage in (srukf.STORAGE_F64, srukf.STORAGE_F32):
+        f = srukf.Filter(N, p); f.set_storage(storage); f.set_state(sc["X0"], sc["S0"])
+        f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        traj[storage] = f.run_frames(0, F)
+        X, S = f.get_state()
+        state[storage] = (X, S)
+        assert np.isfinite(X).all() and np.isfinite(S).all()
+        assert np.all(np.tril(S, -1) == 0.0)
+        assert np.diag(S).min() >= np.sqrt(1e-13) * (1 - 1e-6)                  # EPSILON clamp floor (fp32-rounded under F32)
+        pose, P4 = f.get_robot()
+        Sr = S[:, -4:]
+        np.testing.assert_allclose(P4, Sr.T @ Sr, rtol=1e-12, atol=1e-18)       # robot block of S^T S
+        np.testing.assert_allclose(traj[storage][-1, :4], pose, atol=0)
+        assert np.abs(traj[storage][:, :2] - sc["odo"][1:, :2]).max() < 2e-4    # the filter tracks the truth
+        if storage == srukf.STORAGE_F32:
+            X32, S32 = f.get_state_f32()
+            assert np.array_equal(X, X32.astype(np.float64))
+    d = np.abs(traj[srukf.STORAGE_F32][:, :2] - traj[srukf.STORAGE_F64][:, :2]).max()
+    assert 0 < d < 1e-6                                                         # north-star pose tolerance, fp32 storage
+    dX = np.abs(state[srukf.STORAGE_F32][0] - state[srukf.STORAGE_F64][0]).max()
+    assert dX < 1e-4
