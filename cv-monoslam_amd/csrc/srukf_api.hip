@@ -27,6 +27,9 @@ void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*,
 void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*);
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
 int srukf_gmw_panel_bytes(void);
+int srukf_gmw_sync_bytes(int T);
+int srukf_gmw_build_tasks(int T, short* out);
+void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
@@ -117,6 +120,43 @@ static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_st
 
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
+// ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
+struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tasks = nullptr; int ntasks = 0, T = 0, max_workers = 0; };
+static void gmw_plan_destroy(GmwPlan& g)
+{
+    if (g.pans) hipFree(g.pans);
+    if (g.sync) hipFree(g.sync);
+    if (g.tasks) hipFree(g.tasks);
+    g = GmwPlan();
+}
+static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st)
+{
+    g.T = np / 64;
+    g.ntasks = srukf_gmw_build_tasks(g.T, nullptr);
+    std::vector<short> tk((size_t)4 * (g.ntasks > 0 ? g.ntasks : 1), 0);
+    srukf_gmw_build_tasks(g.T, tk.data());
+    const int step0 = g.T >= 2 ? (g.T - 1) * g.T / 2 - 1 : 0;          // tiles of the first (largest) step
+    g.max_workers = step0 < 1 ? (g.T > 1 ? 1 : 0) : (step0 > 255 ? 255 : step0);
+    const size_t sync_bytes = (size_t)srukf_gmw_sync_bytes(g.T);
+    if (hipMalloc(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T) != hipSuccess ||
+        hipMalloc(&g.sync, sync_bytes) != hipSuccess ||
+        hipMalloc(&g.tasks, sizeof(short) * tk.size()) != hipSuccess) { gmw_plan_destroy(g); return SRUKF_ERR_NOMEM; }
+    GmwSync hs; memset(&hs, 0, sizeof hs); hs.epoch = 1;
+    if (hipMemsetAsync(g.pans, 0, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
+        hipMemsetAsync(g.sync, 0, sync_bytes, st) != hipSuccess ||
+        hipMemcpyAsync(g.sync, &hs, sizeof hs, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(g.tasks, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { gmw_plan_destroy(g); return SRUKF_ERR_HIP; }
+    return SRUKF_OK;
+}
+// 0 = one launch per 64-row panel (default), 1 = one persistent launch per factorisation (SRUKF_GMW_PERSIST=1; experimental)
+static int gmw_persist_mode()
+{
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SRUKF_GMW_PERSIST"); mode = (e && e[0] == '1') ? 1 : 0; }
+    return mode;
+}
+
 struct srukf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -143,7 +183,9 @@ struct srukf_ctx {
     float *S32 = nullptr, *X32 = nullptr;
     int *perm = nullptr, *iperm = nullptr;
     double* Sdis = nullptr;
-    void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered)
+    void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered), one launch per panel
+    GmwPlan gplan;                         // persistent GMW launch: panel buffers, sync block, task list
+    int gmw_workers = 0;                   // worker workgroups of the persistent launch (0 = as many as step 0 has tiles, <= 255)
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
     int n_syrk_tiles = 0, n_pxy_tiles = 0;
     FrameScalars* fs = nullptr;
@@ -283,6 +325,7 @@ static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
 // one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path.
 // need_reset: the gamma/xi accumulators were not just cleared by k_gain (SEQUENTIAL mode, fallbacks).
 // frame_tail: the check kernel also records the trajectory row and advances the staged frame counter.
+static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout);
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
 {
     const KDims& d = c->d;
@@ -300,13 +343,20 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
     if (!slow) {
         // 64-row panels: j0 = -64 factors the first 64x64 region, then one launch per panel
-        int pb = 0;
-        for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1) {
-            const double r2 = np - j0 - 64;
-            // per launch: trailing update 64*r2^2 (upper half, 2 flop) + three-stage slab recompute + next 64x64 diagonal region
-            ProfScope ps(c, KC_GMW_TRAIL, j0 < 0 ? 64.0 * 64.0 * 64.0 / 3.0 : 64.0 * r2 * r2 + 3.0 * 2.0 * 32.0 * 32.0 * r2 + 64.0 * 64.0 * 64.0 / 3.0,
-                         8.0 * (r2 * r2 + 2.0 * 64.0 * r2));
-            srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb ^ 1], c->pan[pb], c->D, c->S);
+        // per panel: trailing update 64*r2^2 (upper half, 2 flop) + three-stage slab recompute + next 64x64 diagonal region
+        auto panel_flop = [&](int j0) { const double r2 = np - j0 - 64; return j0 < 0 ? 64.0 * 64.0 * 64.0 / 3.0 : 64.0 * r2 * r2 + 3.0 * 2.0 * 32.0 * 32.0 * r2 + 64.0 * 64.0 * 64.0 / 3.0; };
+        auto panel_byte = [&](int j0) { const double r2 = np - j0 - 64; return 8.0 * (r2 * r2 + 2.0 * 64.0 * r2); };
+        if (gmw_persist_mode()) {
+            double fl = 0.0, by = 0.0;
+            for (int j0 = -64; j0 + 64 < np; j0 += 64) { fl += panel_flop(j0); by += panel_byte(j0); }
+            ProfScope ps(c, KC_GMW_TRAIL, fl, by);
+            launch_gmw_fast(c, c->G, c->S);
+        } else {
+            int pb = 0;
+            for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1) {
+                ProfScope ps(c, KC_GMW_TRAIL, panel_flop(j0), panel_byte(j0));
+                srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb ^ 1], c->pan[pb], c->D, c->S);
+            }
         }
         quantize_state(c);
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
@@ -321,13 +371,24 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
 }
 // Blocked fast path (or, slow = true, the exact column path) on an arbitrary matrix buffer: Gbuf (upper triangle,
 // destroyed) -> upper-triangular factor rows in Sout (whose lower triangle must already be zero).
+static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout)
+{
+    const int np = c->d.np, n = c->d.n;
+    if (gmw_persist_mode()) {
+        int w = c->gmw_workers > 0 ? c->gmw_workers : c->gplan.max_workers;
+        if (w > c->gplan.max_workers) w = c->gplan.max_workers;
+        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, c->gplan.pans, c->D, Sout, c->gplan.sync, c->gplan.tasks, c->gplan.ntasks, w, c->fs);
+        return;
+    }
+    int pb = 0;
+    for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
+        srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, Gbuf, c->pan[pb ^ 1], c->pan[pb], c->D, Sout);
+}
 static void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow)
 {
     const int np = c->d.np, n = c->d.n;
     if (!slow) {
-        int pb = 0;
-        for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
-            srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, Gbuf, c->pan[pb ^ 1], c->pan[pb], c->D, Sout);
+        launch_gmw_fast(c, Gbuf, Sout);
         srukf_launch_gmw_check(c->stream, n, np, c->D, Sout, c->fs, c->X, 0);
     } else {
         hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 0);
@@ -453,6 +514,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     ALLOC(c->D, np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
     ALLOC(c->vis, N > 0 ? N : 1); ALLOC(c->mcur, N > 0 ? N : 1); ALLOC(c->theta, np); ALLOC(c->fs, 1);
     { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
+    { const int rcg = gmw_plan_create(c->gplan, d.np, c->stream); if (rcg) { g_create_error = "persistent GMW resources: allocation failed"; srukf_destroy(c); return rcg; } }
     {
         // k_syrk: tile (row r, col c >= r); A panel = S columns of r, B panel = S columns of c.  XCD owns rows.
         std::vector<int> ts = build_tile_table(d.np / 32, d.np / 32, true, true, 0);
@@ -491,6 +553,7 @@ int srukf_destroy(srukf_ctx* c)
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles,
                      c->perm, c->iperm, c->Sdis, c->S32, c->X32, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) hipFree(b);
+    gmw_plan_destroy(c->gplan);
     if (c->hstage) hipHostFree(c->hstage);
     if (c->hfs) hipHostFree(c->hfs);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -987,7 +1050,7 @@ static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     const bool own = c->own_stream;
     std::swap(*c, *c2);
     c->own_stream = own; c2->own_stream = false;
-    c->profiling = c2->profiling; c->use_graph = c2->use_graph;
+    c->profiling = c2->profiling; c->use_graph = c2->use_graph; c->gmw_workers = c2->gmw_workers;
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
     c2->profiling = false; c2->pev.clear();
@@ -1196,13 +1259,21 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
     srukf_launch_gmw_stats(st, n, np, dG, dFs);
     FrameScalars fs;
     if (!force_slow) {
-        void* pan[2];
-        hipMalloc(&pan[0], srukf_gmw_panel_bytes()); hipMalloc(&pan[1], srukf_gmw_panel_bytes());
-        int pb = 0;
-        for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
-            srukf_launch_gmw_step64(st, n, np, j0, epsilon, dG, pan[pb ^ 1], pan[pb], dD, dS);
-        hipDeviceSynchronize();
-        hipFree(pan[0]); hipFree(pan[1]);
+        if (gmw_persist_mode()) {
+            GmwPlan gp;
+            if (gmw_plan_create(gp, np, st) != SRUKF_OK) return SRUKF_ERR_NOMEM;
+            srukf_launch_gmw_persist(st, n, np, epsilon, dG, gp.pans, dD, dS, gp.sync, gp.tasks, gp.ntasks, gp.max_workers, dFs);
+            hipDeviceSynchronize();
+            gmw_plan_destroy(gp);
+        } else {
+            void* pan[2];
+            hipMalloc(&pan[0], srukf_gmw_panel_bytes()); hipMalloc(&pan[1], srukf_gmw_panel_bytes());
+            int pb = 0;
+            for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
+                srukf_launch_gmw_step64(st, n, np, j0, epsilon, dG, pan[pb ^ 1], pan[pb], dD, dS);
+            hipDeviceSynchronize();
+            hipFree(pan[0]); hipFree(pan[1]);
+        }
         srukf_launch_gmw_check(st, n, np, dD, dS, dFs, nullptr, 0);
         hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
         if (clamp_hit) *clamp_hit = fs.clamp_rows;

@@ -154,6 +154,45 @@ struct MeasArgs {
     FrameScalars* fs; int gx;                                  // gx = (N + 31) / 32 landmark groups
 };
 
+// ---- agent-scope (device-coherent) accesses: data handed from one workgroup to another INSIDE a launch ----
+// The eight XCDs have private, mutually non-coherent L2s; plain stores stay dirty in the writer's L2 until the kernel
+// ends.  Relaxed agent-scope atomics compile to sc1 loads / stores, which bypass / write through it
+// (scripts/mb/mb_xwg.hip: an 8 KB tile + flag hand-off between two workgroups costs ~2 us, never a stale word).
+__device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool DEV> __device__ __forceinline__ double ld_g(const double* p) { if constexpr (DEV) return ld_dev(p); else return *p; }
+template <bool DEV> __device__ __forceinline__ void st_d4(double* p, d4 v)
+{
+    if constexpr (DEV) { st_dev(p, v[0]); st_dev(p + 1, v[1]); st_dev(p + 2, v[2]); st_dev(p + 3, v[3]); }
+    else *(d4*)p = v;
+}
+
+// ---- synchronisation block of the persistent GMW launch (k_gmw_persist) ----
+// Flags carry (epoch << GMW_EPOCH_SHIFT) + count, so the T*T tile versions never need clearing: values of older runs
+// compare as "not set".  The last workgroup to leave a launch re-arms claim / exited and advances the epoch.
+#define GMW_EPOCH_SHIFT 12
+struct GmwSync {
+    unsigned long long claim;        // next entry of the worker task list
+    unsigned long long epoch;        // run counter (starts at 1)
+    unsigned long long panel_ready;  // (epoch << SHIFT) + number of panels published by the pivot workgroup
+    unsigned int exited;             // workgroups that have left the current launch
+    int abort;                       // a bounded wait expired: everybody leaves, the frame is flagged for the exact path
+    unsigned long long* dbg;         // diagnostic builds: host-visible progress markers (null in the product)
+    // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)
+};
+__device__ __forceinline__ unsigned long long* gmw_sync_ver(GmwSync* sy) { return (unsigned long long*)(sy + 1); }
+
+#ifdef SRUKF_GMW_DBG
+#define GMW_DBG(sy, slot, val) do { if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0 && (sy)->dbg) __hip_atomic_store(&(sy)->dbg[blockIdx.x * 8 + (slot)], (unsigned long long)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#define GMW_DBG2(sy, slot, val) do { if ((sy)->dbg) __hip_atomic_store(&(sy)->dbg[blockIdx.x * 8 + (slot)], (unsigned long long)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+// time stamp (s_memtime) of pivot iteration p, slot 0..7, written by whichever wave executes it
+#define GMW_TS(sy, p, slot) do { if ((sy)->dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __hip_atomic_store(&(sy)->dbg[2048 + (p) * 8 + (slot)], t_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
+#else
+#define GMW_DBG(sy, slot, val)
+#define GMW_DBG2(sy, slot, val)
+#define GMW_TS(sy, p, slot)
+#endif
+
 // ---- optional cycle stamps (diagnostic builds under scripts/mb only; compiled out of the product) ----
 #ifdef SRUKF_STAMPS
 __device__ unsigned long long srukf_stamps[32];

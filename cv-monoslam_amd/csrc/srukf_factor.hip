@@ -170,13 +170,14 @@ struct GmwPanel64 { double Tt1[1024]; double Tt2[1024]; double E[1024]; double D
 // acc[a][b] (+)= sum_k A[k][16a + i] * B[k][16b + j],  k < 32:  A from a 32x32 K-major global array (row stride 32),
 // B from a C-layout register tile (rows = k).  All 16 A fragments are requested before the first MFMA.
 // TRI: A = Tt of a unit lower triangular T (A[k][j] = 0 for k > j): output rows 0..15 only see k < 16.
-template <bool NEG, bool TRI>
+// DEV: operands written by another workgroup of the same launch (agent-scope loads).
+template <bool NEG, bool TRI, bool DEV>
 __device__ __forceinline__ void stage32_regB(d4 (&acc)[2][2], const double* __restrict__ A, const d4 (&B)[2][2], int lane)
 {
     const int lr = lane & 15, lk = lane >> 4;
     double fa0[8], fa1[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { if (!TRI || u < 4) fa0[u] = A[(4 * u + lk) * 32 + lr]; fa1[u] = A[(4 * u + lk) * 32 + 16 + lr]; }
+    for (int u = 0; u < 8; u++) { if (!TRI || u < 4) fa0[u] = ld_g<DEV>(&A[(4 * u + lk) * 32 + lr]); fa1[u] = ld_g<DEV>(&A[(4 * u + lk) * 32 + 16 + lr]); }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int a2 = u >> 2, t = u & 3;                      // k = 16 a2 + 4 t + lk
@@ -193,15 +194,16 @@ __device__ __forceinline__ void stage32_regB(d4 (&acc)[2][2], const double* __re
 
 // first stage of a slab, W1 = T1 G1: A = Tt1 (global, row stride 32, triangular as above), B = 32 rows of G from
 // row pointer Bp (row stride ldb), columns n0 .. n0+31.  All fragments are requested before the first MFMA.
+template <bool DEV>
 __device__ __forceinline__ void stage32_tri_globalB(d4 (&acc)[2][2], const double* __restrict__ A, const double* __restrict__ Bp, int ldb, int n0, int lane)
 {
     const int lr = lane & 15, lk = lane >> 4;
     double fa0[4], fa1[8], fb0[8], fb1[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-        if (u < 4) fa0[u] = A[(4 * u + lk) * 32 + lr];
-        fa1[u] = A[(4 * u + lk) * 32 + 16 + lr];
-        fb0[u] = Bp[(size_t)(4 * u + lk) * ldb + n0 + lr]; fb1[u] = Bp[(size_t)(4 * u + lk) * ldb + n0 + 16 + lr];
+        if (u < 4) fa0[u] = ld_g<DEV>(&A[(4 * u + lk) * 32 + lr]);
+        fa1[u] = ld_g<DEV>(&A[(4 * u + lk) * 32 + 16 + lr]);
+        fb0[u] = ld_g<DEV>(&Bp[(size_t)(4 * u + lk) * ldb + n0 + lr]); fb1[u] = ld_g<DEV>(&Bp[(size_t)(4 * u + lk) * ldb + n0 + 16 + lr]);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -429,6 +431,156 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
     STAMP(8);
 }
 
+// One 64x64 block (by, bx), by <= bx and not (0,0), of the trailing square behind panel JJ = [j0, j0+64):
+//   1. recomputes the panel rows it needs for its row slab and its column slab by the three MFMA stages
+//      above (one 32-column half slab per wave, register resident) and keeps L = W/D and W in LDS;
+//   2. updates its tile  G[r][c] -= sum_{kk<64} L[kk][r] W[kk][c];
+//   3. first block row only: writes the final S rows j0..j0+63 for its column slab.
+// DEV: G tiles and the panel buffer are exchanged with other workgroups of the SAME launch (agent-scope accesses).
+// wait_panel(): called once by ALL threads between the loads that do not depend on the panel buffer (the G tile and
+// the panel's G rows) and those that do; returns false to abandon the tile.  The persistent kernel waits for the
+// pivot's panel_ready flag there, with the G operands already in flight.
+template <bool DEV, class WaitPanel>
+__device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, int bx, double* __restrict__ G,
+                                                const GmwPanel64* cur, double* __restrict__ Sout,
+                                                double (*Lr)[G64_LS], double (*Wc)[G64_LS], int tid, WaitPanel&& wait_panel)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int base = j0 + 64;
+    const int R0 = base + 64 * by, C0 = base + 64 * bx;
+    const bool diagblk = bx == by;
+    const int m0 = R0 + 32 * (wv >> 1), c0 = C0 + 32 * (wv & 1);
+    const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
+    d4 acc[2][2];
+    zero_acc(acc);
+    if (live) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[a][b][t] = ld_g<DEV>(&G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr]);
+    }
+    // 1. half slab of this wave: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
+    const int which = wv >> 1, half = wv & 1;
+    const int n0 = (which ? C0 : R0) + 32 * half;
+    const bool slab = n0 < ld && !(diagblk && which == 1);
+    d4 X2[2][2];
+    double fb0[8], fb1[8];
+    if (slab) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) X2[a][b][t] = ld_g<DEV>(&G[(size_t)(j0 + 32 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            fb0[u] = ld_g<DEV>(&G[(size_t)(j0 + 4 * u + lk) * ld + n0 + lr]); fb1[u] = ld_g<DEV>(&G[(size_t)(j0 + 4 * u + lk) * ld + n0 + 16 + lr]);
+        }
+    }
+    if (!wait_panel()) return false;
+    if (slab) {
+        // every fragment of the three panel matrices is requested before the first MFMA (one memory round trip, not three).
+        // Plain loads, also in the persistent launch: each panel buffer is written once per launch (agent-scope stores, before
+        // its flag) and read only after the flag, so no L2 can hold an older copy — and the ~170 workgroups that want the
+        // same 24 KB at the same moment are served by their XCD's L2 instead of one memory channel.
+        double ta0[4], ta1[8], ea0[8], ea1[8], tb0[4], tb1[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int o = (4 * u + lk) * 32 + lr;
+            if (u < 4) { ta0[u] = cur->Tt1[o]; tb0[u] = cur->Tt2[o]; }
+            ta1[u] = cur->Tt1[o + 16]; tb1[u] = cur->Tt2[o + 16];
+            ea0[u] = cur->E[o]; ea1[u] = cur->E[o + 16];
+        }
+        const bool write_s = (by == 0) && (which == 1 || diagblk);
+        double dr[4][4], sqr[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                dr[q][t] = (which == 0) ? cur->rD[16 * q + lk + 4 * t] : 0.0;
+                sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
+            }
+        d4 W1[2][2], W2[2][2];
+        zero_acc(W1); zero_acc(W2);
+        // W1 = T1 G1 (T1 unit lower triangular: output rows 0..15 only see k < 16)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (u < 4) {
+                W1[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0[u], fb0[u], W1[0][0], 0, 0, 0);
+                W1[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0[u], fb1[u], W1[0][1], 0, 0, 0);
+            }
+            W1[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1[u], fb0[u], W1[1][0], 0, 0, 0);
+            W1[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1[u], fb1[u], W1[1][1], 0, 0, 0);
+        }
+        // G2' = G2 - E^T W1
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int a2 = u >> 2, t = u & 3;
+            X2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea0[u], W1[a2][0][t], X2[0][0], 0, 0, 0);
+            X2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea0[u], W1[a2][1][t], X2[0][1], 0, 0, 0);
+            X2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea1[u], W1[a2][0][t], X2[1][0], 0, 0, 0);
+            X2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea1[u], W1[a2][1][t], X2[1][1], 0, 0, 0);
+        }
+        // W2 = T2 G2'
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int a2 = u >> 2, t = u & 3;
+            if (u < 4) {
+                W2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb0[u], X2[a2][0][t], W2[0][0], 0, 0, 0);
+                W2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb0[u], X2[a2][1][t], W2[0][1], 0, 0, 0);
+            }
+            W2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb1[u], X2[a2][0][t], W2[1][0], 0, 0, 0);
+            W2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb1[u], X2[a2][1][t], W2[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
+                    const double w1 = W1[a][b][t], w2 = W2[a][b][t];
+                    if (which == 0) {
+                        Lr[jj][cc] = w1 * dr[a][t]; Lr[32 + jj][cc] = w2 * dr[2 + a][t];
+                        if (diagblk) { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
+                    } else { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
+                    if (write_s) {
+                        if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = w1 * sqr[a][t];
+                        if (j0 + 32 + jj < n) Sout[(size_t)(j0 + 32 + jj) * ld + n0 + 16 * b + lr] = w2 * sqr[2 + a][t];
+                    }
+                }
+    }
+    __syncthreads();
+    // 2. tile update from LDS fragments, K = 64
+    if (live) {
+        const int ro = m0 - R0, co = c0 - C0;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+            const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
+            const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    double* gp = &G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+                    if constexpr (DEV) st_dev(gp, acc[a][b][t]); else *gp = acc[a][b][t];
+                }
+    }
+    return true;
+}
+
 // k_gmw_step64: one launch per 64-row panel JJ = [j0, j0+64)  (j0 = -64, first = 1: only the first region is factored).
 // Every 64x64 block of the trailing square (base = j0+64):
 //   1. recomputes the panel rows it needs for its row slab and its column slab by the three MFMA stages
@@ -452,85 +604,391 @@ __global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int f
         gmw_step64_block00(n, ld, j0, first, eps, G, cur, nxt, Dall, Sout, Lr, Wc, facreg, xreg, tid);
         return;
     }
-    const int lr = lane & 15, lk = lane >> 4;
-    const int base = j0 + 64;
-    const int R0 = base + 64 * blockIdx.y, C0 = base + 64 * blockIdx.x;
-    const bool diagblk = blockIdx.x == blockIdx.y;
-    const int m0 = R0 + 32 * (wv >> 1), c0 = C0 + 32 * (wv & 1);
-    const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
-    d4 acc[2][2];
-    zero_acc(acc);
-    if (live) {
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+    gmw_tile_update<false>(n, ld, j0, blockIdx.y, blockIdx.x, G, cur, Sout, Lr, Wc, tid, [] { return true; });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form: the whole factorisation in ONE launch (k_gmw_persist).
+//
+// With one launch per panel the chain of T = ld/64 launches pays, per panel, a dispatch gap (~1.5 us) and a cold
+// start (kernarg + first loads from HBM, ~2.3 us: every launch begins with an invalidated L2) on top of the ~9.5 us
+// of arithmetic of the critical-path workgroup.  Here that workgroup ("pivot", blockIdx 0) stays resident: it keeps
+// the panel it has just factored in LDS (T1', E', T2', 1/D), applies it to the next 64x64 diagonal region itself and
+// factors that, panel after panel.  The trailing updates are a task list (step k, tile (by, bx)) in dependency order;
+// the other workgroups ("workers") claim entries with an atomic counter.  Hand-off goes through global memory:
+//   pivot  -> workers : panel buffer pans[k] (agent-scope stores), then panel_ready = k + 1
+//   worker -> anybody : G tile (agent-scope stores), then ver[I][J] = number of panels applied to it
+//   a task (k; by, bx), I = k+1+by, J = k+1+bx, needs panel k, ver[I][J] >= k and the two row-panel tiles
+//   ver[k][I], ver[k][J] >= k;  the pivot, before panel p, needs ver[p-1][p] and ver[p][p] >= p-1
+//   (tiles (0,1) and (1,1) of step p-2: first in that step's list, a whole pivot iteration ahead of their use).
+// Tasks are claimed in list order and only depend on the pivot and on EARLIER entries, so whoever holds an
+// unfinished dependency is already running: no deadlock whatever share of the grid is resident (several filters may
+// share the GPU).  Every wait is bounded; on expiry the launch is abandoned and the frame flagged (exact path reruns it).
+// ------------------------------------------------------------------------------------------------
+// Who polls and who raises flags: WAVE 0 as a whole, under wave-uniform (scalar) conditions, never "if (tid == 0)".
+// A divergent single-thread branch just before the back edge of the task loop and another one right after its head
+// get merged by the structurizer into a lane-divergent loop around the workgroup barrier (wave 0 then executes
+// s_barrier more often than the other waves: hang).  Uniform branches leave EXEC alone; 64 lanes loading or storing
+// the same flag word are one memory request.
+#define GMW_XWG_LIMIT (1 << 18)
+__device__ __forceinline__ unsigned long long gmw_uniform64(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ bool gmw_wait_ge(const unsigned long long* f, unsigned long long want, const int* abort_flag)
+{
+    for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+        if (gmw_uniform64(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= want) return true;
+        if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false;
+        __builtin_amdgcn_s_sleep(1);
     }
-    // 1. half slab of this wave: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
-    {
-        const int which = wv >> 1, half = wv & 1;
-        const int n0 = (which ? C0 : R0) + 32 * half;
-        if (n0 < ld && !(diagblk && which == 1)) {
-            d4 X2[2][2], W1[2][2], W2[2][2];
+    return false;
+}
+__device__ __forceinline__ void gmw_set_flag(unsigned long long* f, unsigned long long v)
+{
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all agent-scope stores of this workgroup have landed -> wave 0 raises the flag (wv0: wave-uniform "this is wave 0")
+__device__ __forceinline__ void gmw_publish(unsigned long long* f, unsigned long long v, bool wv0)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wv0) gmw_set_flag(f, v);
+}
+
+// LDS of the pivot workgroup that survives from one panel to the next
+struct GmwPivotKeep {
+    double* T1;      // [kk][33]   T1'[jj][kk] of the panel factored last (xreg + 2048, written by the T wave of factor 1)
+    double* T2;      // [kk][33]   T2'                                     (xreg, staging buffer of the T wave of factor 2)
+    double* Ep;      // [k][32], column ^ 16*(k&1): E' = W1d / D'
+    double* rD;      // [64] 1/D
+    double* sq;      // [64] sqrt(D)/D
+};
+
+// One wave copies the 64x64 tile at (row0, col0) of G into an LDS array (row stride G64_LS): each request is one
+// 512-byte row, all 64 in flight (one memory round trip).  Agent-scope loads: the tile was written by a worker of this launch.
+__device__ __forceinline__ void gmw_stage_tile(double (*dst)[G64_LS], const double* __restrict__ G, int ld, int row0, int col0, int lane)
+{
+    const double* src = G + (size_t)row0 * ld + col0 + lane;
+    double v[64];
+#pragma unroll
+    for (int r = 0; r < 64; r++) v[r] = ld_dev(src + (size_t)r * ld);
+#pragma unroll
+    for (int r = 0; r < 64; r++) dst[r][lane] = v[r];
+}
+
+// Pivot workgroup: panels p = 0 .. T-1.  Same phases as gmw_step64_block00 (A slab, B tile (0,0), factor 1, C, factor 2);
+// what differs is where the operands come from: the previous panel from LDS, G tiles through agent-scope loads after
+// their version flags, and the panel buffer is published for the workers.
+__device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
+                                                  double* __restrict__ Dall, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
+                                                  double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg, double* xreg, double* keepreg,
+                                                  int* okp, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int qa = wv >> 1, qb = wv & 1;
+    const GmwColsLds ws = gmw_cols_carve(facreg), ws2 = gmw_cols_carve(facreg + GMW_FAC_DOUBLES);
+    double (*X01)[32] = (double (*)[32])xreg;
+    double (*X11)[32] = (double (*)[32])(xreg + 1024);
+    GmwPivotKeep kp;
+    kp.T1 = xreg + 2048; kp.T2 = xreg; kp.Ep = keepreg; kp.rD = keepreg + 1024; kp.sq = keepreg + 1088;
+    unsigned long long* ver = gmw_sync_ver(sy);
+    const int ro = (wv == 1) ? 0 : 32;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);        // wave-uniform copy: scalar branches around everything that polls or raises flags
+    const bool wv0 = wvu == 0, wv1 = wvu == 1, wv3 = wvu == 3;
+    if (wv0) *okp = 1;
+    if (wv3) gmw_stage_tile(Wc, G, ld, 0, 0, lane);            // region R_0 as k_syrk left it
+    __syncthreads();
+    for (int p = 0; p < T; p++) {
+        const int j0 = 64 * (p - 1), base = 64 * p;
+        const bool first = (p == 0);
+        GmwPanel64* nxt = pans + p;
+        if (wv0) GMW_TS(sy, p, 0);
+        // operands staged in LDS by waves 1 / 3 during factor 2 of the previous panel: Lr = tile (p-1, p) (rows of the
+        // current panel, columns of R), Wc = tile (p, p) (R itself)
+        if (wv0) { ws.Dv[lane & 31] = 0.0; ws2.Dv[lane & 31] = 0.0; }
+        d4 g;
+#pragma unroll
+        for (int t = 0; t < 4; t++) g[t] = Wc[16 * qa + lk + 4 * t][16 * qb + lr];
+        d4 acc[2][2];
+        zero_acc(acc);
+        if (wv & 1) {
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int b = 0; b < 2; b++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) X2[a][b][t] = G[(size_t)(j0 + 32 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr];
-            double dr[4][4], sqr[4][4];
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = Wc[ro + 16 * a + lk + 4 * t][32 + 16 * b + lr];
+        }
+        d4 X2[2];
+        double fb[8], dr[4][4];
+        if (!first) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) fb[u] = Lr[4 * u + lk][16 * wv + lr];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) X2[a][t] = Lr[32 + 16 * a + lk + 4 * t][16 * wv + lr];
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int t = 0; t < 4; t++) { dr[q][t] = cur->rD[16 * q + lk + 4 * t]; sqr[q][t] = cur->sq[16 * q + lk + 4 * t]; }
-            zero_acc(W1);
-            stage32_tri_globalB(W1, cur->Tt1, G + (size_t)j0 * ld, ld, n0, lane);
-            stage32_regB<true, false>(X2, cur->E, W1, lane);
-            zero_acc(W2);
-            stage32_regB<false, true>(W2, cur->Tt2, X2, lane);
-            const bool write_s = (blockIdx.y == 0) && (which == 1 || diagblk);
+                for (int t = 0; t < 4; t++) dr[q][t] = kp.rD[16 * q + lk + 4 * t];
+        }
+        __syncthreads();                                       // staged tiles are in registers: Lr / Wc may be rewritten
+        if (!first) {
+            // ---- A: slab for columns cw .. cw+15, panel matrices from LDS ----
+            d4 W1[2] = { (d4){0, 0, 0, 0}, (d4){0, 0, 0, 0} }, W2[2] = { (d4){0, 0, 0, 0}, (d4){0, 0, 0, 0} };
+            const int sw = 16 * (lk & 1);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double* rowp = &kp.T1[(4 * u + lk) * 33];
+                if (u < 4) W1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr], fb[u], W1[0], 0, 0, 0);
+                W1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[16 + lr], fb[u], W1[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double* rowp = &kp.Ep[(4 * u + lk) * 32];
+                X2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rowp[lr ^ sw], W1[u >> 2][u & 3], X2[0], 0, 0, 0);
+                X2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rowp[(16 + lr) ^ sw], W1[u >> 2][u & 3], X2[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double* rowp = &kp.T2[(4 * u + lk) * 33];
+                if (u < 4) W2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr], X2[u >> 2][u & 3], W2[0], 0, 0, 0);
+                W2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[16 + lr], X2[u >> 2][u & 3], W2[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int jj = 16 * a + lk + 4 * t, cc = 16 * wv + lr;
+                    Wc[jj][cc] = W1[a][t];       Lr[jj][cc] = W1[a][t] * dr[a][t];
+                    Wc[32 + jj][cc] = W2[a][t];  Lr[32 + jj][cc] = W2[a][t] * dr[2 + a][t];
+                }
+        }
+        if (wv0) GMW_TS(sy, p, 1);
+        // the panel buffer of the PREVIOUS panel (stores issued during its factor 2) is complete in memory by now:
+        // publish it here, off the end of the iteration, where nobody has to wait for the write acknowledgements
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p >= 1 && wv3) { gmw_set_flag(&sy->panel_ready, ebase + p); GMW_TS(sy, p + 64, 3); }
+        // ---- B: quarter (qa, qb) of tile (0,0), K = 64 ----
+        if (!first) {
+#pragma unroll
+            for (int k = 0; k < 64; k += 4)
+                g = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], g, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) ws.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = g[t];
+        __syncthreads();
+        if (wv0) GMW_TS(sy, p, 2);
+        // ---- factor 1 (+ panel S rows, tiles (0,1), (1,1)) ----
+        if (wv0) gmw_cols_pivot_wave(ws, eps, lane);
+        else if (wvu == 2) gmw_cols_t_wave<0>(ws, lane, nullptr, kp.T1);
+        else {
+            if (!first) {
+#pragma unroll
+                for (int k = 0; k < 64; k += 4) {
+                    const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
+                    const double b0 = Wc[k + lk][32 + lr], b1 = Wc[k + lk][48 + lr];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+            double (*X)[32] = (wv == 1) ? X01 : X11;           // X01 overwrites T2 of the previous panel: dead since phase A
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int b = 0; b < 2; b++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
-                        const double w1 = W1[a][b][t], w2 = W2[a][b][t];
-                        if (which == 0) {
-                            Lr[jj][cc] = w1 * dr[a][t]; Lr[32 + jj][cc] = w2 * dr[2 + a][t];
-                            if (diagblk) { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
-                        } else { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
-                        if (write_s) {
-                            if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = w1 * sqr[a][t];
-                            if (j0 + 32 + jj < n) Sout[(size_t)(j0 + 32 + jj) * ld + n0 + 16 * b + lr] = w2 * sqr[2 + a][t];
-                        }
+                    for (int t = 0; t < 4; t++) X[16 * a + lk + 4 * t][16 * b + lr] = acc[a][b][t];
+            if (!first) {
+                const int c4 = lr * 4;
+#pragma unroll 4
+                for (int i = 0; i < 8; i++) {
+                    const int row = ro + 4 * i + lk;
+                    const double sq = kp.sq[row];
+                    d4 w = *(const d4*)&Wc[row][c4];
+                    w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
+                    *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
+                }
+            }
+        }
+        __syncthreads();
+        if (wv0) GMW_TS(sy, p, 3);
+        // ---- C1: quarter (qa, qb) of W1d = T1' X01 and of E' = W1d / D' ----
+        {
+            d4 wq = (d4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                wq = __builtin_amdgcn_mfma_f64_16x16x4f64(kp.T1[(4 * u + lk) * 33 + 16 * qa + lr], X01[4 * u + lk][16 * qb + lr], wq, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int k = 16 * qa + lk + 4 * t, cc = 16 * qb + lr;
+                const double e = wq[t] * gmw_pivot_rcp(ws.Dv[k]);
+                Wc[k][cc] = wq[t];
+                Lr[k][cc] = e;
+                kp.Ep[k * 32 + (cc ^ (16 * (k & 1)))] = e;
+            }
+        }
+        __syncthreads();
+        // ---- C2: quarter of X11 -= E'^T W1d -> Xm of factor 2 ----
+        {
+            d4 x;
+#pragma unroll
+            for (int t = 0; t < 4; t++) x[t] = X11[16 * qa + lk + 4 * t][16 * qb + lr];
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], x, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) ws2.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = x[t];
+        }
+        __syncthreads();
+        if (wv0) GMW_TS(sy, p, 4);
+        // ---- factor 2.  Waves 1 / 3: E', T1', the (0,1) tile of S, the outputs of factor 1 — then each of them waits for
+        // one of the two tiles the NEXT panel needs (updated by the workers through the previous panel), copies it into
+        // LDS (Lr / Wc are free: wave 1 is the only reader of Lr's E' corner, wave 3 of Wc's W1d corner) — then the
+        // outputs of factor 2 as the pivot wave produces them.
+        if (wv0) { gmw_cols_pivot_wave(ws2, eps, lane); GMW_TS(sy, p + 64, 0); }
+        else if (wvu == 2) gmw_cols_t_wave<2>(ws2, lane, nxt->Tt2, kp.T2);
+        else {
+            const int c4 = (lane & 7) * 4;
+            if (wv1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = 8 * i + (lane >> 3);
+                    st_d4<true>(&nxt->E[row * 32 + c4], *(const d4*)&Lr[row][c4]);
+                }
+                gmw_copy_t<true>(kp.T1, nxt->Tt1, lane);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = 8 * i + (lane >> 3);
+                    const double Dr = ws.Dv[row];
+                    const double sq = (base + row < n) ? sqrt(Dr) * gmw_pivot_rcp(Dr) : 0.0;
+                    d4 w = *(const d4*)&Wc[row][c4];
+                    w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
+                    *(d4*)&Sout[(size_t)(base + row) * ld + base + 32 + c4] = w;
+                }
+            }
+            gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD);
+            if (p + 1 < T) {
+                // tile (p, p+1) -> Lr (wave 1), tile (p+1, p+1) -> Wc (wave 3); both carry the updates of panels 0 .. p-1
+                const int tr = wv1 ? p : p + 1;
+                if (wv1) GMW_TS(sy, p, 5);
+                const bool ready = (p == 0) || gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
+                if (wv1) GMW_TS(sy, p, 6);
+                if (!ready) *okp = 0;
+                else gmw_stage_tile(wv1 ? Lr : Wc, G, ld, 64 * tr, 64 * (p + 1), lane);
+            }
+            gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32);
+            if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
+        }
+        __syncthreads();                                       // closes the iteration: staged tiles visible, LDS arrays reusable
+        if (wv0) GMW_TS(sy, p, 7);
+        if (!*okp) { if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
+    // the last panel buffers are never read by a worker (steps T-2 and T-1 have no trailing tiles)
+}
+
+// k_gmw_persist: grid = 1 + workers (any number >= 0 of workers makes progress; with 0 workers and T > 1 the pivot would wait
+// for tiles nobody updates, so the launcher always provides at least one).
+struct GmwTask { short k, by, bx, pad; };
+__global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, double* __restrict__ G, GmwPanel64* __restrict__ pans,
+                                                     double* __restrict__ Sout, double* __restrict__ Dall, double eps,
+                                                     GmwSync* __restrict__ sy, const GmwTask* __restrict__ tasks, int ntasks,
+                                                     FrameScalars* __restrict__ fs)
+{
+    __shared__ double Lr[64][G64_LS];
+    __shared__ double Wc[64][G64_LS];
+    __shared__ double facreg[2 * GMW_FAC_DOUBLES];
+    __shared__ double xreg[1024 + 1024 + 32 * 33];
+    __shared__ double keepreg[1024 + 64 + 64];
+    __shared__ long long claimed;
+    __shared__ int ok;
+    const int tid = threadIdx.x;
+    const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
+    if (blockIdx.x == 0) {
+        gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, tid);
+    } else {
+        unsigned long long* ver = gmw_sync_ver(sy);
+        const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+        for (;;) {
+            if (wv0) {
+                unsigned long long c = 0;
+                if (tid == 0) c = __hip_atomic_fetch_add(&sy->claim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                claimed = (long long)gmw_uniform64(c);
+            }
+            __syncthreads();
+            const long long t = claimed;
+            GMW_DBG(sy, 0, 1000 + t);
+            if (t >= ntasks) break;
+            const GmwTask tk = tasks[t];
+            const int k = tk.k, I = k + 1 + tk.by, J = k + 1 + tk.bx;
+            // the tile and its two row-panel tiles carry the updates of panels 0 .. k-1 (written by earlier tasks)
+            if (wv0) {
+                bool good = true;
+                if (k > 0) {
+                    const unsigned long long want = ebase + k;
+                    unsigned long long a = 0, b = 0, c = 0;
+                    for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {      // the three flags in ONE round trip
+                        a = __hip_atomic_load(&ver[(size_t)I * T + J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        b = __hip_atomic_load(&ver[(size_t)k * T + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        c = __hip_atomic_load(&ver[(size_t)k * T + J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a = gmw_uniform64(a); b = gmw_uniform64(b); c = gmw_uniform64(c);
+                        if (a >= want && b >= want && c >= want) break;
+                        if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+                        __builtin_amdgcn_s_sleep(1);
                     }
+                    good = a >= want && b >= want && c >= want;
+                }
+                ok = good;
+            }
+            __syncthreads();
+            bool done = ok != 0;
+#ifdef SRUKF_GMW_DBG
+            const bool crit = tk.by == 0 && tk.bx == 1;
+            if (crit && wv0) GMW_TS(sy, 128 + k, 0);
+#endif
+            if (done) {
+                done = gmw_tile_update<true>(n, ld, 64 * k, tk.by, tk.bx, G, pans + k, Sout, Lr, Wc, tid, [&] {
+#ifdef SRUKF_GMW_DBG
+                    if (crit && wv0) GMW_TS(sy, 128 + k, 1);
+#endif
+                    if (wv0) ok = gmw_wait_ge(&sy->panel_ready, ebase + k + 1, &sy->abort);
+#ifdef SRUKF_GMW_DBG
+                    if (crit && wv0) GMW_TS(sy, 128 + k, 2);
+#endif
+                    __syncthreads();
+                    return ok != 0;
+                });
+            }
+            if (!done) { if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+#ifdef SRUKF_GMW_DBG
+            if (crit && wv0) GMW_TS(sy, 128 + k, 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (crit && wv0) GMW_TS(sy, 128 + k, 4);
+#endif
+            gmw_publish(&ver[(size_t)I * T + J], ebase + k + 1, wv0);
+#ifdef SRUKF_GMW_DBG
+            if (crit && wv0) GMW_TS(sy, 128 + k, 5);
+#endif
         }
     }
+    // the last workgroup out re-arms the block for the next launch and reports an abandoned run
+    GMW_DBG(sy, 6, 7777);
     __syncthreads();
-    // 2. tile update from LDS fragments, K = 64
-    if (live) {
-        const int ro = m0 - R0, co = c0 - C0;
-#pragma unroll
-        for (int k = 0; k < 64; k += 4) {
-            const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
-            const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    if (tid == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); }
+            __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->claim, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[a][b][t];
     }
 }
 
@@ -646,6 +1104,32 @@ void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* U
 {
     const int extra = dxp ? (d.n + 255) / 256 : 0;
     hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X);
+}
+int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + sizeof(unsigned long long) * (size_t)T * T); }
+// host-side task list of the persistent launch: step k = 0 .. T-2, tiles (by, bx) of the (T-1-k)^2 trailing square
+// without (0,0); within a step (0,1) and (1,1) first (the pivot waits for them), then the rest of block row 0 (the
+// row-panel tiles every task of the next step reads), then the other rows.  Returns the number of tasks; out may be null.
+int srukf_gmw_build_tasks(int T, short* out)
+{
+    int cnt = 0;
+    auto put = [&](int k, int by, int bx) { if (out) { out[4 * cnt] = (short)k; out[4 * cnt + 1] = (short)by; out[4 * cnt + 2] = (short)bx; out[4 * cnt + 3] = 0; } cnt++; };
+    for (int k = 0; k + 1 < T; k++) {
+        const int Tk = T - 1 - k;
+        if (Tk >= 2) { put(k, 0, 1); put(k, 1, 1); }
+        for (int bx = 2; bx < Tk; bx++) put(k, 0, bx);
+        for (int by = 1; by < Tk; by++)
+            for (int bx = by; bx < Tk; bx++) if (!(by == 1 && bx == 1)) put(k, by, bx);
+    }
+    return cnt;
+}
+void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
+                              void* sync, const void* tasks, int ntasks, int workers, void* fs)
+{
+    const int T = ld / 64;
+    if (T > 1 && workers < 1) workers = 1;
+    if (T <= 1) workers = 0;
+    hipLaunchKernelGGL(k_gmw_persist, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
+                       (GmwSync*)sync, (const GmwTask*)tasks, ntasks, (FrameScalars*)fs);
 }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
 void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)

@@ -194,7 +194,7 @@ template <int J0, int J1> __device__ __forceinline__ void gmw_t_prefetch(GmwTPre
 }
 // Group [J0, J1); [N0, N1) is the group after it (N1 == N0: none), read ahead into nxt before this group's FMAs so that a
 // follower that has fallen behind pays no LDS round trip per group.
-template <int J0, int J1, int N0, int N1, bool GLOBAL>
+template <int J0, int J1, int N0, int N1, int GLOBAL>
 __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w, unsigned dv, int lane,
                                             double* __restrict__ Tt, double* Tl, GmwTPre& cur, GmwTPre& nxt)
 {
@@ -216,19 +216,20 @@ __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w
 #pragma unroll
         for (int r = R0; r < R1; r++) Tl[lane * 33 + r] = t[r];
     }
-    if constexpr (GLOBAL) {
+    if constexpr (GLOBAL != 0) {
         const int kk = (NR == 8) ? (lane >> 1) : lane, jj = R0 + ((NR == 8) ? 4 * (lane & 1) : 0);
         if (NR == 8 || lane < 32) {
             const double* src = &Tl[kk * 33 + jj];
             d4 v = { src[0], src[1], src[2], src[3] };
-            *(d4*)&Tt[kk * 32 + jj] = v;
+            st_d4<GLOBAL == 2>(&Tt[kk * 32 + jj], v);
         }
     }
 }
 
 // Follower wave 1: T = L^{-1}, column c' = lane & 31 per lane, into the LDS array Tl[kk][33] = T[jj][kk] (32 x 33 doubles)
 // and, if GLOBAL, through it to Tt[kk*32 + jj] in global memory (otherwise gmw_copy_t does that later).
-template <bool GLOBAL>
+// GLOBAL: 0 = LDS copy only, 1 = also to Tt with plain stores, 2 = with agent-scope stores (read by other workgroups of the same launch)
+template <int GLOBAL>
 __device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt, double* Tl)
 {
     const int c = lane & 31;
@@ -246,6 +247,7 @@ __device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, d
     gmw_t_group<28, 31, 0, 0, GLOBAL>(t, w, dv, lane, Tt, Tl, pb, pa);
 }
 // Tl[kk][33] -> Tt[kk*32 + jj], one wave, coalesced 128-bit stores
+template <bool DEV = false>
 __device__ __forceinline__ void gmw_copy_t(const double* Tl, double* __restrict__ Tt, int lane)
 {
 #pragma unroll
@@ -253,13 +255,13 @@ __device__ __forceinline__ void gmw_copy_t(const double* Tl, double* __restrict_
         const int kk = 8 * i + (lane >> 3), jj = (lane & 7) * 4;
         const double* src = &Tl[kk * 33 + jj];
         d4 v = { src[0], src[1], src[2], src[3] };
-        *(d4*)&Tt[kk * 32 + jj] = v;
+        st_d4<DEV>(&Tt[kk * 32 + jj], v);
     }
 }
 
 // Follower wave 2: outputs of rows J0..J1-1 — S rows j0+J (diagonal-block part), pivots, per-row scales of the
 // panel buffer.  Lane l handles row J0 + (l >> 3) (when the group has 8 rows) and four columns.
-template <int J0, int J1> __device__ __forceinline__ void gmw_out_group(const GmwColsLds& w, unsigned dv, int lane, int n, int ld, int j0,
+template <int J0, int J1, bool DEV> __device__ __forceinline__ void gmw_out_group(const GmwColsLds& w, unsigned dv, int lane, int n, int ld, int j0,
                                                                         double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
                                                                         double* __restrict__ Dall, double* __restrict__ Sout, double* lsq, double* lrc)
 {
@@ -273,7 +275,9 @@ template <int J0, int J1> __device__ __forceinline__ void gmw_out_group(const Gm
     const double sq = sqrt(D);
     if ((lane & 7) == 0) {
         const double rc = gmw_pivot_rcp(D);
-        pD[j] = D; psq[j] = sq * rc; prD[j] = rc; Dall[j0 + j] = D;
+        if constexpr (DEV) { st_dev(&pD[j], D); st_dev(&psq[j], sq * rc); st_dev(&prD[j], rc); }
+        else { pD[j] = D; psq[j] = sq * rc; prD[j] = rc; }
+        Dall[j0 + j] = D;
         if (lsq) { lsq[j] = sq * rc; lrc[j] = rc; }                    // workgroup-local copies
     }
     // the whole 32-byte chunk is stored: zeros below the diagonal and in the padding rows / columns are what S holds there anyway
@@ -286,17 +290,18 @@ template <int J0, int J1> __device__ __forceinline__ void gmw_out_group(const Gm
     *(d4*)&Sout[(size_t)(j0 + j) * ld + j0 + c0] = v;
 }
 // Two output waves (which = 0 / 1) take alternate groups, so the last group starts the moment its rows exist.
+template <bool DEV = false>
 __device__ __forceinline__ void gmw_cols_out_wave(const GmwColsLds& w, int which, int lane, int n, int ld, int j0,
                                                   double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
                                                   double* __restrict__ Dall, double* __restrict__ Sout, double* lsq = nullptr, double* lrc = nullptr)
 {
     const unsigned dv = lds_off(w.Dv);
     if (which == 0) {
-        gmw_out_group<0, 8>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
-        gmw_out_group<16, 24>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
-        gmw_out_group<28, 32>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<0, 8, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<16, 24, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<28, 32, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     } else {
-        gmw_out_group<8, 16>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
-        gmw_out_group<24, 28>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<8, 16, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<24, 28, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     }
 }
