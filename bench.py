@@ -116,6 +116,7 @@ def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local):
     for b in range(B):
         sc = synth.make_scene(N, W + K, seed=0, p=synth.scene_params(), obs_seed=5000 + b)
         f = srukf.Filter(N, sc["params"], device=local)          # own stream
+        f.set_exclusive(False)                                   # B filters share the GPU: one launch per panel, no residency assumption
         f.set_state(sc["X0"], sc["S0"])
         f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
         fs.append(f)

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <cstddef>
 #include <vector>
 #include <algorithm>
 #include <utility>
@@ -28,7 +29,8 @@ void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, in
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
 int srukf_gmw_panel_bytes(void);
 int srukf_gmw_sync_bytes(int T);
-int srukf_gmw_build_tasks(int T, short* out);
+int srukf_gmw_build_tiles(int T, short* out);
+int srukf_gmw_persist_workers(int T, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
@@ -113,47 +115,49 @@ __global__ __launch_bounds__(256) void k_quantize(int n, int ld, double* __restr
 #define SRUKF_GRAPH_FRAMES 8
 static thread_local std::string g_create_error;
 
-enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_SYRK, KC_GMW_TRAIL, KC_GMW_CHECK,
+enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_SYRK, KC_GMW_TRAIL, KC_GMW_PERSIST, KC_GMW_CHECK,
               KC_GMW_COL, KC_MISC, KC_COUNT };
 static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_syrk",
-                                             "k_gmw_step64", "k_gmw_check", "k_gmw_col", "misc" };
+                                             "k_gmw_step64", "k_gmw_persist", "k_gmw_check", "k_gmw_col", "misc" };
 
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
-struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tasks = nullptr; int ntasks = 0, T = 0, max_workers = 0; };
+struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, workers = -1; };
 static void gmw_plan_destroy(GmwPlan& g)
 {
     if (g.pans) hipFree(g.pans);
     if (g.sync) hipFree(g.sync);
-    if (g.tasks) hipFree(g.tasks);
+    if (g.tiles) hipFree(g.tiles);
     g = GmwPlan();
 }
+// workers = -1 afterwards: the matrix has more tiles than resident workgroups can own (the per-panel launches are used)
 static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st)
 {
     g.T = np / 64;
-    g.ntasks = srukf_gmw_build_tasks(g.T, nullptr);
-    std::vector<short> tk((size_t)4 * (g.ntasks > 0 ? g.ntasks : 1), 0);
-    srukf_gmw_build_tasks(g.T, tk.data());
-    const int step0 = g.T >= 2 ? (g.T - 1) * g.T / 2 - 1 : 0;          // tiles of the first (largest) step
-    g.max_workers = step0 < 1 ? (g.T > 1 ? 1 : 0) : (step0 > 255 ? 255 : step0);
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 2;
+    g.workers = srukf_gmw_persist_workers(g.T, cus - 1);        // one workgroup per CU (LDS), all of them resident
+    g.ntiles = srukf_gmw_build_tiles(g.T, nullptr);
+    std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
+    srukf_gmw_build_tiles(g.T, tk.data());
     const size_t sync_bytes = (size_t)srukf_gmw_sync_bytes(g.T);
     if (hipMalloc(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T) != hipSuccess ||
         hipMalloc(&g.sync, sync_bytes) != hipSuccess ||
-        hipMalloc(&g.tasks, sizeof(short) * tk.size()) != hipSuccess) { gmw_plan_destroy(g); return SRUKF_ERR_NOMEM; }
-    GmwSync hs; memset(&hs, 0, sizeof hs); hs.epoch = 1;
+        hipMalloc(&g.tiles, sizeof(short) * tk.size()) != hipSuccess) { gmw_plan_destroy(g); return SRUKF_ERR_NOMEM; }
+    const unsigned long long epoch1 = 1;                         // everything else starts at zero
     if (hipMemsetAsync(g.pans, 0, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
         hipMemsetAsync(g.sync, 0, sync_bytes, st) != hipSuccess ||
-        hipMemcpyAsync(g.sync, &hs, sizeof hs, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(g.tasks, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync((char*)g.sync + offsetof(GmwSync, epoch), &epoch1, sizeof epoch1, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(g.tiles, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { gmw_plan_destroy(g); return SRUKF_ERR_HIP; }
     return SRUKF_OK;
 }
-// 0 = one launch per 64-row panel (default), 1 = one persistent launch per factorisation (SRUKF_GMW_PERSIST=1; experimental)
+// 1 = one persistent launch per factorisation (default), 0 = one launch per 64-row panel (SRUKF_GMW_PERSIST=0: A/B runs)
 static int gmw_persist_mode()
 {
     static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SRUKF_GMW_PERSIST"); mode = (e && e[0] == '1') ? 1 : 0; }
+    if (mode < 0) { const char* e = getenv("SRUKF_GMW_PERSIST"); mode = (e && e[0] == '0') ? 0 : 1; }
     return mode;
 }
 
@@ -185,7 +189,7 @@ struct srukf_ctx {
     double* Sdis = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered), one launch per panel
     GmwPlan gplan;                         // persistent GMW launch: panel buffers, sync block, task list
-    int gmw_workers = 0;                   // worker workgroups of the persistent launch (0 = as many as step 0 has tiles, <= 255)
+    int gmw_shared = 0;                    // 1: the GPU is shared with other filters — never use the persistent launch (it needs all its workgroups resident)
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
     int n_syrk_tiles = 0, n_pxy_tiles = 0;
     FrameScalars* fs = nullptr;
@@ -325,6 +329,7 @@ static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
 // one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path.
 // need_reset: the gamma/xi accumulators were not just cleared by k_gain (SEQUENTIAL mode, fallbacks).
 // frame_tail: the check kernel also records the trajectory row and advances the staged frame counter.
+static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && !c->gmw_shared && c->gplan.workers >= 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout);
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
 {
@@ -346,10 +351,10 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         // per panel: trailing update 64*r2^2 (upper half, 2 flop) + three-stage slab recompute + next 64x64 diagonal region
         auto panel_flop = [&](int j0) { const double r2 = np - j0 - 64; return j0 < 0 ? 64.0 * 64.0 * 64.0 / 3.0 : 64.0 * r2 * r2 + 3.0 * 2.0 * 32.0 * 32.0 * r2 + 64.0 * 64.0 * 64.0 / 3.0; };
         auto panel_byte = [&](int j0) { const double r2 = np - j0 - 64; return 8.0 * (r2 * r2 + 2.0 * 64.0 * r2); };
-        if (gmw_persist_mode()) {
+        if (gmw_use_persist(c)) {
             double fl = 0.0, by = 0.0;
             for (int j0 = -64; j0 + 64 < np; j0 += 64) { fl += panel_flop(j0); by += panel_byte(j0); }
-            ProfScope ps(c, KC_GMW_TRAIL, fl, by);
+            ProfScope ps(c, KC_GMW_PERSIST, fl, by);
             launch_gmw_fast(c, c->G, c->S);
         } else {
             int pb = 0;
@@ -374,10 +379,11 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout)
 {
     const int np = c->d.np, n = c->d.n;
-    if (gmw_persist_mode()) {
-        int w = c->gmw_workers > 0 ? c->gmw_workers : c->gplan.max_workers;
-        if (w > c->gplan.max_workers) w = c->gplan.max_workers;
-        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, c->gplan.pans, c->D, Sout, c->gplan.sync, c->gplan.tasks, c->gplan.ntasks, w, c->fs);
+    if (gmw_use_persist(c)) {
+        // SRUKF_GMW_TEST_STARVE (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait expires,
+        // the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
+        const int workers = getenv("SRUKF_GMW_TEST_STARVE") ? 0 : c->gplan.workers;
+        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, c->gplan.pans, c->D, Sout, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles, workers, c->fs);
         return;
     }
     int pb = 0;
@@ -752,10 +758,17 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     return SRUKF_OK;
 }
 
+static void drop_graphs(srukf_ctx* c);
 static int read_fs(srukf_ctx* c)
 {
     HIPCHK(c, hipMemcpyAsync(c->hfs, c->fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->hfs->gmw_aborts > 0 && !c->gmw_shared) {
+        // a persistent launch did not get all its workgroups onto the GPU in time (somebody else is using it): the flagged
+        // frame is repeated on the exact path like a clamp frame, and this filter stays with one launch per panel
+        c->gmw_shared = 1;
+        drop_graphs(c);
+    }
     return SRUKF_OK;
 }
 
@@ -834,6 +847,14 @@ static void drop_graphs(srukf_ctx* c)
     if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     if (c->graph8_exec) { hipGraphExecDestroy(c->graph8_exec); c->graph8_exec = nullptr; }
     if (c->graph8) { hipGraphDestroy(c->graph8); c->graph8 = nullptr; }
+}
+int srukf_set_exclusive(srukf_ctx* c, int exclusive)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int shared = exclusive ? 0 : 1;
+    if (shared != c->gmw_shared) { c->gmw_shared = shared; drop_graphs(c); }
+    return SRUKF_OK;
 }
 int srukf_set_storage(srukf_ctx* c, int storage)
 {
@@ -1050,7 +1071,7 @@ static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     const bool own = c->own_stream;
     std::swap(*c, *c2);
     c->own_stream = own; c2->own_stream = false;
-    c->profiling = c2->profiling; c->use_graph = c2->use_graph; c->gmw_workers = c2->gmw_workers;
+    c->profiling = c2->profiling; c->use_graph = c2->use_graph; c->gmw_shared = c2->gmw_shared;
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
     c2->profiling = false; c2->pev.clear();
@@ -1198,7 +1219,8 @@ int srukf_synchronize(srukf_ctx* c)
         c->async_pending = false;
         int rc = read_fs(c); if (rc) return rc;
         if (c->hfs->clamp_rows > 0) {
-            char b[160]; snprintf(b, sizeof b, "GMW theta clamp active on %d pivot rows (first row %d) during async frames", c->hfs->clamp_rows, c->hfs->clamp_first);
+            char b[160]; snprintf(b, sizeof b, "GMW theta clamp active on %d pivot rows (first row %d) during async frames%s", c->hfs->clamp_rows, c->hfs->clamp_first,
+                                 c->hfs->gmw_aborts > 0 ? " (a persistent factorisation launch was abandoned: the GPU is shared; see srukf_set_exclusive)" : "");
             c->err = b;
             return SRUKF_ERR_CLAMP_PENDING;
         }
@@ -1259,10 +1281,10 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
     srukf_launch_gmw_stats(st, n, np, dG, dFs);
     FrameScalars fs;
     if (!force_slow) {
-        if (gmw_persist_mode()) {
+        if (gmw_persist_mode() && srukf_gmw_persist_workers(np / 64, 255) >= 0) {
             GmwPlan gp;
             if (gmw_plan_create(gp, np, st) != SRUKF_OK) return SRUKF_ERR_NOMEM;
-            srukf_launch_gmw_persist(st, n, np, epsilon, dG, gp.pans, dD, dS, gp.sync, gp.tasks, gp.ntasks, gp.max_workers, dFs);
+            srukf_launch_gmw_persist(st, n, np, epsilon, dG, gp.pans, dD, dS, gp.sync, gp.tiles, gp.ntiles, gp.workers, dFs);
             hipDeviceSynchronize();
             gmw_plan_destroy(gp);
         } else {

@@ -42,6 +42,7 @@ struct FrameScalars {
     int frame;                 // frame counter for staged sequences
     int stat_count;            // measurement-statistics slices finished in the current k_pxy launch (last one runs the final pass)
     double* traj_base;         // device trajectory buffer of the current replay (row = absolute frame), or null
+    int gmw_aborts;            // persistent GMW launches abandoned on an expired wait (their frames are flagged like clamp rows)
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -169,15 +170,18 @@ template <bool DEV> __device__ __forceinline__ void st_d4(double* p, d4 v)
 
 // ---- synchronisation block of the persistent GMW launch (k_gmw_persist) ----
 // Flags carry (epoch << GMW_EPOCH_SHIFT) + count, so the T*T tile versions never need clearing: values of older runs
-// compare as "not set".  The last workgroup to leave a launch re-arms claim / exited and advances the epoch.
+// compare as "not set".  The last workgroup to leave a launch re-arms the block and advances the epoch.
 #define GMW_EPOCH_SHIFT 12
+#define GMW_FLAG_COPIES 16          // the two panel flags are polled by every worker at once: one copy per 16 workgroups,
+#define GMW_FLAG_STRIDE 512         // 4 KB apart (unsigned long longs), so that the polls do not all queue on one memory channel
 struct GmwSync {
-    unsigned long long claim;        // next entry of the worker task list
     unsigned long long epoch;        // run counter (starts at 1)
-    unsigned long long panel_ready;  // (epoch << SHIFT) + number of panels published by the pivot workgroup
     unsigned int exited;             // workgroups that have left the current launch
     int abort;                       // a bounded wait expired: everybody leaves, the frame is flagged for the exact path
     unsigned long long* dbg;         // diagnostic builds: host-visible progress markers (null in the product)
+    unsigned long long pad[61];
+    unsigned long long panel_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];  // copy c at [c * STRIDE]: (epoch << SHIFT) + panels published
+    unsigned long long half_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];   // same for the first half of a panel buffer (Tt1, E, pivots of sub-panel 1)
     // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)
 };
 __device__ __forceinline__ unsigned long long* gmw_sync_ver(GmwSync* sy) { return (unsigned long long*)(sy + 1); }

@@ -436,14 +436,25 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
 //      above (one 32-column half slab per wave, register resident) and keeps L = W/D and W in LDS;
 //   2. updates its tile  G[r][c] -= sum_{kk<64} L[kk][r] W[kk][c];
 //   3. first block row only: writes the final S rows j0..j0+63 for its column slab.
-// DEV: G tiles and the panel buffer are exchanged with other workgroups of the SAME launch (agent-scope accesses).
-// wait_panel(): called once by ALL threads between the loads that do not depend on the panel buffer (the G tile and
-// the panel's G rows) and those that do; returns false to abandon the tile.  The persistent kernel waits for the
-// pivot's panel_ready flag there, with the G operands already in flight.
-template <bool DEV, class WaitPanel>
+// The work is ordered by what it needs of the panel buffer, so that a worker of the persistent launch can start while
+// the pivot workgroup is still factoring the panel's second half:
+//   nothing   : the G tile and the panel's G rows (loads)
+//   half one  : Tt1, E, 1/D[0..31]  ->  W1 = T1 G1,  G2' = G2 - E^T W1,  rows 0..31 of the slabs,  K = 0..31 of the update
+//   half two  : Tt2, 1/D[32..63], sqrt(D)/D  ->  W2 = T2 G2',  rows 32..63,  K = 32..63,  tile store,  S rows
+// wait_half() / wait_full(): called once each by ALL threads (they hold the workgroup barrier that separates this
+// call's LDS writes from the previous call's reads); false abandons the tile.  stored(): called by all threads right
+// after the tile store — the persistent kernel raises the tile's flag there, before the S rows nobody waits for.
+// acc: this wave's 32x32 quadrant.  load_tile / store_tile: read it from / write it back to G (the persistent kernel
+// keeps a tile in registers from its first update to its last).
+// DEV: G tiles are exchanged with other workgroups of the SAME launch (agent-scope accesses).  The panel buffer is read
+// with plain loads in both cases: it is written once per launch (agent-scope stores, before its flags) and read only
+// after them, so no L2 can hold an older copy — and the ~170 workgroups that want the same 24 KB at the same moment
+// are served by their XCD's L2 instead of one memory channel.
+template <bool DEV, class WaitHalf, class WaitFull, class Stored>
 __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, int bx, double* __restrict__ G,
                                                 const GmwPanel64* cur, double* __restrict__ Sout,
-                                                double (*Lr)[G64_LS], double (*Wc)[G64_LS], int tid, WaitPanel&& wait_panel)
+                                                double (*Lr)[G64_LS], double (*Wc)[G64_LS], int tid, d4 (&acc)[2][2],
+                                                bool load_tile, bool store_tile, WaitHalf&& wait_half, WaitFull&& wait_full, Stored&& stored)
 {
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -452,9 +463,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
     const bool diagblk = bx == by;
     const int m0 = R0 + 32 * (wv >> 1), c0 = C0 + 32 * (wv & 1);
     const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
-    d4 acc[2][2];
-    zero_acc(acc);
-    if (live) {
+    if (live && load_tile) {
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -463,11 +472,13 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                 for (int t = 0; t < 4; t++)
                     acc[a][b][t] = ld_g<DEV>(&G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr]);
     }
-    // 1. half slab of this wave: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
+    // half slab of this wave: waves 0,1 -> row slab halves, waves 2,3 -> column slab halves
     const int which = wv >> 1, half = wv & 1;
     const int n0 = (which ? C0 : R0) + 32 * half;
     const bool slab = n0 < ld && !(diagblk && which == 1);
-    d4 X2[2][2];
+    const bool write_s = slab && (by == 0) && (which == 1 || diagblk);
+    const int ro = m0 - R0, co = c0 - C0;
+    d4 X2[2][2], W1[2][2], W2[2][2];
     double fb0[8], fb1[8];
     if (slab) {
 #pragma unroll
@@ -481,31 +492,22 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
             fb0[u] = ld_g<DEV>(&G[(size_t)(j0 + 4 * u + lk) * ld + n0 + lr]); fb1[u] = ld_g<DEV>(&G[(size_t)(j0 + 4 * u + lk) * ld + n0 + 16 + lr]);
         }
     }
-    if (!wait_panel()) return false;
+    // ---- first half of the panel ----
+    if (!wait_half()) return false;
     if (slab) {
-        // every fragment of the three panel matrices is requested before the first MFMA (one memory round trip, not three).
-        // Plain loads, also in the persistent launch: each panel buffer is written once per launch (agent-scope stores, before
-        // its flag) and read only after the flag, so no L2 can hold an older copy — and the ~170 workgroups that want the
-        // same 24 KB at the same moment are served by their XCD's L2 instead of one memory channel.
-        double ta0[4], ta1[8], ea0[8], ea1[8], tb0[4], tb1[8];
+        double ta0[4], ta1[8], ea0[8], ea1[8], dr[2][4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < 8; u++) {                          // every fragment is requested before the first MFMA
             const int o = (4 * u + lk) * 32 + lr;
-            if (u < 4) { ta0[u] = cur->Tt1[o]; tb0[u] = cur->Tt2[o]; }
-            ta1[u] = cur->Tt1[o + 16]; tb1[u] = cur->Tt2[o + 16];
+            if (u < 4) ta0[u] = cur->Tt1[o];
+            ta1[u] = cur->Tt1[o + 16];
             ea0[u] = cur->E[o]; ea1[u] = cur->E[o + 16];
         }
-        const bool write_s = (by == 0) && (which == 1 || diagblk);
-        double dr[4][4], sqr[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                dr[q][t] = (which == 0) ? cur->rD[16 * q + lk + 4 * t] : 0.0;
-                sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
-            }
-        d4 W1[2][2], W2[2][2];
-        zero_acc(W1); zero_acc(W2);
+            for (int t = 0; t < 4; t++) dr[q][t] = (which == 0) ? cur->rD[16 * q + lk + 4 * t] : 0.0;
+        zero_acc(W1);
         // W1 = T1 G1 (T1 unit lower triangular: output rows 0..15 only see k < 16)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -525,6 +527,50 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
             X2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea1[u], W1[a2][0][t], X2[1][0], 0, 0, 0);
             X2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea1[u], W1[a2][1][t], X2[1][1], 0, 0, 0);
         }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
+                    const double w1 = W1[a][b][t];
+                    if (which == 0) { Lr[jj][cc] = w1 * dr[a][t]; if (diagblk) Wc[jj][cc] = w1; }
+                    else Wc[jj][cc] = w1;
+                }
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
+            const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // ---- second half ----
+    if (!wait_full()) return false;
+    double sqr[4][4];
+    if (slab) {
+        double tb0[4], tb1[8], dr[2][4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int o = (4 * u + lk) * 32 + lr;
+            if (u < 4) tb0[u] = cur->Tt2[o];
+            tb1[u] = cur->Tt2[o + 16];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) dr[q][t] = (which == 0) ? cur->rD[32 + 16 * q + lk + 4 * t] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
+        zero_acc(W2);
         // W2 = T2 G2'
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -542,24 +588,16 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
             for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const int jj = 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
-                    const double w1 = W1[a][b][t], w2 = W2[a][b][t];
-                    if (which == 0) {
-                        Lr[jj][cc] = w1 * dr[a][t]; Lr[32 + jj][cc] = w2 * dr[2 + a][t];
-                        if (diagblk) { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
-                    } else { Wc[jj][cc] = w1; Wc[32 + jj][cc] = w2; }
-                    if (write_s) {
-                        if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = w1 * sqr[a][t];
-                        if (j0 + 32 + jj < n) Sout[(size_t)(j0 + 32 + jj) * ld + n0 + 16 * b + lr] = w2 * sqr[2 + a][t];
-                    }
+                    const int jj = 32 + 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
+                    const double w2 = W2[a][b][t];
+                    if (which == 0) { Lr[jj][cc] = w2 * dr[a][t]; if (diagblk) Wc[jj][cc] = w2; }
+                    else Wc[jj][cc] = w2;
                 }
     }
     __syncthreads();
-    // 2. tile update from LDS fragments, K = 64
     if (live) {
-        const int ro = m0 - R0, co = c0 - C0;
 #pragma unroll
-        for (int k = 0; k < 64; k += 4) {
+        for (int k = 32; k < 64; k += 4) {
             const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
             const double b0 = Wc[k + lk][co + lr], b1 = Wc[k + lk][co + 16 + lr];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
@@ -567,15 +605,30 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (store_tile) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        double* gp = &G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+                        if constexpr (DEV) st_dev(gp, acc[a][b][t]); else *gp = acc[a][b][t];
+                    }
+        }
+    }
+    stored();
+    // final S rows j0 .. j0+63 of this wave's half slab (first block row only)
+    if (write_s) {
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++)
 #pragma unroll
-                for (int t = 0; t < 4; t++)
-                {
-                    double* gp = &G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
-                    if constexpr (DEV) st_dev(gp, acc[a][b][t]); else *gp = acc[a][b][t];
+                for (int t = 0; t < 4; t++) {
+                    const int jj = 16 * a + lk + 4 * t;
+                    if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = W1[a][b][t] * sqr[a][t];
+                    if (j0 + 32 + jj < n) Sout[(size_t)(j0 + 32 + jj) * ld + n0 + 16 * b + lr] = W2[a][b][t] * sqr[2 + a][t];
                 }
     }
     return true;
@@ -604,7 +657,9 @@ __global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int f
         gmw_step64_block00(n, ld, j0, first, eps, G, cur, nxt, Dall, Sout, Lr, Wc, facreg, xreg, tid);
         return;
     }
-    gmw_tile_update<false>(n, ld, j0, blockIdx.y, blockIdx.x, G, cur, Sout, Lr, Wc, tid, [] { return true; });
+    d4 acc[2][2];
+    zero_acc(acc);
+    gmw_tile_update<false>(n, ld, j0, blockIdx.y, blockIdx.x, G, cur, Sout, Lr, Wc, tid, acc, true, true, [] { return true; }, [] { return true; }, [] {});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -614,23 +669,27 @@ __global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int f
 // start (kernarg + first loads from HBM, ~2.3 us: every launch begins with an invalidated L2) on top of the ~9.5 us
 // of arithmetic of the critical-path workgroup.  Here that workgroup ("pivot", blockIdx 0) stays resident: it keeps
 // the panel it has just factored in LDS (T1', E', T2', 1/D), applies it to the next 64x64 diagonal region itself and
-// factors that, panel after panel.  The trailing updates are a task list (step k, tile (by, bx)) in dependency order;
-// the other workgroups ("workers") claim entries with an atomic counter.  Hand-off goes through global memory:
+// factors that, panel after panel.  Every other 64x64 tile (I, J) of the trailing matrix is OWNED by one worker
+// workgroup, which holds it in registers from its first update to its last: a tile that went back to memory after
+// every panel would need  store + acknowledge + flag + poll + load  (~2 us, scripts/mb/mb_xwg.hip) plus the update
+// itself (~4 us) per panel — longer than the pivot's period, and the tile chains, not the pivot, would set the pace
+// (measured with a task-queue version: 13 us per panel against 9.6 us).  Hand-off through global memory:
 //   pivot  -> workers : panel buffer pans[k] (agent-scope stores), then panel_ready = k + 1
-//   worker -> anybody : G tile (agent-scope stores), then ver[I][J] = number of panels applied to it
-//   a task (k; by, bx), I = k+1+by, J = k+1+bx, needs panel k, ver[I][J] >= k and the two row-panel tiles
-//   ver[k][I], ver[k][J] >= k;  the pivot, before panel p, needs ver[p-1][p] and ver[p][p] >= p-1
-//   (tiles (0,1) and (1,1) of step p-2: first in that step's list, a whole pivot iteration ahead of their use).
-// Tasks are claimed in list order and only depend on the pivot and on EARLIER entries, so whoever holds an
-// unfinished dependency is already running: no deadlock whatever share of the grid is resident (several filters may
-// share the GPU).  Every wait is bounded; on expiry the launch is abandoned and the frame flagged (exact path reruns it).
+//   owner  -> anybody : the tile, once, when it has received its last update: G tile (agent-scope stores), then
+//                       ver[I][J] = number of panel updates it carries (I for I < J; I - 1 on the diagonal, where the
+//                       pivot applies the last panel itself)
+//   step k of tile (I, J) needs panel k and the finished row-panel tiles (k, I), (k, J);
+//   the pivot, before panel p, needs tiles (p-1, p) and (p, p).
+// Every workgroup of the grid must be resident (1 + workers <= CUs; the launcher sees to that, and a filter that
+// shares the GPU with others uses the one-launch-per-panel path).  Every wait is bounded: on expiry the launch is
+// abandoned and the frame flagged, and the caller repeats it on the other path.
 // ------------------------------------------------------------------------------------------------
 // Who polls and who raises flags: WAVE 0 as a whole, under wave-uniform (scalar) conditions, never "if (tid == 0)".
 // A divergent single-thread branch just before the back edge of the task loop and another one right after its head
 // get merged by the structurizer into a lane-divergent loop around the workgroup barrier (wave 0 then executes
 // s_barrier more often than the other waves: hang).  Uniform branches leave EXEC alone; 64 lanes loading or storing
 // the same flag word are one memory request.
-#define GMW_XWG_LIMIT (1 << 18)
+#define GMW_XWG_LIMIT (1 << 16)                 // ~50 ms; a legitimate wait is over in microseconds
 __device__ __forceinline__ unsigned long long gmw_uniform64(unsigned long long v)
 {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
@@ -647,6 +706,11 @@ __device__ __forceinline__ bool gmw_wait_ge(const unsigned long long* f, unsigne
 __device__ __forceinline__ void gmw_set_flag(unsigned long long* f, unsigned long long v)
 {
     __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all copies of a panel flag: lane c < COPIES stores copy c (one instruction; called by a whole wave)
+__device__ __forceinline__ void gmw_set_panel_flag(unsigned long long* f, unsigned long long v, int lane)
+{
+    if (lane < GMW_FLAG_COPIES) __hip_atomic_store(&f[lane * GMW_FLAG_STRIDE], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // all agent-scope stores of this workgroup have landed -> wave 0 raises the flag (wv0: wave-uniform "this is wave 0")
 __device__ __forceinline__ void gmw_publish(unsigned long long* f, unsigned long long v, bool wv0)
@@ -683,7 +747,7 @@ __device__ __forceinline__ void gmw_stage_tile(double (*dst)[G64_LS], const doub
 __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                   double* __restrict__ Dall, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
                                                   double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg, double* xreg, double* keepreg,
-                                                  int* okp, int tid)
+                                                  int* okp, int* halfcnt, int tid)
 {
     const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int qa = wv >> 1, qb = wv & 1;
@@ -706,7 +770,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
         if (wv0) GMW_TS(sy, p, 0);
         // operands staged in LDS by waves 1 / 3 during factor 2 of the previous panel: Lr = tile (p-1, p) (rows of the
         // current panel, columns of R), Wc = tile (p, p) (R itself)
-        if (wv0) { ws.Dv[lane & 31] = 0.0; ws2.Dv[lane & 31] = 0.0; }
+        if (wv0) { ws.Dv[lane & 31] = 0.0; ws2.Dv[lane & 31] = 0.0; *halfcnt = 0; }
         d4 g;
 #pragma unroll
         for (int t = 0; t < 4; t++) g[t] = Wc[16 * qa + lk + 4 * t][16 * qb + lr];
@@ -767,11 +831,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
                 }
         }
         if (wv0) GMW_TS(sy, p, 1);
-        // the panel buffer of the PREVIOUS panel (stores issued during its factor 2) is complete in memory by now:
-        // publish it here, off the end of the iteration, where nobody has to wait for the write acknowledgements
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (p >= 1 && wv3) { gmw_set_flag(&sy->panel_ready, ebase + p); GMW_TS(sy, p + 64, 3); }
         // ---- B: quarter (qa, qb) of tile (0,0), K = 64 ----
         if (!first) {
 #pragma unroll
@@ -847,10 +907,15 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
         }
         __syncthreads();
         if (wv0) GMW_TS(sy, p, 4);
-        // ---- factor 2.  Waves 1 / 3: E', T1', the (0,1) tile of S, the outputs of factor 1 — then each of them waits for
-        // one of the two tiles the NEXT panel needs (updated by the workers through the previous panel), copies it into
-        // LDS (Lr / Wc are free: wave 1 is the only reader of Lr's E' corner, wave 3 of Wc's W1d corner) — then the
-        // outputs of factor 2 as the pivot wave produces them.
+        // ---- factor 2.  Wave 0 pivots, wave 2 follows with T2'.  Waves 1 / 3, in the order of who is waiting for what:
+        //   1. the first half of the panel buffer (wave 1: E' and the pivots of sub-panel 1; wave 3: T1'); whoever sees its
+        //      stores acknowledged last raises half_ready — the workers run their first two MFMA stages while factor 2 is busy;
+        //   2. the (0,1) tile of S and the S rows / pivots of both factors as the pivot wave produces them.
+        // Then EVERY wave fetches 32 rows of the two tiles the NEXT panel needs (tile (p, p+1) -> Lr by waves 1 / 0,
+        // tile (p+1, p+1) -> Wc by waves 3 / 2; finished by their owners with the updates of panels 0 .. p-1).  Lr / Wc are
+        // free: wave 1 is the only reader of Lr's E' corner, wave 3 of Wc's W1d corner, both in rows 0..31 which they
+        // overwrite themselves.  Waiting for those loads also waits for the wave's earlier stores, so after the closing
+        // barrier the panel buffer is complete in memory and panel_ready can be raised at once.
         if (wv0) { gmw_cols_pivot_wave(ws2, eps, lane); GMW_TS(sy, p + 64, 0); }
         else if (wvu == 2) gmw_cols_t_wave<2>(ws2, lane, nxt->Tt2, kp.T2);
         else {
@@ -861,8 +926,18 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
                     const int row = 8 * i + (lane >> 3);
                     st_d4<true>(&nxt->E[row * 32 + c4], *(const d4*)&Lr[row][c4]);
                 }
-                gmw_copy_t<true>(kp.T1, nxt->Tt1, lane);
-            } else {
+                if (lane < 32) {
+                    const double D = ws.Dv[lane], rc = gmw_pivot_rcp(D), sq = sqrt(D) * rc;
+                    st_dev(&nxt->D[lane], D); st_dev(&nxt->sq[lane], sq); st_dev(&nxt->rD[lane], rc);
+                }
+            } else gmw_copy_t<true>(kp.T1, nxt->Tt1, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                int prev = 0;
+                if (lane == 0) prev = __hip_atomic_fetch_add(halfcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(prev) == 1) gmw_set_panel_flag(sy->half_ready, ebase + p + 1, lane);
+            }
+            if (!wv1) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int row = 8 * i + (lane >> 3);
@@ -874,31 +949,81 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
                 }
             }
             gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD);
-            if (p + 1 < T) {
-                // tile (p, p+1) -> Lr (wave 1), tile (p+1, p+1) -> Wc (wave 3); both carry the updates of panels 0 .. p-1
-                const int tr = wv1 ? p : p + 1;
-                if (wv1) GMW_TS(sy, p, 5);
-                const bool ready = (p == 0) || gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
-                if (wv1) GMW_TS(sy, p, 6);
-                if (!ready) *okp = 0;
-                else gmw_stage_tile(wv1 ? Lr : Wc, G, ld, 64 * tr, 64 * (p + 1), lane);
-            }
             gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32);
             if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
         }
+        if (p + 1 < T) {
+            const bool tileA = wvu < 2;                        // waves 0, 1: tile (p, p+1) -> Lr;  waves 2, 3: tile (p+1, p+1) -> Wc
+            const int tr = tileA ? p : p + 1, r0 = (wvu & 1) ? 0 : 32;
+            if (wv1) GMW_TS(sy, p, 5);
+            const bool ready = (p == 0) || gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
+            if (wv1) GMW_TS(sy, p, 6);
+            if (!ready) *okp = 0;
+            else {
+                double (*dst)[G64_LS] = tileA ? Lr : Wc;
+                const double* src = G + (size_t)(64 * tr + r0) * ld + 64 * (p + 1) + lane;
+                double v[32];
+#pragma unroll
+                for (int r = 0; r < 32; r++) v[r] = ld_dev(src + (size_t)r * ld);
+#pragma unroll
+                for (int r = 0; r < 32; r++) dst[r0 + r][lane] = v[r];
+            }
+        }
         __syncthreads();                                       // closes the iteration: staged tiles visible, LDS arrays reusable
+        if (wv3 && p + 1 < T) { gmw_set_panel_flag(sy->panel_ready, ebase + p + 1, lane); GMW_TS(sy, p + 64, 3); }
         if (wv0) GMW_TS(sy, p, 7);
         if (!*okp) { if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     }
     // the last panel buffers are never read by a worker (steps T-2 and T-1 have no trailing tiles)
 }
 
-// k_gmw_persist: grid = 1 + workers (any number >= 0 of workers makes progress; with 0 workers and T > 1 the pivot would wait
-// for tiles nobody updates, so the launcher always provides at least one).
-struct GmwTask { short k, by, bx, pad; };
+// Worker side of one update step of an owned tile; returns false when a wait expired.
+struct GmwOwned { int I, J, nsteps; };
+__device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, const GmwOwned& tl, d4 (&acc)[2][2], double* __restrict__ G,
+                                               GmwPanel64* pans, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
+                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid)
+{
+    unsigned long long* ver = gmw_sync_ver(sy);
+    // the two row-panel tiles (k, I), (k, J) are finished (k updates each) — both flags in one round trip
+    if (wv0) {
+        bool good = true;
+        if (k > 0) {
+            const unsigned long long want = ebase + k;
+            unsigned long long a = 0, b = 0;
+            for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+                a = gmw_uniform64(__hip_atomic_load(&ver[(size_t)k * T + tl.I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b = gmw_uniform64(__hip_atomic_load(&ver[(size_t)k * T + tl.J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (a >= want && b >= want) break;
+                if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            good = a >= want && b >= want;
+        }
+        *okp = good;
+    }
+    __syncthreads();
+    if (!*okp) return false;
+    const bool last = k == tl.nsteps - 1;
+    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, k == 0, last,
+        [&] {
+            if (wv0) *okp = gmw_wait_ge(&sy->half_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
+            __syncthreads();
+            return *okp != 0;
+        },
+        [&] {
+            if (wv0) *okp = gmw_wait_ge(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
+            __syncthreads();
+            return *okp != 0;
+        },
+        [&] { if (last) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); });
+}
+
+// k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any).
+#define GMW_OWNED_MAX 2
+struct GmwTile { short I, J, nsteps, pad; };
 __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
-                                                     GmwSync* __restrict__ sy, const GmwTask* __restrict__ tasks, int ntasks,
+                                                     GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
                                                      FrameScalars* __restrict__ fs)
 {
     __shared__ double Lr[64][G64_LS];
@@ -906,76 +1031,26 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
     __shared__ double facreg[2 * GMW_FAC_DOUBLES];
     __shared__ double xreg[1024 + 1024 + 32 * 33];
     __shared__ double keepreg[1024 + 64 + 64];
-    __shared__ long long claimed;
-    __shared__ int ok;
+    __shared__ int ok, halfcnt;
     const int tid = threadIdx.x;
     const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
     if (blockIdx.x == 0) {
-        gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, tid);
+        gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, tid);
     } else {
-        unsigned long long* ver = gmw_sync_ver(sy);
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
-        for (;;) {
-            if (wv0) {
-                unsigned long long c = 0;
-                if (tid == 0) c = __hip_atomic_fetch_add(&sy->claim, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                claimed = (long long)gmw_uniform64(c);
-            }
-            __syncthreads();
-            const long long t = claimed;
-            GMW_DBG(sy, 0, 1000 + t);
-            if (t >= ntasks) break;
-            const GmwTask tk = tasks[t];
-            const int k = tk.k, I = k + 1 + tk.by, J = k + 1 + tk.bx;
-            // the tile and its two row-panel tiles carry the updates of panels 0 .. k-1 (written by earlier tasks)
-            if (wv0) {
-                bool good = true;
-                if (k > 0) {
-                    const unsigned long long want = ebase + k;
-                    unsigned long long a = 0, b = 0, c = 0;
-                    for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {      // the three flags in ONE round trip
-                        a = __hip_atomic_load(&ver[(size_t)I * T + J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        b = __hip_atomic_load(&ver[(size_t)k * T + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        c = __hip_atomic_load(&ver[(size_t)k * T + J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a = gmw_uniform64(a); b = gmw_uniform64(b); c = gmw_uniform64(c);
-                        if (a >= want && b >= want && c >= want) break;
-                        if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    good = a >= want && b >= want && c >= want;
-                }
-                ok = good;
-            }
-            __syncthreads();
-            bool done = ok != 0;
-#ifdef SRUKF_GMW_DBG
-            const bool crit = tk.by == 0 && tk.bx == 1;
-            if (crit && wv0) GMW_TS(sy, 128 + k, 0);
-#endif
-            if (done) {
-                done = gmw_tile_update<true>(n, ld, 64 * k, tk.by, tk.bx, G, pans + k, Sout, Lr, Wc, tid, [&] {
-#ifdef SRUKF_GMW_DBG
-                    if (crit && wv0) GMW_TS(sy, 128 + k, 1);
-#endif
-                    if (wv0) ok = gmw_wait_ge(&sy->panel_ready, ebase + k + 1, &sy->abort);
-#ifdef SRUKF_GMW_DBG
-                    if (crit && wv0) GMW_TS(sy, 128 + k, 2);
-#endif
-                    __syncthreads();
-                    return ok != 0;
-                });
-            }
-            if (!done) { if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-#ifdef SRUKF_GMW_DBG
-            if (crit && wv0) GMW_TS(sy, 128 + k, 3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (crit && wv0) GMW_TS(sy, 128 + k, 4);
-#endif
-            gmw_publish(&ver[(size_t)I * T + J], ebase + k + 1, wv0);
-#ifdef SRUKF_GMW_DBG
-            if (crit && wv0) GMW_TS(sy, 128 + k, 5);
-#endif
+        const int workers = gridDim.x - 1, w = blockIdx.x - 1;
+        GmwOwned ta = { 0, 0, 0 }, tb = { 0, 0, 0 };
+        if (w < ntiles) { const GmwTile t = tiles[w]; ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; }
+        if (w + workers < ntiles) { const GmwTile t = tiles[w + workers]; tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; }
+        d4 acca[2][2], accb[2][2];
+        zero_acc(acca); zero_acc(accb);
+        const int kmax = max(ta.nsteps, tb.nsteps);
+        bool good = true;
+        for (int k = 0; k < kmax && good; k++) {
+            if (k < ta.nsteps) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
+            if (good && k < tb.nsteps) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
         }
+        if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the last workgroup out re-arms the block for the next launch and reports an abandoned run
     GMW_DBG(sy, 6, 7777);
@@ -983,9 +1058,8 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
     if (tid == 0) {
         const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1) {
-            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); }
+            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
             __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->claim, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1106,30 +1180,37 @@ void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* U
     hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X);
 }
 int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + sizeof(unsigned long long) * (size_t)T * T); }
-// host-side task list of the persistent launch: step k = 0 .. T-2, tiles (by, bx) of the (T-1-k)^2 trailing square
-// without (0,0); within a step (0,1) and (1,1) first (the pivot waits for them), then the rest of block row 0 (the
-// row-panel tiles every task of the next step reads), then the other rows.  Returns the number of tasks; out may be null.
-int srukf_gmw_build_tasks(int T, short* out)
+// host-side tile list of the persistent launch: every tile (I, J), 1 <= I <= J < T, with the number of panel updates
+// its owner applies (I off the diagonal; I - 1 on it: the pivot applies the last one itself), ordered by the step at
+// which it is finished, so that worker w and worker w + workers hold tiles that retire at different times.
+// Returns the number of tiles; out (4 shorts per tile) may be null.
+int srukf_gmw_build_tiles(int T, short* out)
 {
     int cnt = 0;
-    auto put = [&](int k, int by, int bx) { if (out) { out[4 * cnt] = (short)k; out[4 * cnt + 1] = (short)by; out[4 * cnt + 2] = (short)bx; out[4 * cnt + 3] = 0; } cnt++; };
-    for (int k = 0; k + 1 < T; k++) {
-        const int Tk = T - 1 - k;
-        if (Tk >= 2) { put(k, 0, 1); put(k, 1, 1); }
-        for (int bx = 2; bx < Tk; bx++) put(k, 0, bx);
-        for (int by = 1; by < Tk; by++)
-            for (int bx = by; bx < Tk; bx++) if (!(by == 1 && bx == 1)) put(k, by, bx);
-    }
+    for (int I = 1; I < T; I++)
+        for (int J = I; J < T; J++) {
+            const int ns = (I == J) ? I - 1 : I;
+            if (ns < 1) continue;
+            if (out) { out[4 * cnt] = (short)I; out[4 * cnt + 1] = (short)J; out[4 * cnt + 2] = (short)ns; out[4 * cnt + 3] = 0; }
+            cnt++;
+        }
     return cnt;
 }
+// workers the persistent launch needs for T block rows (each owns at most GMW_OWNED_MAX tiles); -1: too many tiles
+int srukf_gmw_persist_workers(int T, int max_workers)
+{
+    const int nt = srukf_gmw_build_tiles(T, nullptr);
+    if (nt == 0) return 0;
+    if (nt <= max_workers) return nt;
+    if (nt <= GMW_OWNED_MAX * max_workers) return max_workers;
+    return -1;
+}
 void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
-                              void* sync, const void* tasks, int ntasks, int workers, void* fs)
+                              void* sync, const void* tiles, int ntiles, int workers, void* fs)
 {
     const int T = ld / 64;
-    if (T > 1 && workers < 1) workers = 1;
-    if (T <= 1) workers = 0;
     hipLaunchKernelGGL(k_gmw_persist, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
-                       (GmwSync*)sync, (const GmwTask*)tasks, ntasks, (FrameScalars*)fs);
+                       (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs);
 }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
 void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)

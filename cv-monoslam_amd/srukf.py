@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -106,6 +106,7 @@ def load_library():
     L.srukf_associate.argtypes = [C.c_void_p, _bp, _dp, _ip, _dp]
     L.srukf_get_match_patch.argtypes = [C.c_void_p, C.c_int, _bp]
     L.srukf_set_storage.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_set_exclusive.argtypes = [C.c_void_p, C.c_int]
     L.srukf_get_state_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.srukf_run_frames_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -257,6 +258,11 @@ class Filter:
         out = np.zeros((17, 17), dtype=np.uint8)
         self._chk(self._lib.srukf_get_match_patch(self._h, int(k), out.ctypes.data_as(C.POINTER(C.c_ubyte))))
         return out
+
+    def set_exclusive(self, exclusive):
+        """True (default): the filter has the GPU to itself (one persistent refactorisation launch per frame);
+        False: several filters replay concurrently on this GPU (one launch per 64-row panel)."""
+        self._chk(self._lib.srukf_set_exclusive(self._h, 1 if exclusive else 0))
 
     def set_storage(self, storage):
         """STORAGE_F64 (default) or STORAGE_F32: precision of the state kept between frames."""

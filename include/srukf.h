@@ -170,6 +170,12 @@ int  srukf_get_match_patch(srukf_ctx* ctx, int k, unsigned char* out);
 /* Select the storage precision (default SRUKF_STORAGE_F64).  With SRUKF_STORAGE_F32 the state is rounded to float at
  * the end of every refactorisation (and by srukf_set_state); srukf_get_state returns those values widened to double,
  * srukf_get_state_f32 the float arrays themselves (X[n], S[n*n] row-major). */
+/* exclusive != 0 (default): this filter has the GPU to itself while it runs, and the refactorisation is ONE persistent
+ * launch whose workgroups all have to be resident.  exclusive == 0: other filters / kernels share the GPU (several
+ * contexts replaying concurrently): one launch per 64-row panel, no residency assumption.  A persistent launch that
+ * cannot get its workgroups in time gives up (bounded waits), its frame is repeated on the exact path, and the context
+ * switches to exclusive == 0 by itself.  No reference counterpart (the reference is single-threaded host code). */
+int  srukf_set_exclusive(srukf_ctx* ctx, int exclusive);
 int  srukf_set_storage(srukf_ctx* ctx, int storage);
 int  srukf_get_state_f32(srukf_ctx* ctx, float* X, float* S);
 

@@ -539,3 +539,39 @@ def test_full_size_tolerance_study_n500(srukf, synth):
     assert 0 < d < 1e-6                                                         # north-star pose tolerance, fp32 storage
     dX = np.abs(state[srukf.STORAGE_F32][0] - state[srukf.STORAGE_F64][0]).max()
     assert dX < 1e-4
+
+
+def test_persistent_and_per_panel_refactor_agree(srukf, synth):
+    """The refactorisation runs as one persistent launch (default) or as one launch per 64-row panel
+    (set_exclusive(False): several filters on one GPU).  Same arithmetic in the same order: identical results."""
+    p = synth.scene_params()
+    for N, F in ((30, 4), (100, 3)):
+        sc = synth.make_scene(N, F, seed=2, p=p)
+        out = []
+        for exclusive in (True, False):
+            f = srukf.Filter(N, p); f.set_exclusive(exclusive); f.set_state(sc["X0"], sc["S0"])
+            f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+            t = f.run_frames(0, F)
+            out.append((t,) + f.get_state())
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+        np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+def test_persistent_launch_without_workers_falls_back(srukf, oracle, synth, monkeypatch):
+    """A persistent launch whose workers never get onto the GPU must not hang: its bounded waits expire, the frame is
+    repeated on the exact path, the filter switches to per-panel launches — and the results are still the oracle's."""
+    p = synth.scene_params()
+    N, F = 30, 3                                                  # n = 184: three block rows, two worker-owned tiles
+    sc = synth.make_scene(N, F, seed=4, p=p)
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    monkeypatch.setenv("SRUKF_GMW_TEST_STARVE", "1")
+    for k in range(F):
+        if k == 1:
+            monkeypatch.delenv("SRUKF_GMW_TEST_STARVE")          # by now the filter no longer uses the persistent launch
+        f.predict_motion(sc["odo"][k], sc["odo"][k + 1]); f.predict_measurement(); f.update(sc["z"][k], sc["matched"][k], mode=srukf.UPDATE_BATCHED)
+        o.predict_motion(sc["odo"][k], sc["odo"][k + 1]); o.predict_measurement(); o.update(sc["z"][k], sc["matched"][k], mode=oracle.Oracle.BATCHED)
+        X, S = f.get_state(); Xo, So = o.get_state()
+        np.testing.assert_allclose(X, Xo, atol=1e-9)
+        np.testing.assert_allclose(S.T @ S, So.T @ So, atol=1e-12)
