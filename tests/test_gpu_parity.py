@@ -575,3 +575,20 @@ def test_persistent_launch_without_workers_falls_back(srukf, oracle, synth, monk
         X, S = f.get_state(); Xo, So = o.get_state()
         np.testing.assert_allclose(X, Xo, atol=1e-9)
         np.testing.assert_allclose(S.T @ S, So.T @ So, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [320, 1204, 1500, 2100])
+def test_gmw_large_sizes_factor_property(srukf, n):
+    """Sizes that exercise the persistent launch with one tile per worker (n = 320, 1204), two tiles per worker
+    (n = 1500: 276 tiles, 255 workers) and the per-panel launches (n = 2100: more tiles than the workers can own).
+    No oracle at these sizes inside a unit test: S upper triangular with S^T S = G, pivots = those of LAPACK's Cholesky."""
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n + 8))
+    G = A @ A.T / n + 0.05 * np.eye(n)
+    S, D, hit = srukf.gmw(G)
+    assert hit == 0
+    assert np.all(np.tril(S, -1) == 0.0)
+    np.testing.assert_allclose(S.T @ S, G, atol=1e-12 * np.abs(G).max() * n)
+    R = np.linalg.cholesky(G).T
+    np.testing.assert_allclose(np.abs(np.diag(S)), np.diag(R), rtol=1e-9)
+    np.testing.assert_allclose(D, np.diag(R) ** 2, rtol=1e-9)
