@@ -747,7 +747,7 @@ __device__ __forceinline__ void gmw_stage_tile(double (*dst)[G64_LS], const doub
 __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                   double* __restrict__ Dall, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
                                                   double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg, double* xreg, double* keepreg,
-                                                  int* okp, int* halfcnt, int tid)
+                                                  int* okp, int* halfcnt, int* stageok, int tid)
 {
     const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int qa = wv >> 1, qb = wv & 1;
@@ -770,7 +770,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
         if (wv0) GMW_TS(sy, p, 0);
         // operands staged in LDS by waves 1 / 3 during factor 2 of the previous panel: Lr = tile (p-1, p) (rows of the
         // current panel, columns of R), Wc = tile (p, p) (R itself)
-        if (wv0) { ws.Dv[lane & 31] = 0.0; ws2.Dv[lane & 31] = 0.0; *halfcnt = 0; }
+        if (wv0) { ws.Dv[lane & 31] = 0.0; ws2.Dv[lane & 31] = 0.0; *halfcnt = 0; stageok[lane & 1] = 0; }
         d4 g;
 #pragma unroll
         for (int t = 0; t < 4; t++) g[t] = Wc[16 * qa + lk + 4 * t][16 * qb + lr];
@@ -917,8 +917,20 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
         // overwrite themselves.  Waiting for those loads also waits for the wave's earlier stores, so after the closing
         // barrier the panel buffer is complete in memory and panel_ready can be raised at once.
         if (wv0) { gmw_cols_pivot_wave(ws2, eps, lane); GMW_TS(sy, p + 64, 0); }
-        else if (wvu == 2) gmw_cols_t_wave<2>(ws2, lane, nxt->Tt2, kp.T2);
-        else {
+        else if (wvu == 2) {
+            // this wave has slack while it follows the pivots: it asks early whether the owners of the two tiles of the NEXT
+            // panel have finished them (normally yes) and tells the others through LDS — saves every wave the ~1 us poll
+            // round trip at the end of the iteration
+            unsigned long long fa = 0, fb = 0;
+            if (p >= 1 && p + 1 < T) {
+                fa = __hip_atomic_load(&ver[(size_t)p * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fb = __hip_atomic_load(&ver[(size_t)(p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            gmw_cols_t_wave<2>(ws2, lane, nxt->Tt2, kp.T2, [&] {
+                if (p == 0 || gmw_uniform64(fa) >= ebase + p) stageok[0] = 1;
+                if (p == 0 || gmw_uniform64(fb) >= ebase + p) stageok[1] = 1;
+            });
+        } else {
             const int c4 = (lane & 7) * 4;
             if (wv1) {
 #pragma unroll
@@ -956,7 +968,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
             const bool tileA = wvu < 2;                        // waves 0, 1: tile (p, p+1) -> Lr;  waves 2, 3: tile (p+1, p+1) -> Wc
             const int tr = tileA ? p : p + 1, r0 = (wvu & 1) ? 0 : 32;
             if (wv1) GMW_TS(sy, p, 5);
-            const bool ready = (p == 0) || gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
+            const bool ready = p == 0 || __builtin_amdgcn_readfirstlane(stageok[tileA ? 0 : 1]) != 0 || gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
             if (wv1) GMW_TS(sy, p, 6);
             if (!ready) *okp = 0;
             else {
@@ -1031,11 +1043,11 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
     __shared__ double facreg[2 * GMW_FAC_DOUBLES];
     __shared__ double xreg[1024 + 1024 + 32 * 33];
     __shared__ double keepreg[1024 + 64 + 64];
-    __shared__ int ok, halfcnt;
+    __shared__ int ok, halfcnt, stageok[2];
     const int tid = threadIdx.x;
     const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
     if (blockIdx.x == 0) {
-        gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, tid);
+        gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid);
     } else {
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
         const int workers = gridDim.x - 1, w = blockIdx.x - 1;

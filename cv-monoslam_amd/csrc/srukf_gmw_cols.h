@@ -229,8 +229,10 @@ __device__ __forceinline__ void gmw_t_group(double (&t)[32], const GmwColsLds& w
 // Follower wave 1: T = L^{-1}, column c' = lane & 31 per lane, into the LDS array Tl[kk][33] = T[jj][kk] (32 x 33 doubles)
 // and, if GLOBAL, through it to Tt[kk*32 + jj] in global memory (otherwise gmw_copy_t does that later).
 // GLOBAL: 0 = LDS copy only, 1 = also to Tt with plain stores, 2 = with agent-scope stores (read by other workgroups of the same launch)
-template <int GLOBAL>
-__device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt, double* Tl)
+struct GmwNoMid { __device__ __forceinline__ void operator()() const {} };
+// mid(): called once between the groups 16..23 and 24..27, where this wave is ahead of the pivot wave anyway
+template <int GLOBAL, class Mid = GmwNoMid>
+__device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, double* __restrict__ Tt, double* Tl, Mid&& mid = Mid())
 {
     const int c = lane & 31;
     const unsigned dv = lds_off(w.Dv);
@@ -243,6 +245,7 @@ __device__ __forceinline__ void gmw_cols_t_wave(const GmwColsLds& w, int lane, d
     gmw_t_group<4, 8, 8, 16, GLOBAL>(t, w, dv, lane, Tt, Tl, pb, pa);
     gmw_t_group<8, 16, 16, 24, GLOBAL>(t, w, dv, lane, Tt, Tl, pa, pb);
     gmw_t_group<16, 24, 24, 28, GLOBAL>(t, w, dv, lane, Tt, Tl, pb, pa);
+    mid();
     gmw_t_group<24, 28, 28, 31, GLOBAL>(t, w, dv, lane, Tt, Tl, pa, pb);
     gmw_t_group<28, 31, 0, 0, GLOBAL>(t, w, dv, lane, Tt, Tl, pb, pa);
 }
