@@ -31,8 +31,9 @@ int srukf_gmw_panel_bytes(void);
 int srukf_gmw_sync_bytes(int T);
 int srukf_gmw_build_tiles(int T, short* out);
 int srukf_gmw_persist_workers(int T, int max_workers);
-void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*);
-void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int);
+void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int);
+int srukf_gmw_head_rows(void);
+void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
 void srukf_launch_landmarks_cartesian(hipStream_t, KDims, const double*, const double*, double*, double*);
@@ -191,7 +192,8 @@ struct srukf_ctx {
     GmwPlan gplan;                         // persistent GMW launch: panel buffers, sync block, task list
     int gmw_shared = 0;                    // 1: the GPU is shared with other filters — never use the persistent launch (it needs all its workgroups resident)
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
-    int n_syrk_tiles = 0, n_pxy_tiles = 0;
+    int *syrk_head_tiles = nullptr;                    // k_syrk tiles of the first srukf_gmw_head_rows() rows only (fused refactor)
+    int n_syrk_tiles = 0, n_pxy_tiles = 0, n_syrk_head_tiles = 0;
     FrameScalars* fs = nullptr;
     // staged sequence
     int seqF = 0;
@@ -329,6 +331,13 @@ static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
 // one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path.
 // need_reset: the gamma/xi accumulators were not just cleared by k_gain (SEQUENTIAL mode, fallbacks).
 // frame_tail: the check kernel also records the trajectory row and advances the staged frame counter.
+// SRUKF_GMW_FUSED=0: the persistent launch reads every tile from G (k_syrk computes all of them): A/B runs
+static int gmw_fused_mode()
+{
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SRUKF_GMW_FUSED"); mode = (e && e[0] == '0') ? 0 : 1; }
+    return mode;
+}
 static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && !c->gmw_shared && c->gplan.workers >= 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout);
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
@@ -339,10 +348,21 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         ProfScope ps(c, KC_MISC, 0, 8.0 * np);
         hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
     }
+    // Fused form (replay path): k_syrk only for the first block rows, the persistent launch computes the other tiles of
+    // S^T S - U U^T itself while it is already factoring; it reads the filter's S for that, so the factor goes to the
+    // scratch buffer Wf and k_gmw_check copies it into S.
+    // Measured (frames/s, fused against not fused): N = 200 2 965 / 2 910, N = 100 5 247 / 5 262, N = 50 9 256 / 9 465,
+    // N = 300 (two tiles per worker, both to be computed first) 1 544 / 1 663 — so only with one tile per worker and T >= 16.
+    const bool fused = !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
+                       c->gplan.ntiles <= c->gplan.workers && c->gplan.T >= 16 &&
+                       !getenv("SRUKF_GMW_TEST_STARVE") && gmw_fused_mode();
+    const double nn = n;
+    const double syrk_flop = nn * nn * nn / 3.0 + nn * nn * (ue - ub), syrk_byte = 8.0 * (nn * nn + (double)(ue - ub) * nn);
+    const double head_frac = fused ? fmin(1.0, 2.0 * srukf_gmw_head_rows() / nn) : 1.0;      // share of the tiles k_syrk still computes (rows / n, upper triangle)
     {
-        const double nn = n;
-        ProfScope ps(c, KC_SYRK, nn * nn * nn / 3.0 + nn * nn * (ue - ub), 8.0 * (nn * nn + (double)(ue - ub) * nn));
-        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X);
+        ProfScope ps(c, KC_SYRK, syrk_flop * head_frac, syrk_byte * head_frac);
+        srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, fused ? c->syrk_head_tiles : c->syrk_tiles,
+                          fused ? c->n_syrk_head_tiles : c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X);
         c->dx_pending = false;
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
@@ -354,8 +374,10 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         if (gmw_use_persist(c)) {
             double fl = 0.0, by = 0.0;
             for (int j0 = -64; j0 + 64 < np; j0 += 64) { fl += panel_flop(j0); by += panel_byte(j0); }
-            ProfScope ps(c, KC_GMW_PERSIST, fl, by);
-            launch_gmw_fast(c, c->G, c->S);
+            ProfScope ps(c, KC_GMW_PERSIST, fl + syrk_flop * (1.0 - head_frac), by + syrk_byte * (1.0 - head_frac));
+            if (fused) srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->G, c->gplan.pans, c->D, c->Wf, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles,
+                                                c->gplan.workers, c->fs, c->S, c->Ut, ub, ue);
+            else launch_gmw_fast(c, c->G, c->S);
         } else {
             int pb = 0;
             for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1) {
@@ -365,7 +387,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         }
         quantize_state(c);
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * (double)n * n / 2);
-        srukf_launch_gmw_check(c->stream, n, np, c->D, c->S, c->fs, c->X, frame_tail ? 1 : 0);
+        srukf_launch_gmw_check(c->stream, n, np, c->D, fused ? c->Wf : c->S, c->fs, c->X, frame_tail ? 1 : 0, fused ? c->S : nullptr);
     } else {
         ProfScope ps(c, KC_GMW_COL, (double)n * n * n / 3.0, 8.0 * (double)n * n * n / 3.0);
         for (int j = 0; j < n; j++)
@@ -383,7 +405,7 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout)
         // SRUKF_GMW_TEST_STARVE (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait expires,
         // the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
         const int workers = getenv("SRUKF_GMW_TEST_STARVE") ? 0 : c->gplan.workers;
-        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, c->gplan.pans, c->D, Sout, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles, workers, c->fs);
+        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, c->gplan.pans, c->D, Sout, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles, workers, c->fs, nullptr, nullptr, 0, 0);
         return;
     }
     int pb = 0;
@@ -395,7 +417,7 @@ static void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow)
     const int np = c->d.np, n = c->d.n;
     if (!slow) {
         launch_gmw_fast(c, Gbuf, Sout);
-        srukf_launch_gmw_check(c->stream, n, np, c->D, Sout, c->fs, c->X, 0);
+        srukf_launch_gmw_check(c->stream, n, np, c->D, Sout, c->fs, c->X, 0, nullptr);
     } else {
         hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 0);
         for (int j = 0; j < n; j++) srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, Gbuf, c->Wf, c->D, c->theta, c->fs, Sout);
@@ -528,6 +550,14 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
         std::vector<int> tp = build_tile_table(d.np / 32, d.mp / 32, false, false, 1);
         c->n_syrk_tiles = (int)ts.size() / 2; c->n_pxy_tiles = (int)tp.size() / 2;
         ALLOC(c->syrk_tiles, ts.size()); ALLOC(c->pxy_tiles, tp.size());
+        // the same order, restricted to the tile rows the persistent launch does not compute itself
+        std::vector<int> th;
+        for (size_t q = 0; q + 1 < ts.size(); q += 2) if (ts[q] >= 0 && ts[q] * 32 < srukf_gmw_head_rows()) { th.push_back(ts[q]); th.push_back(ts[q + 1]); }
+        c->n_syrk_head_tiles = (int)th.size() / 2;
+        ALLOC(c->syrk_head_tiles, th.size() ? th.size() : 2);
+        if (!th.empty() && hipMemcpyAsync(c->syrk_head_tiles, th.data(), sizeof(int) * th.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            g_create_error = "tile table upload failed"; srukf_destroy(c); return SRUKF_ERR_HIP;
+        }
         // same stream as the zero-fill of ALLOC (a copy on the null stream could be overtaken by it)
         if (hipMemcpyAsync(c->syrk_tiles, ts.data(), sizeof(int) * ts.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipMemcpyAsync(c->pxy_tiles, tp.data(), sizeof(int) * tp.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
@@ -556,7 +586,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8_exec) hipGraphExecDestroy(c->graph8_exec);
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
-                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles,
+                     c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
                      c->perm, c->iperm, c->Sdis, c->S32, c->X32, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) hipFree(b);
     gmw_plan_destroy(c->gplan);
@@ -1284,7 +1314,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
         if (gmw_persist_mode() && srukf_gmw_persist_workers(np / 64, 255) >= 0) {
             GmwPlan gp;
             if (gmw_plan_create(gp, np, st) != SRUKF_OK) return SRUKF_ERR_NOMEM;
-            srukf_launch_gmw_persist(st, n, np, epsilon, dG, gp.pans, dD, dS, gp.sync, gp.tiles, gp.ntiles, gp.workers, dFs);
+            srukf_launch_gmw_persist(st, n, np, epsilon, dG, gp.pans, dD, dS, gp.sync, gp.tiles, gp.ntiles, gp.workers, dFs, nullptr, nullptr, 0, 0);
             hipDeviceSynchronize();
             gmw_plan_destroy(gp);
         } else {
@@ -1296,7 +1326,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
             hipDeviceSynchronize();
             hipFree(pan[0]); hipFree(pan[1]);
         }
-        srukf_launch_gmw_check(st, n, np, dD, dS, dFs, nullptr, 0);
+        srukf_launch_gmw_check(st, n, np, dD, dS, dFs, nullptr, 0, nullptr);
         hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
         if (clamp_hit) *clamp_hit = fs.clamp_rows;
         if (fs.clamp_rows > 0) force_slow = 2;   // same contract as srukf_update: redo on the exact path

@@ -990,7 +990,8 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
 }
 
 // Worker side of one update step of an owned tile; returns false when a wait expired.
-struct GmwOwned { int I, J, nsteps; };
+struct GmwOwned { int I, J, nsteps; bool computed; };
+struct KDimsLite { int n, ld; };
 __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, const GmwOwned& tl, d4 (&acc)[2][2], double* __restrict__ G,
                                                GmwPanel64* pans, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
                                                double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid)
@@ -1016,7 +1017,7 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
     __syncthreads();
     if (!*okp) return false;
     const bool last = k == tl.nsteps - 1;
-    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, k == 0, last,
+    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, k == 0 && !tl.computed, last,
         [&] {
             if (wv0) *okp = gmw_wait_ge(&sy->half_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
             __syncthreads();
@@ -1033,10 +1034,43 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
 // k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any).
 #define GMW_OWNED_MAX 2
 struct GmwTile { short I, J, nsteps, pad; };
+// S0 != null: the tiles of block rows I >= GMW_HEAD_ROWS are not read from G but COMPUTED by their owners,
+//   G[r][c] = sum_k S0[k][r] S0[k][c] - sum_{u0 <= m < u1} Ut0[m][r] Ut0[m][c]      (what k_syrk does, SLAM.cpp:2118-2120, 2149),
+// while the pivot is already factoring the first panels (k_syrk then only runs for block rows 0 and 1: a few
+// microseconds instead of ~37).  The owner of tile (I, J) needs 12.5 + 1.7 I us for it and has ~12 I us until somebody waits
+// for the tile.  S0 must not be the buffer the factor is written to (Sout).
+#define GMW_HEAD_ROWS 2
+__device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
+                                               int I, int J, d4 (&acc)[2][2], FrameScalars* __restrict__ fs, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = 64 * I + 32 * (wv >> 1), c0 = 64 * J + 32 * (wv & 1);
+    zero_acc(acc);
+    if (m0 >= d.ld || c0 >= d.ld || c0 + 32 <= m0) return;
+    tile32_tn<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, d.ld), lane);      // S0[k][r] = 0 for k > r
+    tile32_tn<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
+    double gmax = 0.0, xmax = 0.0;                             // gamma / xi of the GMW bound, as in k_syrk
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r = m0 + 16 * a + lk + 4 * t, c = c0 + 16 * b + lr;
+                if (r < d.n && c < d.n && c >= r) { if (r == c) gmax = fmax(gmax, acc[a][b][t]); else xmax = fmax(xmax, acc[a][b][t]); }
+            }
+    gmax = wave_max(gmax); xmax = wave_max(xmax);
+    if (lane == 0) {
+        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
                                                      GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
-                                                     FrameScalars* __restrict__ fs)
+                                                     FrameScalars* __restrict__ fs,
+                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1)
 {
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
@@ -1051,11 +1085,16 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
     } else {
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
         const int workers = gridDim.x - 1, w = blockIdx.x - 1;
-        GmwOwned ta = { 0, 0, 0 }, tb = { 0, 0, 0 };
+        GmwOwned ta = { 0, 0, 0, false }, tb = { 0, 0, 0, false };
         if (w < ntiles) { const GmwTile t = tiles[w]; ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; }
         if (w + workers < ntiles) { const GmwTile t = tiles[w + workers]; tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; }
         d4 acca[2][2], accb[2][2];
         zero_acc(acca); zero_acc(accb);
+        if (S0) {
+            const KDimsLite dl = { n, ld };
+            if (ta.nsteps > 0 && ta.I >= GMW_HEAD_ROWS) { gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid); ta.computed = true; }
+            if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid); tb.computed = true; }
+        }
         const int kmax = max(ta.nsteps, tb.nsteps);
         bool good = true;
         for (int k = 0; k < kmax && good; k++) {
@@ -1082,8 +1121,11 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
 // theta_j = max_{i>j} |C[i][j]| = sqrt(D_j) * max_{i>j} |S[j][i]|  (S[j][i] = C[i][j]/sqrt(D_j)),
 // beta^2 = max(gamma, xi/nu, 1e-15), nu = max(1, sqrt(n^2-1))   (SLAM.cpp:2204-2211, 2264-2285).
 // One workgroup per pivot row.
+// Scopy != null: S is a scratch buffer the factorisation wrote its rows to (its input was still being read from the
+// filter's own S, see k_gmw_persist): row j, columns j.., is copied into the filter's S on the way.
 __global__ __launch_bounds__(256) void k_gmw_check(int n, int ld, const double* __restrict__ D, const double* __restrict__ S,
-                                                   FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj)
+                                                   FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj,
+                                                   double* __restrict__ Scopy)
 {
     __shared__ double red[4];
     const int j = blockIdx.x;
@@ -1109,7 +1151,15 @@ __global__ __launch_bounds__(256) void k_gmw_check(int n, int ld, const double* 
         return;
     }
     double mx = 0.0;
-    for (int i = j + 1 + threadIdx.x; i < n; i += 256) mx = fmax(mx, fabs(S[(size_t)j * ld + i]));
+    if (Scopy) {
+        for (int i = j + threadIdx.x; i < n; i += 256) {
+            const double v = S[(size_t)j * ld + i];
+            Scopy[(size_t)j * ld + i] = v;
+            if (i > j) mx = fmax(mx, fabs(v));
+        }
+    } else {
+        for (int i = j + 1 + threadIdx.x; i < n; i += 256) mx = fmax(mx, fabs(S[(size_t)j * ld + i]));
+    }
     mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
@@ -1217,13 +1267,16 @@ int srukf_gmw_persist_workers(int T, int max_workers)
     if (nt <= GMW_OWNED_MAX * max_workers) return max_workers;
     return -1;
 }
+// S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G)
 void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
-                              void* sync, const void* tiles, int ntiles, int workers, void* fs)
+                              void* sync, const void* tiles, int ntiles, int workers, void* fs,
+                              const double* S0, const double* Ut0, int u0, int u1)
 {
     const int T = ld / 64;
     hipLaunchKernelGGL(k_gmw_persist, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
-                       (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs);
+                       (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
 }
+int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
 void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)
 {
@@ -1233,9 +1286,9 @@ void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, 
     hipLaunchKernelGGL(k_gmw_step64, dim3(T, T), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, G, (const GmwPanel64*)cur, Sout, (GmwPanel64*)nxt, D, eps);
 }
 int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel64); }
-void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj)
+void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj, double* Scopy)
 {
-    hipLaunchKernelGGL(k_gmw_check, dim3(n + (do_traj ? 1 : 0)), dim3(256), 0, st, n, ld, D, S, fs, X, do_traj);
+    hipLaunchKernelGGL(k_gmw_check, dim3(n + (do_traj ? 1 : 0)), dim3(256), 0, st, n, ld, D, S, fs, X, do_traj, Scopy);
 }
 void srukf_launch_gmw_col(hipStream_t st, int n, int ld, int j, double eps, const double* G, double* Wf, double* D,
                           unsigned long long* theta_bits, FrameScalars* fs, double* Sout)
