@@ -137,7 +137,7 @@ __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, 
 }
 
 // ---- state update X += sum of the k_gain slice partials (fixed order): 256 state rows per workgroup ----
-#define GAIN_SLICES 8
+#define GAIN_SLICES 32
 __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job)
 {
     const int r = job * 256 + threadIdx.x;

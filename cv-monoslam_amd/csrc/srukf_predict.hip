@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void k_meas_final(KDims d, KWeights w, const d
 // launch that follows adds the slice partials to X in fixed order (deterministic) in a few extra
 // workgroups (srukf_gain_dx_job).  Block (0,0) also clears the gamma / xi accumulators of that k_syrk.
 // ------------------------------------------------------------------------------------------------
+#define GAIN_LM_MAX 64
 __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               double* __restrict__ Ut, const double* __restrict__ PxyR,
                                               const double* __restrict__ Si, const int* __restrict__ vis,
@@ -312,30 +313,46 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     const double sc = w.wi * w.gamma;
     const int per = (N + GAIN_SLICES - 1) / GAIN_SLICES;
     const int k_beg = blockIdx.y * per, k_end = min(N, k_beg + per);
+    // per-landmark constants of this slice once per workgroup (they are a chain of small dependent loads: fetched per
+    // thread and iteration they cost more than the streaming of Ut itself): Si^{-1}, Si^{-T}(z - h), "matched and visible"
+    __shared__ double lk[GAIN_LM_MAX][6];
+    __shared__ int lon[GAIN_LM_MAX];
     double dx = 0.0;
-    for (int k = k_beg + sl; k < k_end; k += 4) {
-        const bool on = (mt[k] != 0) && (vis[k] != 0);
-        double u0 = 0.0, u1 = 0.0;
-        if (on && r < n) {
+    for (int k0 = k_beg; k0 < k_end; k0 += GAIN_LM_MAX) {
+        __syncthreads();
+        const int cnt = min(GAIN_LM_MAX, k_end - k0);
+        if ((int)threadIdx.x < cnt) {
+            const int k = k0 + threadIdx.x;
+            const bool on = (mt[k] != 0) && (vis[k] != 0);
             const double s00 = Si[4 * k], s01 = Si[4 * k + 1], s10 = Si[4 * k + 2], s11 = Si[4 * k + 3];
             double det = s00 * s11 - s01 * s10;
             double i00 = 0, i01 = 0, i10 = 0, i11 = 0;
             if (det != 0.0) { det = 1.0 / det; i00 = s11 * det; i01 = -s01 * det; i10 = -s10 * det; i11 = s00 * det; }
-            double p0, p1;
-            if (r < n - 4) {
-                p0 = sc * Ut[(size_t)(2 * k) * ld + r];
-                p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
-            } else {
-                p0 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k];
-                p1 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k + 1];
-            }
-            u0 = p0 * i00 + p1 * i10;
-            u1 = p0 * i01 + p1 * i11;
             const double v0 = z[2 * k] - h[2 * k], v1 = z[2 * k + 1] - h[2 * k + 1];
-            dx += u0 * (i00 * v0 + i10 * v1) + u1 * (i01 * v0 + i11 * v1);
+            lk[threadIdx.x][0] = i00; lk[threadIdx.x][1] = i01; lk[threadIdx.x][2] = i10; lk[threadIdx.x][3] = i11;
+            lk[threadIdx.x][4] = i00 * v0 + i10 * v1; lk[threadIdx.x][5] = i01 * v0 + i11 * v1;
+            lon[threadIdx.x] = on ? 1 : 0;
         }
-        Ut[(size_t)(2 * k) * ld + r] = u0;
-        Ut[(size_t)(2 * k + 1) * ld + r] = u1;
+        __syncthreads();
+        for (int q = sl; q < cnt; q += 4) {
+            const int k = k0 + q;
+            double u0 = 0.0, u1 = 0.0;
+            if (lon[q] && r < n) {
+                double p0, p1;
+                if (r < n - 4) {
+                    p0 = sc * Ut[(size_t)(2 * k) * ld + r];
+                    p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
+                } else {
+                    p0 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k];
+                    p1 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k + 1];
+                }
+                u0 = p0 * lk[q][0] + p1 * lk[q][2];
+                u1 = p0 * lk[q][1] + p1 * lk[q][3];
+                dx += u0 * lk[q][4] + u1 * lk[q][5];
+            }
+            Ut[(size_t)(2 * k) * ld + r] = u0;
+            Ut[(size_t)(2 * k + 1) * ld + r] = u1;
+        }
     }
     red[sl][rl] = dx;
     __syncthreads();
