@@ -217,9 +217,10 @@ __global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_para
                                                  const double* __restrict__ sigR,
                                                  double* __restrict__ Z, double* __restrict__ DZ)
 {
-    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ii = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (k >= d.N || ii > d.Na) return;
+    // flat (direction, landmark) index: no idle lanes when N is not a multiple of the wave size (N = 200: 78 % -> 100 %)
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int ii = g / d.N, k = g - ii * d.N;
+    if (ii > d.Na) return;
     const int n = d.n, Na = d.Na, ld = d.np, mp = d.mp;
     const double f1 = p.cam_f / p.cam_dx, f2 = p.cam_f / p.cam_dy;
     double base[6];
@@ -454,7 +455,7 @@ void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, do
 void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
                           double* Z, double* DZ)
 {
-    dim3 grid((d.N + 63) / 64, (d.Na + 1 + 3) / 4);
+    dim3 grid(((d.Na + 1) * d.N + 255) / 256);
     hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, d, w, p, X, S, sigR, Z, DZ);
 }
 void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* X, const double* sigR, const double* Z,
