@@ -1,0 +1,502 @@
+// srukf_gmw_persist.hip — the blocked GMW factorisation (modifiedCholeskyDecomposition, SLAM.cpp:2197-2327) as ONE
+// persistent launch: a resident pivot workgroup and worker workgroups that own the trailing tiles.  gfx950 only.
+// The per-panel form, the theta-clamp check and the exact column path are in srukf_factor.hip.
+#include <hip/hip_runtime.h>
+#include "srukf_device.h"
+#include "srukf_tiles.h"
+#include "srukf_gmw_cols.h"
+#include "srukf_gmw_panel.h"
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form: the whole factorisation in ONE launch (k_gmw_persist).
+//
+// With one launch per panel the chain of T = ld/64 launches pays, per panel, a dispatch gap (~1.5 us) and a cold
+// start (kernarg + first loads from HBM, ~2.3 us: every launch begins with an invalidated L2) on top of the ~9.5 us
+// of arithmetic of the critical-path workgroup.  Here that workgroup ("pivot", blockIdx 0) stays resident: it keeps
+// the panel it has just factored in LDS (T1', E', T2', 1/D), applies it to the next 64x64 diagonal region itself and
+// factors that, panel after panel.  Every other 64x64 tile (I, J) of the trailing matrix is OWNED by one worker
+// workgroup, which holds it in registers from its first update to its last: a tile that went back to memory after
+// every panel would need  store + acknowledge + flag + poll + load  (~2 us, scripts/mb/mb_xwg.hip) plus the update
+// itself (~4 us) per panel — longer than the pivot's period, and the tile chains, not the pivot, would set the pace
+// (measured with a task-queue version: 13 us per panel against 9.6 us).  Hand-off through global memory:
+//   pivot  -> workers : panel buffer pans[k] (agent-scope stores), then panel_ready = k + 1
+//   owner  -> anybody : the tile, once, when it has received its last update: G tile (agent-scope stores), then
+//                       ver[I][J] = number of panel updates it carries (I for I < J; I - 1 on the diagonal, where the
+//                       pivot applies the last panel itself)
+//   step k of tile (I, J) needs panel k and the finished row-panel tiles (k, I), (k, J);
+//   the pivot, before panel p, needs tiles (p-1, p) and (p, p).
+// Every workgroup of the grid must be resident (1 + workers <= CUs; the launcher sees to that, and a filter that
+// shares the GPU with others uses the one-launch-per-panel path).  Every wait is bounded: on expiry the launch is
+// abandoned and the frame flagged, and the caller repeats it on the other path.
+// ------------------------------------------------------------------------------------------------
+// Who polls and who raises flags: WAVE 0 as a whole, under wave-uniform (scalar) conditions, never "if (tid == 0)".
+// A divergent single-thread branch just before the back edge of the task loop and another one right after its head
+// get merged by the structurizer into a lane-divergent loop around the workgroup barrier (wave 0 then executes
+// s_barrier more often than the other waves: hang).  Uniform branches leave EXEC alone; 64 lanes loading or storing
+// the same flag word are one memory request.
+#define GMW_XWG_LIMIT (1 << 16)                 // ~50 ms; a legitimate wait is over in microseconds
+__device__ __forceinline__ unsigned long long gmw_uniform64(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ bool gmw_wait_ge(const unsigned long long* f, unsigned long long want, const int* abort_flag)
+{
+    for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+        if (gmw_uniform64(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= want) return true;
+        if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+__device__ __forceinline__ void gmw_set_flag(unsigned long long* f, unsigned long long v)
+{
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all copies of a panel flag: lane c < COPIES stores copy c (one instruction; called by a whole wave)
+__device__ __forceinline__ void gmw_set_panel_flag(unsigned long long* f, unsigned long long v, int lane)
+{
+    if (lane < GMW_FLAG_COPIES) __hip_atomic_store(&f[lane * GMW_FLAG_STRIDE], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all agent-scope stores of this workgroup have landed -> wave 0 raises the flag (wv0: wave-uniform "this is wave 0")
+__device__ __forceinline__ void gmw_publish(unsigned long long* f, unsigned long long v, bool wv0)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wv0) gmw_set_flag(f, v);
+}
+
+// LDS of the pivot workgroup that survives from one panel to the next
+struct GmwPivotKeep {
+    double* T1;      // [kk][33]   T1'[jj][kk] of the panel factored last (xreg + 2048, written by the T wave of factor 1)
+    double* T2;      // [kk][33]   T2'                                     (xreg, staging buffer of the T wave of factor 2)
+    double* Ep;      // [k][32], column ^ 16*(k&1): E' = W1d / D'
+    double* rD;      // [64] 1/D
+    double* sq;      // [64] sqrt(D)/D
+};
+
+// One wave copies the 64x64 tile at (row0, col0) of G into an LDS array (row stride G64_LS): each request is one
+// 512-byte row, all 64 in flight (one memory round trip).  Agent-scope loads: the tile was written by a worker of this launch.
+__device__ __forceinline__ void gmw_stage_tile(double (*dst)[G64_LS], const double* __restrict__ G, int ld, int row0, int col0, int lane)
+{
+    const double* src = G + (size_t)row0 * ld + col0 + lane;
+    double v[64];
+#pragma unroll
+    for (int r = 0; r < 64; r++) v[r] = ld_dev(src + (size_t)r * ld);
+#pragma unroll
+    for (int r = 0; r < 64; r++) dst[r][lane] = v[r];
+}
+
+// Pivot workgroup: panels p = 0 .. T-1.  Same phases as gmw_step64_block00 (A slab, B tile (0,0), factor 1, C, factor 2);
+// what differs is where the operands come from: the previous panel from LDS, G tiles through agent-scope loads after
+// their version flags, and the panel buffer is published for the workers.
+__device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
+                                                  double* __restrict__ Dall, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
+                                                  double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg, double* xreg, double* keepreg,
+                                                  int* okp, int* halfcnt, int* stageok, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int qa = wv >> 1, qb = wv & 1;
+    const GmwColsLds ws = gmw_cols_carve(facreg), ws2 = gmw_cols_carve(facreg + GMW_FAC_DOUBLES);
+    double (*X01)[32] = (double (*)[32])xreg;
+    double (*X11)[32] = (double (*)[32])(xreg + 1024);
+    GmwPivotKeep kp;
+    kp.T1 = xreg + 2048; kp.T2 = xreg; kp.Ep = keepreg; kp.rD = keepreg + 1024; kp.sq = keepreg + 1088;
+    unsigned long long* ver = gmw_sync_ver(sy);
+    const int ro = (wv == 1) ? 0 : 32;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);        // wave-uniform copy: scalar branches around everything that polls or raises flags
+    const bool wv0 = wvu == 0, wv1 = wvu == 1, wv3 = wvu == 3;
+    if (wv0) *okp = 1;
+    if (wv3) gmw_stage_tile(Wc, G, ld, 0, 0, lane);            // region R_0 as k_syrk left it
+    __syncthreads();
+    for (int p = 0; p < T; p++) {
+        const int j0 = 64 * (p - 1), base = 64 * p;
+        const bool first = (p == 0);
+        GmwPanel64* nxt = pans + p;
+        if (wv0) GMW_TS(sy, p, 0);
+        // operands staged in LDS by waves 1 / 3 during factor 2 of the previous panel: Lr = tile (p-1, p) (rows of the
+        // current panel, columns of R), Wc = tile (p, p) (R itself)
+        if (wv0) { ws.Dv[lane & 31] = 0.0; ws2.Dv[lane & 31] = 0.0; *halfcnt = 0; stageok[lane & 1] = 0; }
+        d4 g;
+#pragma unroll
+        for (int t = 0; t < 4; t++) g[t] = Wc[16 * qa + lk + 4 * t][16 * qb + lr];
+        d4 acc[2][2];
+        zero_acc(acc);
+        if (wv & 1) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = Wc[ro + 16 * a + lk + 4 * t][32 + 16 * b + lr];
+        }
+        d4 X2[2];
+        double fb[8], dr[4][4];
+        if (!first) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) fb[u] = Lr[4 * u + lk][16 * wv + lr];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) X2[a][t] = Lr[32 + 16 * a + lk + 4 * t][16 * wv + lr];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) dr[q][t] = kp.rD[16 * q + lk + 4 * t];
+        }
+        __syncthreads();                                       // staged tiles are in registers: Lr / Wc may be rewritten
+        if (!first) {
+            // ---- A: slab for columns cw .. cw+15, panel matrices from LDS ----
+            d4 W1[2] = { (d4){0, 0, 0, 0}, (d4){0, 0, 0, 0} }, W2[2] = { (d4){0, 0, 0, 0}, (d4){0, 0, 0, 0} };
+            const int sw = 16 * (lk & 1);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double* rowp = &kp.T1[(4 * u + lk) * 33];
+                if (u < 4) W1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr], fb[u], W1[0], 0, 0, 0);
+                W1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[16 + lr], fb[u], W1[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double* rowp = &kp.Ep[(4 * u + lk) * 32];
+                X2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rowp[lr ^ sw], W1[u >> 2][u & 3], X2[0], 0, 0, 0);
+                X2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-rowp[(16 + lr) ^ sw], W1[u >> 2][u & 3], X2[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double* rowp = &kp.T2[(4 * u + lk) * 33];
+                if (u < 4) W2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[lr], X2[u >> 2][u & 3], W2[0], 0, 0, 0);
+                W2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rowp[16 + lr], X2[u >> 2][u & 3], W2[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int jj = 16 * a + lk + 4 * t, cc = 16 * wv + lr;
+                    Wc[jj][cc] = W1[a][t];       Lr[jj][cc] = W1[a][t] * dr[a][t];
+                    Wc[32 + jj][cc] = W2[a][t];  Lr[32 + jj][cc] = W2[a][t] * dr[2 + a][t];
+                }
+        }
+        if (wv0) GMW_TS(sy, p, 1);
+        __syncthreads();
+        // ---- B: quarter (qa, qb) of tile (0,0), K = 64 ----
+        if (!first) {
+#pragma unroll
+            for (int k = 0; k < 64; k += 4)
+                g = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], g, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) ws.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = g[t];
+        __syncthreads();
+        if (wv0) GMW_TS(sy, p, 2);
+        // ---- factor 1 (+ panel S rows, tiles (0,1), (1,1)) ----
+        if (wv0) gmw_cols_pivot_wave(ws, eps, lane);
+        else if (wvu == 2) gmw_cols_t_wave<0>(ws, lane, nullptr, kp.T1);
+        else {
+            if (!first) {
+#pragma unroll
+                for (int k = 0; k < 64; k += 4) {
+                    const double a0 = -Lr[k + lk][ro + lr], a1 = -Lr[k + lk][ro + 16 + lr];
+                    const double b0 = Wc[k + lk][32 + lr], b1 = Wc[k + lk][48 + lr];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+            double (*X)[32] = (wv == 1) ? X01 : X11;           // X01 overwrites T2 of the previous panel: dead since phase A
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) X[16 * a + lk + 4 * t][16 * b + lr] = acc[a][b][t];
+            if (!first) {
+                const int c4 = lr * 4;
+#pragma unroll 4
+                for (int i = 0; i < 8; i++) {
+                    const int row = ro + 4 * i + lk;
+                    const double sq = kp.sq[row];
+                    d4 w = *(const d4*)&Wc[row][c4];
+                    w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
+                    *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
+                }
+            }
+        }
+        __syncthreads();
+        if (wv0) GMW_TS(sy, p, 3);
+        // ---- C1: quarter (qa, qb) of W1d = T1' X01 and of E' = W1d / D' ----
+        {
+            d4 wq = (d4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                wq = __builtin_amdgcn_mfma_f64_16x16x4f64(kp.T1[(4 * u + lk) * 33 + 16 * qa + lr], X01[4 * u + lk][16 * qb + lr], wq, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int k = 16 * qa + lk + 4 * t, cc = 16 * qb + lr;
+                const double e = wq[t] * gmw_pivot_rcp(ws.Dv[k]);
+                Wc[k][cc] = wq[t];
+                Lr[k][cc] = e;
+                kp.Ep[k * 32 + (cc ^ (16 * (k & 1)))] = e;
+            }
+        }
+        __syncthreads();
+        // ---- C2: quarter of X11 -= E'^T W1d -> Xm of factor 2 ----
+        {
+            d4 x;
+#pragma unroll
+            for (int t = 0; t < 4; t++) x[t] = X11[16 * qa + lk + 4 * t][16 * qb + lr];
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lr[k + lk][16 * qa + lr], Wc[k + lk][16 * qb + lr], x, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) ws2.Xm[16 * qa + lk + 4 * t][16 * qb + lr] = x[t];
+        }
+        __syncthreads();
+        if (wv0) GMW_TS(sy, p, 4);
+        // ---- factor 2.  Wave 0 pivots, wave 2 follows with T2'.  Waves 1 / 3, in the order of who is waiting for what:
+        //   1. the first half of the panel buffer (wave 1: E' and the pivots of sub-panel 1; wave 3: T1'); whoever sees its
+        //      stores acknowledged last raises half_ready — the workers run their first two MFMA stages while factor 2 is busy;
+        //   2. the (0,1) tile of S and the S rows / pivots of both factors as the pivot wave produces them.
+        // Then EVERY wave fetches 32 rows of the two tiles the NEXT panel needs (tile (p, p+1) -> Lr by waves 1 / 0,
+        // tile (p+1, p+1) -> Wc by waves 3 / 2; finished by their owners with the updates of panels 0 .. p-1).  Lr / Wc are
+        // free: wave 1 is the only reader of Lr's E' corner, wave 3 of Wc's W1d corner, both in rows 0..31 which they
+        // overwrite themselves.  Waiting for those loads also waits for the wave's earlier stores, so after the closing
+        // barrier the panel buffer is complete in memory and panel_ready can be raised at once.
+        if (wv0) { gmw_cols_pivot_wave(ws2, eps, lane); GMW_TS(sy, p + 64, 0); }
+        else if (wvu == 2) {
+            // this wave has slack while it follows the pivots: it asks early whether the owners of the two tiles of the NEXT
+            // panel have finished them (normally yes) and tells the others through LDS — saves every wave the ~1 us poll
+            // round trip at the end of the iteration
+            unsigned long long fa = 0, fb = 0;
+            if (p >= 1 && p + 1 < T) {
+                fa = __hip_atomic_load(&ver[(size_t)p * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fb = __hip_atomic_load(&ver[(size_t)(p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            gmw_cols_t_wave<2>(ws2, lane, nxt->Tt2, kp.T2, [&] {
+                if (p == 0 || gmw_uniform64(fa) >= ebase + p) stageok[0] = 1;
+                if (p == 0 || gmw_uniform64(fb) >= ebase + p) stageok[1] = 1;
+            });
+        } else {
+            const int c4 = (lane & 7) * 4;
+            if (wv1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = 8 * i + (lane >> 3);
+                    st_d4<true>(&nxt->E[row * 32 + c4], *(const d4*)&Lr[row][c4]);
+                }
+                if (lane < 32) {
+                    const double D = ws.Dv[lane], rc = gmw_pivot_rcp(D), sq = sqrt(D) * rc;
+                    st_dev(&nxt->D[lane], D); st_dev(&nxt->sq[lane], sq); st_dev(&nxt->rD[lane], rc);
+                }
+            } else gmw_copy_t<true>(kp.T1, nxt->Tt1, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                int prev = 0;
+                if (lane == 0) prev = __hip_atomic_fetch_add(halfcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(prev) == 1) gmw_set_panel_flag(sy->half_ready, ebase + p + 1, lane);
+            }
+            if (!wv1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = 8 * i + (lane >> 3);
+                    const double Dr = ws.Dv[row];
+                    const double sq = (base + row < n) ? sqrt(Dr) * gmw_pivot_rcp(Dr) : 0.0;
+                    d4 w = *(const d4*)&Wc[row][c4];
+                    w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
+                    *(d4*)&Sout[(size_t)(base + row) * ld + base + 32 + c4] = w;
+                }
+            }
+            gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD);
+            gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32);
+            if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
+        }
+        if (p + 1 < T) {
+            const bool tileA = wvu < 2;                        // waves 0, 1: tile (p, p+1) -> Lr;  waves 2, 3: tile (p+1, p+1) -> Wc
+            const int tr = tileA ? p : p + 1, r0 = (wvu & 1) ? 0 : 32;
+            if (wv1) GMW_TS(sy, p, 5);
+            const bool ready = p == 0 || __builtin_amdgcn_readfirstlane(stageok[tileA ? 0 : 1]) != 0 || gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
+            if (wv1) GMW_TS(sy, p, 6);
+            if (!ready) *okp = 0;
+            else {
+                double (*dst)[G64_LS] = tileA ? Lr : Wc;
+                const double* src = G + (size_t)(64 * tr + r0) * ld + 64 * (p + 1) + lane;
+                double v[32];
+#pragma unroll
+                for (int r = 0; r < 32; r++) v[r] = ld_dev(src + (size_t)r * ld);
+#pragma unroll
+                for (int r = 0; r < 32; r++) dst[r0 + r][lane] = v[r];
+            }
+        }
+        __syncthreads();                                       // closes the iteration: staged tiles visible, LDS arrays reusable
+        if (wv3 && p + 1 < T) { gmw_set_panel_flag(sy->panel_ready, ebase + p + 1, lane); GMW_TS(sy, p + 64, 3); }
+        if (wv0) GMW_TS(sy, p, 7);
+        if (!*okp) { if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
+    // the last panel buffers are never read by a worker (steps T-2 and T-1 have no trailing tiles)
+}
+
+// Worker side of one update step of an owned tile; returns false when a wait expired.
+struct GmwOwned { int I, J, nsteps; bool computed; };
+struct KDimsLite { int n, ld; };
+__device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, const GmwOwned& tl, d4 (&acc)[2][2], double* __restrict__ G,
+                                               GmwPanel64* pans, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
+                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid)
+{
+    unsigned long long* ver = gmw_sync_ver(sy);
+    // the two row-panel tiles (k, I), (k, J) are finished (k updates each) — both flags in one round trip
+    if (wv0) {
+        bool good = true;
+        if (k > 0) {
+            const unsigned long long want = ebase + k;
+            unsigned long long a = 0, b = 0;
+            for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+                a = gmw_uniform64(__hip_atomic_load(&ver[(size_t)k * T + tl.I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b = gmw_uniform64(__hip_atomic_load(&ver[(size_t)k * T + tl.J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (a >= want && b >= want) break;
+                if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            good = a >= want && b >= want;
+        }
+        *okp = good;
+    }
+    __syncthreads();
+    if (!*okp) return false;
+    const bool last = k == tl.nsteps - 1;
+    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, k == 0 && !tl.computed, last,
+        [&] {
+            if (wv0) *okp = gmw_wait_ge(&sy->half_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
+            __syncthreads();
+            return *okp != 0;
+        },
+        [&] {
+            if (wv0) *okp = gmw_wait_ge(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
+            __syncthreads();
+            return *okp != 0;
+        },
+        [&] { if (last) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); });
+}
+
+// k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any).
+#define GMW_OWNED_MAX 2
+struct GmwTile { short I, J, nsteps, pad; };
+// S0 != null: the tiles of block rows I >= GMW_HEAD_ROWS are not read from G but COMPUTED by their owners,
+//   G[r][c] = sum_k S0[k][r] S0[k][c] - sum_{u0 <= m < u1} Ut0[m][r] Ut0[m][c]      (what k_syrk does, SLAM.cpp:2118-2120, 2149),
+// while the pivot is already factoring the first panels (k_syrk then only runs for block rows 0 and 1: a few
+// microseconds instead of ~37).  The owner of tile (I, J) needs 12.5 + 1.7 I us for it and has ~12 I us until somebody waits
+// for the tile.  S0 must not be the buffer the factor is written to (Sout).
+#define GMW_HEAD_ROWS 2
+__device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
+                                               int I, int J, d4 (&acc)[2][2], FrameScalars* __restrict__ fs, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = 64 * I + 32 * (wv >> 1), c0 = 64 * J + 32 * (wv & 1);
+    zero_acc(acc);
+    if (m0 >= d.ld || c0 >= d.ld || c0 + 32 <= m0) return;
+    tile32_tn<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, d.ld), lane);      // S0[k][r] = 0 for k > r
+    tile32_tn<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
+    double gmax = 0.0, xmax = 0.0;                             // gamma / xi of the GMW bound, as in k_syrk
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r = m0 + 16 * a + lk + 4 * t, c = c0 + 16 * b + lr;
+                if (r < d.n && c < d.n && c >= r) { if (r == c) gmax = fmax(gmax, acc[a][b][t]); else xmax = fmax(xmax, acc[a][b][t]); }
+            }
+    gmax = wave_max(gmax); xmax = wave_max(xmax);
+    if (lane == 0) {
+        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, double* __restrict__ G, GmwPanel64* __restrict__ pans,
+                                                     double* __restrict__ Sout, double* __restrict__ Dall, double eps,
+                                                     GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
+                                                     FrameScalars* __restrict__ fs,
+                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1)
+{
+    __shared__ double Lr[64][G64_LS];
+    __shared__ double Wc[64][G64_LS];
+    __shared__ double facreg[2 * GMW_FAC_DOUBLES];
+    __shared__ double xreg[1024 + 1024 + 32 * 33];
+    __shared__ double keepreg[1024 + 64 + 64];
+    __shared__ int ok, halfcnt, stageok[2];
+    const int tid = threadIdx.x;
+    const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
+    if (blockIdx.x == 0) {
+        gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid);
+    } else {
+        const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+        const int workers = gridDim.x - 1, w = blockIdx.x - 1;
+        GmwOwned ta = { 0, 0, 0, false }, tb = { 0, 0, 0, false };
+        if (w < ntiles) { const GmwTile t = tiles[w]; ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; }
+        if (w + workers < ntiles) { const GmwTile t = tiles[w + workers]; tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; }
+        d4 acca[2][2], accb[2][2];
+        zero_acc(acca); zero_acc(accb);
+        if (S0) {
+            const KDimsLite dl = { n, ld };
+            if (ta.nsteps > 0 && ta.I >= GMW_HEAD_ROWS) { gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid); ta.computed = true; }
+            if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid); tb.computed = true; }
+        }
+        const int kmax = max(ta.nsteps, tb.nsteps);
+        bool good = true;
+        for (int k = 0; k < kmax && good; k++) {
+            if (k < ta.nsteps) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
+            if (good && k < tb.nsteps) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
+        }
+        if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the last workgroup out re-arms the block for the next launch and reports an abandoned run
+    GMW_DBG(sy, 6, 7777);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
+            __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" {
+int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + sizeof(unsigned long long) * (size_t)T * T); }
+// host-side tile list of the persistent launch: every tile (I, J), 1 <= I <= J < T, with the number of panel updates
+// its owner applies (I off the diagonal; I - 1 on it: the pivot applies the last one itself), ordered by the step at
+// which it is finished, so that worker w and worker w + workers hold tiles that retire at different times.
+// Returns the number of tiles; out (4 shorts per tile) may be null.
+int srukf_gmw_build_tiles(int T, short* out)
+{
+    int cnt = 0;
+    for (int I = 1; I < T; I++)
+        for (int J = I; J < T; J++) {
+            const int ns = (I == J) ? I - 1 : I;
+            if (ns < 1) continue;
+            if (out) { out[4 * cnt] = (short)I; out[4 * cnt + 1] = (short)J; out[4 * cnt + 2] = (short)ns; out[4 * cnt + 3] = 0; }
+            cnt++;
+        }
+    return cnt;
+}
+// workers the persistent launch needs for T block rows (each owns at most GMW_OWNED_MAX tiles); -1: too many tiles
+int srukf_gmw_persist_workers(int T, int max_workers)
+{
+    const int nt = srukf_gmw_build_tiles(T, nullptr);
+    if (nt == 0) return 0;
+    if (nt <= max_workers) return nt;
+    if (nt <= GMW_OWNED_MAX * max_workers) return max_workers;
+    return -1;
+}
+// S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G)
+void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
+                              void* sync, const void* tiles, int ntiles, int workers, void* fs,
+                              const double* S0, const double* Ut0, int u0, int u1)
+{
+    const int T = ld / 64;
+    hipLaunchKernelGGL(k_gmw_persist, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
+                       (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
+}
+int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
+}  // extern "C"
