@@ -87,6 +87,8 @@ __device__ __forceinline__ void stage32_tri_globalB(d4 (&acc)[2][2], const doubl
 // wait_half() / wait_full(): called once each by ALL threads (they hold the workgroup barrier that separates this
 // call's LDS writes from the previous call's reads); false abandons the tile.  stored(): called by all threads right
 // after the tile store — the persistent kernel raises the tile's flag there, before the S rows nobody waits for.
+// early2: the whole panel buffer is known to be complete already (a worker that is behind): the second half's operands
+// are requested together with the first half's — one memory round trip per step instead of two.
 // acc: this wave's 32x32 quadrant.  load_tile / store_tile: read it from / write it back to G (the persistent kernel
 // keeps a tile in registers from its first update to its last).
 // DEV: G tiles are exchanged with other workgroups of the SAME launch (agent-scope accesses).  The panel buffer is read
@@ -97,7 +99,8 @@ template <bool DEV, class WaitHalf, class WaitFull, class Stored>
 __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, int bx, double* __restrict__ G,
                                                 const GmwPanel64* cur, double* __restrict__ Sout,
                                                 double (*Lr)[G64_LS], double (*Wc)[G64_LS], int tid, d4 (&acc)[2][2],
-                                                bool load_tile, bool store_tile, WaitHalf&& wait_half, WaitFull&& wait_full, Stored&& stored)
+                                                bool load_tile, bool store_tile, WaitHalf&& wait_half, WaitFull&& wait_full, Stored&& stored,
+                                                bool early2 = false)
 {
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -123,6 +126,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
     const int ro = m0 - R0, co = c0 - C0;
     d4 X2[2][2], W1[2][2], W2[2][2];
     double fb0[8], fb1[8];
+    double tb0[4], tb1[8], dr2[2][4], sqr[4][4];
     if (slab) {
 #pragma unroll
         for (int a = 0; a < 2; a++)
@@ -145,6 +149,22 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
             if (u < 4) ta0[u] = cur->Tt1[o];
             ta1[u] = cur->Tt1[o + 16];
             ea0[u] = cur->E[o]; ea1[u] = cur->E[o + 16];
+        }
+        if (early2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int o = (4 * u + lk) * 32 + lr;
+                if (u < 4) tb0[u] = cur->Tt2[o];
+                tb1[u] = cur->Tt2[o + 16];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) dr2[q][t] = (which == 0) ? cur->rD[32 + 16 * q + lk + 4 * t] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 2; q++)
@@ -196,23 +216,23 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
     }
     // ---- second half ----
     if (!wait_full()) return false;
-    double sqr[4][4];
     if (slab) {
-        double tb0[4], tb1[8], dr[2][4];
+        if (!early2) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int o = (4 * u + lk) * 32 + lr;
-            if (u < 4) tb0[u] = cur->Tt2[o];
-            tb1[u] = cur->Tt2[o + 16];
+            for (int u = 0; u < 8; u++) {
+                const int o = (4 * u + lk) * 32 + lr;
+                if (u < 4) tb0[u] = cur->Tt2[o];
+                tb1[u] = cur->Tt2[o + 16];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) dr2[q][t] = (which == 0) ? cur->rD[32 + 16 * q + lk + 4 * t] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
         }
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) dr[q][t] = (which == 0) ? cur->rD[32 + 16 * q + lk + 4 * t] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
         zero_acc(W2);
         // W2 = T2 G2'
 #pragma unroll
@@ -233,7 +253,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                 for (int t = 0; t < 4; t++) {
                     const int jj = 32 + 16 * a + lk + 4 * t, cc = 32 * half + 16 * b + lr;
                     const double w2 = W2[a][b][t];
-                    if (which == 0) { Lr[jj][cc] = w2 * dr[a][t]; if (diagblk) Wc[jj][cc] = w2; }
+                    if (which == 0) { Lr[jj][cc] = w2 * dr2[a][t]; if (diagblk) Wc[jj][cc] = w2; }
                     else Wc[jj][cc] = w2;
                 }
     }

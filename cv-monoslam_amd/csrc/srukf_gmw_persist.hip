@@ -342,38 +342,43 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
                                                double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid)
 {
     unsigned long long* ver = gmw_sync_ver(sy);
-    // the two row-panel tiles (k, I), (k, J) are finished (k updates each) — both flags in one round trip
+    // the two row-panel tiles (k, I), (k, J) are finished (k updates each) — both flags, and the panel flag, in one round
+    // trip.  A worker that finds panel k complete already is behind the pivot: it then asks for ALL operands of the step
+    // at once and skips the two panel waits (6-7 us per step instead of ~11: it catches up).
     if (wv0) {
-        bool good = true;
-        if (k > 0) {
-            const unsigned long long want = ebase + k;
-            unsigned long long a = 0, b = 0;
-            for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
-                a = gmw_uniform64(__hip_atomic_load(&ver[(size_t)k * T + tl.I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                b = gmw_uniform64(__hip_atomic_load(&ver[(size_t)k * T + tl.J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (a >= want && b >= want) break;
-                if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
-                __builtin_amdgcn_s_sleep(1);
+        const unsigned long long want = ebase + k;
+        unsigned long long a = want, b = want, pr = 0;
+        for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+            if (k > 0) {
+                a = __hip_atomic_load(&ver[(size_t)k * T + tl.I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b = __hip_atomic_load(&ver[(size_t)k * T + tl.J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            good = a >= want && b >= want;
+            pr = __hip_atomic_load(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a = gmw_uniform64(a); b = gmw_uniform64(b); pr = gmw_uniform64(pr);
+            if (a >= want && b >= want) break;
+            if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+            __builtin_amdgcn_s_sleep(1);
         }
-        *okp = good;
+        *okp = (a >= want && b >= want) ? ((pr >= ebase + k + 1) ? 2 : 1) : 0;
     }
     __syncthreads();
     if (!*okp) return false;
+    const bool behind = *okp == 2;
     const bool last = k == tl.nsteps - 1;
+    __syncthreads();                                           // *okp is rewritten by the panel waits below
     return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, k == 0 && !tl.computed, last,
         [&] {
-            if (wv0) *okp = gmw_wait_ge(&sy->half_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
+            if (!behind) { if (wv0) *okp = gmw_wait_ge(&sy->half_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort); }
             __syncthreads();
             return *okp != 0;
         },
         [&] {
-            if (wv0) *okp = gmw_wait_ge(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
+            if (!behind) { if (wv0) *okp = gmw_wait_ge(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort); }
             __syncthreads();
             return *okp != 0;
         },
-        [&] { if (last) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); });
+        [&] { if (last) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); },
+        behind);
 }
 
 // k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any).
