@@ -397,8 +397,8 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
     const int m0 = 64 * I + 32 * (wv >> 1), c0 = 64 * J + 32 * (wv & 1);
     zero_acc(acc);
     if (m0 >= d.ld || c0 >= d.ld || c0 + 32 <= m0) return;
-    tile32_tn<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, d.ld), lane);      // S0[k][r] = 0 for k > r
-    tile32_tn<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
+    tile32_tn_deep<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, d.ld), lane);      // S0[k][r] = 0 for k > r
+    tile32_tn_deep<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
     double gmax = 0.0, xmax = 0.0;                             // gamma / xi of the GMW bound, as in k_syrk
 #pragma unroll
     for (int a = 0; a < 2; a++)

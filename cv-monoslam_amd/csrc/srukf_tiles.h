@@ -48,6 +48,61 @@ __device__ __forceinline__ void tile32_tn(d4 (&acc)[2][2], const double* __restr
     }
 }
 
+// The same contraction for a wave that has its SIMD to itself (the tile owners of the persistent GMW launch: one
+// workgroup per CU): nobody else hides the operand latency, so FOUR rotating fragment buffers keep three groups of loads
+// (48 requests) in flight while one group is multiplied.  sched_barrier pins the order (hipcc otherwise sinks the loads
+// down to their first use).  Costs 128 VGPRs of fragments — an occupancy step in k_syrk / k_pxy, free here.
+struct TileFrag { double a0[4], a1[4], b0[4], b1[4]; };
+__device__ __forceinline__ void tile_frag_load(TileFrag& f, const double* __restrict__ pa, const double* __restrict__ pb, size_t sa, size_t sb)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++) { f.a0[u] = pa[u * sa]; f.a1[u] = pa[u * sa + 16]; f.b0[u] = pb[u * sb]; f.b1[u] = pb[u * sb + 16]; }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <bool NEG>
+__device__ __forceinline__ void tile_frag_mma(d4 (&acc)[2][2], const TileFrag& f)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const double a0 = NEG ? -f.a0[u] : f.a0[u], a1 = NEG ? -f.a1[u] : f.a1[u];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f.b0[u], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f.b1[u], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f.b0[u], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f.b1[u], acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <bool NEG>
+__device__ __forceinline__ void tile32_tn_deep(d4 (&acc)[2][2], const double* __restrict__ A, int lda,
+                                               const double* __restrict__ B, int ldb, int m0, int n0, int kb, int ke, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ng = (ke - kb) >> 4;
+    if (ng <= 0) return;
+    const double* pa = A + (size_t)(kb + lk) * lda + m0 + lr;
+    const double* pb = B + (size_t)(kb + lk) * ldb + n0 + lr;
+    const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb, ga = 4 * sa, gb = 4 * sb;
+    const int last = ng - 1;                                   // loads past the last group are clamped onto it (in bounds, unused)
+    TileFrag f0, f1, f2, f3;
+    tile_frag_load(f0, pa, pb, sa, sb);
+    { const int h = min(1, last); tile_frag_load(f1, pa + h * ga, pb + h * gb, sa, sb); }
+    { const int h = min(2, last); tile_frag_load(f2, pa + h * ga, pb + h * gb, sa, sb); }
+    int g = 0;
+    for (; g + 4 <= ng; g += 4) {
+        tile_frag_load(f3, pa + (g + 3) * ga, pb + (g + 3) * gb, sa, sb);
+        tile_frag_mma<NEG>(acc, f0);
+        { const int h = min(g + 4, last); tile_frag_load(f0, pa + h * ga, pb + h * gb, sa, sb); }
+        tile_frag_mma<NEG>(acc, f1);
+        { const int h = min(g + 5, last); tile_frag_load(f1, pa + h * ga, pb + h * gb, sa, sb); }
+        tile_frag_mma<NEG>(acc, f2);
+        { const int h = min(g + 6, last); tile_frag_load(f2, pa + h * ga, pb + h * gb, sa, sb); }
+        tile_frag_mma<NEG>(acc, f3);
+    }
+    if (g < ng) tile_frag_mma<NEG>(acc, f0);
+    if (g + 1 < ng) tile_frag_mma<NEG>(acc, f1);
+    if (g + 2 < ng) tile_frag_mma<NEG>(acc, f2);
+}
+
 __device__ __forceinline__ void zero_acc(d4 (&acc)[2][2])
 {
 #pragma unroll
