@@ -60,6 +60,72 @@ def dist_env():
     return rank, world, local
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(nproc, argv, timeout=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) with
+    torch.distributed.run and relay rank 0's JSON line.  Called BEFORE this process imports torch or
+    touches HIP — the parent never initialises a GPU and never re-execs; it only waits for the children.
+    Returns (returncode, json_line or None)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    line = None
+    for ln in r.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)
+    return r.returncode, line
+
+
+def launch_selftest(rank, world):
+    """`--launch-selftest`: the launcher and every collective of the N-rank run on the gloo backend with CPU
+    tensors and NO filter (tests/test_distributed_cpu.py; this container has no GPU).  Exercises: spawn, rendezvous,
+    broadcast of rank 0's map, max-over-ranks of the wall time, all-gather of the trajectories, one JSON line whose
+    n_gpus is the world size the process group saw."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 16
+    sc = {"X0": np.full(n, 1.0 + rank), "S0": np.triu(np.full((n, n), 2.0 + rank))}
+    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, torch.device("cpu"))
+    same = bool((X0 == 1.0).all() and (S0 == torch.triu(torch.full((n, n), 2.0, dtype=torch.float64))).all())
+    traj = torch.full((3, 8), float(rank), dtype=torch.float64)
+    tt = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        allt = [torch.empty_like(traj) for _ in range(world)]
+        dist.all_gather(allt, traj)
+        seen = dist.get_world_size()
+    else:
+        allt, seen = [traj], 1
+    ok = same and [float(t[0, 0]) for t in allt] == [float(r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "srukf_updates_per_sec", "value": None, "unit": "frames/s", "n_gpus": seen,
+                          "selftest": True, "collectives_ok": ok, "wall_max": float(tt.item()), "scaling": "weak"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def build_inputs(synth, N, F, rank, map_seed=0):
     """Same map and odometry on every rank (seed map_seed), independent measurement noise."""
     return synth.make_scene(N, F, seed=map_seed, p=synth.scene_params(), obs_seed=1000 + rank)
@@ -149,9 +215,23 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--sequences-per-gpu", type=int, default=8,
                     help="extra measurement: B concurrent independent sequences on one GPU (0 = skip)")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="CPU/gloo check of the N-rank launcher and collectives only (no filter, no GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher.  Nothing in this process has touched torch / HIP yet.
+        rc, line = spawn_ranks(args.gpus, sys.argv[1:])
+        if line:
+            print(line, flush=True)
+        if rc != 0 or not line:
+            raise SystemExit(rc or 1)
+        return
     rank, world, local = dist_env()
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
+    if args.launch_selftest:
+        raise SystemExit(launch_selftest(rank, world))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge

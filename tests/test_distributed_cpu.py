@@ -35,3 +35,28 @@ def test_two_rank_gloo(tmp_path):
     assert not np.array_equal(t0[0], t0[1])                      # independent measurement noise per rank
     assert out[0]["z0"] != out[1]["z0"]
     assert np.abs(t0[0][:, :2] - t0[1][:, :2]).max() < 1e-3      # ...but the same underlying trajectory
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` (no launcher, as the driver calls it) must start two rank processes itself.
+    --launch-selftest runs the launcher + collectives on gloo with no filter; n_gpus is what the process group saw."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                      # exactly one JSON line, relayed from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["collectives_ok"] and out["wall_max"] == 0.2
+
+
+def test_bench_gpus_flag_fails_in_the_children_without_gpus():
+    """Without GPUs the real bench must fail inside the two spawned ranks (device acquisition), not run one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
