@@ -19,7 +19,7 @@ void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const doub
 void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
-                       const double*, const int*, const int*, FrameScalars*, double*, double*);
+                       const double*, const int*, const int*, FrameScalars*, double*, double*, const double*);
 int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
@@ -61,7 +61,7 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
     fs->frame = frame;
     fs->stat_count = 0;
     fs->traj_base = nullptr;
-    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; }
+    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; }
 }
 __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base = traj_base; }
 
@@ -191,6 +191,9 @@ struct srukf_ctx {
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered), one launch per panel
     GmwPlan gplan;                         // persistent GMW launch: panel buffers, sync block, task list
     int gmw_shared = 0;                    // 1: the GPU is shared with other filters — never use the persistent launch (it needs all its workgroups resident)
+    int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
+    int clamp_frame_host = -1, clamp_row_host = -1;   // what the last SRUKF_ERR_CLAMP_PENDING was about (srukf_clamp_info)
+    double *ckS = nullptr, *ckX = nullptr; // srukf_run_frames: state before the block of frames in flight (recovery from a theta-clamp frame)
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
     int *syrk_head_tiles = nullptr;                    // k_syrk tiles of the first srukf_gmw_head_rows() rows only (fused refactor)
     int n_syrk_tiles = 0, n_pxy_tiles = 0, n_syrk_head_tiles = 0;
@@ -355,7 +358,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     // N = 300 (two tiles per worker, both to be computed first) 1 544 / 1 663 — so only with one tile per worker and T >= 16.
     const bool fused = !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
                        c->gplan.ntiles <= c->gplan.workers && c->gplan.T >= 16 &&
-                       !getenv("SRUKF_GMW_TEST_STARVE") && gmw_fused_mode();
+                       !c->debug_starve && gmw_fused_mode();
     const double nn = n;
     const double syrk_flop = nn * nn * nn / 3.0 + nn * nn * (ue - ub), syrk_byte = 8.0 * (nn * nn + (double)(ue - ub) * nn);
     const double head_frac = fused ? fmin(1.0, 2.0 * srukf_gmw_head_rows() / nn) : 1.0;      // share of the tiles k_syrk still computes (rows / n, upper triangle)
@@ -402,9 +405,9 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout)
 {
     const int np = c->d.np, n = c->d.n;
     if (gmw_use_persist(c)) {
-        // SRUKF_GMW_TEST_STARVE (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait expires,
-        // the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
-        const int workers = getenv("SRUKF_GMW_TEST_STARVE") ? 0 : c->gplan.workers;
+        // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
+        // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
+        const int workers = c->debug_starve ? 0 : c->gplan.workers;
         srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, c->gplan.pans, c->D, Sout, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles, workers, c->fs, nullptr, nullptr, 0, 0);
         return;
     }
@@ -472,7 +475,7 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
-        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X);
+        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z);
         c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
 }
@@ -587,7 +590,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->S32, c->X32, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->S32, c->X32, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) hipFree(b);
     gmw_plan_destroy(c->gplan);
     if (c->hstage) hipHostFree(c->hstage);
@@ -793,6 +796,7 @@ static int read_fs(srukf_ctx* c)
 {
     HIPCHK(c, hipMemcpyAsync(c->hfs, c->fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->hfs->clamp_rows > 0 && c->hfs->clamp_frame == 0x7fffffff) c->hfs->clamp_frame = c->hfs->frame - 1;   // the run's last frame
     if (c->hfs->gmw_aborts > 0 && !c->gmw_shared) {
         // a persistent launch did not get all its workgroups onto the GPU in time (somebody else is using it): the flagged
         // frame is repeated on the exact path like a clamp frame, and this filter stays with one launch per panel
@@ -1225,18 +1229,96 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     return SRUKF_OK;
 }
 
+// One staged frame (index `frame`) through the path that checks the theta clamp on the host and repeats the
+// refactorisation column by column when the reference's third pivot candidate would have won — what srukf_update does,
+// with the staged inputs.  traj_row: device pointer of this frame's trajectory row, or null.
+static int run_staged_frame_exact(srukf_ctx* c, int frame, double* traj_row)
+{
+    const KDims& d = c->d;
+    double* tb = traj_row ? traj_row - (size_t)8 * frame : nullptr;
+    hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, frame, 1);
+    hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, tb);
+    seq_predict_motion(c, nullptr);
+    seq_predict_measurement(c, true);
+    seq_gain(c, nullptr, nullptr, true);
+    seq_refactor(c, 0, d.mp, false, true, false, false);
+    int rc = read_fs(c); if (rc) return rc;
+    if (c->hfs->clamp_rows > 0) {
+        hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, frame, 1);
+        hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, tb);
+        hipLaunchKernelGGL(k_refactor_reset, dim3((d.np + 255) / 256), dim3(256), 0, c->stream, d.np, c->theta, c->fs, 0);
+        HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
+        ProfScope ps(c, KC_GMW_COL, 0, 0);
+        for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+        quantize_state(c);
+    }
+    srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return SRUKF_OK;
+}
+
+// Synchronous form.  Unlike the asynchronous replay it never returns SRUKF_ERR_CLAMP_PENDING: the state before the
+// block is kept, and when a frame is flagged (theta clamp of the modified Cholesky, SLAM.cpp:2279-2285, or an abandoned
+// persistent launch) the block is rewound to that state, the frames before the flagged one are replayed, the flagged
+// frame runs on the exact path, and the replay continues behind it.
 int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_host)
 {
     if (!c || count < 1) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    const size_t np = c->d.np;
+    if (!c->ckS) {
+        if (hipMalloc((void**)&c->ckS, sizeof(double) * np * np) != hipSuccess || hipMalloc((void**)&c->ckX, sizeof(double) * np) != hipSuccess) {
+            c->err = "run_frames: out of device memory (checkpoint)"; return SRUKF_ERR_NOMEM;
+        }
+    }
     double* dt = nullptr;
     HIPCHK(c, hipMalloc((void**)&dt, sizeof(double) * 8 * (size_t)count));
-    int rc = srukf_run_frames_async(c, first, count, mode, dt);
-    if (rc == SRUKF_OK) rc = srukf_synchronize(c);
-    if (traj_host && (rc == SRUKF_OK || rc == SRUKF_ERR_CLAMP_PENDING))
-        hipMemcpy(traj_host, dt, sizeof(double) * 8 * (size_t)count, hipMemcpyDeviceToHost);
+    auto checkpoint = [&](bool save) {
+        hipMemcpyAsync(save ? c->ckS : c->S, save ? c->S : c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(save ? c->ckX : c->X, save ? c->X : c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
+        if (!save) quantize_state(c);
+    };
+    int rc = SRUKF_OK, done = 0;
+    while (done < count) {
+        checkpoint(true);
+        rc = srukf_run_frames_async(c, first + done, count - done, mode, dt + (size_t)8 * done);
+        if (rc == SRUKF_OK) rc = srukf_synchronize(c);
+        if (rc != SRUKF_ERR_CLAMP_PENDING) break;
+        const int fc = c->clamp_frame_host;                               // absolute index of the first flagged frame
+        if (fc < first + done || fc >= first + count) { c->err = "run_frames: flagged frame outside the block"; rc = SRUKF_ERR_HIP; break; }
+        checkpoint(false);
+        const int good = fc - (first + done);
+        if (good > 0) {
+            rc = srukf_run_frames_async(c, first + done, good, mode, dt + (size_t)8 * done);
+            if (rc == SRUKF_OK) rc = srukf_synchronize(c);
+            if (rc != SRUKF_OK) break;                                    // (the same frames passed a moment ago)
+        }
+        rc = run_staged_frame_exact(c, fc, dt + (size_t)8 * (fc - first));
+        if (rc != SRUKF_OK) break;
+        done = fc - first + 1;
+    }
+    if (traj_host && rc == SRUKF_OK) hipMemcpy(traj_host, dt, sizeof(double) * 8 * (size_t)count, hipMemcpyDeviceToHost);
     hipFree(dt);
     return rc;
+}
+
+// What the last SRUKF_ERR_CLAMP_PENDING of srukf_synchronize was about: the first flagged staged frame (frames before it
+// are valid) and the first flagged pivot row.  -1 / -1 if there was none.
+int srukf_clamp_info(srukf_ctx* c, int* frame, int* row)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    if (frame) *frame = c->clamp_frame_host;
+    if (row) *row = c->clamp_row_host;
+    return SRUKF_OK;
+}
+// Tests only: persistent factorisation launches of this context start WITHOUT their worker workgroups, as if another
+// process held the GPU — exercises the bounded waits and the fallback to per-panel launches.
+int srukf_debug_starve_workers(srukf_ctx* c, int on)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    c->debug_starve = on ? 1 : 0;
+    return SRUKF_OK;
 }
 
 int srukf_synchronize(srukf_ctx* c)
@@ -1249,7 +1331,8 @@ int srukf_synchronize(srukf_ctx* c)
         c->async_pending = false;
         int rc = read_fs(c); if (rc) return rc;
         if (c->hfs->clamp_rows > 0) {
-            char b[160]; snprintf(b, sizeof b, "GMW theta clamp active on %d pivot rows (first row %d) during async frames%s", c->hfs->clamp_rows, c->hfs->clamp_first,
+            c->clamp_frame_host = c->hfs->clamp_frame; c->clamp_row_host = c->hfs->clamp_first;
+            char b[220]; snprintf(b, sizeof b, "GMW theta clamp active on %d pivot rows (first row %d), first in staged frame %d, during async frames%s", c->hfs->clamp_rows, c->hfs->clamp_first, c->hfs->clamp_frame,
                                  c->hfs->gmw_aborts > 0 ? " (a persistent factorisation launch was abandoned: the GPU is shared; see srukf_set_exclusive)" : "");
             c->err = b;
             return SRUKF_ERR_CLAMP_PENDING;
@@ -1300,52 +1383,54 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
     const size_t bytes = sizeof(double) * (size_t)np * np;
     std::vector<double> hG((size_t)np * np, 0.0), hS((size_t)np * np, 0.0), hD(np, 0.0);
     for (int r = 0; r < n; r++) for (int c = r; c < n; c++) hG[(size_t)r * np + c] = G[(size_t)r * n + c];
-    double *dG, *dS, *dWp, *dLp, *dD, *dWf; unsigned long long* dTh; FrameScalars* dFs;
-    if (hipMalloc((void**)&dG, bytes) != hipSuccess) return SRUKF_ERR_HIP;
-    hipMalloc((void**)&dS, bytes); hipMalloc((void**)&dWf, bytes); hipMalloc((void**)&dWp, sizeof(double) * 32 * np); hipMalloc((void**)&dLp, sizeof(double) * 32 * np);
-    hipMalloc((void**)&dD, sizeof(double) * np); hipMalloc((void**)&dTh, sizeof(unsigned long long) * np); hipMalloc((void**)&dFs, sizeof(FrameScalars));
-    hipMemcpy(dG, hG.data(), bytes, hipMemcpyHostToDevice);
-    hipMemset(dS, 0, bytes); hipMemset(dWf, 0, bytes); hipMemset(dTh, 0, sizeof(unsigned long long) * np); hipMemset(dFs, 0, sizeof(FrameScalars));
-    hipMemset(dD, 0, sizeof(double) * np);
+    // every device resource of the call in one holder: released on every path out
+    struct Res {
+        double *dG = nullptr, *dS = nullptr, *dD = nullptr, *dWf = nullptr; unsigned long long* dTh = nullptr; FrameScalars* dFs = nullptr;
+        void* pan[2] = { nullptr, nullptr }; GmwPlan gp;
+        ~Res() { for (void* b : { (void*)dG, (void*)dS, (void*)dD, (void*)dWf, (void*)dTh, (void*)dFs, pan[0], pan[1] }) if (b) hipFree(b); gmw_plan_destroy(gp); }
+    } r;
+#define GH(call) do { if ((call) != hipSuccess) return SRUKF_ERR_HIP; } while (0)
+    GH(hipMalloc((void**)&r.dG, bytes)); GH(hipMalloc((void**)&r.dS, bytes)); GH(hipMalloc((void**)&r.dWf, bytes));
+    GH(hipMalloc((void**)&r.dD, sizeof(double) * np)); GH(hipMalloc((void**)&r.dTh, sizeof(unsigned long long) * np)); GH(hipMalloc((void**)&r.dFs, sizeof(FrameScalars)));
+    GH(hipMemcpy(r.dG, hG.data(), bytes, hipMemcpyHostToDevice));
+    GH(hipMemset(r.dS, 0, bytes)); GH(hipMemset(r.dWf, 0, bytes)); GH(hipMemset(r.dTh, 0, sizeof(unsigned long long) * np));
+    GH(hipMemset(r.dFs, 0, sizeof(FrameScalars))); GH(hipMemset(r.dD, 0, sizeof(double) * np));
     hipStream_t st = nullptr;
-    srukf_launch_gmw_stats(st, n, np, dG, dFs);
+    srukf_launch_gmw_stats(st, n, np, r.dG, r.dFs);
     FrameScalars fs;
     if (!force_slow) {
-        if (gmw_persist_mode() && srukf_gmw_persist_workers(np / 64, 255) >= 0) {
-            GmwPlan gp;
-            if (gmw_plan_create(gp, np, st) != SRUKF_OK) return SRUKF_ERR_NOMEM;
-            srukf_launch_gmw_persist(st, n, np, epsilon, dG, gp.pans, dD, dS, gp.sync, gp.tiles, gp.ntiles, gp.workers, dFs, nullptr, nullptr, 0, 0);
-            hipDeviceSynchronize();
-            gmw_plan_destroy(gp);
+        // the plan knows how many workgroups THIS device can keep resident (CU count); workers < 0: per-panel launches
+        if (gmw_persist_mode()) { const int rc = gmw_plan_create(r.gp, np, st); if (rc) return rc; }
+        if (gmw_persist_mode() && r.gp.workers >= 0) {
+            srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0);
         } else {
-            void* pan[2];
-            hipMalloc(&pan[0], srukf_gmw_panel_bytes()); hipMalloc(&pan[1], srukf_gmw_panel_bytes());
+            GH(hipMalloc(&r.pan[0], srukf_gmw_panel_bytes())); GH(hipMalloc(&r.pan[1], srukf_gmw_panel_bytes()));
+            GH(hipMemset(r.pan[0], 0, srukf_gmw_panel_bytes())); GH(hipMemset(r.pan[1], 0, srukf_gmw_panel_bytes()));
             int pb = 0;
             for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
-                srukf_launch_gmw_step64(st, n, np, j0, epsilon, dG, pan[pb ^ 1], pan[pb], dD, dS);
-            hipDeviceSynchronize();
-            hipFree(pan[0]); hipFree(pan[1]);
+                srukf_launch_gmw_step64(st, n, np, j0, epsilon, r.dG, r.pan[pb ^ 1], r.pan[pb], r.dD, r.dS);
         }
-        srukf_launch_gmw_check(st, n, np, dD, dS, dFs, nullptr, 0, nullptr);
-        hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
+        GH(hipDeviceSynchronize());
+        srukf_launch_gmw_check(st, n, np, r.dD, r.dS, r.dFs, nullptr, 0, nullptr);
+        GH(hipMemcpy(&fs, r.dFs, sizeof fs, hipMemcpyDeviceToHost));
         if (clamp_hit) *clamp_hit = fs.clamp_rows;
         if (fs.clamp_rows > 0) force_slow = 2;   // same contract as srukf_update: redo on the exact path
     }
     if (force_slow) {
-        hipMemcpy(dG, hG.data(), bytes, hipMemcpyHostToDevice);
-        hipMemset(dTh, 0, sizeof(unsigned long long) * np);
-        hipMemset(dS, 0, bytes);
-        for (int j = 0; j < n; j++) srukf_launch_gmw_col(st, n, np, j, epsilon, dG, dWf, dD, dTh, dFs, dS);
-        hipMemcpy(&fs, dFs, sizeof fs, hipMemcpyDeviceToHost);
+        GH(hipMemcpy(r.dG, hG.data(), bytes, hipMemcpyHostToDevice));
+        GH(hipMemset(r.dTh, 0, sizeof(unsigned long long) * np));
+        GH(hipMemset(r.dS, 0, bytes));
+        for (int j = 0; j < n; j++) srukf_launch_gmw_col(st, n, np, j, epsilon, r.dG, r.dWf, r.dD, r.dTh, r.dFs, r.dS);
+        GH(hipMemcpy(&fs, r.dFs, sizeof fs, hipMemcpyDeviceToHost));
         if (clamp_hit && force_slow == 1) *clamp_hit = fs.clamp_rows;
     }
-    hipError_t e = hipDeviceSynchronize();
-    hipMemcpy(hS.data(), dS, bytes, hipMemcpyDeviceToHost);
-    hipMemcpy(hD.data(), dD, sizeof(double) * np, hipMemcpyDeviceToHost);
-    for (int r = 0; r < n; r++) memcpy(S_out + (size_t)r * n, hS.data() + (size_t)r * np, sizeof(double) * n);
+    GH(hipDeviceSynchronize());
+    GH(hipMemcpy(hS.data(), r.dS, bytes, hipMemcpyDeviceToHost));
+    GH(hipMemcpy(hD.data(), r.dD, sizeof(double) * np, hipMemcpyDeviceToHost));
+#undef GH
+    for (int rr = 0; rr < n; rr++) memcpy(S_out + (size_t)rr * n, hS.data() + (size_t)rr * np, sizeof(double) * n);
     if (D_out) memcpy(D_out, hD.data(), sizeof(double) * n);
-    hipFree(dG); hipFree(dS); hipFree(dWf); hipFree(dWp); hipFree(dLp); hipFree(dD); hipFree(dTh); hipFree(dFs);
-    return e == hipSuccess ? SRUKF_OK : SRUKF_ERR_HIP;
+    return SRUKF_OK;
 }
 
 int srukf_project_host(int device, const srukf_params* p, int count, const double* feat6, const double* pos3, const double* psi,

@@ -13,6 +13,7 @@
 // cross correlation.  matchPatch persists from frame to frame: pixels whose warp leaves the init
 // patch keep their previous value, as in the reference (the Mat is only zeroed at creation).
 #include "srukf_device.h"
+#include "srukf_crtrig.h"
 
 #define HP_INIT 10             // SLAM.cpp:41-42
 #define HP_MATCH 8             // SLAM.cpp:43-44
@@ -21,34 +22,44 @@
 #define APP_PATCH_STRIDE 448   // bytes per landmark in the initPatch array (441 used)
 #define APP_TMPL_STRIDE 320    // bytes per landmark in the matchPatch array (289 used)
 
+// Everything below feeds floor / ceil / a truncating uchar cast (wrapPatch 1884-1900): this file is compiled with
+// -ffp-contract=off and every expression keeps the reference's association, operation for operation, so that the
+// bytes of matchPatch are the ones the reference's arithmetic produces.  pow(x, int literal) is the Visual C++ 2010
+// overload pow(double, int) = repeated multiplication by squaring: (x,2) = x*x, (x,3) = x*(x*x), (x,4) = (x*x)*(x*x),
+// (x,5) = x*((x*x)*(x*x)).
 // undistortOnePointRW, SLAM.cpp:3224-3236
 __device__ __forceinline__ void dev_undistort(const srukf_params& p, double dx, double dy, double& ux, double& uy)
 {
     const double xd = (dx - p.cam_cx) * p.cam_dx, yd = (dy - p.cam_cy) * p.cam_dy;
     const double rd = sqrt(xd * xd + yd * yd);
-    const double d = 1 + p.cam_k1 * (rd * rd) + p.cam_k2 * ((rd * rd) * (rd * rd));
-    ux = p.cam_cx + (xd * d) / p.cam_dx;
-    uy = p.cam_cy + (yd * d) / p.cam_dy;
+    const double rd2 = rd * rd;
+    const double d = 1 + p.cam_k1 * rd2 + p.cam_k2 * (rd2 * rd2);                                        // 3230
+    const double xu = xd * d, yu = yd * d;
+    ux = p.cam_cx + xu / p.cam_dx;
+    uy = p.cam_cy + yu / p.cam_dy;
 }
-// distortOnePointRW, SLAM.cpp:3177-3213 (Newton loop left at its fixed point: bit-exact, see srukf_device.h)
+// distortOnePointRW, SLAM.cpp:3177-3213.  The 100 Newton iterations stop at the first fixed point (every later
+// iteration would reproduce it bit for bit).
 __device__ __forceinline__ void dev_distort(const srukf_params& p, double ux, double uy, double& ox, double& oy)
 {
     const double k1 = p.cam_k1, k2 = p.cam_k2;
     const double xu = (ux - p.cam_cx) * p.cam_dx, yu = (uy - p.cam_cy) * p.cam_dy;
     const double ru = sqrt(xu * xu + yu * yu);
     const double ru2 = ru * ru;
-    double rd = ru / (1.0 + k1 * ru2 + k2 * ru2 * ru2);
+    double rd = ru / (1 + k1 * ru * ru + k2 * (ru2 * ru2));                                              // 3184
     for (int it = 0; it < p.newton_iters; it++) {
-        const double rd2 = rd * rd;
-        const double f = rd + k1 * rd2 * rd + k2 * rd2 * rd2 * rd - ru;
-        const double ff = 1.0 + 3.0 * k1 * rd2 + 5.0 * k2 * rd2 * rd2;
-        const double rn = rd - f / ff;
+        const double rd2 = rd * rd, rd4 = rd2 * rd2;
+        const double f = rd + k1 * (rd * rd2) + k2 * (rd * rd4) - ru;                                    // 3190
+        const double ff = 1.0 + 3.0 * k1 * rd * rd + 5.0 * k2 * rd4;                                     // 3191
+        const double rn = rd - f / ff;                                                                   // 3192
         if (rn == rd) break;
         rd = rn;
     }
-    double d = 1.0 + k1 * rd * rd + k2 * rd * rd * rd * rd;
+    const double rdsq = rd * rd;
+    double d = 1 + k1 * rd * rd + k2 * (rdsq * rdsq);                                                    // 3195
     if (d == 0.0) d = p.epsilon;
-    const double vx = p.cam_cx + (xu / d) / p.cam_dx, vy = p.cam_cy + (yu / d) / p.cam_dy;
+    const double xd = xu / d, yd = yu / d;
+    const double vx = p.cam_cx + xd / p.cam_dx, vy = p.cam_cy + yd / p.cam_dy;
     const bool vis = (vx >= 0.0) && (vx <= p.image_w) && (vy >= 0.0) && (vy <= p.image_h);
     ox = vis ? vx : 0.0; oy = vis ? vy : 0.0;
 }
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(320) void k_warp_patch(KDims d, srukf_params p, con
         const int n = d.n;
         const double rob[4] = { X[n - 4], X[n - 3], X[n - 2], X[n - 1] };
         double sn, cs;
-        sincos(rob[3], &sn, &cs);
+        crt_sincos(rob[3], &sn, &cs);                                // correctly rounded (srukf_crtrig.h): the bytes below depend on the last bit
         const double Rwc[9] = { cs, -sn, 0, sn, cs, 0, 0, 0, 1 };                                     // getTransferMatrix, 1031-1037
         const double* iR = appR + 9 * k; const double* iT = appT + 3 * k;
         double C0W[16], C1W[16];

@@ -43,6 +43,8 @@ struct FrameScalars {
     int stat_count;            // measurement-statistics slices finished in the current k_pxy launch (last one runs the final pass)
     double* traj_base;         // device trajectory buffer of the current replay (row = absolute frame), or null
     int gmw_aborts;            // persistent GMW launches abandoned on an expired wait (their frames are flagged like clamp rows)
+    int clamp_frame;           // staged replay: index of the FIRST frame whose refactorisation was flagged (0x7fffffff: none).  Set by
+                               // the k_motion of the following frame (or by the host at the end of a run): frames before it are valid
 };
 
 __device__ __forceinline__ double wave_sum(double v)

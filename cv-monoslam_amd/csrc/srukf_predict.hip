@@ -64,6 +64,8 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
         sh[10] = cos(rot2); sh[11] = sin(rot2);
         for (int q = 0; q < 3; q++) { fs->Ut[q] = sh[q]; fs->Mt[q] = sh[3 + q]; }
         for (int q = 0; q < 4; q++) fs->Xr0[q] = sh[6 + q];
+        // staged replay: the previous frame's refactorisation was flagged (theta clamp / abandoned launch) -> remember which
+        if (!odo_pair && fs->clamp_rows > 0 && fs->clamp_frame == 0x7fffffff) fs->clamp_frame = fs->frame - 1;
     }
     __syncthreads();
     const double rot1 = sh[0], trans = sh[1], rot2 = sh[2];
@@ -359,6 +361,63 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     __syncthreads();
     if (sl == 0) dxp[(size_t)blockIdx.y * ld + r] = (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
 }
+// k_gain_center: weight types with wc0 != wm0 (FLAG_4_WEIGHT2, SLAM.cpp:1077-1088: wc0 = wm0 + 1 - alpha^2 + beta).
+// calculateOneFeatureCrossCovariance centres on the RUNNING state (s1 = sigma_i - m_X_k, 2030) which KalmanUpdate has
+// already moved by dX_<k = sum of the earlier landmarks' Ki (z - h) (2079).  With sum_c wm_c (Z_c - h) = 0 the
+// dependence on the running state collapses to the centre column:
+//     Pxy_k = Pxy_k(frozen X) - (wc0 - wm0) dX_<k (Z_0k - h_k)^T
+//  => U_k = Pxy_k Si^-1 = U_k(frozen) - (wc0 - wm0) dX_<k g_k^T,   g_k = Si^-T (Z_0k - h_k)
+//     dX_<=k = dX_<k + U_k Si^-T (z_k - h_k)
+// a recurrence over the matched landmarks in list order (2066) whose coefficients are per-landmark scalars, so every
+// state row runs it on its own: one thread per row, Ut rows read and rewritten coalesced.  For wc0 == wm0 (types 0
+// and 2) the term vanishes and the kernel is not launched.  Replaces the dX slice partials of k_gain.
+__global__ __launch_bounds__(256) void k_gain_center(KDims d, KWeights w, double* __restrict__ Ut, const double* __restrict__ Z,
+                                                     const double* __restrict__ Si, const int* __restrict__ vis,
+                                                     const double* __restrict__ h, const double* __restrict__ z_seq,
+                                                     const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
+                                                     const FrameScalars* __restrict__ fs, double* __restrict__ dxp)
+{
+    __shared__ double lk[GAIN_LM_MAX][4];
+    __shared__ int lon[GAIN_LM_MAX];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int n = d.n, ld = d.np, N = d.N;
+    const double* z = z_cur ? z_cur : (z_seq + (size_t)fs->frame * 2 * N);
+    const int* mt = m_cur ? m_cur : (m_seq + (size_t)fs->frame * N);
+    const double cw = w.wc0 - w.wm0;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < N; k0 += GAIN_LM_MAX) {
+        __syncthreads();
+        const int cnt = min(GAIN_LM_MAX, N - k0);
+        if ((int)threadIdx.x < cnt) {
+            const int k = k0 + threadIdx.x;
+            const double s00 = Si[4 * k], s01 = Si[4 * k + 1], s10 = Si[4 * k + 2], s11 = Si[4 * k + 3];
+            double det = s00 * s11 - s01 * s10;
+            double i00 = 0, i01 = 0, i10 = 0, i11 = 0;
+            if (det != 0.0) { det = 1.0 / det; i00 = s11 * det; i01 = -s01 * det; i10 = -s10 * det; i11 = s00 * det; }
+            const double v0 = z[2 * k] - h[2 * k], v1 = z[2 * k + 1] - h[2 * k + 1];
+            const double a0 = Z[2 * k] - h[2 * k], a1 = Z[2 * k + 1] - h[2 * k + 1];          // centre column Z_0 - h
+            lk[threadIdx.x][0] = i00 * v0 + i10 * v1; lk[threadIdx.x][1] = i01 * v0 + i11 * v1;   // Si^-T (z - h)
+            lk[threadIdx.x][2] = a0 * i00 + a1 * i10; lk[threadIdx.x][3] = a0 * i01 + a1 * i11;   // (Z_0 - h)^T Si^-1
+            lon[threadIdx.x] = ((mt[k] != 0) && (vis[k] != 0)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (r < n) {
+            for (int q = 0; q < cnt; q++) {
+                if (!lon[q]) continue;
+                const int k = k0 + q;
+                const double u0 = Ut[(size_t)(2 * k) * ld + r] - cw * acc * lk[q][2];
+                const double u1 = Ut[(size_t)(2 * k + 1) * ld + r] - cw * acc * lk[q][3];
+                Ut[(size_t)(2 * k) * ld + r] = u0;
+                Ut[(size_t)(2 * k + 1) * ld + r] = u1;
+                acc += u0 * lk[q][0] + u1 * lk[q][1];
+            }
+        }
+    }
+    if (r < ld) {
+        dxp[r] = (r < n) ? acc : 0.0;
+        for (int u = 1; u < GAIN_SLICES; u++) dxp[(size_t)u * ld + r] = 0.0;
+    }
+}
 // k_traj: per-frame record (x, y, z, theta, P00, P01, P10, P11) of the robot = RobotPath.txt
 // columns (SLAM.cpp:3549-3556) with P = S^T S restricted to the robot x/y block (2404); also
 // advances the staged-sequence frame counter.  One workgroup.
@@ -467,9 +526,11 @@ void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* 
 int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
-                       FrameScalars* fs, double* dxp, double* X)
+                       FrameScalars* fs, double* dxp, double* X, const double* Z)
 {
     hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
+    if (w.wc0 != w.wm0)
+        hipLaunchKernelGGL(k_gain_center, dim3(d.np / 256 + 1), dim3(256), 0, st, d, w, Ut, Z, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
 }
 int srukf_gain_part_doubles(int np) { return GAIN_SLICES * np; }
 void srukf_launch_traj(hipStream_t st, KDims d, const double* X, const double* S, FrameScalars* fs, double* traj, int advance)

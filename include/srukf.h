@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRUKF_ABI_VERSION 2
+#define SRUKF_ABI_VERSION 3
 
 typedef enum srukf_status {
     SRUKF_OK                =  0,
@@ -195,12 +195,18 @@ int  srukf_stage_sequence(srukf_ctx* ctx, int n_frames, const double* odo, const
  * stream.  traj, if not NULL, is a DEVICE buffer of count*8 doubles receiving per frame
  * (x, y, z, theta, P00, P01, P10, P11) — the RobotPath.txt columns of SLAM.cpp:3549-3556. */
 int  srukf_run_frames_async(srukf_ctx* ctx, int first, int count, int mode, double* d_traj);
-/* Synchronous convenience form: runs the frames, waits, and copies the trajectory to the HOST
- * buffer traj_host[count*8] (may be NULL). */
+/* Synchronous form: runs the frames, waits, and copies the trajectory to the HOST buffer traj_host[count*8] (may be
+ * NULL).  Never returns SRUKF_ERR_CLAMP_PENDING: the state before the block is kept on the device, and when a frame
+ * needs the reference's theta-clamp branch of the modified Cholesky (SLAM.cpp:2279-2285) the block is rewound, the
+ * frames before it are replayed, that frame runs on the exact column-by-column path (as srukf_update does) and the
+ * replay continues behind it. */
 int  srukf_run_frames(srukf_ctx* ctx, int first, int count, int mode, double* traj_host);
-/* Wait for the stream; reports SRUKF_ERR_CLAMP_PENDING if any async frame needed the
- * reference's theta-clamp branch of the modified Cholesky (results then invalid). */
+/* Wait for the stream; reports SRUKF_ERR_CLAMP_PENDING if any async frame needed the reference's theta-clamp branch of
+ * the modified Cholesky: the frames BEFORE the first such frame are valid, that frame and the later ones are not
+ * (srukf_clamp_info names it; restore the state the block started from and use srukf_run_frames or the step-wise API). */
 int  srukf_synchronize(srukf_ctx* ctx);
+/* First flagged staged frame / pivot row of the last SRUKF_ERR_CLAMP_PENDING (-1, -1: none).  Either may be NULL. */
+int  srukf_clamp_info(srukf_ctx* ctx, int* frame, int* row);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 
@@ -213,6 +219,10 @@ int  srukf_profile_count(srukf_ctx* ctx);
 int  srukf_profile_get(srukf_ctx* ctx, int i, const char** name, double* total_ms, long long* launches,
                        double* alg_flops, double* alg_bytes);
 int  srukf_profile_reset(srukf_ctx* ctx);
+
+/* Test hook, not for hosts: persistent factorisation launches of this context start without their worker workgroups, as
+ * if another process held the GPU (exercises the bounded waits and the fallback to per-panel launches). */
+int  srukf_debug_starve_workers(srukf_ctx* ctx, int on);
 
 /* Problem sizes of a context: N, n, Na, L. */
 int  srukf_dims(const srukf_ctx* ctx, int* N, int* n, int* Na, int* L);

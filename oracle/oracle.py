@@ -65,6 +65,7 @@ def lib():
         L.orc_set_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_set_newton_early_exit.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_frozen_center.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_clamp_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.orc_predict_motion.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_predict_measurement.argtypes = [C.c_void_p, _dp, _dp, _ip]
@@ -129,6 +130,10 @@ class Oracle:
 
     def set_newton_early_exit(self, on):
         lib().orc_set_newton_early_exit(self._h, int(on))
+
+    def set_frozen_center(self, on):
+        """Test knob (not the reference): centre the cross covariance on the state at the start of the update."""
+        lib().orc_set_frozen_center(self._h, int(on))
 
     def clamp_stats(self):
         out = (C.c_longlong * 3)()

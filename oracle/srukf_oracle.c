@@ -19,6 +19,13 @@
  *     beta = -sign(alpha)*hypot(alpha, |x|), tau = 0 when the sub-column is already zero.
  *   - OpenCV 2.4.3 (README.md:12): Mat::inv() on 2x2 / 3x3 (closed-form cofactor inverse in
  *     cv::invert), addWeighted (a*alpha + b*beta + gamma), Mat*Mat (plain gemm), minMaxLoc.
+ *   - Visual C++ 2010 runtime (MonoSLAM.sln:2-3 "Format Version 11.00 / Visual Studio 2010", MonoSLAM.vcxproj:2 ToolsVersion 4.0): every pow() on the path has an int
+ *     literal exponent (SLAM.cpp:1053,1056,3184,3190,3191,3195,3230), which in that compiler's <math.h> selects the
+ *     overload pow(double, int) -> _Pow_int: repeated multiplication by squaring, NOT the transcendental pow.
+ *     Restated as pow_di below (recalled from the VC10 header; the header is not in /root/reference).  sin / cos
+ *     come from the same runtime and are not reproducible bit for bit by any other libm: the filter path uses
+ *     this host's libm (results are compared with tolerances), the byte-producing wrapPatch uses correctly
+ *     rounded values (libquadmath, rounded once) so that its uchar output is defined independently of a libm.
  *
  * Structure follows the reference, not a textbook SRUKF: deviations from sigma_0 (not the
  * mean) in every QR, no centre-weight term in the QRs, x/y swap in the projection, Mt/Qt used
@@ -29,6 +36,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <quadmath.h>
 #include "../include/srukf.h"
 
 #define ORC_API __attribute__((visibility("default")))
@@ -48,18 +56,34 @@ typedef struct orc_state {
     double Ut[3], Mt[3], Qt[2];     /* SLAM.h:287-289; Mt, Qt diagonal                 */
     double wm0, wc0, wi, wi_sr, gamma, wm0_sr, wc0_sr;   /* SLAM.h:251-257            */
     int newton_early_exit;          /* 1: leave the 100-iteration loop once rd is a fixed point (bit-exact) */
+    int frozen_center;              /* test knob, NOT the reference: 1 = the cross covariance centres on the state at the
+                                       start of KalmanUpdate instead of the running m_X_k (SLAM.cpp:2030); quantifies
+                                       what the running-state term is worth when wc0 != wm0 (tests only)            */
+    const double *Xcenter;          /* state the cross covariance centres on (X, or the frozen copy)                 */
     long long clamp_eps, clamp_theta, pivots;            /* GMW statistics             */
 } orc_state;
+
+/* pow(double, int) of the Visual C++ 2010 <math.h> (_Pow_int): Z = 1; for each bit of |y| from the lowest:
+ * if set Z *= X; X *= X.  pow_di(x, 2) = x*x, (x, 3) = x*(x*x), (x, 4) = (x*x)*(x*x), (x, 5) = x*((x*x)*(x*x)). */
+static double pow_di(double x, int y)
+{
+    unsigned int n = y >= 0 ? (unsigned int)y : (unsigned int)(-y);
+    double z = 1.0;
+    for (;; x *= x) {
+        if (n & 1u) z *= x;
+        if ((n >>= 1) == 0) return y < 0 ? 1.0 / z : z;
+    }
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* calculateSampleParameter, SLAM.cpp:1050-1103                                                */
 ORC_API void orc_sample_parameter(int Na, int weight_type, double alpha, double beta, double out[7])
 {
     double Kappa  = 0;                                           /* 1052 */
-    double Lammda = pow(alpha, 2) * (Na + Kappa) - Na;           /* 1053 */
+    double Lammda = pow_di(alpha, 2) * (Na + Kappa) - Na;           /* 1053 */
     double Gamma  = sqrt(Na + Lammda);                           /* 1054 */
     double s_wm0  = Lammda / (Na + Lammda);                      /* 1055 */
-    double s_wc0  = s_wm0 + (1 - pow(alpha, 2) + beta);          /* 1056 */
+    double s_wc0  = s_wm0 + (1 - pow_di(alpha, 2) + beta);          /* 1056 */
     double s_wi   = 1.0 / (2 * (Na + Lammda));                   /* 1057 */
     double wm0, wm0_sr, wc0, wc0_sr, wi, wi_sr, gamma;
     switch (weight_type) {
@@ -226,6 +250,16 @@ static void transfer_matrix(double Rwc[9], double theta)
     Rwc[6] = 0;          Rwc[7] = 0;           Rwc[8] = 1;
 }
 
+/* getTransferMatrix with correctly rounded cos / sin (binary128 libquadmath value rounded once to double): used by
+ * wrapPatch only, whose uchar output depends on the last bit of these two numbers (see the header). */
+static void transfer_matrix_cr(double Rwc[9], double theta)
+{
+    const double c = (double)cosq((__float128)theta), s = (double)sinq((__float128)theta);
+    Rwc[0] = c; Rwc[1] = -s; Rwc[2] = 0;
+    Rwc[3] = s; Rwc[4] =  c; Rwc[5] = 0;
+    Rwc[6] = 0; Rwc[7] = 0;  Rwc[8] = 1;
+}
+
 /* cv::Mat::inv() on a 3x3 CV_64F (SLAM.cpp:1643): OpenCV 2.4.3 cv::invert closed form
  * (determinant, then cofactors scaled by 1/det).  Un-vendored dependency, restated. */
 static void inv3(const double a[9], double t[9])
@@ -256,16 +290,16 @@ static void distort_rw(const orc_state *st, const srukf_params *p, double uvu_x,
     double xu = (uvu_x - p->cam_cx) * p->cam_dx;                                  /* 3181 */
     double yu = (uvu_y - p->cam_cy) * p->cam_dy;                                  /* 3182 */
     double ru = sqrt(xu * xu + yu * yu);                                          /* 3183 */
-    double rd = ru / (1 + p->cam_k1 * ru * ru + p->cam_k2 * pow(ru, 4));          /* 3184 */
+    double rd = ru / (1 + p->cam_k1 * ru * ru + p->cam_k2 * pow_di(ru, 4));          /* 3184 */
     int iters = p->newton_iters;                                                  /* 3186 */
     for (int i = 0; i < iters; i++) {                                             /* 3188-3193 */
-        f  = rd + p->cam_k1 * pow(rd, 3) + p->cam_k2 * pow(rd, 5) - ru;
-        ff = 1.0 + 3.0 * p->cam_k1 * rd * rd + 5.0 * p->cam_k2 * pow(rd, 4);
+        f  = rd + p->cam_k1 * pow_di(rd, 3) + p->cam_k2 * pow_di(rd, 5) - ru;
+        ff = 1.0 + 3.0 * p->cam_k1 * rd * rd + 5.0 * p->cam_k2 * pow_di(rd, 4);
         double rd_new = rd - f / ff;
         if (st && st->newton_early_exit && rd_new == rd) { rd = rd_new; break; }   /* fixed point: later iterations are idempotent */
         rd = rd_new;
     }
-    double d = 1 + p->cam_k1 * rd * rd + p->cam_k2 * pow(rd, 4);                  /* 3195 */
+    double d = 1 + p->cam_k1 * rd * rd + p->cam_k2 * pow_di(rd, 4);                  /* 3195 */
     if (d == 0) d = p->epsilon;                                                   /* 3197-3198 */
     double xd = xu / d, yd = yu / d;                                              /* 3200-3201 */
     *uvd_x = p->cam_cx + xd / p->cam_dx;                                          /* 3203 */
@@ -280,7 +314,7 @@ static void undistort_rw(const srukf_params *p, double uvd_x, double uvd_y, doub
     double xd = (uvd_x - p->cam_cx) * p->cam_dx;
     double yd = (uvd_y - p->cam_cy) * p->cam_dy;
     double rd = sqrt(xd * xd + yd * yd);
-    double d  = 1 + p->cam_k1 * pow(rd, 2) + p->cam_k2 * pow(rd, 4);
+    double d  = 1 + p->cam_k1 * pow_di(rd, 2) + p->cam_k2 * pow_di(rd, 4);
     double xu = xd * d, yu = yd * d;
     *uvu_x = p->cam_cx + xu / p->cam_dx;
     *uvu_y = p->cam_cy + yu / p->cam_dy;
@@ -379,6 +413,7 @@ ORC_API void orc_get_state(const orc_state *st, double *X, double *S)
     if (S) memcpy(S, st->S, sizeof(double) * (size_t)st->n * st->n);
 }
 ORC_API void orc_set_newton_early_exit(orc_state *st, int on) { st->newton_early_exit = on; }
+ORC_API void orc_set_frozen_center(orc_state *st, int on) { st->frozen_center = on; }
 ORC_API void orc_get_clamp_stats(const orc_state *st, long long out[3]) { out[0] = st->clamp_eps; out[1] = st->clamp_theta; out[2] = st->pivots; }
 ORC_API const double *orc_sigma_ptr(const orc_state *st) { return st->sigma; }
 ORC_API const double *orc_Z_ptr(const orc_state *st) { return st->Z; }
@@ -588,7 +623,7 @@ static void cross_cov(const orc_state *st, int id, const double hi[2], double *P
         double s2[2] = { Z[(size_t)(2 * id) * L + i] - hi[0], Z[(size_t)(2 * id + 1) * L + i] - hi[1] };   /* 2031 */
         double w = i ? st->wi : st->wc0;
         for (int r = 0; r < dim; r++) {
-            double s1 = sg[(size_t)r * L + i] - st->X[r];                          /* 2030 */
+            double s1 = sg[(size_t)r * L + i] - st->Xcenter[r];                    /* 2030 (Xcenter = m_X_k) */
             if (!i) { Pxy[2 * r] = w * s1 * s2[0] + 0; Pxy[2 * r + 1] = w * s1 * s2[1] + 0; }   /* 2034 */
             else    { Pxy[2 * r] += w * s1 * s2[0];    Pxy[2 * r + 1] += w * s1 * s2[1]; }      /* 2036 */
         }
@@ -612,6 +647,9 @@ ORC_API int orc_update(orc_state *st, const double *z, const int *matched, int r
     double *P   = (double *)malloc(sizeof(double) * (size_t)n * n);
     double *Uall = NULL; int ncols = 0;
     if (mode == SRUKF_UPDATE_BATCHED) Uall = (double *)malloc(sizeof(double) * (size_t)2 * nm * n);
+    double *Xfrozen = NULL;
+    st->Xcenter = st->X;                                                           /* the reference: the running m_X_k */
+    if (st->frozen_center) { Xfrozen = (double *)malloc(sizeof(double) * n); memcpy(Xfrozen, st->X, sizeof(double) * n); st->Xcenter = Xfrozen; }
 
     for (int id = 0; id < N; id++) {                                               /* 2066 */
         if (!matched[id]) continue;                                                /* 2068 */
@@ -653,7 +691,8 @@ ORC_API int orc_update(orc_state *st, const double *z, const int *matched, int r
         st->pivots += n;
         free(Uall);
     }
-    free(Pxy); free(Ki); free(U); free(u); free(P);
+    free(Pxy); free(Ki); free(U); free(u); free(P); free(Xfrozen);
+    st->Xcenter = st->X;
     return SRUKF_OK;
 }
 
@@ -807,7 +846,7 @@ ORC_API void orc_warp_patch(const srukf_params *p, const double robot[4], const 
 {
     orc_state tmp; memset(&tmp, 0, sizeof tmp); tmp.newton_early_exit = 1;
     const double f1 = p->cam_f / p->cam_dx, f2 = p->cam_f / p->cam_dy;
-    double Rwc[9]; transfer_matrix(Rwc, robot[3]);                                  /* 1806-1807 */
+    double Rwc[9]; transfer_matrix_cr(Rwc, robot[3]);                               /* 1806-1807 */
     double C0W[16] = { 0 }, C1W[16] = { 0 };                                        /* 1821-1827 */
     for (int r = 0; r < 3; r++) {
         for (int c = 0; c < 3; c++) { C0W[4 * r + c] = initR[3 * r + c] + 0; C1W[4 * r + c] = Rwc[3 * r + c] + 0; }

@@ -74,4 +74,25 @@ def test_cslam_facade_replay_matches_golden(tmp_path, golden, synth, mode):
         np.testing.assert_allclose(feat[k, 3:12].reshape(3, 3), cov, rtol=1e-9, atol=1e-9 * np.abs(cov).max())
         lam = np.linalg.eigvalsh(feat[k, 3:12].reshape(3, 3))
         np.testing.assert_allclose(np.sort(feat[k, 16:19] ** 2), np.maximum(lam, 0.0), rtol=1e-6, atol=1e-9 * lam.max())   # Jacobi stops at |offdiag| < EPSILON
-        assert np.all(np.isfinite(feat[k, 12:16]))
+        # ellipsoid orientation (calculateEigenvaluesAndEigenvectors 2815-2892 + matrix2Quaternion 2903-2948): the Jacobi
+        # eigenvector matrix V is a proper rotation (identity times plane rotations); the quaternion encodes V^T in the
+        # tr > 0 branch ((m23 - m32) ordering, 2916-2921) and V in the three other branches (2925-2947).  Either way the
+        # rotation of the quaternion must diagonalise the covariance with the reported semi-axes, in their order.
+        q = feat[k, 12:16]
+        assert abs(np.linalg.norm(q) - 1.0) < 1e-9
+        r, x, y, z = q
+        Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * r), 2 * (x * z + y * r)],
+                       [2 * (x * y + z * r), 1 - 2 * (x * x + z * z), 2 * (y * z - x * r)],
+                       [2 * (x * z - y * r), 2 * (y * z + x * r), 1 - 2 * (x * x + y * y)]])
+        C3 = feat[k, 3:12].reshape(3, 3)
+        D = np.diag(feat[k, 16:19] ** 2)
+        rec = min(np.abs(M @ D @ M.T - C3).max() for M in (Rq, Rq.T))
+        assert rec < 1e-6 * np.abs(C3).max() + 1e-12, (k, rec)
+        # and against numpy's eigen-decomposition: every axis is an eigenvector (up to sign) of its eigenvalue
+        lam_np, V_np = np.linalg.eigh(C3)
+        V = Rq if np.abs(Rq @ D @ Rq.T - C3).max() <= np.abs(Rq.T @ D @ Rq - C3).max() else Rq.T
+        for a in range(3):
+            j = int(np.argmin(np.abs(lam_np - feat[k, 16 + a] ** 2)))
+            gap = np.min(np.abs(np.delete(lam_np, j) - lam_np[j]))
+            if gap > 1e-3 * lam_np.max():                               # direction defined only for a separated eigenvalue
+                assert abs(abs(V[:, a] @ V_np[:, j]) - 1.0) < 1e-5, (k, a)

@@ -392,9 +392,8 @@ def test_data_association_matches_oracle(srukf, oracle, synth):
         n_vis += 1
         mp_o = oracle.warp_patch(p, X[-4:], R0, pose0[:3], init_px[k], xyz[k], h.reshape(N, 2)[k], patches[k], np.zeros((17, 17), dtype=np.uint8))
         mp_d = f.get_match_patch(k)
-        dpx = np.abs(mp_o.astype(int) - mp_d.astype(int))
-        assert dpx.max() <= 1 or (dpx > 1).mean() < 0.02         # truncating uchar casts of values a rounding error apart
-        ok, best, loc = oracle.associate_one(p, frame, h.reshape(N, 2)[k], Si.reshape(N, 4)[k], mp_d)   # same template: isolates the search
+        assert np.array_equal(mp_o, mp_d), (k, np.abs(mp_o.astype(int) - mp_d.astype(int)).max())   # byte work: bit-exact
+        ok, best, loc = oracle.associate_one(p, frame, h.reshape(N, 2)[k], Si.reshape(N, 4)[k], mp_o)   # the ORACLE's template
         assert abs(best - cr[k]) < 1e-9
         assert bool(m[k]) == ok
         if ok:
@@ -408,12 +407,15 @@ def test_data_association_matches_oracle(srukf, oracle, synth):
     Rc = np.array([[np.cos(pose[3]), -np.sin(pose[3]), 0], [np.sin(pose[3]), np.cos(pose[3]), 0], [0, 0, 1.0]])
     for k in range(N):
         f.set_landmark_appearance(k, patches[k], Rc, pose[:3], init_px[k])
+    mp_prev = [np.zeros((17, 17), dtype=np.uint8) for _ in range(N)]   # set_landmark_appearance zeroes matchPatch (SLAM.cpp:926)
     z, m, cr = f.associate(frame)
     found = 0
     for k in range(N):
         if not vis[k] or np.array_equal(init_px[k], [320.0, 240.0]):
             continue
-        ok, best, loc = oracle.associate_one(p, frame, h.reshape(N, 2)[k], Si.reshape(N, 4)[k], f.get_match_patch(k))
+        mp_o = oracle.warp_patch(p, pose, Rc, pose[:3], init_px[k], xyz[k], h.reshape(N, 2)[k], patches[k], mp_prev[k])
+        assert np.array_equal(mp_o, f.get_match_patch(k)), k      # identity view: every warped coordinate sits next to an integer
+        ok, best, loc = oracle.associate_one(p, frame, h.reshape(N, 2)[k], Si.reshape(N, 4)[k], mp_o)
         assert bool(m[k]) == ok and abs(best - cr[k]) < 1e-9
         if m[k]:
             np.testing.assert_allclose(z[2 * k:2 * k + 2], loc, atol=1e-9)
@@ -567,7 +569,7 @@ def test_persistent_and_per_panel_refactor_agree(srukf, synth):
         np.testing.assert_allclose(P0, P1, rtol=0, atol=1e-15 + 1e-11 * np.abs(P1).max())
 
 
-def test_persistent_launch_without_workers_falls_back(srukf, oracle, synth, monkeypatch):
+def test_persistent_launch_without_workers_falls_back(srukf, oracle, synth):
     """A persistent launch whose workers never get onto the GPU must not hang: its bounded waits expire, the frame is
     repeated on the exact path, the filter switches to per-panel launches — and the results are still the oracle's."""
     p = synth.scene_params()
@@ -575,10 +577,10 @@ def test_persistent_launch_without_workers_falls_back(srukf, oracle, synth, monk
     sc = synth.make_scene(N, F, seed=4, p=p)
     o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
     f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
-    monkeypatch.setenv("SRUKF_GMW_TEST_STARVE", "1")
+    f.debug_starve_workers(True)
     for k in range(F):
         if k == 1:
-            monkeypatch.delenv("SRUKF_GMW_TEST_STARVE")          # by now the filter no longer uses the persistent launch
+            f.debug_starve_workers(False)                        # by now the filter no longer uses the persistent launch
         f.predict_motion(sc["odo"][k], sc["odo"][k + 1]); f.predict_measurement(); f.update(sc["z"][k], sc["matched"][k], mode=srukf.UPDATE_BATCHED)
         o.predict_motion(sc["odo"][k], sc["odo"][k + 1]); o.predict_measurement(); o.update(sc["z"][k], sc["matched"][k], mode=oracle.Oracle.BATCHED)
         X, S = f.get_state(); Xo, So = o.get_state()

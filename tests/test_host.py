@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(lib, n), f"libsrukf_hip.so does not export {n}"
     assert sorted(pkg.srukf.EXPORTS) == names
-    assert lib.srukf_abi_version() == 2
+    assert lib.srukf_abi_version() == 3
 
 
 def test_default_params_match_reference_constants(pkg):
@@ -83,3 +83,26 @@ def test_figure8_closes(synth):
     odo = synth.figure8_odometry(600)
     assert np.abs(odo[600, :2] - odo[0, :2]).max() < 0.05
     assert np.ptp(odo[:, 0]) < 0.12 and np.ptp(odo[:, 1]) < 0.3
+
+
+def test_device_sincos_header_is_correctly_rounded(tmp_path):
+    """srukf_crtrig.h (what k_warp_patch uses for the heading's cos / sin) against binary128 values rounded once — the
+    definition orc_warp_patch uses.  Same source, +, -, *, fma only, so the device computes the same bits.  The host
+    libm (glibc, < 0.55 ulp) is NOT correctly rounded: about 0.15 % of arguments differ, which is why neither side
+    of the byte-exact wrapPatch comparison takes its cos / sin from a libm."""
+    import ctypes as C
+    import subprocess
+    so = str(tmp_path / "crtrig_host.so")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tests", "crtrig_host.c"), "-lquadmath", "-lm"])
+    L = C.CDLL(so)
+    L.crt_sweep.argtypes = [C.c_long, C.c_double, C.c_uint64, C.POINTER(C.c_long)]
+    for n, rng in [(400000, 3.2), (100000, 50.0), (100000, 1e-3), (100000, 1e5)]:
+        out = (C.c_long * 4)()
+        L.crt_sweep(n, rng, 12345, out)
+        assert out[0] == 0 and out[1] == 0, (rng, list(out))
+    s, c = C.c_double(), C.c_double()
+    L.crt_sincos_host.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    for x in [0.0, -0.0, np.pi / 4, -np.pi / 2, np.pi, 1e-300, 2.0 ** 20]:
+        L.crt_sincos_host(x, C.byref(s), C.byref(c))
+        assert abs(s.value - np.sin(x)) <= 2 * np.spacing(abs(np.sin(x))) and abs(c.value - np.cos(x)) <= 2 * np.spacing(abs(np.cos(x)))
