@@ -144,11 +144,15 @@ def broadcast_map(torch, dist, sc, n, rank, world, device):
     return X, S
 
 
-def cpu_baseline(synth, sc, N, frames):
-    """The oracle (a port: the reference binary cannot be built) timed on this box's host cores:
-    `frames` whole frames in the batched formulation (algorithm-matched to the GPU path), plus a
-    few measurement columns of the reference's per-column refactor to extrapolate the faithful
-    structure.  Single thread (the reference is single-threaded)."""
+def cpu_baseline(synth, sc, N, frames, matched_frames=24):
+    """CPU figures of the same workload on this box's host cores (the reference binary cannot be built: a port).
+      value          — oracle/srukf_matched.c: the GPU path's own formulation (structured motion update, one batched
+                       refactor, blocked modified Cholesky) with OpenMP and AVX-512/AVX2 register tiles, best over a
+                       few thread counts up to all host cores; `cores` = the threads of the best run.  This is the
+                       algorithm-matched, multi-core baseline the >= 30x target has to be read against.
+      port_value     — oracle/srukf_oracle.c, single thread, batched-refactor mode: `frames` whole frames.
+      faithful_value — the reference's own structure (2M refactors per frame, single thread): a few measurement columns
+                       timed and extrapolated."""
     from oracle import oracle as O
     p = sc["params"]
     o = O.Oracle(N, p)
@@ -166,12 +170,42 @@ def cpu_baseline(synth, sc, N, frames):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
+    # algorithm-matched multi-core baseline: a few thread counts, `matched_frames` frames each after 2 warm-up frames.
+    # The container may own fewer CPUs than the machine has (cgroup CFS quota): threads beyond the quota only fight for it.
+    ncpu = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    usable = int(min(ncpu, quota)) if quota else ncpu
+    os.environ.setdefault("OMP_PROC_BIND", "close")      # read by libgomp when libsrukf_matched.so is loaded (first use below)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    tried, best = {}, None
+    F = matched_frames + 2
+    for th in sorted({max(1, usable // 4), max(1, usable // 2), usable, min(ncpu, 2 * usable)}, reverse=True):
+        m = O.Matched(N, p, threads=th)
+        m.set_state(sc["X0"], sc["S0"])
+        m.run_frames(sc["odo"][:3], sc["z"][:2], sc["matched"][:2])
+        t2 = time.perf_counter()
+        mt = m.run_frames(sc["odo"][2:F + 1], sc["z"][2:F], sc["matched"][2:F])
+        fps = matched_frames / (time.perf_counter() - t2)
+        tried[str(th)] = round(fps, 2)
+        if best is None or fps > best[0]:
+            best = (fps, th, m.isa, {k: round(v / F * 1e3, 3) for k, v in m.phase_times().items()}, m.clamp_fallbacks())
+        m.close()
     return {
-        "value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"{frames} whole frames at N={N} of oracle/srukf_oracle.c in batched-refactor mode "
-                  f"({dt:.1f} s); reference-structured per-column refactor timed on {cols} of {2 * N} columns "
-                  f"({dcol:.3f} s/column) and extrapolated",
-        "faithful_value": 1.0 / faithful_frame, "cpu_model": model, "host_cores_available": os.cpu_count(),
+        "value": best[0], "unit": "frames/s", "cores": best[1], "kind": "port",
+        "sample": f"{matched_frames} whole frames at N={N} of oracle/srukf_matched.c (algorithm-matched to the GPU path: batched refactor, "
+                  f"structured motion update; OpenMP, {best[2]} tiles) per thread count {sorted(int(k) for k in tried)}, best kept; "
+                  f"single-thread oracle/srukf_oracle.c: {frames} frames in batched-refactor mode ({dt:.1f} s) and {cols} of {2 * N} "
+                  f"columns of the reference-structured refactor ({dcol:.3f} s/column) extrapolated",
+        "matched_by_threads": tried, "matched_ms_per_phase": best[3], "matched_clamp_fallbacks": best[4],
+        "port_value": frames / dt, "port_cores": 1,
+        "faithful_value": 1.0 / faithful_frame, "faithful_cores": 1,
+        "cpu_model": model, "host_cores_available": ncpu, "host_cpu_quota": quota,
+        "note": "host_cpu_quota = CPUs' worth of time the container's cgroup grants (cpu.max); thread counts above it lose",
     }, traj
 
 
@@ -344,6 +378,8 @@ def main():
             g.stage_sequence(sc["odo"][:args.cpu_frames + 1], sc["z"][:args.cpu_frames], sc["matched"][:args.cpu_frames])
             gt = g.run_frames(0, args.cpu_frames)
             out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = {"matched_all_cores": out["value"] / cb["value"], "port_1_thread": out["value"] / cb["port_value"],
+                                   "reference_structure_1_thread": out["value"] / cb["faithful_value"]}
             out["pose_rmse_vs_oracle_m"] = float(np.sqrt(np.mean((gt[:, :2] - otraj[:, :2]) ** 2)))
             out["max_abs_dP_robot_vs_oracle"] = float(np.abs(gt[:, 4:] - otraj[:, 4:]).max())
         print(json.dumps(out))

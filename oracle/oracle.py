@@ -35,13 +35,16 @@ class Params(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "srukf_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("srukf_oracle.c", "srukf_matched.c")]
+    libs = [_LIB_PATH, _MATCHED_PATH]
+    if force or any(not os.path.exists(l) or os.path.getmtime(l) < max(os.path.getmtime(s) for s in srcs) for l in libs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
 
+_MATCHED_PATH = os.path.join(_HERE, "libsrukf_matched.so")
 _lib = None
+_mlib = None
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -258,3 +261,74 @@ def joint_init(params, X, S, uv):
     rc = lib().orc_joint_init(C.byref(p), dim, _d(X), _d(S), K, _d(uv), _d(Xn), _d(Sn))
     assert rc == 0
     return Xn, Sn
+
+
+def matched_lib():
+    """libsrukf_matched.so: the algorithm-matched, OpenMP CPU baseline (srukf_matched.c)."""
+    global _mlib
+    if _mlib is None:
+        build()
+        L = C.CDLL(_MATCHED_PATH)
+        L.mt_create.restype = C.c_void_p
+        L.mt_create.argtypes = [C.c_int, C.POINTER(Params), C.c_int]
+        L.mt_destroy.argtypes = [C.c_void_p]
+        L.mt_set_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.mt_get_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.mt_frame.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip]
+        L.mt_run_frames.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp]
+        L.mt_clamp_fallbacks.restype = C.c_longlong
+        L.mt_clamp_fallbacks.argtypes = [C.c_void_p]
+        L.mt_phase_times.argtypes = [C.c_void_p, _dp]
+        L.mt_isa_name.restype = C.c_char_p
+        _mlib = L
+    return _mlib
+
+
+class Matched:
+    """The B-matched CPU baseline: same formulation as the GPU path (batched refactor, structured motion update),
+    OpenMP on `threads` cores (0 = the OpenMP default, i.e. all)."""
+
+    def __init__(self, N, params, threads=0):
+        self.N, self.n = N, 6 * N + 4
+        self._p = Params.from_dict(params)
+        self._h = matched_lib().mt_create(N, C.byref(self._p), int(threads))
+        self.threads = matched_lib().mt_threads()
+        self.isa = matched_lib().mt_isa_name().decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            matched_lib().mt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, X, S):
+        X, S = _c(X), _c(S)
+        matched_lib().mt_set_state(self._h, _d(X), _d(S))
+
+    def get_state(self):
+        X, S = np.empty(self.n), np.empty((self.n, self.n))
+        matched_lib().mt_get_state(self._h, _d(X), _d(S))
+        return X, S
+
+    def run_frames(self, odo, z, matched):
+        odo, z, m = _c(odo), _c(z), _c(matched, np.int32)
+        F = z.shape[0]
+        traj = np.empty((F, 8))
+        rc = matched_lib().mt_run_frames(self._h, F, _d(odo), _d(z), _i(m), _d(traj))
+        if rc != 0:
+            raise RuntimeError(f"mt_run_frames rc={rc}")
+        return traj
+
+    def clamp_fallbacks(self):
+        return int(matched_lib().mt_clamp_fallbacks(self._h))
+
+    def phase_times(self):
+        """Seconds spent so far in (motion, measurement, gains, S^T S - U U^T, factorisation, exact fallback)."""
+        t = np.zeros(6)
+        matched_lib().mt_phase_times(self._h, _d(t))
+        return dict(zip(("motion", "measure", "gain", "syrk", "gmw", "fallback"), t.tolist()))

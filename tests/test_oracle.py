@@ -280,3 +280,34 @@ def test_warp_patch_identity_view(oracle, synth):
         assert np.abs(out[:16, :16].astype(int) - ref[:16, :16].astype(int)).max() <= 1
         edge = np.abs(out.astype(int) - ref.astype(int)) > 1
         assert np.all(out[edge] == 0)
+
+
+@pytest.mark.parametrize("N,F,kw", [(1, 3, {}), (8, 4, {}), (20, 3, {}), (8, 3, {"weight_type": 1}), (8, 3, {"weight_type": 2})])
+def test_matched_cpu_baseline_equals_oracle(oracle, synth, N, F, kw):
+    """oracle/srukf_matched.c (the algorithm-matched OpenMP baseline bench.py times beside the GPU) against the
+    reference-structured oracle in batched mode: same trajectory, same X, same P."""
+    p = synth.scene_params(); p.update(kw)
+    sc = synth.make_scene(N, F, seed=30 + N, p=p)
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    to = o.run_frames(sc["odo"], sc["z"], sc["matched"], mode=oracle.Oracle.BATCHED)
+    m = oracle.Matched(N, p, threads=2); m.set_state(sc["X0"], sc["S0"])
+    tm = m.run_frames(sc["odo"], sc["z"], sc["matched"])
+    Xo, So = o.get_state(); Xm, Sm = m.get_state()
+    tol = 1e-6 if kw.get("weight_type") == 1 else 1e-11          # type 1 cancels six digits in every weighted mean
+    np.testing.assert_allclose(tm, to, rtol=0, atol=tol)
+    np.testing.assert_allclose(Xm, Xo, rtol=0, atol=tol)
+    np.testing.assert_allclose(Sm.T @ Sm, So.T @ So, rtol=0, atol=tol)
+    assert np.all(np.tril(Sm, -1) == 0.0) and m.clamp_fallbacks() == 0
+
+
+def test_matched_cpu_baseline_theta_clamp_fallback(oracle, synth):
+    """With the shipped a1..a4 = 8 the theta clamp fires in frame 3: the blocked factorisation notices afterwards and
+    repeats that refactor with the exact orc_gmw, like the device path."""
+    p = synth.default_params()
+    sc = synth.make_scene(8, 3, seed=1, p=p)
+    o = oracle.Oracle(8, p); o.set_state(sc["X0"], sc["S0"])
+    to = o.run_frames(sc["odo"], sc["z"], sc["matched"], mode=oracle.Oracle.BATCHED)
+    m = oracle.Matched(8, p, threads=2); m.set_state(sc["X0"], sc["S0"])
+    tm = m.run_frames(sc["odo"], sc["z"], sc["matched"])
+    assert m.clamp_fallbacks() >= 1
+    assert np.all(np.abs(tm - to) <= 1e-9 * np.maximum(1.0, np.abs(to)))
