@@ -53,6 +53,17 @@ def pmc_traffic(kernel):
     return (k["traffic_bytes"] if k else None), os.path.relpath(files[-1], ROOT)
 
 
+def pmc_mfma(kernel):
+    """Busy % of the matrix pipes over the kernel's duration (SQ_VALU_MFMA_BUSY_CYCLES, own rocprofv3 --pmc pass) and the
+    MFMA flops the hardware counted, from the newest profiles/*_mfma.json of this workload; (None, None, None) without one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma.json")))
+    if not files:
+        return None, None, None
+    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    return (k.get("mfma_busy_pct_of_kernel_time") if k else None), (k.get("mfma_gflop") if k else None), os.path.relpath(files[-1], ROOT)
+
+
 def dist_env():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -349,6 +360,7 @@ def main():
             roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
+        roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma(dom)
         roof["kernel"] = dom
         roof["avg_launch_us"] = avg_s * 1e6
         roof["launches_per_frame"] = d["launches"] / PF

@@ -48,7 +48,14 @@ void CSLAM::initializeParameters()
     m_odoCounter = 0; m_showCounter = 1;
     m_nMapFeatures = m_nPredicts = m_nMatches = m_nAddings = 0;
     m_frameTime = m_totalTime = 0;
-    map.clear();
+    mapStore.clear(); relinkMap();
+}
+
+// `map` = head of the singly linked list over mapStore (state order), NULL when the map is empty (SLAM.h:69, 154)
+void CSLAM::relinkMap()
+{
+    for (size_t k = 0; k < mapStore.size(); k++) mapStore[k].next = (k + 1 < mapStore.size()) ? &mapStore[k + 1] : nullptr;
+    map = mapStore.empty() ? nullptr : mapStore.data();
 }
 
 void CSLAM::resetAllParameters()
@@ -65,7 +72,7 @@ bool CSLAM::setMap(int N, const double* X, const double* S, const double* px, in
     if (!check(srukf_set_state(ctx_, X, S))) return false;
     const int n = 6 * N + 4;
     m_X_k.create(n, 1); m_S_k.create(n, n); m_P_k.create(n, n);
-    map.assign(N, PointsMap());
+    mapStore.assign(N, PointsMap()); relinkMap();
     for (int k = 0; k < N; k++) { map[k].ID = k + 1; if (px) { map[k].initPixel.x = px[2 * k]; map[k].initPixel.y = px[2 * k + 1]; } }
     m_nMapFeatures = N;
     m_nAddings = n_added;    // 0 = steady state: FLAG_4_NEEDNOT_REORDER (SLAM.cpp:2083-2090)
@@ -79,12 +86,13 @@ bool CSLAM::integrateFeaturesInformation(int K, const double* kp)
     if (K <= 0) { m_nAddings = 0; return true; }                                                                // SLAM.cpp:820-821
     if (!ctx_) {                                                                                                // frame 1: robot block only (221-231)
         if (!check(srukf_create(&ctx_, 0, &m_params, device_, nullptr))) return false;
-        m_nMapFeatures = 0; map.clear();
+        m_nMapFeatures = 0; mapStore.clear(); relinkMap();
     }
     if (!check(srukf_add_landmarks(ctx_, K, kp))) return false;
     const int N = m_nMapFeatures + K, n = 6 * N + 4;
     m_X_k.create(n, 1); m_S_k.create(n, n); m_P_k.create(n, n);
-    for (int k = 0; k < K; k++) { PointsMap pm; pm.ID = m_nMapFeatures + k + 1; pm.initPixel.x = kp[2 * k]; pm.initPixel.y = kp[2 * k + 1]; map.push_back(pm); }
+    for (int k = 0; k < K; k++) { PointsMap pm; pm.ID = m_nMapFeatures + k + 1; pm.initPixel.x = kp[2 * k]; pm.initPixel.y = kp[2 * k + 1]; mapStore.push_back(pm); }
+    relinkMap();
     m_nMapFeatures = N;                                                                                         // 766
     m_nAddings = K;                                                                                             // 758-765 (m_nFilters = m_nAddings = counter)
     refreshMirrors();
@@ -95,7 +103,7 @@ bool CSLAM::deleteOneFeature(int id)
 {
     if (!ctx_ || id < 0 || id >= m_nMapFeatures) { lastError = "deleteOneFeature: no such landmark"; return false; }
     if (!check(srukf_delete_landmark(ctx_, id))) return false;                                                  // 2643-2668
-    map.erase(map.begin() + id);                                                                                // 2670-2705
+    mapStore.erase(mapStore.begin() + id); relinkMap();                                                                                // 2670-2705
     m_nMapFeatures--;                                                                                           // 2664
     if (m_nAddings > 0 && id >= m_nMapFeatures + 1 - m_nAddings) m_nAddings--;                                  // 2468-2492
     const int n = 6 * m_nMapFeatures + 4;

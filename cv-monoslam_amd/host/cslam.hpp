@@ -38,6 +38,7 @@ struct PointsMap {
     int     ID = 0;
     bool    isVisible = false;
     bool    isMatching = false;
+    bool    isLoop = false;           // delayed deletion flag the OpenGL view colours by (OpenGlDisplay.cpp:497)      (SLAM.h:52)
     int     nPredictTimes = 0;
     int     nMatchTimes = 0;
     Point2d predictLocation;
@@ -48,6 +49,7 @@ struct PointsMap {
     Quaternion axis;                  // orientation of the 1-sigma ellipsoid            (SLAM.h:66)
     Point3d sigma;                    // its semi-axes = sqrt of the eigenvalues of cov  (SLAM.h:67)
     double  cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // Cartesian 3x3 covariance
+    PointsMap* next = nullptr;        // singly linked list in state order, NULL-terminated                           (SLAM.h:69)
 };
 
 // SLAM.h:85-92
@@ -113,7 +115,12 @@ public:
     std::function<void(CSLAM&)> dataAssociation;
 
     // ---- public state, reference names (SLAM.h:154-290) -----------------------------------------
-    std::vector<PointsMap> map;          // linked list in the reference; order = state order
+    // The reference's map is a singly linked list the host walks (`PointsMap* map_p = SLAM->map; while (NULL != map_p)
+    // { ... map_p = map_p->next; }`, OpenGlDisplay.cpp:403-424, 460-509; SLAM.h:154).  Same here: `map` is the head (NULL
+    // for an empty map), `next` links the nodes in state order.  The nodes live contiguously in mapStore, so map[k] is
+    // also the k-th landmark; the links are rebuilt whenever landmarks are added or deleted.
+    PointsMap* map = nullptr;
+    std::vector<PointsMap> mapStore;
     FrameInfo m_frame;
     srukf_params m_params;               // the tunables of SLAM.cpp:172-198, 221-224, 329-337
     int    m_updateMode = SRUKF_UPDATE_BATCHED;
@@ -129,6 +136,7 @@ public:
     std::string lastError;
 
 private:
+    void relinkMap();
     void refreshMirrors();
     bool check(int rc);
     srukf_ctx* ctx_ = nullptr;

@@ -58,7 +58,9 @@ int main(int argc, char** argv)
     {
         std::string fn = std::string(argv[4]) + ".features";
         FILE* ff = fopen(fn.c_str(), "wb");
-        for (const monoslam::PointsMap& pm : SLAM.map) {
+        // walked the way the reference's OpenGL view walks it (OpenGlDisplay.cpp:403-424): head pointer + next
+        for (const monoslam::PointsMap* map_p = SLAM.map; NULL != map_p; map_p = map_p->next) {
+            const monoslam::PointsMap& pm = *map_p;
             const double rec[19] = { pm.xyz.x, pm.xyz.y, pm.xyz.z, pm.cov[0], pm.cov[1], pm.cov[2], pm.cov[3], pm.cov[4], pm.cov[5], pm.cov[6], pm.cov[7], pm.cov[8],
                                      pm.axis.r, pm.axis.x, pm.axis.y, pm.axis.z, pm.sigma.x, pm.sigma.y, pm.sigma.z };
             fwrite(rec, 8, 19, ff);
