@@ -278,14 +278,59 @@ bool CSLAM::loadOdometryData(const std::string& path)
     return true;
 }
 
-// SLAM.cpp:1430-1465.  The redirection sub-map restart (1354-1428) needs landmark augmentation and
-// is not built; a flagged frame is reported through lastError and processed as an ordinary frame.
+// The redirection branch of predictMotion (SLAM.cpp:1354-1428): the odometry heading jumped by more than MIN_STEP_THETA
+// (flag in m_odoTheta row 2, loadOdometryData 438-445).  The current map is archived landmark by landmark in
+// m_featuresAllInfo (1357-1378), a fresh 4-state filter starts at the current x / y with the odometry heading and the
+// initial robot sqrt covariance (1396-1406), the host's key points are joint-initialised (addFeatures, 1414-1416), and
+// the frame counter moves on to the next odometry sample whose heading replaces the robot heading (1420-1427).
+bool CSLAM::redirection()
+{
+    const int c = m_frame.counter, n = m_X_k.rows;
+    if (m_nMapFeatures > 0 && !updateFeaturesInformation()) return false;                                      // xyz / cov / axis / sigma of every landmark
+    if (!check(srukf_get_state(ctx_, m_X_k.data.data(), nullptr))) return false;
+    int id = 0;
+    for (const PointsMap* map_p = map; NULL != map_p; map_p = map_p->next, id++) {                             // 1357-1378
+        FeatureInfo fi;
+        fi.ID = map_p->ID; fi.isLoop = map_p->isLoop; fi.nPredictTimes = map_p->nPredictTimes; fi.nMatchTimes = map_p->nMatchTimes;
+        fi.initXYZ = map_p->xyz; fi.initPixel = map_p->initPixel;
+        for (int e = 0; e < 6; e++) fi.state[e] = m_X_k.at(6 * id + e, 0);
+        fi.position = map_p->xyz;
+        memcpy(fi.cov, map_p->cov, sizeof fi.cov);
+        fi.axis = map_p->axis; fi.sigma = map_p->sigma;
+        m_featuresAllInfo.push_back(fi);
+    }
+    const double X4[4] = { m_X_k.at(n - 4, 0), m_X_k.at(n - 3, 0), 0.0, m_odoTheta.at(1, c) };                 // 1396-1400
+    const double S4[16] = { m_params.sigma_x, 0, 0, 0,  0, m_params.sigma_y, 0, 0,  0, 0, m_params.sigma_z, 0,  0, 0, 0, m_params.sigma_theta };   // 1402-1406
+    srukf_destroy(ctx_); ctx_ = nullptr;
+    if (!check(srukf_create(&ctx_, 0, &m_params, device_, nullptr))) return false;
+    if (!check(srukf_set_state(ctx_, X4, S4))) return false;
+    m_nStoreMap = m_nMapFeatures; m_nStorePredicts = m_nPredicts; m_nStoreMatches = m_nMatches;                // 1408-1410
+    m_nMapFeatures = 0; m_nPredicts = 0; m_nMatches = 0; m_nAddings = 0;                                       // 1412-1416
+    mapStore.clear(); relinkMap();
+    m_X_k.create(4, 1); m_S_k.create(4, 4); m_P_k.create(4, 4);
+    std::vector<double> keyPoints;
+    const int K = addFeatures ? addFeatures(*this, keyPoints) : 0;                                             // 1418-1420 (isAdding; addFeatures 552-562)
+    if (K > 0 && !integrateFeaturesInformation(K, keyPoints.data())) return false;
+    m_nShowMap = m_nMapFeatures + m_nStoreMap;                                                                 // 1422
+    m_frame.counter++;                                                                                         // 1424-1425
+    m_frame.index = (int)m_odoTheta.at(0, m_frame.counter);
+    const int dim = 6 * m_nMapFeatures + 4;                                                                    // 1427-1428: heading of the next odometry sample
+    std::vector<double> X(dim), S((size_t)dim * dim);
+    if (!check(srukf_get_state(ctx_, X.data(), S.data()))) return false;
+    X[dim - 1] = m_odoTheta.at(1, m_frame.counter);
+    if (!check(srukf_set_state(ctx_, X.data(), S.data()))) return false;
+    if (m_nAddings > 0 && !check(srukf_set_new_landmarks(ctx_, m_nAddings))) return false;                     // set_state keeps K_new; explicit for clarity
+    refreshMirrors();
+    return true;
+}
+
+// SLAM.cpp:1343-1465: the redirection restart, then the numeric tail 1430-1465 on the device.
 void CSLAM::predictMotion()
 {
     if (!ctx_) { lastError = "predictMotion before setMap"; return; }
+    m_frame.index = (int)m_odoTheta.at(0, m_frame.counter);                                                    // 1351
+    if (m_odoTheta.at(2, m_frame.counter) == 1 && !redirection()) return;                                      // 1354-1428
     const int c = m_frame.counter;
-    m_frame.index = (int)m_odoTheta.at(0, c);                                                                  // 1351
-    if (m_odoTheta.at(2, c) == 1) lastError = "redirection frame (SLAM.cpp:1354-1428) is outside the built path";
     const double prev[3] = { m_odoXY[2 * c - 2], m_odoXY[2 * c - 1], m_odoTheta.at(1, c - 1) };               // 1444-1450
     const double cur[3]  = { m_odoXY[2 * c], m_odoXY[2 * c + 1], m_odoTheta.at(1, c) };
     check(srukf_predict_motion(ctx_, prev, cur));

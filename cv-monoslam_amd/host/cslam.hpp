@@ -52,6 +52,19 @@ struct PointsMap {
     PointsMap* next = nullptr;        // singly linked list in state order, NULL-terminated                           (SLAM.h:69)
 };
 
+// SLAM.h:94-112 (numeric fields): what the redirection restart archives per landmark of the map it leaves behind
+struct FeatureInfo {
+    bool    isLoop = false;
+    int     ID = 0, nPredictTimes = 0, nMatchTimes = 0;
+    Point3d initXYZ;
+    Point2d initPixel;
+    double  state[6] = {0, 0, 0, 0, 0, 0};   // the landmark's six rows of m_X_k
+    Point3d position;                        // Cartesian mean
+    double  cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Quaternion axis;
+    Point3d sigma;
+};
+
 // SLAM.h:85-92
 struct FrameInfo { int rate = 0, start = 1, stop = 0, index = 0, counter = 1; };
 
@@ -113,6 +126,14 @@ public:
 
     // the reference's loadPictures()+dataAssociation() slot (SLAM.cpp:95-97)
     std::function<void(CSLAM&)> dataAssociation;
+    // the reference's addFeatures() -> detectAndfilteringFeatures / insureEnoughFeatures slot (SLAM.cpp:552-562, 574-808):
+    // the host detects key points on its current image and returns them as (u, v) pairs (distorted pixels); the facade
+    // joint-initialises them (integrateFeaturesInformation).  Used by the redirection restart of predictMotion.
+    std::function<int(CSLAM&, std::vector<double>& keyPoints)> addFeatures;
+    // ---- redirection (SLAM.cpp:1354-1428): when the odometry heading jumps by more than MIN_STEP_THETA the reference
+    //      archives the current map in m_featuresAllInfo and restarts a fresh 4-state filter at the current position ----
+    std::vector<FeatureInfo> m_featuresAllInfo;          // SLAM.h:170
+    int m_nStoreMap = 0, m_nStorePredicts = 0, m_nStoreMatches = 0, m_nShowMap = 0;   // 1408-1410, 1418
 
     // ---- public state, reference names (SLAM.h:154-290) -----------------------------------------
     // The reference's map is a singly linked list the host walks (`PointsMap* map_p = SLAM->map; while (NULL != map_p)
@@ -136,6 +157,7 @@ public:
     std::string lastError;
 
 private:
+    bool redirection();
     void relinkMap();
     void refreshMirrors();
     bool check(int rc);

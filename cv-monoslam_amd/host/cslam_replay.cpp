@@ -1,7 +1,10 @@
 // cslam_replay — minimal C++ host that drives the CSLAM facade exactly the way the MFC view drives
 // the reference class (construct, initializeParameters, loop SLAM(), read fields), with the image
 // pipeline replaced by pre-computed "matched pixels" (synthetic data association).
-//   cslam_replay scene.bin odometry.txt RobotPath.txt traj.bin [sequential]
+//   cslam_replay scene.bin odometry.txt RobotPath.txt traj.bin [sequential|batched] [redirect=<counter>]
+// redirect=<counter>: flags that odometry sample as a heading jump (what loadOdometryData does for |dtheta| > 45 deg,
+//   SLAM.cpp:438-445), so that predictMotion takes the redirection restart (1354-1428); the host's addFeatures callback
+//   "detects" the landmarks where the flagged frame's image shows them.
 // scene.bin: int32 N, int32 F, double a1..a4, double X0[n], double S0[n*n], double z[F][2N]
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +29,8 @@ int main(int argc, char** argv)
     monoslam::CSLAM SLAM;                                   // MonoSLAMView.h:44
     SLAM.m_params.a1 = a[0]; SLAM.m_params.a2 = a[1]; SLAM.m_params.a3 = a[2]; SLAM.m_params.a4 = a[3];   // CSetParameters dialog (MonoSLAMView.cpp:386-443)
     if (argc > 5 && !strcmp(argv[5], "sequential")) SLAM.m_updateMode = SRUKF_UPDATE_SEQUENTIAL;
+    int redirect = 0;
+    for (int a = 5; a < argc; a++) if (!strncmp(argv[a], "redirect=", 9)) redirect = atoi(argv[a] + 9);
     if (!SLAM.setMap(N, X0.data(), S0.data(), nullptr)) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
     SLAM.MIN_STEP_X = SLAM.MIN_STEP_Y = 0.0;             // the synthetic odometry is already one pose per frame: keep every sample
     if (!SLAM.loadOdometryData(argv[2])) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
@@ -41,8 +46,17 @@ int main(int argc, char** argv)
             p.matchLocation.y = z[(size_t)fr * 2 * N + 2 * k + 1];
         }
     };
+    if (redirect > 0) {
+        SLAM.m_odoTheta.at(2, redirect) = 1;
+        SLAM.addFeatures = [&](monoslam::CSLAM& s, std::vector<double>& kp) {     // detectAndfilteringFeatures stand-in
+            const int fr = s.m_frame.counter - 1;           // detections on the image of the flagged frame index (cvLoadImage(image_dir, m_frame.index), 1381-1392)
+            kp.assign(z.begin() + (size_t)fr * 2 * N, z.begin() + (size_t)(fr + 1) * 2 * N);
+            return N;
+        };
+    }
     std::vector<double> traj((size_t)F * 8);
-    for (int fr = 0; fr < F; fr++) {                        // OnBnClickedAuto loop, MonoSLAMView.cpp:526-572
+    const int steps = redirect > 0 ? F - 1 : F;             // the restart consumes one odometry sample (1424-1425)
+    for (int fr = 0; fr < steps; fr++) {                    // OnBnClickedAuto loop, MonoSLAMView.cpp:526-572
         SLAM.SLAM();
         if (!SLAM.lastError.empty()) { fprintf(stderr, "frame %d: %s\n", fr, SLAM.lastError.c_str()); return 1; }
         const int nn = SLAM.m_X_k.rows;
@@ -67,6 +81,7 @@ int main(int argc, char** argv)
         }
         fclose(ff);
     }
+    if (redirect > 0) printf("redirection: archived %d  stored map %d  show map %d\n", (int)SLAM.m_featuresAllInfo.size(), SLAM.m_nStoreMap, SLAM.m_nShowMap);
     printf("frames %d  landmarks %d  predicts %d  matches %d  total %.3f s\n", F, SLAM.m_nMapFeatures, SLAM.m_nPredicts, SLAM.m_nMatches, SLAM.m_totalTime);
     return 0;
 }
