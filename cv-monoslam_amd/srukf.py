@@ -32,7 +32,7 @@ STATUS = {0: "SRUKF_OK", -1: "SRUKF_ERR_BAD_ARG", -2: "SRUKF_ERR_DIM_MISMATCH", 
           -4: "SRUKF_ERR_NO_DEVICE", -5: "SRUKF_ERR_SEQUENCE", -6: "SRUKF_ERR_UNSUPPORTED",
           -7: "SRUKF_ERR_CLAMP_PENDING", -8: "SRUKF_ERR_NOMEM"}
 
-STORAGE_F64, STORAGE_F32 = 0, 1
+STORAGE_F64, STORAGE_F32, STORAGE_F32_MIXED = 0, 1, 2
 UPDATE_SEQUENTIAL, UPDATE_BATCHED = 0, 1
 NEED_REORDER, NEEDNOT_REORDER = 0, 1
 

@@ -75,7 +75,14 @@ typedef enum srukf_reorder { SRUKF_NEED_REORDER = 0, SRUKF_NEEDNOT_REORDER = 1 }
 /* Precision of the filter state that lives from frame to frame (arithmetic is fp64 in both).  F32 is BASELINE
  * configs[4] ("500 landmarks fp32 SRUKF ..., tolerance study"): X and S are kept as float and every frame computes
  * from exactly those rounded values. */
-typedef enum srukf_storage { SRUKF_STORAGE_F64 = 0, SRUKF_STORAGE_F32 = 1 } srukf_storage;
+/* F32_MIXED adds the mixed-precision downdate of that config: the covariance that is re-factorised, S^T S - U U^T
+ * (SLAM.cpp:2118-2120, 2149), is formed on the fp32 matrix pipe from the fp32 state and U^T rounded once, in K chunks of
+ * <= 1024 summed in FP64; pivots, diagonal blocks and trailing updates of the modified Cholesky stay FP64.  BATCHED
+ * updates only use it (a SEQUENTIAL / single-column refactor keeps the FP64 contraction).  srukf_set_storage refuses it
+ * (SRUKF_ERR_UNSUPPORTED) unless params.epsilon >= 1e-9: P is permanently rank deficient and the reference's clamp
+ * EPSILON = 1e-13 lies below the rounding an fp32-formed S^T S - U U^T leaves in its null space (the tolerance study in
+ * diverges at 1e-13, within 1.3e-6 m of the fp64 / 1e-13 run at 1e-8). */
+typedef enum srukf_storage { SRUKF_STORAGE_F64 = 0, SRUKF_STORAGE_F32 = 1, SRUKF_STORAGE_F32_MIXED = 2 } srukf_storage;
 
 typedef struct srukf_ctx srukf_ctx;   /* opaque; owns all device buffers + pinned staging */
 

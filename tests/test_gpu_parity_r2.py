@@ -175,3 +175,41 @@ def test_replay_recovers_from_theta_clamp_frame(srukf, oracle, synth):
     assert np.all(np.abs(traj[:3, 4:] - to[:3, 4:]) <= 1e-9 * np.maximum(1.0, np.abs(to[:3, 4:])))
     np.testing.assert_allclose(X, Xo, rtol=0, atol=1e-8)
     np.testing.assert_allclose(S.T @ S, So.T @ So, rtol=0, atol=1e-6 * scale)    # the filter diverges with these constants (|P| ~ 1e8)
+
+
+@pytest.mark.parametrize("N", [20, 50, 200])
+def test_mixed_precision_downdate(srukf, oracle, synth, N):
+    """SRUKF_STORAGE_F32_MIXED (BASELINE configs[4]): fp32 state, S^T S - U U^T on the fp32 matrix pipe in K chunks summed in
+    FP64, pivots and trailing updates FP64.  Refused with the reference's EPSILON = 1e-13 (the fp32-formed covariance cannot
+    resolve that clamp: it diverges, scripts/mixed_eps_study.py); with the clamp at 1e-8 one frame from the float-rounded
+    state matches the oracle's fp64 frame to what single-precision products imply, and the trajectory stays within 1e-6 m of
+    the fp64 run with the same clamp."""
+    p = synth.scene_params()
+    g = srukf.Filter(N, p)
+    with pytest.raises(srukf.SrukfError) as e:
+        g.set_storage(srukf.STORAGE_F32_MIXED)
+    assert e.value.rc == -6
+    p["epsilon"] = 1e-8
+    F = 12 if N < 200 else 6
+    sc = synth.make_scene(N, F, seed=3, p=p)
+    X0 = sc["X0"].astype(np.float32).astype(np.float64); S0 = np.triu(sc["S0"]).astype(np.float32).astype(np.float64)
+    f = srukf.Filter(N, p); f.set_storage(srukf.STORAGE_F32_MIXED); f.set_state(X0, S0)
+    o = oracle.Oracle(N, p); o.set_state(X0, S0)
+    f.predict_motion(sc["odo"][0], sc["odo"][1]); o.predict_motion(sc["odo"][0], sc["odo"][1])
+    f.predict_measurement(); o.predict_measurement()
+    f.update(sc["z"][0], sc["matched"][0]); o.update(sc["z"][0], sc["matched"][0], 1, 0, 1)
+    X, S = f.get_state(); Xo, So = o.get_state()
+    assert np.all(np.tril(S, -1) == 0.0)
+    eps32 = float(np.finfo(np.float32).eps)
+    np.testing.assert_allclose(X, Xo, rtol=eps32, atol=1e-9)
+    P, Po = S.T @ S, So.T @ So
+    sd = np.sqrt(np.diag(Po))
+    rel = np.abs(P - Po) / (np.outer(sd, sd) + 1e-30)
+    assert rel.max() < 4e-6, rel.max()                            # measured 5e-7: fp32 products of the stored factors + the clamp level
+    tr = {}
+    for st in (srukf.STORAGE_F64, srukf.STORAGE_F32_MIXED):
+        g = srukf.Filter(N, p); g.set_storage(st); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        tr[st] = g.run_frames(0, F)
+    d = np.abs(tr[srukf.STORAGE_F32_MIXED][:, :2] - tr[srukf.STORAGE_F64][:, :2]).max()
+    assert 0 < d < 1e-6, d
+    assert np.abs(tr[srukf.STORAGE_F32_MIXED][:, :2] - sc["odo"][1:F + 1, :2]).max() < 2e-4      # still tracks the truth
