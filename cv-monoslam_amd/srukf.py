@@ -24,7 +24,7 @@ EXPORTS = [
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
     "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
-    "srukf_clamp_info", "srukf_debug_starve_workers", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
+    "srukf_clamp_info", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
 
@@ -114,6 +114,7 @@ def load_library():
     L.srukf_synchronize.argtypes = [C.c_void_p]
     L.srukf_clamp_info.argtypes = [C.c_void_p, _ip, _ip]
     L.srukf_debug_starve_workers.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_debug_allow_mixed.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.srukf_profile_count.argtypes = [C.c_void_p]
     L.srukf_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), _dp, C.POINTER(C.c_longlong), _dp, _dp]
@@ -305,6 +306,10 @@ class Filter:
         fr, row = C.c_int(), C.c_int()
         self._chk(self._lib.srukf_clamp_info(self._h, C.byref(fr), C.byref(row)))
         return fr.value, row.value
+
+    def debug_allow_mixed(self, on):
+        """Study hook: accept STORAGE_F32_MIXED below its epsilon floor."""
+        self._chk(self._lib.srukf_debug_allow_mixed(self._h, int(on)))
 
     def debug_starve_workers(self, on):
         """Test hook: persistent factorisation launches start without their workers."""

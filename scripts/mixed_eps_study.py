@@ -12,7 +12,7 @@ out = {"landmarks": N, "frames": F, "by_epsilon": {}}
 for eps in (1e-13, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6):
     for name, st in (("f64", srukf.STORAGE_F64), ("f32_mixed", srukf.STORAGE_F32_MIXED)):
         q = dict(p); q["epsilon"] = eps
-        g = srukf.Filter(N, q); g.set_storage(st); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        g = srukf.Filter(N, q); g.debug_allow_mixed(True); g.set_storage(st); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
         try:
             t = g.run_frames(0, F)
             d = np.sqrt(np.sum((t[:, :2] - ref[:, :2]) ** 2, axis=1))
