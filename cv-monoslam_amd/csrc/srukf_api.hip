@@ -55,6 +55,36 @@ int srukf_app_patch_stride(void);
 int srukf_app_tmpl_stride(void);
 }
 
+// ---- device memory: the stream-ordered pool of the device instead of hipMalloc / hipFree ------------------------------
+// A context is rebuilt whenever the map changes size (srukf_add_landmarks / srukf_delete_landmark): ~25 buffers freed and
+// ~25 allocated.  hipMalloc / hipFree go to the driver every time (and hipFree synchronises the whole device): 12.6 ms per
+// augmentation at N = 200, almost all of it there.  The default memory pool keeps freed blocks (release threshold raised
+// to "never") and hands them out again in microseconds.  Allocation is made visible to every stream by synchronising the
+// null stream it is ordered on; every free below happens after the streams that used the block have been synchronised.
+static void srukf_pool_init()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    int dev = 0; hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+        unsigned long long keep = ~0ull;
+        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+}
+static hipError_t srukf_dmalloc_raw(void** p, size_t bytes)
+{
+    srukf_pool_init();
+    hipError_t e = hipMallocAsync(p, bytes ? bytes : 8, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+template <class T> static hipError_t srukf_dmalloc(T** p, size_t bytes) { return srukf_dmalloc_raw((void**)p, bytes); }
+static hipError_t srukf_dfree(void* p) { return p ? hipFreeAsync(p, nullptr) : hipSuccess; }
+// the same, ordered on a context's own stream (no synchronisation: everything that touches the block is on that stream)
+template <class T> static hipError_t srukf_dmalloc_on(T** p, size_t bytes, hipStream_t st) { srukf_pool_init(); return hipMallocAsync((void**)p, bytes ? bytes : 8, st); }
+static hipError_t srukf_dfree_on(void* p, hipStream_t st) { return p ? hipFreeAsync(p, st) : hipSuccess; }
+
 // resets the per-refactor accumulators (theta row maxima, gamma/xi)
 __global__ void k_refactor_reset(int np, unsigned long long* theta_bits, FrameScalars* fs, int reset_stats)
 {
@@ -121,6 +151,8 @@ __global__ __launch_bounds__(256) void k_quantize(int n, int ld, double* __restr
 
 #define SRUKF_GRAPH_FRAMES 8
 static thread_local std::string g_create_error;
+static thread_local double* g_spare_stage = nullptr;       // one pinned staging buffer handed from a destroyed context to the next one
+static thread_local size_t g_spare_stage_bytes = 0;
 
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_SYRK, KC_GMW_TRAIL, KC_GMW_PERSIST, KC_GMW_CHECK,
               KC_GMW_COL, KC_MISC, KC_COUNT };
@@ -131,11 +163,11 @@ struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
 struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, workers = -1; };
-static void gmw_plan_destroy(GmwPlan& g)
+static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 {
-    if (g.pans) hipFree(g.pans);
-    if (g.sync) hipFree(g.sync);
-    if (g.tiles) hipFree(g.tiles);
+    if (g.pans) srukf_dfree_on(g.pans, st);
+    if (g.sync) srukf_dfree_on(g.sync, st);
+    if (g.tiles) srukf_dfree_on(g.tiles, st);
     g = GmwPlan();
 }
 // workers = -1 afterwards: the matrix has more tiles than resident workgroups can own (the per-panel launches are used)
@@ -149,15 +181,15 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st)
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
     srukf_gmw_build_tiles(g.T, tk.data());
     const size_t sync_bytes = (size_t)srukf_gmw_sync_bytes(g.T);
-    if (hipMalloc(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T) != hipSuccess ||
-        hipMalloc(&g.sync, sync_bytes) != hipSuccess ||
-        hipMalloc(&g.tiles, sizeof(short) * tk.size()) != hipSuccess) { gmw_plan_destroy(g); return SRUKF_ERR_NOMEM; }
+    if (srukf_dmalloc_on(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
+        srukf_dmalloc_on(&g.sync, sync_bytes, st) != hipSuccess ||
+        srukf_dmalloc_on(&g.tiles, sizeof(short) * tk.size(), st) != hipSuccess) { gmw_plan_destroy(g, st); return SRUKF_ERR_NOMEM; }
     const unsigned long long epoch1 = 1;                         // everything else starts at zero
     if (hipMemsetAsync(g.pans, 0, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
         hipMemsetAsync(g.sync, 0, sync_bytes, st) != hipSuccess ||
         hipMemcpyAsync((char*)g.sync + offsetof(GmwSync, epoch), &epoch1, sizeof epoch1, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(g.tiles, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { gmw_plan_destroy(g); return SRUKF_ERR_HIP; }
+        hipStreamSynchronize(st) != hipSuccess) { gmw_plan_destroy(g, st); return SRUKF_ERR_HIP; }
     return SRUKF_OK;
 }
 // 1 = one persistent launch per factorisation (default), 0 = one launch per 64-row panel (SRUKF_GMW_PERSIST=0: A/B runs)
@@ -456,7 +488,7 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
     const KDims& d = c->d;
     const int np = d.np, n = d.n, r = n - 3 * c->K_new;
     const size_t bytes = sizeof(double) * (size_t)np * np;
-    if (!c->Sdis) { if (hipMalloc((void**)&c->Sdis, bytes) != hipSuccess) { c->err = "out of device memory (NEED_REORDER buffer)"; return SRUKF_ERR_NOMEM; } }
+    if (!c->Sdis) { if (srukf_dmalloc((void**)&c->Sdis, bytes) != hipSuccess) { c->err = "out of device memory (NEED_REORDER buffer)"; return SRUKF_ERR_NOMEM; } }
     hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
     srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X);
     c->dx_pending = false;
@@ -519,7 +551,7 @@ const char* srukf_last_error(const srukf_ctx* ctx) { return ctx ? ctx->err.c_str
 
 static int alloc_zero(srukf_ctx* c, void** p, size_t bytes)
 {
-    HIPCHK(c, hipMalloc(p, bytes));
+    HIPCHK(c, srukf_dmalloc_on(p, bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(*p, 0, bytes, c->stream));
     return SRUKF_OK;
 }
@@ -586,7 +618,10 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
         }
     }
     c->hstage_bytes = sizeof(double) * (np * np + 4096);
-    if (hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars)) != hipSuccess) {
+    if (g_spare_stage && g_spare_stage_bytes >= c->hstage_bytes) {         // pinned staging of a context that was just rebuilt (map change)
+        c->hstage = g_spare_stage; c->hstage_bytes = g_spare_stage_bytes; g_spare_stage = nullptr; g_spare_stage_bytes = 0;
+    }
+    if ((!c->hstage && hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess) || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars)) != hipSuccess) {
         g_create_error = "hipHostMalloc failed"; srukf_destroy(c); return SRUKF_ERR_NOMEM;
     }
     int rc = srukf_reset(c);
@@ -608,9 +643,14 @@ int srukf_destroy(srukf_ctx* c)
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
                      c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
-    for (void* b : bufs) if (b) hipFree(b);
-    gmw_plan_destroy(c->gplan);
-    if (c->hstage) hipHostFree(c->hstage);
+    for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
+    gmw_plan_destroy(c->gplan, c->stream);
+    if (c->own_stream && c->stream) hipStreamSynchronize(c->stream);
+    if (c->hstage) {
+        // keep ONE pinned staging buffer for the next context (pinning 16 MB costs milliseconds; map changes rebuild contexts)
+        if (!g_spare_stage || g_spare_stage_bytes < c->hstage_bytes) { if (g_spare_stage) hipHostFree(g_spare_stage); g_spare_stage = c->hstage; g_spare_stage_bytes = c->hstage_bytes; }
+        else hipHostFree(c->hstage);
+    }
     if (c->hfs) hipHostFree(c->hfs);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -923,8 +963,8 @@ int srukf_set_storage(srukf_ctx* c, int storage)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t np = c->d.np, mp = c->d.mp;
     if (storage != SRUKF_STORAGE_F64 && !c->S32) {
-        HIPCHK(c, hipMalloc((void**)&c->S32, sizeof(float) * np * np));
-        HIPCHK(c, hipMalloc((void**)&c->X32, sizeof(float) * np));
+        HIPCHK(c, srukf_dmalloc((void**)&c->S32, sizeof(float) * np * np));
+        HIPCHK(c, srukf_dmalloc((void**)&c->X32, sizeof(float) * np));
         HIPCHK(c, hipMemsetAsync(c->S32, 0, sizeof(float) * np * np, c->stream));
         HIPCHK(c, hipMemsetAsync(c->X32, 0, sizeof(float) * np, c->stream));
     }
@@ -933,10 +973,10 @@ int srukf_set_storage(srukf_ctx* c, int storage)
         const int ntasks = srukf_mixed_build_tasks((int)np, (int)mp, nullptr, nullptr, &ntiles);
         std::vector<short> tk((size_t)4 * ntasks); std::vector<int> tl((size_t)2 * ntiles);
         srukf_mixed_build_tasks((int)np, (int)mp, tk.data(), tl.data(), &ntiles);
-        HIPCHK(c, hipMalloc((void**)&c->U32, sizeof(float) * mp * np));
-        HIPCHK(c, hipMalloc((void**)&c->mx_part, srukf_mixed_part_bytes(ntasks)));
-        HIPCHK(c, hipMalloc(&c->mx_tasks, sizeof(short) * tk.size()));
-        HIPCHK(c, hipMalloc(&c->mx_tiles, sizeof(int) * tl.size()));
+        HIPCHK(c, srukf_dmalloc((void**)&c->U32, sizeof(float) * mp * np));
+        HIPCHK(c, srukf_dmalloc((void**)&c->mx_part, srukf_mixed_part_bytes(ntasks)));
+        HIPCHK(c, srukf_dmalloc(&c->mx_tasks, sizeof(short) * tk.size()));
+        HIPCHK(c, srukf_dmalloc(&c->mx_tiles, sizeof(int) * tl.size()));
         HIPCHK(c, hipMemcpy(c->mx_tasks, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->mx_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
         c->mx_ntasks = ntasks; c->mx_ntiles = ntiles;
@@ -976,7 +1016,7 @@ int srukf_set_new_landmarks(srukf_ctx* c, int K_new)
         for (int e = 0; e < 3; e++) perm[dimOld - 4 + 6 * id + 3 + e] = dimOld + 3 * id + e;
     }
     for (int r2 = 0; r2 < n; r2++) iperm[perm[r2]] = r2;
-    if (!c->perm) { HIPCHK(c, hipMalloc((void**)&c->perm, sizeof(int) * c->d.np)); HIPCHK(c, hipMalloc((void**)&c->iperm, sizeof(int) * c->d.np)); }
+    if (!c->perm) { HIPCHK(c, srukf_dmalloc((void**)&c->perm, sizeof(int) * c->d.np)); HIPCHK(c, srukf_dmalloc((void**)&c->iperm, sizeof(int) * c->d.np)); }
     HIPCHK(c, hipMemcpy(c->perm, perm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->iperm, iperm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     return SRUKF_OK;
@@ -989,14 +1029,14 @@ static int ensure_appearance(srukf_ctx* c)
     if (c->app_patch) return SRUKF_OK;
     const size_t N = c->d.N > 0 ? c->d.N : 1;
     const size_t img = (size_t)c->p.image_w * c->p.image_h;
-    HIPCHK(c, hipMalloc((void**)&c->app_patch, N * srukf_app_patch_stride()));
-    HIPCHK(c, hipMalloc((void**)&c->app_tmpl, N * srukf_app_tmpl_stride()));
-    HIPCHK(c, hipMalloc((void**)&c->d_image, img));
-    HIPCHK(c, hipMalloc((void**)&c->appR, sizeof(double) * 9 * N));
-    HIPCHK(c, hipMalloc((void**)&c->appT, sizeof(double) * 3 * N));
-    HIPCHK(c, hipMalloc((void**)&c->appPx, sizeof(double) * 2 * N));
-    HIPCHK(c, hipMalloc((void**)&c->corr, sizeof(double) * N));
-    HIPCHK(c, hipMalloc((void**)&c->has_app, sizeof(int) * N));
+    HIPCHK(c, srukf_dmalloc((void**)&c->app_patch, N * srukf_app_patch_stride()));
+    HIPCHK(c, srukf_dmalloc((void**)&c->app_tmpl, N * srukf_app_tmpl_stride()));
+    HIPCHK(c, srukf_dmalloc((void**)&c->d_image, img));
+    HIPCHK(c, srukf_dmalloc((void**)&c->appR, sizeof(double) * 9 * N));
+    HIPCHK(c, srukf_dmalloc((void**)&c->appT, sizeof(double) * 3 * N));
+    HIPCHK(c, srukf_dmalloc((void**)&c->appPx, sizeof(double) * 2 * N));
+    HIPCHK(c, srukf_dmalloc((void**)&c->corr, sizeof(double) * N));
+    HIPCHK(c, srukf_dmalloc((void**)&c->has_app, sizeof(int) * N));
     HIPCHK(c, hipMemsetAsync(c->app_patch, 0, N * srukf_app_patch_stride(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->app_tmpl, 0, N * srukf_app_tmpl_stride(), c->stream));
     HIPCHK(c, hipMemsetAsync(c->has_app, 0, sizeof(int) * N, c->stream));
@@ -1097,10 +1137,10 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
         }
     }
     double *d_uv = nullptr, *d_ang = nullptr, *d_A = nullptr, *d_mu = nullptr; int* d_perm = nullptr;
-    auto cleanup = [&]() { for (void* b : { (void*)d_uv, (void*)d_ang, (void*)d_A, (void*)d_mu, (void*)d_perm }) if (b) hipFree(b); };
-    if (hipMalloc((void**)&d_uv, sizeof(double) * 2 * K) != hipSuccess || hipMalloc((void**)&d_ang, sizeof(double) * (size_t)L * 3 * K) != hipSuccess ||
-        hipMalloc((void**)&d_A, sizeof(double) * (size_t)rows_p * ldn) != hipSuccess || hipMalloc((void**)&d_mu, sizeof(double) * 3 * K) != hipSuccess ||
-        hipMalloc((void**)&d_perm, sizeof(int) * dimn) != hipSuccess) {
+    auto cleanup = [&]() { for (void* b : { (void*)d_uv, (void*)d_ang, (void*)d_A, (void*)d_mu, (void*)d_perm }) if (b) srukf_dfree(b); };
+    if (srukf_dmalloc((void**)&d_uv, sizeof(double) * 2 * K) != hipSuccess || srukf_dmalloc((void**)&d_ang, sizeof(double) * (size_t)L * 3 * K) != hipSuccess ||
+        srukf_dmalloc((void**)&d_A, sizeof(double) * (size_t)rows_p * ldn) != hipSuccess || srukf_dmalloc((void**)&d_mu, sizeof(double) * 3 * K) != hipSuccess ||
+        srukf_dmalloc((void**)&d_perm, sizeof(int) * dimn) != hipSuccess) {
         cleanup(); srukf_destroy(c2); c->err = "add_landmarks: out of device memory"; return SRUKF_ERR_NOMEM;
     }
     hipMemcpyAsync(d_uv, uv, sizeof(double) * 2 * K, hipMemcpyHostToDevice, c->stream);
@@ -1170,7 +1210,7 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     std::vector<int> map(nn);
     for (int a = 0; a < nn; a++) map[a] = a < 6 * id ? a : a + 6;
     int* d_map = nullptr;
-    if (hipMalloc((void**)&d_map, sizeof(int) * nn) != hipSuccess) { srukf_destroy(c2); c->err = "delete_landmark: out of device memory"; return SRUKF_ERR_NOMEM; }
+    if (srukf_dmalloc((void**)&d_map, sizeof(int) * nn) != hipSuccess) { srukf_destroy(c2); c->err = "delete_landmark: out of device memory"; return SRUKF_ERR_NOMEM; }
     hipMemcpy(d_map, map.data(), sizeof(int) * nn, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
     srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X);   // P = S^T S
@@ -1184,11 +1224,11 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
         run_gmw(c2, c2->Gbak, c2->S, slow != 0);
         if (slow) break;
         rc = read_fs(c2);
-        if (rc) { c->err = c2->err; hipFree(d_map); srukf_destroy(c2); return rc; }
+        if (rc) { c->err = c2->err; srukf_dfree(d_map); srukf_destroy(c2); return rc; }
         if (c2->hfs->clamp_rows == 0) break;
     }
     hipError_t e = hipStreamSynchronize(c->stream);
-    hipFree(d_map);
+    srukf_dfree(d_map);
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("delete_landmark: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
     // m_nFilters-- when one of the landmarks added last is the one that goes (SLAM.cpp:2468-2492)
     const int k_new = c->K_new > 0 ? (id >= N - c->K_new ? c->K_new - 1 : c->K_new) : 0;
@@ -1209,14 +1249,15 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
     if (!c || F < 1 || !odo || !z || !matched) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->d.N;
-    if (c->odo_seq) { hipFree(c->odo_seq); hipFree(c->z_seq); hipFree(c->m_seq); c->odo_seq = nullptr; c->z_seq = nullptr; c->m_seq = nullptr; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));             // frames in flight may still read the staged inputs
+    if (c->odo_seq) { srukf_dfree(c->odo_seq); srukf_dfree(c->z_seq); srukf_dfree(c->m_seq); c->odo_seq = nullptr; c->z_seq = nullptr; c->m_seq = nullptr; }
     if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     if (c->graph8_exec) { hipGraphExecDestroy(c->graph8_exec); c->graph8_exec = nullptr; }
     if (c->graph8) { hipGraphDestroy(c->graph8); c->graph8 = nullptr; }
-    HIPCHK(c, hipMalloc((void**)&c->odo_seq, sizeof(double) * 3 * (F + 1)));
-    HIPCHK(c, hipMalloc((void**)&c->z_seq, sizeof(double) * (size_t)F * 2 * N));
-    HIPCHK(c, hipMalloc((void**)&c->m_seq, sizeof(int) * (size_t)F * N));
+    HIPCHK(c, srukf_dmalloc((void**)&c->odo_seq, sizeof(double) * 3 * (F + 1)));
+    HIPCHK(c, srukf_dmalloc((void**)&c->z_seq, sizeof(double) * (size_t)F * 2 * N));
+    HIPCHK(c, srukf_dmalloc((void**)&c->m_seq, sizeof(int) * (size_t)F * N));
     HIPCHK(c, hipMemcpy(c->odo_seq, odo, sizeof(double) * 3 * (F + 1), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->z_seq, z, sizeof(double) * (size_t)F * 2 * N, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->m_seq, matched, sizeof(int) * (size_t)F * N, hipMemcpyHostToDevice));
@@ -1307,12 +1348,12 @@ int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_
     HIPCHK(c, hipSetDevice(c->device));
     const size_t np = c->d.np;
     if (!c->ckS) {
-        if (hipMalloc((void**)&c->ckS, sizeof(double) * np * np) != hipSuccess || hipMalloc((void**)&c->ckX, sizeof(double) * np) != hipSuccess) {
+        if (srukf_dmalloc((void**)&c->ckS, sizeof(double) * np * np) != hipSuccess || srukf_dmalloc((void**)&c->ckX, sizeof(double) * np) != hipSuccess) {
             c->err = "run_frames: out of device memory (checkpoint)"; return SRUKF_ERR_NOMEM;
         }
     }
     double* dt = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dt, sizeof(double) * 8 * (size_t)count));
+    HIPCHK(c, srukf_dmalloc((void**)&dt, sizeof(double) * 8 * (size_t)count));
     auto checkpoint = [&](bool save) {
         hipMemcpyAsync(save ? c->ckS : c->S, save ? c->S : c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync(save ? c->ckX : c->X, save ? c->X : c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
@@ -1338,7 +1379,7 @@ int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_
         done = fc - first + 1;
     }
     if (traj_host && rc == SRUKF_OK) hipMemcpy(traj_host, dt, sizeof(double) * 8 * (size_t)count, hipMemcpyDeviceToHost);
-    hipFree(dt);
+    srukf_dfree(dt);
     return rc;
 }
 
@@ -1434,11 +1475,11 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
     struct Res {
         double *dG = nullptr, *dS = nullptr, *dD = nullptr, *dWf = nullptr; unsigned long long* dTh = nullptr; FrameScalars* dFs = nullptr;
         void* pan[2] = { nullptr, nullptr }; GmwPlan gp;
-        ~Res() { for (void* b : { (void*)dG, (void*)dS, (void*)dD, (void*)dWf, (void*)dTh, (void*)dFs, pan[0], pan[1] }) if (b) hipFree(b); gmw_plan_destroy(gp); }
+        ~Res() { for (void* b : { (void*)dG, (void*)dS, (void*)dD, (void*)dWf, (void*)dTh, (void*)dFs, pan[0], pan[1] }) if (b) srukf_dfree(b); gmw_plan_destroy(gp); }
     } r;
 #define GH(call) do { if ((call) != hipSuccess) return SRUKF_ERR_HIP; } while (0)
-    GH(hipMalloc((void**)&r.dG, bytes)); GH(hipMalloc((void**)&r.dS, bytes)); GH(hipMalloc((void**)&r.dWf, bytes));
-    GH(hipMalloc((void**)&r.dD, sizeof(double) * np)); GH(hipMalloc((void**)&r.dTh, sizeof(unsigned long long) * np)); GH(hipMalloc((void**)&r.dFs, sizeof(FrameScalars)));
+    GH(srukf_dmalloc((void**)&r.dG, bytes)); GH(srukf_dmalloc((void**)&r.dS, bytes)); GH(srukf_dmalloc((void**)&r.dWf, bytes));
+    GH(srukf_dmalloc((void**)&r.dD, sizeof(double) * np)); GH(srukf_dmalloc((void**)&r.dTh, sizeof(unsigned long long) * np)); GH(srukf_dmalloc((void**)&r.dFs, sizeof(FrameScalars)));
     GH(hipMemcpy(r.dG, hG.data(), bytes, hipMemcpyHostToDevice));
     GH(hipMemset(r.dS, 0, bytes)); GH(hipMemset(r.dWf, 0, bytes)); GH(hipMemset(r.dTh, 0, sizeof(unsigned long long) * np));
     GH(hipMemset(r.dFs, 0, sizeof(FrameScalars))); GH(hipMemset(r.dD, 0, sizeof(double) * np));
@@ -1451,7 +1492,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
         if (gmw_persist_mode() && r.gp.workers >= 0) {
             srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0);
         } else {
-            GH(hipMalloc(&r.pan[0], srukf_gmw_panel_bytes())); GH(hipMalloc(&r.pan[1], srukf_gmw_panel_bytes()));
+            GH(srukf_dmalloc(&r.pan[0], srukf_gmw_panel_bytes())); GH(srukf_dmalloc(&r.pan[1], srukf_gmw_panel_bytes()));
             GH(hipMemset(r.pan[0], 0, srukf_gmw_panel_bytes())); GH(hipMemset(r.pan[1], 0, srukf_gmw_panel_bytes()));
             int pb = 0;
             for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
@@ -1488,14 +1529,14 @@ int srukf_project_host(int device, const srukf_params* p, int count, const doubl
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SRUKF_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return SRUKF_ERR_NO_DEVICE;
     double *df, *dp, *ds, *de, *dout;
-    hipMalloc((void**)&df, sizeof(double) * 6 * count); hipMalloc((void**)&dp, sizeof(double) * 3 * count);
-    hipMalloc((void**)&ds, sizeof(double) * count); hipMalloc((void**)&de, sizeof(double) * 2 * count); hipMalloc((void**)&dout, sizeof(double) * 2 * count);
+    srukf_dmalloc((void**)&df, sizeof(double) * 6 * count); srukf_dmalloc((void**)&dp, sizeof(double) * 3 * count);
+    srukf_dmalloc((void**)&ds, sizeof(double) * count); srukf_dmalloc((void**)&de, sizeof(double) * 2 * count); srukf_dmalloc((void**)&dout, sizeof(double) * 2 * count);
     hipMemcpy(df, feat6, sizeof(double) * 6 * count, hipMemcpyHostToDevice); hipMemcpy(dp, pos3, sizeof(double) * 3 * count, hipMemcpyHostToDevice);
     hipMemcpy(ds, psi, sizeof(double) * count, hipMemcpyHostToDevice); hipMemcpy(de, err2, sizeof(double) * 2 * count, hipMemcpyHostToDevice);
     srukf_launch_project_points(nullptr, *p, count, df, dp, ds, de, dout);
     hipError_t e = hipDeviceSynchronize();
     hipMemcpy(uv_out, dout, sizeof(double) * 2 * count, hipMemcpyDeviceToHost);
-    hipFree(df); hipFree(dp); hipFree(ds); hipFree(de); hipFree(dout);
+    srukf_dfree(df); srukf_dfree(dp); srukf_dfree(ds); srukf_dfree(de); srukf_dfree(dout);
     return e == hipSuccess ? SRUKF_OK : SRUKF_ERR_HIP;
 }
 
