@@ -337,9 +337,12 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
 // Worker side of one update step of an owned tile; returns false when a wait expired.
 struct GmwOwned { int I, J, nsteps; bool computed; };
 struct KDimsLite { int n, ld; };
+// memtile: the tile lives in G between the steps (k_gmw_persist<true>: a worker owns more tiles than accumulator sets would
+// fit): it is read at the start of every step and written back at the end — by the same lanes, with agent-scope accesses, so
+// every lane sees its own earlier stores.
 __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, const GmwOwned& tl, d4 (&acc)[2][2], double* __restrict__ G,
                                                GmwPanel64* pans, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
-                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid)
+                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid, bool memtile = false)
 {
     unsigned long long* ver = gmw_sync_ver(sy);
     // the two row-panel tiles (k, I), (k, J) are finished (k updates each) — both flags, and the panel flag, in one round
@@ -366,7 +369,7 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
     const bool behind = *okp == 2;
     const bool last = k == tl.nsteps - 1;
     __syncthreads();                                           // *okp is rewritten by the panel waits below
-    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, k == 0 && !tl.computed, last,
+    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, memtile || (k == 0 && !tl.computed), memtile || last,
         [&] {
             if (!behind) { if (wv0) *okp = gmw_wait_ge(&sy->half_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort); }
             __syncthreads();
@@ -381,8 +384,15 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
         behind);
 }
 
-// k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any).
+// k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any), both kept in accumulator
+// registers from their first update to their last.
+// k_gmw_persist<MEM = true>: matrices with more tiles than 2 x workers (N >= 340: 1 081 tiles at N = 500).  Worker w owns
+// tiles[w - 1 + m workers], m = 0 .. GMW_OWNED_MEM - 1; every tile lives in G and passes through one accumulator set per step
+// (read, update, write back: ~2 us more per step than a register-resident tile, against a dispatch gap, a cold L2 and the pivot's
+// reload per panel in the one-launch-per-panel form).  Tiles are listed in the order they retire, so within a step a worker
+// takes the tile of the smallest block row first: the next step's row-panel tiles are the ones everybody waits for.
 #define GMW_OWNED_MAX 2
+#define GMW_OWNED_MEM 6
 struct GmwTile { short I, J, nsteps, pad; };
 // S0 != null: the tiles of block rows I >= GMW_HEAD_ROWS are not read from G but COMPUTED by their owners,
 //   G[r][c] = sum_k S0[k][r] S0[k][c] - sum_{u0 <= m < u1} Ut0[m][r] Ut0[m][c]      (what k_syrk does, SLAM.cpp:2118-2120, 2149),
@@ -416,6 +426,7 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
     }
 }
 
+template <bool MEM>
 __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
                                                      GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
@@ -435,6 +446,22 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
     } else {
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
         const int workers = gridDim.x - 1, w = blockIdx.x - 1;
+        bool good = true;
+        if constexpr (MEM) {
+            int kmax = 0;
+            for (int m = 0; m < GMW_OWNED_MEM; m++) if (w + m * workers < ntiles) kmax = max(kmax, (int)tiles[w + m * workers].nsteps);
+            for (int k = 0; k < kmax && good; k++)
+                for (int m = 0; m < GMW_OWNED_MEM && good; m++) {
+                    const int ti = w + m * workers;
+                    if (ti >= ntiles) break;
+                    const GmwTile t = tiles[ti];
+                    if (k >= t.nsteps) continue;
+                    const GmwOwned tm = { t.I, t.J, t.nsteps, false };
+                    d4 accm[2][2];
+                    zero_acc(accm);
+                    good = gmw_owner_step(n, ld, T, k, tm, accm, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, true);
+                }
+        } else {
         GmwOwned ta = { 0, 0, 0, false }, tb = { 0, 0, 0, false };
         if (w < ntiles) { const GmwTile t = tiles[w]; ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; }
         if (w + workers < ntiles) { const GmwTile t = tiles[w + workers]; tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; }
@@ -446,10 +473,10 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
             if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid); tb.computed = true; }
         }
         const int kmax = max(ta.nsteps, tb.nsteps);
-        bool good = true;
         for (int k = 0; k < kmax && good; k++) {
             if (k < ta.nsteps) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
             if (good && k < tb.nsteps) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
+        }
         }
         if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -491,7 +518,7 @@ int srukf_gmw_persist_workers(int T, int max_workers)
     const int nt = srukf_gmw_build_tiles(T, nullptr);
     if (nt == 0) return 0;
     if (nt <= max_workers) return nt;
-    if (nt <= GMW_OWNED_MAX * max_workers) return max_workers;
+    if (nt <= GMW_OWNED_MEM * max_workers) return max_workers;   // > GMW_OWNED_MAX tiles per worker: the memory-tile form
     return -1;
 }
 // S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G)
@@ -500,8 +527,12 @@ void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double*
                               const double* S0, const double* Ut0, int u0, int u1)
 {
     const int T = ld / 64;
-    hipLaunchKernelGGL(k_gmw_persist, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
-                       (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
+    if (workers > 0 && ntiles > GMW_OWNED_MAX * workers)
+        hipLaunchKernelGGL(k_gmw_persist<true>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
+    else
+        hipLaunchKernelGGL(k_gmw_persist<false>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 }  // extern "C"

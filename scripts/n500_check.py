@@ -1,12 +1,16 @@
-import sys, time; sys.path.insert(0, '/root/repo')
-import torch, numpy as np
-import __graft_entry__ as ge
+"""frames/s at large N (GPU box): python scripts/n500_check.py [N ...]"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, __graft_entry__ as ge
 pkg = ge.load_package(); synth, srukf = pkg.synth, pkg.srukf
-for N, F in ((50, 40), (500, 6)):
-    p = synth.scene_params()
-    t = time.time(); sc = synth.make_scene(N, F, seed=0, p=p); print('scene', N, time.time() - t)
-    f = srukf.Filter(N, p); f.set_state(sc['X0'], sc['S0']); f.stage_sequence(sc['odo'], sc['z'], sc['matched'])
-    f.run_frames(0, 2)
-    t = time.time(); traj = f.run_frames(2, F - 2); dt = time.time() - t
-    print(f'N={N}: {(F-2)/dt:.1f} fps; pose err vs truth {np.abs(traj[:, :2] - sc["odo"][3:F+1, :2]).max():.2e}')
-    X, S = f.get_state(); print('  finite', np.isfinite(X).all() and np.isfinite(S).all(), 'min diag', np.diag(S).min())
+for N in [int(a) for a in sys.argv[1:]] or [500]:
+    p = synth.scene_params(); F = 24
+    sc = synth.make_scene(N, F, seed=0, p=p)
+    out = {}
+    for excl in (True, False):
+        f = srukf.Filter(N, p); f.set_exclusive(excl); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        f.run_frames(0, 4); f.set_state(sc["X0"], sc["S0"])
+        t = time.perf_counter(); tr = f.run_frames(0, F); dt = time.perf_counter() - t
+        out[excl] = (F / dt, tr)
+    d = np.abs(out[True][1] - out[False][1]).max()
+    print(f"N={N}: persistent {out[True][0]:.1f} frames/s, per-panel {out[False][0]:.1f} frames/s, max traj diff {d:.2e}, err vs truth {np.abs(out[True][1][:, :2] - sc['odo'][1:F+1, :2]).max():.2e}", flush=True)
