@@ -9,6 +9,17 @@ import json
 import shutil
 import sys
 
+import re
+
+
+def kname(raw):
+    """Kernel_Name as rocprofv3 prints it -> bare kernel name: no return type, template or argument list."""
+    k = raw.split("(")[0].strip()
+    if k.startswith("void "):
+        k = k[5:]
+    return re.sub(r"<.*>$", "", k)
+
+
 tag, stats, fetch, write = sys.argv[1:5]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
@@ -16,7 +27,7 @@ shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 def agg(path):
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = kname(r["Kernel_Name"])
         d[k][0] += 1
         d[k][1] += float(r["Counter_Value"])
     return d
@@ -42,13 +53,13 @@ print(json.dumps(out["kernels"], indent=1))
 if len(sys.argv) > 5:
     per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for r in csv.DictReader(open(sys.argv[5])):
-        k = r["Kernel_Name"].split("(")[0]
+        k = kname(r["Kernel_Name"])
         c = per[k][r["Counter_Name"]]
         c[0] += 1
         c[1] += float(r["Counter_Value"])
     dur = {}
     for r in csv.DictReader(open(stats)):
-        dur[r["Name"].split("(")[0]] = float(r["AverageNs"])
+        dur[kname(r["Name"])] = float(r["AverageNs"])
     res = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE "
                      "(own pass, eager launches), bench.py N=200; per launch averages",
            "formulas": {"mfma_util_pct": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024) * 100", "mfma_gflop": "SQ_INSTS_VALU_MFMA_MOPS_F64 * 512 / 1e9",
