@@ -15,7 +15,7 @@
 
 extern "C" {
 void srukf_launch_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, FrameScalars*, const double*, const double*);
-void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const double*, const double*, const double*, double*, double*);
+void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const double*, const double*, const double*, double*, double*, const FrameScalars*);
 void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
@@ -26,7 +26,7 @@ void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int, KWeights, MeasArgs);
 void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*);
-void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*);
+void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const FrameScalars*);
 int srukf_gmw_panel_bytes(void);
 int srukf_gmw_sync_bytes(int T);
 int srukf_gmw_build_tiles(int T, short* out);
@@ -97,7 +97,7 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
     fs->frame = frame;
     fs->stat_count = 0;
     fs->traj_base = nullptr;
-    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; }
+    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; }
 }
 __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base = traj_base; }
 
@@ -365,7 +365,7 @@ static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
     const KDims& d = c->d;
     {
         ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N));
-        srukf_launch_project(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Z, c->DZ);
+        srukf_launch_project(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Z, c->DZ, c->fs);
     }
     if (!fused_stats) {
         ProfScope ps(c, KC_STATS, 30.0 * d.L * d.N, 8.0 * 3.0 * d.L * 2 * d.N);
@@ -434,7 +434,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             int pb = 0;
             for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1) {
                 ProfScope ps(c, KC_GMW_TRAIL, panel_flop(j0), panel_byte(j0));
-                srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb ^ 1], c->pan[pb], c->D, c->S);
+                srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, c->G, c->pan[pb ^ 1], c->pan[pb], c->D, c->S, c->fs);
             }
         }
         quantize_state(c);
@@ -462,7 +462,7 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout)
     }
     int pb = 0;
     for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
-        srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, Gbuf, c->pan[pb ^ 1], c->pan[pb], c->D, Sout);
+        srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, Gbuf, c->pan[pb ^ 1], c->pan[pb], c->D, Sout, c->fs);
 }
 static void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow)
 {
@@ -1496,7 +1496,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
             GH(hipMemset(r.pan[0], 0, srukf_gmw_panel_bytes())); GH(hipMemset(r.pan[1], 0, srukf_gmw_panel_bytes()));
             int pb = 0;
             for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
-                srukf_launch_gmw_step64(st, n, np, j0, epsilon, r.dG, r.pan[pb ^ 1], r.pan[pb], r.dD, r.dS);
+                srukf_launch_gmw_step64(st, n, np, j0, epsilon, r.dG, r.pan[pb ^ 1], r.pan[pb], r.dD, r.dS, nullptr);
         }
         GH(hipDeviceSynchronize());
         srukf_launch_gmw_check(st, n, np, r.dD, r.dS, r.dFs, nullptr, 0, nullptr);

@@ -45,6 +45,9 @@ struct FrameScalars {
     int gmw_aborts;            // persistent GMW launches abandoned on an expired wait (their frames are flagged like clamp rows)
     int clamp_frame;           // staged replay: index of the FIRST frame whose refactorisation was flagged (0x7fffffff: none).  Set by
                                // the k_motion of the following frame (or by the host at the end of a run): frames before it are valid
+    int frozen;                // staged replay: a frame was flagged -> k_motion and the persistent factorisation of the later frames of the run
+                               // return at once (three quarters of a frame's time; the other kernels would pay a memory round trip per launch
+                               // for the test); cleared with the clamp counters (k_set_frame) and by the step-wise API
 };
 
 __device__ __forceinline__ double wave_sum(double v)

@@ -375,7 +375,7 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
 // grid = (T, T), T = (ld - base)/64; blocks strictly below the diagonal exit.
 __global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int first, double* __restrict__ G,
                                                     const GmwPanel64* __restrict__ cur, double* __restrict__ Sout, GmwPanel64* __restrict__ nxt,
-                                                    double* __restrict__ Dall, double eps)
+                                                    double* __restrict__ Dall, double eps, const FrameScalars* __restrict__ fs)
 {
     if (blockIdx.x < blockIdx.y) return;
     STAMP(0);
@@ -518,12 +518,13 @@ void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* U
     hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X);
 }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
-void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout)
+void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout,
+                             const FrameScalars* fs)
 {
     const int rem = ld - j0 - 64;
     if (rem <= 0) return;
     const int T = (j0 < 0) ? 1 : rem / 64;
-    hipLaunchKernelGGL(k_gmw_step64, dim3(T, T), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, G, (const GmwPanel64*)cur, Sout, (GmwPanel64*)nxt, D, eps);
+    hipLaunchKernelGGL(k_gmw_step64, dim3(T, T), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, G, (const GmwPanel64*)cur, Sout, (GmwPanel64*)nxt, D, eps, fs);
 }
 int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel64); }
 void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj, double* Scopy)

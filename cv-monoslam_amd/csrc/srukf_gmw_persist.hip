@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
     __shared__ double keepreg[1024 + 64 + 64];
     __shared__ int ok, halfcnt, stageok[2];
     const int tid = threadIdx.x;
+    if (fs->frozen) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
     const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
     if (blockIdx.x == 0) {
         gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid);

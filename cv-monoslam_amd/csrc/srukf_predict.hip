@@ -32,6 +32,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
     __shared__ double part2[14][33];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n = d.n, Na = d.Na, L = d.L, ld = d.np;
+    if (!odo_pair && fs->frozen) return;                       // staged replay behind a flagged frame: nothing to compute from
 
     STAMP(0);
     // the S rows of this thread's directions are requested before the control block: their round trip then overlaps
@@ -65,7 +66,11 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
         for (int q = 0; q < 3; q++) { fs->Ut[q] = sh[q]; fs->Mt[q] = sh[3 + q]; }
         for (int q = 0; q < 4; q++) fs->Xr0[q] = sh[6 + q];
         // staged replay: the previous frame's refactorisation was flagged (theta clamp / abandoned launch) -> remember which
-        if (!odo_pair && fs->clamp_rows > 0 && fs->clamp_frame == 0x7fffffff) fs->clamp_frame = fs->frame - 1;
+        if (!odo_pair && fs->clamp_rows > 0) {
+            if (fs->clamp_frame == 0x7fffffff) fs->clamp_frame = fs->frame - 1;
+            fs->frozen = 1;                                    // the rest of this frame and all later frames of the run return at once
+        }
+        if (odo_pair) fs->frozen = 0;                          // step-wise API: the host has taken over
     }
     __syncthreads();
     const double rot1 = sh[0], trans = sh[1], rot2 = sh[2];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
 __global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_params p,
                                                  const double* __restrict__ X, const double* __restrict__ S,
                                                  const double* __restrict__ sigR,
-                                                 double* __restrict__ Z, double* __restrict__ DZ)
+                                                 double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs)
 {
     // flat (direction, landmark) index: no idle lanes when N is not a multiple of the wave size (N = 200: 78 % -> 100 %)
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -512,10 +517,10 @@ void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, do
     hipLaunchKernelGGL(k_motion, dim3(1), dim3(512), 0, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair);
 }
 void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
-                          double* Z, double* DZ)
+                          double* Z, double* DZ, const FrameScalars* fs)
 {
     dim3 grid(((d.Na + 1) * d.N + 255) / 256);
-    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, d, w, p, X, S, sigR, Z, DZ);
+    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, d, w, p, X, S, sigR, Z, DZ, fs);
 }
 void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* X, const double* sigR, const double* Z,
                              double* part, double* h, double* Si, int* vis, double* PxyR)

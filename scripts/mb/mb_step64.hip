@@ -17,14 +17,14 @@ int main()
         hipMemcpy(G, h.data(), sizeof(double) * ld * ld, hipMemcpyHostToDevice);
         hipEventRecord(a, st);
         int pb = 0, nl = 0;
-        for (int j0 = -64; j0 + 64 < ld; j0 += 64, pb ^= 1, nl++) srukf_launch_gmw_step64(st, n, ld, j0, 1e-13, G, pan[pb ^ 1], pan[pb], D, S);
+        for (int j0 = -64; j0 + 64 < ld; j0 += 64, pb ^= 1, nl++) srukf_launch_gmw_step64(st, n, ld, j0, 1e-13, G, pan[pb ^ 1], pan[pb], D, S, nullptr);
         hipEventRecord(b, st); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         printf("whole factorisation: %.1f us (%d launches)\n", ms * 1000, nl);
     }
     hipMemcpy(G, h.data(), sizeof(double) * ld * ld, hipMemcpyHostToDevice);
     int pb = 0;
-    for (int j0 = -64; j0 <= 512; j0 += 64, pb ^= 1) srukf_launch_gmw_step64(st, n, ld, j0, 1e-13, G, pan[pb ^ 1], pan[pb], D, S);
+    for (int j0 = -64; j0 <= 512; j0 += 64, pb ^= 1) srukf_launch_gmw_step64(st, n, ld, j0, 1e-13, G, pan[pb ^ 1], pan[pb], D, S, nullptr);
     hipStreamSynchronize(st);
     unsigned long long hs[16];
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(srukf_stamps), sizeof hs);
