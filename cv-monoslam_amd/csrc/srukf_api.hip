@@ -29,9 +29,12 @@ void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, in
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const FrameScalars*);
 int srukf_gmw_panel_bytes(void);
 int srukf_gmw_sync_bytes(int T);
-int srukf_gmw_build_tiles(int T, short* out);
-int srukf_gmw_persist_workers(int T, int max_workers);
-void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int);
+int srukf_gmw_build_tiles(int T, int Tp, short* out);
+int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
+void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int);
+void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
+void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*);
 int srukf_gmw_head_rows(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
@@ -162,7 +165,7 @@ static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_st
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
-struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, workers = -1; };
+struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1; };
 static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 {
     if (g.pans) srukf_dfree_on(g.pans, st);
@@ -171,15 +174,16 @@ static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
     g = GmwPlan();
 }
 // workers = -1 afterwards: the matrix has more tiles than resident workgroups can own (the per-panel launches are used)
-static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st)
+static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0)
 {
     g.T = np / 64;
+    g.Tp = (Tp > 0 && Tp < g.T) ? Tp : g.T;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 2;
-    g.workers = srukf_gmw_persist_workers(g.T, cus - 1);        // one workgroup per CU (LDS), all of them resident
-    g.ntiles = srukf_gmw_build_tiles(g.T, nullptr);
+    g.workers = srukf_gmw_persist_workers(g.T, g.Tp, cus - 1);  // one workgroup per CU (LDS), all of them resident
+    g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
-    srukf_gmw_build_tiles(g.T, tk.data());
+    srukf_gmw_build_tiles(g.T, g.Tp, tk.data());
     const size_t sync_bytes = (size_t)srukf_gmw_sync_bytes(g.T);
     if (srukf_dmalloc_on(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
         srukf_dmalloc_on(&g.sync, sync_bytes, st) != hipSuccess ||
@@ -230,6 +234,11 @@ struct srukf_ctx {
     double* Sdis = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered), one launch per panel
     GmwPlan gplan;                         // persistent GMW launch: panel buffers, sync block, task list
+    // rank-aware refactorisation (srukf_rank.hip): red_r > 0 = the n - red_r structurally null directions are not pivoted
+    int red_r = 0, red_Tp = 0;
+    int *red_perm = nullptr, *red_iperm = nullptr;     // permuted position <-> state index, kept indices first
+    double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
+    GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
     int gmw_shared = 0;                    // 1: the GPU is shared with other filters — never use the persistent launch (it needs all its workgroups resident)
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
@@ -383,7 +392,7 @@ static int gmw_fused_mode()
     return mode;
 }
 static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && !c->gmw_shared && c->gplan.workers >= 0; }
-static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout);
+static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
 {
     const KDims& d = c->d;
@@ -397,7 +406,9 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     // scratch buffer Wf and k_gmw_check copies it into S.
     // Measured (frames/s, fused against not fused): N = 200 2 965 / 2 910, N = 100 5 247 / 5 262, N = 50 9 256 / 9 465,
     // N = 300 (two tiles per worker, both to be computed first) 1 544 / 1 663 — so only with one tile per worker and T >= 16.
-    const bool fused = !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
+    // rank-aware form (srukf_rank.hip): permute the null directions to the end, pivot only the leading red_Tp panels
+    const bool reduced = !slow && c->red_r > 0 && c->storage == SRUKF_STORAGE_F64;
+    const bool fused = !reduced && !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
                        c->gplan.ntiles <= c->gplan.workers && c->gplan.T >= 16 &&
                        !c->debug_starve && gmw_fused_mode();
     const double nn = n;
@@ -418,6 +429,24 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         c->dx_pending = false;
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
+    if (reduced) {
+        // Gp = Pi^T G Pi into Wf (+ its diagonal), factor the leading red_Tp panels of Gp with the factor rows going to G (scratch
+        // now), then back to state order with the theta check, the null-direction check and the frame tail in one kernel
+        {
+            ProfScope ps(c, KC_MISC, 0, 16.0 * nn * nn);
+            hipLaunchKernelGGL(k_sym_permute, dim3(np), dim3(256), 0, c->stream, n, np, c->G, np, c->Wf, c->red_perm);
+            srukf_launch_rank_diag(c->stream, n, np, c->G, c->red_perm, c->gdiag);
+        }
+        {
+            const double rr = 64.0 * c->red_Tp;
+            ProfScope ps(c, gmw_use_persist(c) && c->gplan_red.workers >= 0 ? KC_GMW_PERSIST : KC_GMW_TRAIL, rr * rr * rr / 3.0 + rr * rr * (nn - rr) + rr * (nn - rr) * (nn - rr) / 2.0,
+                         8.0 * (rr * nn));
+            launch_gmw_fast(c, c->Wf, c->G, true);
+        }
+        ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * nn * nn);
+        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S);
+        return;
+    }
     if (!slow) {
         // 64-row panels: j0 = -64 factors the first 64x64 region, then one launch per panel
         // per panel: trailing update 64*r2^2 (upper half, 2 flop) + three-stage slab recompute + next 64x64 diagonal region
@@ -428,7 +457,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             for (int j0 = -64; j0 + 64 < np; j0 += 64) { fl += panel_flop(j0); by += panel_byte(j0); }
             ProfScope ps(c, KC_GMW_PERSIST, fl + syrk_flop * (1.0 - head_frac), by + syrk_byte * (1.0 - head_frac));
             if (fused) srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->G, c->gplan.pans, c->D, c->Wf, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles,
-                                                c->gplan.workers, c->fs, c->S, c->Ut, ub, ue);
+                                                c->gplan.workers, c->fs, c->S, c->Ut, ub, ue, 0);
             else launch_gmw_fast(c, c->G, c->S);
         } else {
             int pb = 0;
@@ -450,18 +479,21 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
 }
 // Blocked fast path (or, slow = true, the exact column path) on an arbitrary matrix buffer: Gbuf (upper triangle,
 // destroyed) -> upper-triangular factor rows in Sout (whose lower triangle must already be zero).
-static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout)
+static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced)
 {
     const int np = c->d.np, n = c->d.n;
-    if (gmw_use_persist(c)) {
+    const GmwPlan& gp = reduced ? c->gplan_red : c->gplan;
+    const int Tp = reduced ? c->red_Tp : np / 64;
+    if (gmw_use_persist(c) && gp.workers >= 0) {
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
-        const int workers = c->debug_starve ? 0 : c->gplan.workers;
-        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, c->gplan.pans, c->D, Sout, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles, workers, c->fs, nullptr, nullptr, 0, 0);
+        const int workers = c->debug_starve ? 0 : gp.workers;
+        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp);
         return;
     }
+    // one launch per panel; rank-aware form: the step after the last pivoted panel still runs (it writes that panel's S rows)
     int pb = 0;
-    for (int j0 = -64; j0 + 64 < np; j0 += 64, pb ^= 1)
+    for (int j0 = -64; j0 + 64 < np && j0 + 64 <= 64 * Tp; j0 += 64, pb ^= 1)
         srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, Gbuf, c->pan[pb ^ 1], c->pan[pb], c->D, Sout, c->fs);
 }
 static void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow)
@@ -527,6 +559,47 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
         srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z);
         c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
+}
+
+// Which directions of the state are structurally null (srukf_rank.hip)?  Called whenever a state arrives from outside
+// (srukf_set_state*, map changes): row energies of S on the device, the lists on the host.  SRUKF_RANK_AWARE=0 switches it off.
+static void drop_graphs(srukf_ctx* c);
+#define SRUKF_NULL_ENERGY 1e-12
+static int update_null_set(srukf_ctx* c)
+{
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("SRUKF_RANK_AWARE"); enabled = (e && e[0] == '0') ? 0 : 1; }
+    const int n = c->d.n, np = c->d.np, T = np / 64;
+    const int was = c->red_r;
+    c->red_r = 0;
+    if (enabled && n >= 128) {
+        srukf_launch_row_energy(c->stream, n, np, c->S, c->D);
+        HIPCHK(c, hipMemcpyAsync(c->hstage, c->D, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<int> perm, drop;
+        for (int k = 0; k < n; k++) ((k < n - 4 && c->hstage[k] < SRUKF_NULL_ENERGY) ? drop : perm).push_back(k);
+        const int r = (int)perm.size(), Tp = (r + 63) / 64;
+        if (!drop.empty() && Tp < T) {                            // worth it only if at least one whole panel leaves the pivot chain
+            perm.insert(perm.end(), drop.begin(), drop.end());
+            for (int k = n; k < np; k++) perm.push_back(k);
+            std::vector<int> iperm(np);
+            for (int a = 0; a < np; a++) iperm[perm[a]] = a;
+            if (!c->red_perm) {
+                HIPCHK(c, srukf_dmalloc(&c->red_perm, sizeof(int) * np)); HIPCHK(c, srukf_dmalloc(&c->red_iperm, sizeof(int) * np));
+                HIPCHK(c, srukf_dmalloc(&c->gdiag, sizeof(double) * np));
+            }
+            HIPCHK(c, hipMemcpy(c->red_perm, perm.data(), sizeof(int) * np, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->red_iperm, iperm.data(), sizeof(int) * np, hipMemcpyHostToDevice));
+            if (c->gplan_red.Tp != Tp || !c->gplan_red.pans) {
+                gmw_plan_destroy(c->gplan_red, c->stream);
+                const int rc = gmw_plan_create(c->gplan_red, np, c->stream, Tp);
+                if (rc) { c->err = "rank-aware refactorisation: allocation failed"; return rc; }
+            }
+            c->red_r = r; c->red_Tp = Tp;
+        }
+    }
+    if (was || c->red_r) drop_graphs(c);                          // the captured frames contain one or the other launch sequence
+    return SRUKF_OK;
 }
 
 // ---- C-ABI --------------------------------------------------------------------------------------
@@ -642,9 +715,10 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
+    gmw_plan_destroy(c->gplan_red, c->stream);
     if (c->own_stream && c->stream) hipStreamSynchronize(c->stream);
     if (c->hstage) {
         // keep ONE pinned staging buffer for the next context (pinning 16 MB costs milliseconds; map changes rebuild contexts)
@@ -673,6 +747,7 @@ int srukf_reset(srukf_ctx* c)
     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase = 0; c->async_pending = false;
+    if (c->red_r) { c->red_r = 0; drop_graphs(c); }            // the state is the robot block only: nothing to reduce until a state arrives
     return SRUKF_OK;
 }
 
@@ -699,7 +774,7 @@ int srukf_set_state(srukf_ctx* c, const double* X, const double* S)
     quantize_state(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase = 0;
-    return SRUKF_OK;
+    return update_null_set(c);
 }
 
 int srukf_get_state(srukf_ctx* c, double* X, double* S)
@@ -733,7 +808,7 @@ int srukf_set_state_device(srukf_ctx* c, const double* dX, const double* dS, int
     quantize_state(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase = 0;
-    return SRUKF_OK;
+    return update_null_set(c);
 }
 
 int srukf_get_state_device(srukf_ctx* c, double* dX, double* dS, int S_ld)
@@ -1174,6 +1249,7 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     const int storage = c->storage;
     adopt_context(c, c2);
     rc = srukf_set_storage(c, storage); if (rc) return rc;
+    rc = update_null_set(c); if (rc) return rc;
     return srukf_set_new_landmarks(c, K);
 }
 
@@ -1241,6 +1317,7 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     const int storage = c->storage;
     adopt_context(c, c2);
     rc = srukf_set_storage(c, storage); if (rc) return rc;
+    rc = update_null_set(c); if (rc) return rc;
     return srukf_set_new_landmarks(c, k_new);
 }
 
@@ -1490,7 +1567,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
         // the plan knows how many workgroups THIS device can keep resident (CU count); workers < 0: per-panel launches
         if (gmw_persist_mode()) { const int rc = gmw_plan_create(r.gp, np, st); if (rc) return rc; }
         if (gmw_persist_mode() && r.gp.workers >= 0) {
-            srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0);
+            srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0, 0);
         } else {
             GH(srukf_dmalloc(&r.pan[0], srukf_gmw_panel_bytes())); GH(srukf_dmalloc(&r.pan[1], srukf_gmw_panel_bytes()));
             GH(hipMemset(r.pan[0], 0, srukf_gmw_panel_bytes())); GH(hipMemset(r.pan[1], 0, srukf_gmw_panel_bytes()));

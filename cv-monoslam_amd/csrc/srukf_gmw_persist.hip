@@ -89,7 +89,10 @@ __device__ __forceinline__ void gmw_stage_tile(double (*dst)[G64_LS], const doub
 // Pivot workgroup: panels p = 0 .. T-1.  Same phases as gmw_step64_block00 (A slab, B tile (0,0), factor 1, C, factor 2);
 // what differs is where the operands come from: the previous panel from LDS, G tiles through agent-scope loads after
 // their version flags, and the panel buffer is published for the workers.
-__device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
+// Tp <= T: number of 64-row panels that are actually pivoted.  Tp < T = rank-aware form: the matrix arrives permuted so that its
+// structurally null directions come last, only the leading Tp panels are factored, and the column blocks behind them are carried
+// along as ordinary off-diagonal tiles (row block Tp exists in the tile list so that somebody writes the last panel's S rows).
+__device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                   double* __restrict__ Dall, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
                                                   double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg, double* xreg, double* keepreg,
                                                   int* okp, int* halfcnt, int* stageok, int tid)
@@ -108,7 +111,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
     if (wv0) *okp = 1;
     if (wv3) gmw_stage_tile(Wc, G, ld, 0, 0, lane);            // region R_0 as k_syrk left it
     __syncthreads();
-    for (int p = 0; p < T; p++) {
+    for (int p = 0; p < Tp; p++) {
         const int j0 = 64 * (p - 1), base = 64 * p;
         const bool first = (p == 0);
         GmwPanel64* nxt = pans + p;
@@ -267,7 +270,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
             // panel have finished them (normally yes) and tells the others through LDS — saves every wave the ~1 us poll
             // round trip at the end of the iteration
             unsigned long long fa = 0, fb = 0;
-            if (p >= 1 && p + 1 < T) {
+            if (p >= 1 && p + 1 < Tp) {
                 fa = __hip_atomic_load(&ver[(size_t)p * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 fb = __hip_atomic_load(&ver[(size_t)(p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -309,7 +312,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
             gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32);
             if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
         }
-        if (p + 1 < T) {
+        if (p + 1 < Tp) {
             const bool tileA = wvu < 2;                        // waves 0, 1: tile (p, p+1) -> Lr;  waves 2, 3: tile (p+1, p+1) -> Wc
             const int tr = tileA ? p : p + 1, r0 = (wvu & 1) ? 0 : 32;
             if (wv1) GMW_TS(sy, p, 5);
@@ -326,6 +329,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, double e
                 for (int r = 0; r < 32; r++) dst[r0 + r][lane] = v[r];
             }
         }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last pivoted panel: nothing to stage, but its stores must have landed before panel_ready
         __syncthreads();                                       // closes the iteration: staged tiles visible, LDS arrays reusable
         if (wv3 && p + 1 < T) { gmw_set_panel_flag(sy->panel_ready, ebase + p + 1, lane); GMW_TS(sy, p + 64, 3); }
         if (wv0) GMW_TS(sy, p, 7);
@@ -427,7 +431,7 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
 }
 
 template <bool MEM>
-__global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, double* __restrict__ G, GmwPanel64* __restrict__ pans,
+__global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int Tp, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
                                                      GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
                                                      FrameScalars* __restrict__ fs,
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, doubl
     if (fs->frozen) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
     const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
     if (blockIdx.x == 0) {
-        gmw_pivot_persist(n, ld, T, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid);
+        gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid);
     } else {
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
         const int workers = gridDim.x - 1, w = blockIdx.x - 1;
@@ -501,12 +505,13 @@ int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + sizeof(unsigned
 // its owner applies (I off the diagonal; I - 1 on it: the pivot applies the last one itself), ordered by the step at
 // which it is finished, so that worker w and worker w + workers hold tiles that retire at different times.
 // Returns the number of tiles; out (4 shorts per tile) may be null.
-int srukf_gmw_build_tiles(int T, short* out)
+int srukf_gmw_build_tiles(int T, int Tp, short* out)
 {
     int cnt = 0;
-    for (int I = 1; I < T; I++)
+    const int Imax = (Tp < T) ? Tp : T - 1;                     // rank-aware form: row block Tp carries the last pivoted panel's S rows
+    for (int I = 1; I <= Imax; I++)
         for (int J = I; J < T; J++) {
-            const int ns = (I == J) ? I - 1 : I;
+            const int ns = (I == J && I < Tp) ? I - 1 : I;      // the pivot applies the last update of the diagonal tiles it factors
             if (ns < 1) continue;
             if (out) { out[4 * cnt] = (short)I; out[4 * cnt + 1] = (short)J; out[4 * cnt + 2] = (short)ns; out[4 * cnt + 3] = 0; }
             cnt++;
@@ -514,25 +519,27 @@ int srukf_gmw_build_tiles(int T, short* out)
     return cnt;
 }
 // workers the persistent launch needs for T block rows (each owns at most GMW_OWNED_MAX tiles); -1: too many tiles
-int srukf_gmw_persist_workers(int T, int max_workers)
+int srukf_gmw_persist_workers(int T, int Tp, int max_workers)
 {
-    const int nt = srukf_gmw_build_tiles(T, nullptr);
+    const int nt = srukf_gmw_build_tiles(T, Tp, nullptr);
     if (nt == 0) return 0;
     if (nt <= max_workers) return nt;
+    if (nt <= GMW_OWNED_MAX * max_workers) return max_workers;
     if (nt <= GMW_OWNED_MEM * max_workers) return max_workers;   // > GMW_OWNED_MAX tiles per worker: the memory-tile form
     return -1;
 }
 // S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G)
 void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
                               void* sync, const void* tiles, int ntiles, int workers, void* fs,
-                              const double* S0, const double* Ut0, int u0, int u1)
+                              const double* S0, const double* Ut0, int u0, int u1, int Tp)
 {
     const int T = ld / 64;
+    if (Tp <= 0 || Tp > T) Tp = T;
     if (workers > 0 && ntiles > GMW_OWNED_MAX * workers)
-        hipLaunchKernelGGL(k_gmw_persist<true>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
+        hipLaunchKernelGGL(k_gmw_persist<true>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
                            (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
     else
-        hipLaunchKernelGGL(k_gmw_persist<false>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, G, (GmwPanel64*)pans, Sout, D, eps,
+        hipLaunchKernelGGL(k_gmw_persist<false>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
                            (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }

@@ -1,0 +1,119 @@
+// srukf_rank.hip — rank-aware refactorisation: the structurally null pivots are not factored.
+//
+// The anchors (xi, yi, zi) of landmarks initialised in one batch are copies of ONE robot position (SLAM.cpp:1223, 1247):
+// identical random variables for the rest of the filter's life, since every Kalman update preserves the equality.  Of the
+// n = 6N + 4 pivots of G = S^T S - U U^T, 3 (K - 1) per batch of K landmarks are therefore null by construction; the
+// reference's modifiedCholeskyDecomposition meets them as c_jj = 0 (+ rounding) and ends at D_j = EPSILON (SLAM.cpp:2279-2285),
+// their multipliers L = C / D are rounding noise, and their rank-1 updates of the trailing matrix are of size
+// (1e-17)^2 / 1e-13.  They cost the dependent pivot chain exactly as much as any other pivot.
+//
+// Rows of S whose energy sum_i S[k][i]^2 is below SRUKF_NULL_ENERGY = 1e-12 are such directions (dropping the row changes no entry
+// of P = S^T S by more than 1e-12, Cauchy-Schwarz: inside the 1e-11 the parity tests hold P to).  The refactorisation then runs
+// on G permuted so that these indices come last, in the same relative order otherwise:
+//     Gp = Pi^T G Pi  ->  only the leading Tp = ceil(r / 64) panels are pivoted, all n columns are carried along
+//     (k_gmw_persist with Tp < T)  ->  k_rank_expand: kept rows go back to state order (an upper triangular row: what stood left
+//     of the diagonal in state order is the residual of a column that is a linear combination of earlier ones, i.e. zero),
+//     dropped rows become sqrt(EPSILON) e_k — what the reference's clamp leaves there.
+// The kept rows are, operation for operation, the rows the reference's state-order factorisation produces (the skipped pivots'
+// updates are the (1e-17)^2 / 1e-13 terms), so the sigma set of the next frame is the reference's.  k_rank_expand also verifies
+// the assumption for every dropped index: G_kk - sum_{a<r} Sp[a][k]^2 <= 1e-12, else the frame is flagged like a theta-clamp
+// frame and repeated on the exact column path.
+#include <hip/hip_runtime.h>
+#include "srukf_device.h"
+
+// e[k] = sum_i S[k][i]^2, one workgroup per row
+__global__ __launch_bounds__(256) void k_row_energy(int n, int ld, const double* __restrict__ S, double* __restrict__ e)
+{
+    __shared__ double red[16];
+    const int k = blockIdx.x;
+    double v[1] = { 0.0 };
+    for (int i = k + threadIdx.x; i < n; i += 256) { const double s = S[(size_t)k * ld + i]; v[0] += s * s; }
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) e[k] = v[0];
+}
+
+// gdiag[a] = G[perm[a]][perm[a]] (the diagonal is overwritten by the in-place factorisation)
+__global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* __restrict__ G, const int* __restrict__ perm, double* __restrict__ gdiag)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < n) { const int j = perm[a]; gdiag[a] = G[(size_t)j * ld + j]; }
+}
+
+// One workgroup per state row j (+ one for the frame tail).  Sp: factor rows in permuted order (row a < r valid for columns
+// b >= a), D: pivots in permuted order, perm[a] = state index at permuted position a, iperm = inverse.
+__global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
+                                                     const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
+                                                     FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S)
+{
+    __shared__ double red[16 * 3];
+    const int j = blockIdx.x;
+    if (j == n) {
+        // frame tail: RobotPath.txt row (SLAM.cpp:3549-3556) with P = S^T S restricted to the robot x / y block (2404): the
+        // dropped rows have no entry in the robot columns
+        const int bx = iperm[n - 4], by = iperm[n - 3];
+        double v[3] = { 0, 0, 0 };
+        for (int a = threadIdx.x; a < r; a += 256) {
+            const double p = (bx >= a) ? Sp[(size_t)a * ld + bx] : 0.0, q = (by >= a) ? Sp[(size_t)a * ld + by] : 0.0;
+            v[0] += p * p; v[1] += p * q; v[2] += q * q;
+        }
+        block_sum<3>(v, red);
+        if (threadIdx.x == 0 && do_traj) {
+            double* traj = fs->traj_base;
+            if (traj) {
+                double* t = traj + (size_t)8 * fs->frame;
+                for (int e = 0; e < 4; e++) t[e] = X[n - 4 + e];
+                t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
+            }
+            fs->frame += 1;
+        }
+        return;
+    }
+    const int a = iperm[j];
+    double* out = S + (size_t)j * ld;
+    if (a >= r) {
+        // dropped direction: what the clamp leaves, and the check that it really is null in this frame's G
+        for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == j) ? sqrt(eps) : 0.0;
+        double v[1] = { 0.0 };
+        for (int k = threadIdx.x; k < r; k += 256) { const double s = Sp[(size_t)k * ld + a]; v[0] += s * s; }
+        block_sum<1>(v, red);
+        if (threadIdx.x == 0 && gdiag[a] - v[0] > 1e-12) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, j); }
+        return;
+    }
+    const double* src = Sp + (size_t)a * ld;
+    double mx = 0.0;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        double v = 0.0;
+        if (c >= j && c < n) { v = src[iperm[c]]; if (c > j) mx = fmax(mx, fabs(v)); }
+        out[c] = v;
+    }
+    // theta clamp of the reference evaluated afterwards, as k_gmw_check does (SLAM.cpp:2204-2211, 2264-2285)
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        const double gamma = __longlong_as_double((long long)fs->gmax_bits);
+        const double xi = __longlong_as_double((long long)fs->ximax_bits);
+        const double nu = fmax(1.0, sqrt((double)n * n - 1.0));
+        const double beta2 = fmax(fmax(gamma, xi / nu), 1e-15);
+        const double dj = D[a];
+        const double th = mx * sqrt(dj);
+        if (th * th / beta2 > dj) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, j); }
+    }
+}
+
+extern "C" {
+void srukf_launch_row_energy(hipStream_t st, int n, int ld, const double* S, double* e)
+{
+    hipLaunchKernelGGL(k_row_energy, dim3(n), dim3(256), 0, st, n, ld, S, e);
+}
+void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, const int* perm, double* gdiag)
+{
+    hipLaunchKernelGGL(k_rank_diag, dim3((n + 255) / 256), dim3(256), 0, st, n, ld, G, perm, gdiag);
+}
+void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
+                              const double* gdiag, void* fs, const double* X, int do_traj, double* S)
+{
+    hipLaunchKernelGGL(k_rank_expand, dim3(n + 1), dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S);
+}
+}  // extern "C"
