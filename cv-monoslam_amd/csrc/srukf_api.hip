@@ -236,6 +236,7 @@ struct srukf_ctx {
     GmwPlan gplan;                         // persistent GMW launch: panel buffers, sync block, task list
     // rank-aware refactorisation (srukf_rank.hip): red_r > 0 = the n - red_r structurally null directions are not pivoted
     int red_r = 0, red_Tp = 0;
+    int rank_aware = 1;                                // srukf_set_rank_aware
     int *red_perm = nullptr, *red_iperm = nullptr;     // permuted position <-> state index, kept indices first
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
@@ -572,7 +573,7 @@ static int update_null_set(srukf_ctx* c)
     const int n = c->d.n, np = c->d.np, T = np / 64;
     const int was = c->red_r;
     c->red_r = 0;
-    if (enabled && n >= 128) {
+    if (enabled && c->rank_aware && n >= 128) {
         srukf_launch_row_energy(c->stream, n, np, c->S, c->D);
         HIPCHK(c, hipMemcpyAsync(c->hstage, c->D, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1469,6 +1470,17 @@ int srukf_clamp_info(srukf_ctx* c, int* frame, int* row)
     if (row) *row = c->clamp_row_host;
     return SRUKF_OK;
 }
+// Rank-aware refactorisation on / off (default on); re-derives the null set from the current state.
+int srukf_set_rank_aware(srukf_ctx* c, int on)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rank_aware = on ? 1 : 0;
+    return update_null_set(c);
+}
+// How many of the n pivots the refactorisation skips (0: the rank-aware form is off or found nothing to skip).
+int srukf_null_directions(srukf_ctx* c) { return c ? (c->red_r > 0 ? c->d.n - c->red_r : 0) : SRUKF_ERR_BAD_ARG; }
 // Tolerance study only (scripts/mixed_eps_study.py): lets srukf_set_storage accept SRUKF_STORAGE_F32_MIXED below epsilon 1e-9,
 // where it is known to diverge — that divergence is what the study documents.
 int srukf_debug_allow_mixed(srukf_ctx* c, int on)

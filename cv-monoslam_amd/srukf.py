@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_clamp_info", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -107,6 +107,8 @@ def load_library():
     L.srukf_get_match_patch.argtypes = [C.c_void_p, C.c_int, _bp]
     L.srukf_set_storage.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_exclusive.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_set_rank_aware.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_null_directions.argtypes = [C.c_void_p]
     L.srukf_get_state_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.srukf_run_frames_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -266,6 +268,13 @@ class Filter:
         """True (default): the filter has the GPU to itself (one persistent refactorisation launch per frame);
         False: several filters replay concurrently on this GPU (one launch per 64-row panel)."""
         self._chk(self._lib.srukf_set_exclusive(self._h, 1 if exclusive else 0))
+
+    def set_rank_aware(self, on):
+        """Rank-aware refactorisation (default on): structurally null pivots are not factored."""
+        self._chk(self._lib.srukf_set_rank_aware(self._h, 1 if on else 0))
+
+    def null_directions(self):
+        return self._lib.srukf_null_directions(self._h)
 
     def set_storage(self, storage):
         """STORAGE_F64 (default) or STORAGE_F32: precision of the state kept between frames."""

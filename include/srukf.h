@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRUKF_ABI_VERSION 3
+#define SRUKF_ABI_VERSION 4
 
 typedef enum srukf_status {
     SRUKF_OK                =  0,
@@ -183,6 +183,16 @@ int  srukf_get_match_patch(srukf_ctx* ctx, int k, unsigned char* out);
  * cannot get its workgroups in time gives up (bounded waits), its frame is repeated on the exact path, and the context
  * switches to exclusive == 0 by itself.  No reference counterpart (the reference is single-threaded host code). */
 int  srukf_set_exclusive(srukf_ctx* ctx, int exclusive);
+/* Rank-aware refactorisation (default on).  The anchors of landmarks initialised in one batch are copies of one robot
+ * position (SLAM.cpp:1223, 1247) and stay identical random variables for the life of the filter, so 3 (K - 1) pivots per
+ * batch are null by construction: the reference's modified Cholesky meets them as c_jj = 0 and clamps them to EPSILON
+ * (SLAM.cpp:2279-2285).  Whenever a state arrives (srukf_set_state*, map changes) the rows of S with energy < 1e-12 are
+ * taken as such directions; the refactorisation then pivots only the others (same relative order: the kept rows are the
+ * reference's rows) and writes sqrt(EPSILON) e_k for the rest, which changes no entry of P = S^T S by more than 1e-12.
+ * Every frame verifies that the skipped directions are still null in its S^T S - U U^T and otherwise takes the exact path.
+ * srukf_null_directions: how many pivots are skipped at present.  No reference counterpart. */
+int  srukf_set_rank_aware(srukf_ctx* ctx, int on);
+int  srukf_null_directions(srukf_ctx* ctx);
 int  srukf_set_storage(srukf_ctx* ctx, int storage);
 int  srukf_get_state_f32(srukf_ctx* ctx, float* X, float* S);
 

@@ -213,3 +213,105 @@ def test_mixed_precision_downdate(srukf, oracle, synth, N):
     d = np.abs(tr[srukf.STORAGE_F32_MIXED][:, :2] - tr[srukf.STORAGE_F64][:, :2]).max()
     assert 0 < d < 1e-6, d
     assert np.abs(tr[srukf.STORAGE_F32_MIXED][:, :2] - sc["odo"][1:F + 1, :2]).max() < 2e-4      # still tracks the truth
+
+
+@pytest.mark.parametrize("N", [20, 50, 200])
+def test_rank_aware_refactor(srukf, oracle, synth, N):
+    """The rank-aware refactorisation (structurally null pivots permuted to the end and not factored) against the plain one
+    and against the oracle: 3 (N - 1) directions are skipped on a jointly initialised map (+ the three robot-position rows that
+    are still copies of the anchors at frame 0), X and P agree with the full factorisation to what the EPSILON clamp leaves
+    (1e-13-level entries), S stays upper triangular with sqrt(EPSILON) on the skipped pivots, and the two paths give the same
+    trajectory over a staged replay."""
+    p = synth.scene_params()
+    F = 8 if N < 200 else 4
+    sc = synth.make_scene(N, F, seed=5, p=p)
+    res = {}
+    for on in (True, False):
+        f = srukf.Filter(N, p); f.set_rank_aware(on); f.set_state(sc["X0"], sc["S0"])
+        nd = f.null_directions()
+        n = 6 * N + 4                                     # skipping pays only when it removes a whole 64-row panel
+        pays = -(-(n - 3 * (N - 1)) // 64) < -(-n // 64)
+        assert nd == (3 * (N - 1) if on and pays else 0), nd
+        for t in range(2):
+            f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); f.predict_measurement(); f.update(sc["z"][t], sc["matched"][t])
+        X, S = f.get_state()
+        g = srukf.Filter(N, p); g.set_rank_aware(on); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        res[on] = (X, S, g.run_frames(0, F))
+    (Xa, Sa, ta), (Xb, Sb, tb) = res[True], res[False]
+    assert np.all(np.tril(Sa, -1) == 0.0)
+    np.testing.assert_allclose(Xa, Xb, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sa.T @ Sa, Sb.T @ Sb, rtol=0, atol=2e-12)
+    np.testing.assert_allclose(ta, tb, rtol=0, atol=1e-10)
+    # the skipped pivots: sqrt(EPSILON) on the diagonal, nothing else in the row; the kept rows are the full factorisation's rows
+    if srukf.Filter(N, p).null_directions() == 0 and N == 20:
+        return                                            # 124 states: two panels either way, the plain path ran twice
+    dropped = [6 * k + e for k in range(1, N) for e in range(3)]
+    assert np.all(np.diag(Sa)[dropped] == np.sqrt(1e-13))
+    off = Sa[dropped].copy(); off[np.arange(len(dropped)), dropped] = 0.0
+    assert np.all(off == 0.0)
+    kept = np.setdiff1d(np.arange(6 * N + 4), dropped)
+    np.testing.assert_allclose(np.abs(Sa[kept]), np.abs(Sb[kept]), rtol=0, atol=1e-9)
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    for t in range(2):
+        o.predict_motion(sc["odo"][t], sc["odo"][t + 1]); o.predict_measurement(); o.update(sc["z"][t], sc["matched"][t], 1, 0, 1)
+    Xo, So = o.get_state()
+    np.testing.assert_allclose(Xa, Xo, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Sa.T @ Sa, So.T @ So, rtol=0, atol=1e-11)
+
+
+def test_rank_aware_follows_map_changes(srukf, oracle, synth):
+    """The set of skipped pivots is re-derived whenever the map changes: deleting the landmark whose anchor carried the
+    batch's pivots hands them to the next landmark of the batch; a new batch of K landmarks adds 3 (K - 1) null anchors
+    (+3: the new anchors are copies of the robot position until the next motion step separates them); and the frames after
+    each change agree with the oracle started from the same state."""
+    p = synth.scene_params()
+    N, K = 60, 12
+    sc = synth.make_scene(N, 4, seed=8, p=p)
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    assert f.null_directions() == 3 * (N - 1)
+    f.predict_motion(sc["odo"][0], sc["odo"][1]); f.predict_measurement(); f.update(sc["z"][0], sc["matched"][0])
+    f.delete_landmark(0)
+    X, S = f.get_state()
+    e = np.sum(S * S, axis=1)
+    # the set is read off the state itself (row energy of S < 1e-12); the reference's six rank-one updates of the deletion
+    # (SLAM.cpp:2654-2668) may leave a few anchors slightly above that, which are then simply factored
+    assert f.null_directions() == int(np.sum(e[:-4] < 1e-12))
+    assert 3 * (N - 6) <= f.null_directions() <= 3 * (N - 2)
+    assert np.all(e[0:3] > 1e-6)                          # landmark 1's anchor carries the batch's pivots now
+    sel = np.arange(1, N)
+    o = oracle.Oracle(N - 1, p); o.set_state(X, S)
+    z, m = sc["z"][1].reshape(N, 2)[sel].ravel(), sc["matched"][1][sel]
+    f.predict_motion(sc["odo"][1], sc["odo"][2]); f.predict_measurement(); f.update(z, m)
+    o.predict_motion(sc["odo"][1], sc["odo"][2]); o.predict_measurement(); o.update(z, m, mode=oracle.Oracle.BATCHED)
+    X1, S1 = f.get_state(); Xo, So = o.get_state()
+    np.testing.assert_allclose(X1, Xo, atol=1e-9)
+    np.testing.assert_allclose(S1.T @ S1, So.T @ So, atol=1e-10)
+    # a second batch
+    rng = np.random.default_rng(4)
+    uv = np.column_stack([rng.uniform(60, 580, K), rng.uniform(60, 420, K)])
+    f.add_landmarks(uv)
+    Na = N - 1 + K
+    X2, S2 = f.get_state()
+    e2 = np.sum(S2 * S2, axis=1)
+    assert f.null_directions() == int(np.sum(e2[:-4] < 1e-12)) >= 3 * (N - 6) + 3 * (K - 1)
+    o2 = oracle.Oracle(Na, p); o2.set_state(X2, S2)
+    f.predict_motion(sc["odo"][2], sc["odo"][3]); h, Si, vis = f.predict_measurement()
+    o2.predict_motion(sc["odo"][2], sc["odo"][3]); ho, _, _ = o2.predict_measurement()
+    np.testing.assert_allclose(h, ho, atol=1e-8)
+    z = h + rng.normal(0, 0.5, h.shape); m = np.asarray(vis, dtype=np.int32)
+    f.update(z, m, reorder=srukf.NEED_REORDER, mode=srukf.UPDATE_SEQUENTIAL)      # the frame right after an augmentation (2126-2131)
+    o2.update(z, m, reorder=oracle.Oracle.NEED_REORDER, k_new=K, mode=oracle.Oracle.SEQUENTIAL)
+    X3, S3 = f.get_state(); Xo3, So3 = o2.get_state()
+    np.testing.assert_allclose(X3, Xo3, atol=1e-8)
+    np.testing.assert_allclose(S3.T @ S3, So3.T @ So3, atol=1e-9)
+    # and an ordinary batched frame on the enlarged map, both sides from the device's state
+    f.set_state(X3, S3); o3 = oracle.Oracle(Na, p); o3.set_state(X3, S3)
+    e3 = np.sum(S3 * S3, axis=1)
+    assert f.null_directions() == int(np.sum(e3[:-4] < 1e-12))
+    f.predict_motion(sc["odo"][3], sc["odo"][4]); h, Si, vis = f.predict_measurement()
+    o3.predict_motion(sc["odo"][3], sc["odo"][4]); o3.predict_measurement()
+    z = h + rng.normal(0, 0.5, h.shape); m = np.asarray(vis, dtype=np.int32)
+    f.update(z, m); o3.update(z, m, mode=oracle.Oracle.BATCHED)
+    X4, S4 = f.get_state(); Xo4, So4 = o3.get_state()
+    np.testing.assert_allclose(X4, Xo4, atol=1e-8)
+    np.testing.assert_allclose(S4.T @ S4, So4.T @ So4, atol=1e-9)
