@@ -12,29 +12,31 @@
 #include <algorithm>
 #include <utility>
 #include "srukf_device.h"
+#include "srukf_rank.h"
 
 extern "C" {
-void srukf_launch_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, FrameScalars*, const double*, const double*);
+void srukf_launch_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, FrameScalars*, const double*, const double*, RankArgs);
 void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const double*, const double*, const double*, double*, double*, const FrameScalars*);
 void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
-                       const double*, const int*, const int*, FrameScalars*, double*, double*, const double*);
+                       const double*, const int*, const int*, FrameScalars*, double*, double*, const double*, RankArgs);
 int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int, KWeights, MeasArgs);
-void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*);
+void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*, RankArgs);
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const FrameScalars*);
 int srukf_gmw_panel_bytes(void);
 int srukf_gmw_sync_bytes(int T);
 int srukf_gmw_build_tiles(int T, int Tp, short* out);
 int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
-void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int);
+void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*);
+void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
 int srukf_gmw_head_rows(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
@@ -239,6 +241,8 @@ struct srukf_ctx {
     int rank_aware = 1;                                // srukf_set_rank_aware
     int *red_perm = nullptr, *red_iperm = nullptr;     // permuted position <-> state index, kept indices first
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
+    double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
+    double red_fac_flop = 0, red_own_flop = 0;         // algorithmic flop of the rank-aware persistent launch: factorisation / owners' tiles of S^T S - U U^T
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
     int gmw_shared = 0;                    // 1: the GPU is shared with other filters — never use the persistent launch (it needs all its workgroups resident)
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
@@ -363,11 +367,18 @@ static void quantize_state(srukf_ctx* c)
     if (c->storage != SRUKF_STORAGE_F64)
         hipLaunchKernelGGL(k_quantize, dim3(c->d.n + 1), dim3(256), 0, c->stream, c->d.n, c->d.np, c->S, c->X, c->S32, c->X32);
 }
+// rank-aware replay form: what k_motion / k_gain / k_syrk carry along (all null when the shadow copy does not exist)
+static RankArgs rank_args(const srukf_ctx* c)
+{
+    RankArgs ra = {};
+    if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.r = c->red_r; }
+    return ra;
+}
 static void seq_predict_motion(srukf_ctx* c, const double* odo_pair_dev)
 {
     const KDims& d = c->d;
     ProfScope ps(c, KC_MOTION, 60.0 * d.L, 8.0 * (4.0 * d.n + 8.0 * d.L + 4.0 * d.n));
-    srukf_launch_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->fs, c->odo_seq, odo_pair_dev);
+    srukf_launch_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->fs, c->odo_seq, odo_pair_dev, rank_args(c));
 }
 // fused_stats: the statistics ride on the k_pxy launch of seq_gain (replay path, no host in between)
 static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
@@ -392,6 +403,18 @@ static int gmw_fused_mode()
     if (mode < 0) { const char* e = getenv("SRUKF_GMW_FUSED"); mode = (e && e[0] == '0') ? 0 : 1; }
     return mode;
 }
+// SRUKF_RANK_FUSED=0: the rank-aware form always goes through the full k_syrk + permutation pass: A/B runs
+static int rank_fused_mode()
+{
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SRUKF_RANK_FUSED"); mode = (e && e[0] == '0') ? 0 : 1; }
+    return mode;
+}
+static double nnf(int n) { return (double)n; }
+static void shadow_rebuild(srukf_ctx* c)
+{
+    if (c->red_r > 0 && c->shadowA) srukf_launch_rank_shadow(c->stream, c->d.n, c->d.np, c->red_r, c->S, c->red_perm, c->shadowA);
+}
 static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && !c->gmw_shared && c->gplan.workers >= 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
@@ -409,6 +432,28 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     // N = 300 (two tiles per worker, both to be computed first) 1 544 / 1 663 — so only with one tile per worker and T >= 16.
     // rank-aware form (srukf_rank.hip): permute the null directions to the end, pivot only the leading red_Tp panels
     const bool reduced = !slow && c->red_r > 0 && c->storage == SRUKF_STORAGE_F64;
+    // ... and on the replay path directly in permuted order from the shadow copy (no full k_syrk, no permutation pass)
+    const bool red_fused = reduced && c->shadowA && !keep_backup && ub == 0 && ue == d.mp && c->w.wc0 == c->w.wm0 && gmw_use_persist(c) &&
+                           c->gplan_red.workers >= 0 && c->gplan_red.ntiles <= 2 * c->gplan_red.workers && !c->debug_starve && gmw_fused_mode() && rank_fused_mode();
+    if (red_fused) {
+        const double rr = c->red_r, hr = srukf_gmw_head_rows();
+        {
+            // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
+            ProfScope ps(c, KC_SYRK, 2.0 * hr * nnf(n) * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * ((hr + d.mp) * nnf(n) + (n - rr) * (rr + d.mp)));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c));
+            c->dx_pending = false;
+        }
+        {
+            // factorisation of the leading red_Tp panels (all n columns carried along) + the owners' tiles of S^T S - U U^T
+            // (kept rows below the head x all columns, K <= r and 2N): red_*_flop, update_null_set
+            ProfScope ps(c, KC_GMW_PERSIST, c->red_fac_flop + c->red_own_flop, 8.0 * (2.0 * rr * n + (double)d.mp * n));
+            srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
+                                     c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15);
+        }
+        ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
+        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
+        return;
+    }
     const bool fused = !reduced && !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
                        c->gplan.ntiles <= c->gplan.workers && c->gplan.T >= 16 &&
                        !c->debug_starve && gmw_fused_mode();
@@ -426,7 +471,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     } else {
         ProfScope ps(c, KC_SYRK, syrk_flop * head_frac, syrk_byte * head_frac);
         srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, fused ? c->syrk_head_tiles : c->syrk_tiles,
-                          fused ? c->n_syrk_head_tiles : c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X);
+                          fused ? c->n_syrk_head_tiles : c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{});
         c->dx_pending = false;
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
@@ -445,7 +490,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * nn * nn);
-        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S);
+        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
         return;
     }
     if (!slow) {
@@ -458,7 +503,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             for (int j0 = -64; j0 + 64 < np; j0 += 64) { fl += panel_flop(j0); by += panel_byte(j0); }
             ProfScope ps(c, KC_GMW_PERSIST, fl + syrk_flop * (1.0 - head_frac), by + syrk_byte * (1.0 - head_frac));
             if (fused) srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->G, c->gplan.pans, c->D, c->Wf, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles,
-                                                c->gplan.workers, c->fs, c->S, c->Ut, ub, ue, 0);
+                                                c->gplan.workers, c->fs, c->S, c->Ut, ub, ue, 0, 0);
             else launch_gmw_fast(c, c->G, c->S);
         } else {
             int pb = 0;
@@ -477,6 +522,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         quantize_state(c);
         if (frame_tail) srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     }
+    shadow_rebuild(c);                                 // S was rewritten by a path that does not keep the permuted copy in step
 }
 // Blocked fast path (or, slow = true, the exact column path) on an arbitrary matrix buffer: Gbuf (upper triangle,
 // destroyed) -> upper-triangular factor rows in Sout (whose lower triangle must already be zero).
@@ -489,7 +535,7 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
         const int workers = c->debug_starve ? 0 : gp.workers;
-        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp);
+        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp, 0);
         return;
     }
     // one launch per panel; rank-aware form: the step after the last pivoted panel still runs (it writes that panel's S rows)
@@ -523,13 +569,13 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
     const size_t bytes = sizeof(double) * (size_t)np * np;
     if (!c->Sdis) { if (srukf_dmalloc((void**)&c->Sdis, bytes) != hipSuccess) { c->err = "out of device memory (NEED_REORDER buffer)"; return SRUKF_ERR_NOMEM; } }
     hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
-    srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X);
+    srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{});
     c->dx_pending = false;
     for (int stage = 0; stage < 2; stage++) {
         double* out = stage == 0 ? c->Sdis : c->S;
         if (stage == 1) {
             hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
-            srukf_launch_syrk(c->stream, d, c->Sdis, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X);
+            srukf_launch_syrk(c->stream, d, c->Sdis, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{});
         }
         for (int slow = 0; slow < 2; slow++) {
             hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
@@ -557,7 +603,7 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
-        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z);
+        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c));
         c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
 }
@@ -597,6 +643,21 @@ static int update_null_set(srukf_ctx* c)
                 if (rc) { c->err = "rank-aware refactorisation: allocation failed"; return rc; }
             }
             c->red_r = r; c->red_Tp = Tp;
+            {
+                // algorithmic flop of the rank-aware refactorisation (DESIGN.md "flop model"): pivots j < rp update rows (j, rp) x
+                // columns [row, n) of the upper triangle; the owners form the tiles of rows [head, rp) from K = min(row + 32, r) + 2N terms
+                const double rp = 64.0 * Tp, nn = n, kr = (r + 15) & ~15;
+                c->red_fac_flop = (nn - rp) * rp * rp + rp * rp * rp / 3.0;
+                c->red_own_flop = 0.0;
+                for (int I = srukf_gmw_head_rows() / 64; I < Tp; I++)
+                    for (int J = I; J < T; J++)
+                        for (int h = 0; h < 2; h++) c->red_own_flop += 2.0 * 32.0 * 64.0 * (fmin(64.0 * I + 32.0 * h + 32.0, kr) + c->d.mp) * (I == J ? 0.75 : 1.0);
+            }
+            if (!c->shadowA) {
+                HIPCHK(c, srukf_dmalloc(&c->shadowA, sizeof(double) * (size_t)np * np)); HIPCHK(c, srukf_dmalloc(&c->Utp, sizeof(double) * (size_t)c->d.mp * np));
+                HIPCHK(c, hipMemsetAsync(c->Utp, 0, sizeof(double) * (size_t)c->d.mp * np, c->stream));
+            }
+            shadow_rebuild(c);
         }
     }
     if (was || c->red_r) drop_graphs(c);                          // the captured frames contain one or the other launch sequence
@@ -716,7 +777,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->shadowA, c->Utp, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -882,7 +943,7 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     if (!c || !P) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X);
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{});
     HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) { const double v = c->hstage[(size_t)r * np + cc]; P[(size_t)r * n + cc] = v; P[(size_t)cc * n + r] = v; }
@@ -1003,6 +1064,10 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
             }
         }
     }
+    // rank-aware form: the reorder path and the exact column path write S without the permuted copy (and a reordered factor
+    // may have other null rows)
+    if (reorder == SRUKF_NEED_REORDER) { const int rc = update_null_set(c); if (rc) return rc; }
+    else shadow_rebuild(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     return SRUKF_OK;
@@ -1290,7 +1355,7 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     if (srukf_dmalloc((void**)&d_map, sizeof(int) * nn) != hipSuccess) { srukf_destroy(c2); c->err = "delete_landmark: out of device memory"; return SRUKF_ERR_NOMEM; }
     hipMemcpy(d_map, map.data(), sizeof(int) * nn, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X);   // P = S^T S
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{});   // P = S^T S
     hipLaunchKernelGGL(k_gather, dim3((ldn + 255) / 256), dim3(256), 0, c->stream, nn, ldn, c->X, c2->X, d_map);
     for (int slow = 0; slow < 2; slow++) {
         hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c2->fs, 0, 1);
@@ -1409,6 +1474,7 @@ static int run_staged_frame_exact(srukf_ctx* c, int frame, double* traj_row)
         ProfScope ps(c, KC_GMW_COL, 0, 0);
         for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
         quantize_state(c);
+        shadow_rebuild(c);
     }
     srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1435,7 +1501,7 @@ int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_
     auto checkpoint = [&](bool save) {
         hipMemcpyAsync(save ? c->ckS : c->S, save ? c->S : c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync(save ? c->ckX : c->X, save ? c->X : c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
-        if (!save) quantize_state(c);
+        if (!save) { quantize_state(c); shadow_rebuild(c); }
     };
     int rc = SRUKF_OK, done = 0;
     while (done < count) {
@@ -1579,7 +1645,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
         // the plan knows how many workgroups THIS device can keep resident (CU count); workers < 0: per-panel launches
         if (gmw_persist_mode()) { const int rc = gmw_plan_create(r.gp, np, st); if (rc) return rc; }
         if (gmw_persist_mode() && r.gp.workers >= 0) {
-            srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0, 0);
+            srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0, 0, 0);
         } else {
             GH(srukf_dmalloc(&r.pan[0], srukf_gmw_panel_bytes())); GH(srukf_dmalloc(&r.pan[1], srukf_gmw_panel_bytes()));
             GH(hipMemset(r.pan[0], 0, srukf_gmw_panel_bytes())); GH(hipMemset(r.pan[1], 0, srukf_gmw_panel_bytes()));

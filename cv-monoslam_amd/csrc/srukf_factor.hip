@@ -9,6 +9,7 @@
 //   D: reg t of lane l is D[row = (l>>4) + 4t][col = l&15]
 #include "srukf_device.h"
 #include "srukf_tiles.h"
+#include "srukf_rank.h"
 #include "srukf_gmw_cols.h"
 #include "srukf_meas.h"
 
@@ -78,9 +79,12 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
                                               int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
-                                              const int2* __restrict__ tiles, int ntiles, const double* __restrict__ dxp, double* __restrict__ X)
+                                              const int2* __restrict__ tiles, int ntiles, const double* __restrict__ dxp, double* __restrict__ X,
+                                              int krows, int ndx, const RankArgs ra)
 {
-    // workgroups past the tile list: the state update X += sum_k K_k (z_k - h_k) left over by k_gain
+    // workgroups past the tile list: the state update X += sum_k K_k (z_k - h_k) left over by k_gain, then (rank-aware replay)
+    // the diagonal of G at the dropped positions
+    if ((int)blockIdx.x >= ntiles + ndx) { srukf_rank_gdiag_job(d.n, d.np, ue, ra, &fs->gmax_bits, blockIdx.x - ntiles - ndx); return; }
     if ((int)blockIdx.x >= ntiles) { srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles); return; }
     __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
     const int n0 = tl.y * 32;    // col c
     d4 acc[2][2];
     zero_acc(acc);
-    int ke = m0 + 32; if (ke > d.np) ke = d.np;          // S[k][r] = 0 for k > r
+    int ke = m0 + 32; if (ke > krows) ke = krows;        // S[k][r] = 0 for k > r; krows: rows of S that hold anything (a multiple of 16)
     const int u0 = ub & ~3, u1 = (ue + 3) & ~3;
     const bool full = (ub == u0) && (ue == u1) && (((u1 - u0) & 15) == 0);
     const int ngs = ke >> 4, ngu = full ? ((u1 - u0) >> 4) : 0, ng = ngs + ngu;
@@ -511,11 +515,14 @@ void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S
     hipLaunchKernelGGL(k_pxy, dim3(ntiles + extra), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles, ntiles, w, ms);
 }
 // dxp != null: (n + 255)/256 extra workgroups apply the pending state update
+// ra.A != null (rank-aware replay): S / Ut are the permuted operands, ceil((n - r) / 16) more workgroups form the dropped diagonal
 void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs,
-                       const void* tiles, int ntiles, const double* dxp, double* X)
+                       const void* tiles, int ntiles, const double* dxp, double* X, RankArgs ra)
 {
-    const int extra = dxp ? (d.n + 255) / 256 : 0;
-    hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X);
+    const int ndx = dxp ? (d.n + 255) / 256 : 0;
+    const int krows = ra.A ? min(d.np, (ra.r + 15) & ~15) : d.np;
+    const int extra = ndx + (ra.A ? (d.n - ra.r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS : 0);
+    hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X, krows, ndx, ra);
 }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
 void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout,

@@ -405,13 +405,13 @@ struct GmwTile { short I, J, nsteps, pad; };
 // for the tile.  S0 must not be the buffer the factor is written to (Sout).
 #define GMW_HEAD_ROWS 2
 __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
-                                               int I, int J, d4 (&acc)[2][2], FrameScalars* __restrict__ fs, int tid)
+                                               int I, int J, d4 (&acc)[2][2], FrameScalars* __restrict__ fs, int tid, int krows)
 {
     const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int m0 = 64 * I + 32 * (wv >> 1), c0 = 64 * J + 32 * (wv & 1);
     zero_acc(acc);
     if (m0 >= d.ld || c0 >= d.ld || c0 + 32 <= m0) return;
-    tile32_tn_deep<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, d.ld), lane);      // S0[k][r] = 0 for k > r
+    tile32_tn_deep<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, krows), lane);     // S0[k][r] = 0 for k > r and for k >= krows
     tile32_tn_deep<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
     double gmax = 0.0, xmax = 0.0;                             // gamma / xi of the GMW bound, as in k_syrk
 #pragma unroll
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
                                                      GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
                                                      FrameScalars* __restrict__ fs,
-                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1)
+                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows)
 {
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
@@ -474,8 +474,9 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         zero_acc(acca); zero_acc(accb);
         if (S0) {
             const KDimsLite dl = { n, ld };
-            if (ta.nsteps > 0 && ta.I >= GMW_HEAD_ROWS) { gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid); ta.computed = true; }
-            if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid); tb.computed = true; }
+            // (rank-aware form: block row Tp only passes the last pivoted panel's factor rows on; its own values are never used)
+            if (ta.nsteps > 0 && ta.I >= GMW_HEAD_ROWS) { if (ta.I < Tp) gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid, krows); ta.computed = true; }
+            if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { if (tb.I < Tp) gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid, krows); tb.computed = true; }
         }
         const int kmax = max(ta.nsteps, tb.nsteps);
         for (int k = 0; k < kmax && good; k++) {
@@ -531,16 +532,17 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers)
 // S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G)
 void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
                               void* sync, const void* tiles, int ntiles, int workers, void* fs,
-                              const double* S0, const double* Ut0, int u0, int u1, int Tp)
+                              const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows)
 {
     const int T = ld / 64;
     if (Tp <= 0 || Tp > T) Tp = T;
+    if (krows <= 0 || krows > ld) krows = ld;
     if (workers > 0 && ntiles > GMW_OWNED_MAX * workers)
         hipLaunchKernelGGL(k_gmw_persist<true>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows);
     else
         hipLaunchKernelGGL(k_gmw_persist<false>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1);
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 }  // extern "C"

@@ -3,6 +3,49 @@
 // gfx950 only.  See srukf_device.h for the HBM layout.
 #include "srukf_device.h"
 #include "srukf_meas.h"
+#include "srukf_rank.h"
+
+// One sigma point's robot rows through the odometry model (generateSigmaPoints 1159-1160 restricted to the robot and
+// control-noise rows, passSigmaThroughMotionFunction 1492-1523): r[] = propagated pose, (c2, s2) = cos / sin of its heading.
+struct MotionCtl { double rot1, trans, rot2, crot2, srot2; };
+__device__ __forceinline__ void srukf_motion_point(const MotionCtl& m, const double (&xr)[4], const double (&srow)[4], const double (&mnoise)[3],
+                                                   double gs, double (&r)[4], double& c2, double& s2)
+{
+    double q[3];
+#pragma unroll
+    for (int e = 0; e < 4; e++) r[e] = xr[e] * 1 + srow[e] * gs + 0;       // generateSigmaPoints, 1159-1160
+#pragma unroll
+    for (int e = 0; e < 3; e++) q[e] = 0.0 * 1 + mnoise[e] * gs + 0;
+    const double r1 = m.rot1 - q[0], tr = m.trans - q[1], r2 = m.rot2 - q[2];     // 1492-1494
+    double sn, cs;
+    sincos(r[3] + r1, &sn, &cs);
+    r[0] += tr * cs;                                                         // 1518-1523
+    r[1] += tr * sn;
+    r[2] += 0.0;
+    r[3] += r1 + r2;
+    // cos/sin of the final heading by angle addition; the rot2-noise columns evaluate it directly
+    if (q[2] == 0.0) { c2 = cs * m.crot2 - sn * m.srot2; s2 = sn * m.crot2 + cs * m.srot2; }
+    else sincos(r[3], &s2, &c2);
+}
+__device__ __forceinline__ void srukf_motion_centre(const MotionCtl& m, const double (&xr)[4], double (&s0)[4], double& c0s, double& s0s)
+{
+    double sn, cs;
+    sincos(xr[3] + m.rot1, &sn, &cs);
+    s0[0] = xr[0] + m.trans * cs; s0[1] = xr[1] + m.trans * sn; s0[2] = xr[2] + 0.0; s0[3] = xr[3] + (m.rot1 + m.rot2);
+    c0s = cs * m.crot2 - sn * m.srot2; s0s = sn * m.crot2 + cs * m.srot2;
+}
+// control from two odometry poses (SLAM.cpp:1444-1458): Ut = (rot1, trans, rot2), Mt = control-noise sigmas
+__device__ __forceinline__ void srukf_motion_control(const srukf_params& p, const double* o, double (&ut)[3], double (&mt)[3])
+{
+    const double dx = o[3] - o[0], dy = o[4] - o[1];
+    const double rot1 = atan2(dy, dx) - o[2];
+    const double trans = sqrt(dy * dy + dx * dx);
+    const double rot2 = o[5] - o[2] - rot1;
+    ut[0] = rot1; ut[1] = trans; ut[2] = rot2;
+    mt[0] = p.a1 * rot1 * rot1 + p.a2 * trans * trans;
+    mt[1] = p.a3 * trans * trans + p.a4 * rot1 * rot1 + p.a4 * rot2 * rot2;
+    mt[2] = p.a1 * rot2 * rot2 + p.a2 * trans * trans;
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_motion: predictMotion numeric tail (SLAM.cpp:1430-1465) fused:
@@ -24,7 +67,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
                                                 double* __restrict__ X, double* __restrict__ S,
                                                 double* __restrict__ sigR, double* __restrict__ Cmat,
                                                 FrameScalars* __restrict__ fs,
-                                                const double* __restrict__ odo_seq, const double* odo_pair)
+                                                const double* __restrict__ odo_seq, const double* odo_pair, const RankArgs ra)
 {
     __shared__ double red[16];
     __shared__ double sh[24];
@@ -39,10 +82,12 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
     // thread 0's dependent chain  frame counter -> odometry pair  instead of following it
     constexpr int MAXIT = 4;                                   // the first 4 * 512 directions; the rest load in the loop
     double2 pre[MAXIT][2];
+    int prow[MAXIT];                                           // rank-aware replay: row of the shadow copy that mirrors S row i (or none)
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
         const int i = tid + it * 512;
         pre[it][0] = make_double2(0.0, 0.0); pre[it][1] = make_double2(0.0, 0.0);
+        prow[it] = (ra.A && i < n - 4) ? ra.iperm[i] : 0x7fffffff;
         if (i < n) {
             // S[i][n-4..n-1]: 16-byte aligned (n-4 = 6N is even, ld a multiple of 64); the strictly lower
             // triangle of S is kept zero, so rows inside the robot block need no masking
@@ -53,14 +98,10 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
     // ---- control (SLAM.cpp:1444-1458) ----
     if (tid == 0) {
         const double* o = odo_pair ? odo_pair : (odo_seq + 3 * fs->frame);
-        const double dx = o[3] - o[0], dy = o[4] - o[1];
-        const double rot1 = atan2(dy, dx) - o[2];
-        const double trans = sqrt(dy * dy + dx * dx);
-        const double rot2 = o[5] - o[2] - rot1;
-        sh[0] = rot1; sh[1] = trans; sh[2] = rot2;
-        sh[3] = p.a1 * rot1 * rot1 + p.a2 * trans * trans;
-        sh[4] = p.a3 * trans * trans + p.a4 * rot1 * rot1 + p.a4 * rot2 * rot2;
-        sh[5] = p.a1 * rot2 * rot2 + p.a2 * trans * trans;
+        double ut[3], mt[3];
+        srukf_motion_control(p, o, ut, mt);
+        const double rot2 = ut[2];
+        for (int q = 0; q < 3; q++) { sh[q] = ut[q]; sh[3 + q] = mt[q]; }
         for (int q = 0; q < 4; q++) sh[6 + q] = X[n - 4 + q];
         sh[10] = cos(rot2); sh[11] = sin(rot2);
         for (int q = 0; q < 3; q++) { fs->Ut[q] = sh[q]; fs->Mt[q] = sh[3 + q]; }
@@ -83,12 +124,8 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
     //      model; the deviations from sigma_0 feed R12 and the Gram matrix of the residual rows ----
     // sigma_0 (centre point through the motion model, no noise): every thread needs it, so every thread computes it
     double s0[4], c0s, s0s;
-    {
-        double sn, cs;
-        sincos(xr[3] + rot1, &sn, &cs);
-        s0[0] = xr[0] + trans * cs; s0[1] = xr[1] + trans * sn; s0[2] = xr[2] + 0.0; s0[3] = xr[3] + (rot1 + rot2);
-        c0s = cs * crot2 - sn * srot2; s0s = sn * crot2 + cs * srot2;
-    }
+    const MotionCtl mc = { rot1, trans, rot2, crot2, srot2 };
+    srukf_motion_centre(mc, xr, s0, c0s, s0s);
     const double k2 = w.wi_sr * 0.70710678118654752440;
     double acc[14];                // [0..3] weighted mean of the robot rows, [4..13] upper triangle of C^T C
 #pragma unroll
@@ -99,7 +136,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[e] = w.wm0 * s0[e];
     }
-    auto direction = [&](const int i, const double2 u0, const double2 u1) {
+    auto direction = [&](const int i, const double2 u0, const double2 u1, const int arow) {
         double srow[4] = { 0, 0, 0, 0 }, mnoise[3] = { 0, 0, 0 };
         if (i < n) {
             srow[0] = u0.x; srow[1] = u0.y; srow[2] = u1.x; srow[3] = u1.y;
@@ -110,22 +147,8 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
 #pragma unroll
         for (int sg = 0; sg < 2; sg++) {
             const double gs = sg ? -w.gamma : w.gamma;
-            double r[4], q[3];
-#pragma unroll
-            for (int e = 0; e < 4; e++) r[e] = xr[e] * 1 + srow[e] * gs + 0;       // generateSigmaPoints, 1159-1160
-#pragma unroll
-            for (int e = 0; e < 3; e++) q[e] = 0.0 * 1 + mnoise[e] * gs + 0;
-            const double r1 = rot1 - q[0], tr = trans - q[1], r2 = rot2 - q[2];     // 1492-1494
-            double sn, cs;
-            sincos(r[3] + r1, &sn, &cs);
-            r[0] += tr * cs;                                                         // 1518-1523
-            r[1] += tr * sn;
-            r[2] += 0.0;
-            r[3] += r1 + r2;
-            // cos/sin of the final heading by angle addition; the rot2-noise columns evaluate it directly
-            double s2, c2;
-            if (q[2] == 0.0) { c2 = cs * crot2 - sn * srot2; s2 = sn * crot2 + cs * srot2; }
-            else sincos(r[3], &s2, &c2);
+            double r[4], c2, s2;
+            srukf_motion_point(mc, xr, srow, mnoise, gs, r, c2, s2);
             double4* o = reinterpret_cast<double4*>(sigR + (size_t)(1 + sg * Na + i) * 8);
             o[0] = make_double4(r[0], r[1], r[2], r[3]);
             o[1] = make_double4(c2, s2, 0.0, 0.0);
@@ -136,6 +159,10 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
             double c[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) { S[(size_t)i * ld + (n - 4 + e)] = k2 * (dev[0][e] - dev[1][e]); c[e] = k2 * (dev[0][e] + dev[1][e]); }
+            if (arow < ra.r) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) ra.A[(size_t)arow * ld + (ra.r - 4 + e)] = k2 * (dev[0][e] - dev[1][e]);
+            }
             int q = 4;
 #pragma unroll
             for (int a = 0; a < 4; a++)
@@ -152,12 +179,12 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
         const int i = tid + it * 512;
-        if (i < Na) direction(i, pre[it][0], pre[it][1]);
+        if (i < Na) direction(i, pre[it][0], pre[it][1], prow[it]);
     }
     for (int i = tid + MAXIT * 512; i < Na; i += 512) {         // more than 2048 directions (N > 339): plain loads
         double2 u0 = make_double2(0.0, 0.0), u1 = u0;
         if (i < n) { const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4)); u0 = sp2[0]; u1 = sp2[1]; }
-        direction(i, u0, u1);
+        direction(i, u0, u1, (ra.A && i < n - 4) ? ra.iperm[i] : 0x7fffffff);
     }
     STAMP(2);
     // block reduction through LDS only (wave shuffles of 14 doubles cost more LDS-pipeline time than this tree):
@@ -209,6 +236,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
             }
         }
         for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = R[a][b];
+        if (ra.A) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) ra.A[(size_t)(ra.r - 4 + a) * ld + (ra.r - 4 + b)] = R[a][b];
     }
     STAMP(5);
 }
@@ -227,8 +255,8 @@ __global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_para
     // flat (direction, landmark) index: no idle lanes when N is not a multiple of the wave size (N = 200: 78 % -> 100 %)
     const int g = blockIdx.x * 256 + threadIdx.x;
     const int ii = g / d.N, k = g - ii * d.N;
-    if (ii > d.Na) return;
     const int n = d.n, Na = d.Na, ld = d.np, mp = d.mp;
+    if (ii > d.Na) return;
     const double f1 = p.cam_f / p.cam_dx, f2 = p.cam_f / p.cam_dy;
     double base[6];
 #pragma unroll
@@ -309,7 +337,7 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               const double* __restrict__ Si, const int* __restrict__ vis,
                                               const double* __restrict__ h, const double* __restrict__ z_seq,
                                               const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
-                                              FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */)
+                                              FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra)
 {
     __shared__ double red[4][64];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
@@ -321,6 +349,7 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     const double sc = w.wi * w.gamma;
     const int per = (N + GAIN_SLICES - 1) / GAIN_SLICES;
     const int k_beg = blockIdx.y * per, k_end = min(N, k_beg + per);
+    const int rp = ra.Utp ? ra.iperm[r] : 0;                  // rank-aware replay: U^T also with permuted columns
     // per-landmark constants of this slice once per workgroup (they are a chain of small dependent loads: fetched per
     // thread and iteration they cost more than the streaming of Ut itself): Si^{-1}, Si^{-T}(z - h), "matched and visible"
     __shared__ double lk[GAIN_LM_MAX][6];
@@ -360,6 +389,7 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
             }
             Ut[(size_t)(2 * k) * ld + r] = u0;
             Ut[(size_t)(2 * k + 1) * ld + r] = u1;
+            if (ra.Utp) { ra.Utp[(size_t)(2 * k) * ld + rp] = u0; ra.Utp[(size_t)(2 * k + 1) * ld + rp] = u1; }
         }
     }
     red[sl][rl] = dx;
@@ -512,9 +542,9 @@ void srukf_launch_landmarks_cartesian(hipStream_t st, KDims d, const double* X, 
     hipLaunchKernelGGL(k_landmarks_cartesian, dim3(d.N), dim3(256), 0, st, d, X, S, xyz, cov);
 }
 void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, double* X, double* S, double* sigR, double* Cmat,
-                         FrameScalars* fs, const double* odo_seq, const double* odo_pair)
+                         FrameScalars* fs, const double* odo_seq, const double* odo_pair, RankArgs ra)
 {
-    hipLaunchKernelGGL(k_motion, dim3(1), dim3(512), 0, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair);
+    hipLaunchKernelGGL(k_motion, dim3(1), dim3(512), 0, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair, ra);
 }
 void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
                           double* Z, double* DZ, const FrameScalars* fs)
@@ -531,9 +561,9 @@ void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* 
 int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
-                       FrameScalars* fs, double* dxp, double* X, const double* Z)
+                       FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra)
 {
-    hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
+    hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra);
     if (w.wc0 != w.wm0)
         hipLaunchKernelGGL(k_gain_center, dim3(d.np / 256 + 1), dim3(256), 0, st, d, w, Ut, Z, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
 }

@@ -1,0 +1,46 @@
+// srukf_rank.h — rank-aware refactorisation (srukf_rank.hip): pieces other kernels carry along.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// What the replay path of the rank-aware form hands to k_motion / k_gain / k_syrk (all null / 0: the plain path).
+struct RankArgs {
+    double* A;             // shadow of the kept rows of S in permuted column order (r rows, ld columns)
+    double* Utp;           // U^T with permuted columns
+    double* gdiag;         // [ld] diagonal of G at the dropped positions (permuted index)
+    const int* iperm;      // state index -> permuted position
+    int r;                 // kept pivots (robot last: positions r-4 .. r-1)
+};
+
+// gdiag[a] = sum_{k<r} A[k][a]^2 - sum_{m<mu} Utp[m][a]^2 for 16 dropped positions a = r + 16 blk .. (16 columns x 16 row lanes,
+// eight independent loads in flight per lane: a plain loop is one memory round trip per iteration); also feeds
+// gamma = max diag(G) of the GMW bound (SLAM.cpp:2204-2211).  256 threads.
+#define SRUKF_RANK_COLS 16
+__device__ __forceinline__ double srukf_rank_colsq(const double* __restrict__ M, int ld, int rows, int a, int kl)
+{
+    double v = 0.0;
+    int k = kl;
+    for (; k + 7 * 16 < rows; k += 8 * 16) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = M[(size_t)(k + 16 * u) * ld + a];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u] * t[u];
+    }
+    for (; k < rows; k += 16) { const double t = M[(size_t)k * ld + a]; v += t * t; }
+    return v;
+}
+__device__ __forceinline__ void srukf_rank_gdiag_job(int n, int ld, int mu, const RankArgs ra, unsigned long long* gmax_bits, int blk)
+{
+    __shared__ double cs[16][17];
+    const int a = ra.r + SRUKF_RANK_COLS * blk + (threadIdx.x & 15), kl = threadIdx.x >> 4;
+    double v = 0.0;
+    if (a < n) v = srukf_rank_colsq(ra.A, ld, ra.r, a, kl) - srukf_rank_colsq(ra.Utp, ld, mu, a, kl);
+    cs[kl][threadIdx.x & 15] = v;
+    __syncthreads();
+    if (threadIdx.x < 16 && a < n) {
+        double t = 0.0;
+        for (int q = 0; q < 16; q++) t += cs[q][threadIdx.x];
+        ra.gdiag[a] = t;
+        if (t > 0.0) atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(t));
+    }
+}

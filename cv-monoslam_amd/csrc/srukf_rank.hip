@@ -18,8 +18,25 @@
 // updates are the (1e-17)^2 / 1e-13 terms), so the sigma set of the next frame is the reference's.  k_rank_expand also verifies
 // the assumption for every dropped index: G_kk - sum_{a<r} Sp[a][k]^2 <= 1e-12, else the frame is flagged like a theta-clamp
 // frame and repeated on the exact column path.
+//
+// Replay path (k_rank_shadow, "shadow" below): the kept rows are also held in PERMUTED column order in a second buffer A
+// (r rows, upper triangular in that order, rows >= r zero), which k_motion and k_rank_expand keep in step with S, and k_gain
+// writes U^T with permuted columns next to U^T.  S^T S - U U^T is then formed directly in permuted order — the head rows by
+// k_syrk, the other tiles by their owners inside the persistent launch, with K = r instead of n — and neither the full k_syrk
+// nor the permutation pass runs.  The diagonal of the dropped indices, which no tile covers, comes from srukf_rank_gdiag_job.
 #include <hip/hip_runtime.h>
 #include "srukf_device.h"
+#include "srukf_rank.h"
+
+// A[a][b] = S[perm[a]][perm[b]] for a < r (the kept rows in permuted column order), zero rows below
+__global__ __launch_bounds__(256) void k_rank_shadow(int n, int ld, int r, const double* __restrict__ S, const int* __restrict__ perm, double* __restrict__ A)
+{
+    const int a = blockIdx.x;
+    double* out = A + (size_t)a * ld;
+    if (a >= r) { for (int b = threadIdx.x; b < ld; b += 256) out[b] = 0.0; return; }
+    const double* src = S + (size_t)perm[a] * ld;
+    for (int b = threadIdx.x; b < ld; b += 256) out[b] = (b >= a && b < n) ? src[perm[b]] : 0.0;
+}
 
 // e[k] = sum_i S[k][i]^2, one workgroup per row
 __global__ __launch_bounds__(256) void k_row_energy(int n, int ld, const double* __restrict__ S, double* __restrict__ e)
@@ -39,11 +56,13 @@ __global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* 
     if (a < n) { const int j = perm[a]; gdiag[a] = G[(size_t)j * ld + j]; }
 }
 
-// One workgroup per state row j (+ one for the frame tail).  Sp: factor rows in permuted order (row a < r valid for columns
-// b >= a), D: pivots in permuted order, perm[a] = state index at permuted position a, iperm = inverse.
+// One workgroup per state row j, one for the frame tail, and one per 16 dropped indices for the null-direction check.
+// Sp: factor rows in permuted order (row a < r valid for columns b >= a), D: pivots in permuted order, perm[a] = state index at
+// permuted position a, iperm = inverse.  A (may be null): the shadow copy of the kept rows in permuted order.
 __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
                                                      const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
-                                                     FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S)
+                                                     FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
+                                                     double* __restrict__ A)
 {
     __shared__ double red[16 * 3];
     const int j = blockIdx.x;
@@ -68,15 +87,23 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         }
         return;
     }
+    if (j > n) {
+        // the check that 16 dropped directions really are null in this frame's G: G_aa - sum_{k<r} Sp[k][a]^2 <= 1e-12
+        const int a = r + SRUKF_RANK_COLS * (j - n - 1) + (threadIdx.x & 15), kl = threadIdx.x >> 4;
+        __shared__ double cs[16][17];
+        cs[kl][threadIdx.x & 15] = (a < n) ? srukf_rank_colsq(Sp, ld, r, a, kl) : 0.0;
+        __syncthreads();
+        if (threadIdx.x < 16 && a < n) {
+            double t = 0.0;
+            for (int q = 0; q < 16; q++) t += cs[q][threadIdx.x];
+            if (gdiag[a] - t > 1e-12) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, perm[a]); }
+        }
+        return;
+    }
     const int a = iperm[j];
     double* out = S + (size_t)j * ld;
-    if (a >= r) {
-        // dropped direction: what the clamp leaves, and the check that it really is null in this frame's G
+    if (a >= r) {                                              // dropped direction: what the reference's clamp leaves
         for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == j) ? sqrt(eps) : 0.0;
-        double v[1] = { 0.0 };
-        for (int k = threadIdx.x; k < r; k += 256) { const double s = Sp[(size_t)k * ld + a]; v[0] += s * s; }
-        block_sum<1>(v, red);
-        if (threadIdx.x == 0 && gdiag[a] - v[0] > 1e-12) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, j); }
         return;
     }
     const double* src = Sp + (size_t)a * ld;
@@ -85,6 +112,10 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         double v = 0.0;
         if (c >= j && c < n) { v = src[iperm[c]]; if (c > j) mx = fmax(mx, fabs(v)); }
         out[c] = v;
+    }
+    if (A) {
+        double* sh = A + (size_t)a * ld;
+        for (int b = threadIdx.x; b < ld; b += 256) sh[b] = (b >= a && b < n) ? src[b] : 0.0;
     }
     // theta clamp of the reference evaluated afterwards, as k_gmw_check does (SLAM.cpp:2204-2211, 2264-2285)
     mx = wave_max(mx);
@@ -112,8 +143,12 @@ void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, cons
     hipLaunchKernelGGL(k_rank_diag, dim3((n + 255) / 256), dim3(256), 0, st, n, ld, G, perm, gdiag);
 }
 void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
-                              const double* gdiag, void* fs, const double* X, int do_traj, double* S)
+                              const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A)
 {
-    hipLaunchKernelGGL(k_rank_expand, dim3(n + 1), dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S);
+    hipLaunchKernelGGL(k_rank_expand, dim3(n + 1 + (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS), dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A);
+}
+void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
+{
+    hipLaunchKernelGGL(k_rank_shadow, dim3(ld), dim3(256), 0, st, n, ld, r, S, perm, A);
 }
 }  // extern "C"

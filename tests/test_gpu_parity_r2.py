@@ -304,14 +304,20 @@ def test_rank_aware_follows_map_changes(srukf, oracle, synth):
     X3, S3 = f.get_state(); Xo3, So3 = o2.get_state()
     np.testing.assert_allclose(X3, Xo3, atol=1e-8)
     np.testing.assert_allclose(S3.T @ S3, So3.T @ So3, atol=1e-9)
-    # and an ordinary batched frame on the enlarged map, both sides from the device's state
-    f.set_state(X3, S3); o3 = oracle.Oracle(Na, p); o3.set_state(X3, S3)
+    # and ordinary batched frames on the enlarged map as a staged replay, straight from the state the reorder frame left
+    # (no set_state in between: the null set and the permuted copy must have followed the reorder path by themselves)
+    o3 = oracle.Oracle(Na, p); o3.set_state(X3, S3)
     e3 = np.sum(S3 * S3, axis=1)
-    assert f.null_directions() == int(np.sum(e3[:-4] < 1e-12))
-    f.predict_motion(sc["odo"][3], sc["odo"][4]); h, Si, vis = f.predict_measurement()
-    o3.predict_motion(sc["odo"][3], sc["odo"][4]); o3.predict_measurement()
-    z = h + rng.normal(0, 0.5, h.shape); m = np.asarray(vis, dtype=np.int32)
-    f.update(z, m); o3.update(z, m, mode=oracle.Oracle.BATCHED)
+    assert f.null_directions() == int(np.sum(e3[:-4] < 1e-12)) > 0
+    F2 = 3
+    odo2 = np.vstack([sc["odo"][3], sc["odo"][4], sc["odo"][4] + (sc["odo"][4] - sc["odo"][3]), sc["odo"][4] + 2 * (sc["odo"][4] - sc["odo"][3])])
+    zs, ms = np.zeros((F2, 2 * Na)), np.zeros((F2, Na), dtype=np.int32)
+    for t in range(F2):
+        o3.predict_motion(odo2[t], odo2[t + 1]); ho, _, viso = o3.predict_measurement()
+        zs[t] = ho + rng.normal(0, 0.5, ho.shape); ms[t] = np.asarray(viso, dtype=np.int32)
+        o3.update(zs[t], ms[t], mode=oracle.Oracle.BATCHED)
+    f.stage_sequence(odo2, zs, ms)
+    f.run_frames(0, F2)
     X4, S4 = f.get_state(); Xo4, So4 = o3.get_state()
     np.testing.assert_allclose(X4, Xo4, atol=1e-8)
     np.testing.assert_allclose(S4.T @ S4, So4.T @ So4, atol=1e-9)
