@@ -243,7 +243,7 @@ def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local):
     for b in range(B):
         sc = synth.make_scene(N, W + K, seed=0, p=synth.scene_params(), obs_seed=5000 + b)
         f = srukf.Filter(N, sc["params"], device=local)          # own stream
-        f.set_exclusive(False)                                   # B filters share the GPU: one launch per panel, no residency assumption
+        f.set_exclusive(srukf.GPU_SHARED)                        # B filters share the GPU: persistent launches of half the CUs, two admitted at a time
         f.set_state(sc["X0"], sc["S0"])
         f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
         fs.append(f)
@@ -274,7 +274,7 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
-    ap.add_argument("--sequences-per-gpu", type=int, default=8,
+    ap.add_argument("--sequences-per-gpu", type=int, default=3,
                     help="extra measurement: B concurrent independent sequences on one GPU (0 = skip)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="CPU/gloo check of the N-rank launcher and collectives only (no filter, no GPU)")
@@ -402,7 +402,8 @@ def main():
             B = args.sequences_per_gpu
             out["multi_sequence"] = {"sequences_per_gpu": B, "frames_per_s_aggregate": multi_sequence_throughput(
                 torch, synth, srukf, N, B, min(K, 100), 10, local),
-                "note": "B independent Monte-Carlo sequences replayed concurrently on one GPU (one context/stream each); not the headline value"}
+                "note": "B independent Monte-Carlo sequences replayed concurrently on one GPU (one context/stream each, SRUKF_GPU_SHARED: "
+                        "persistent launches of half the CUs, at most two admitted at a time); not the headline value"}
         if world == 1 and not args.no_cpu_baseline:
             cb, otraj = cpu_baseline(synth, sc, N, args.cpu_frames)
             g = srukf.Filter(N, sc["params"], device=local)

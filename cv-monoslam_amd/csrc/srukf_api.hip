@@ -32,7 +32,7 @@ int srukf_gmw_panel_bytes(void);
 int srukf_gmw_sync_bytes(int T);
 int srukf_gmw_build_tiles(int T, int Tp, short* out);
 int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
-void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int);
+void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*);
@@ -167,7 +167,7 @@ static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_st
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
-struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1; };
+struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1, tenants = 1; };
 static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 {
     if (g.pans) srukf_dfree_on(g.pans, st);
@@ -176,13 +176,16 @@ static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
     g = GmwPlan();
 }
 // workers = -1 afterwards: the matrix has more tiles than resident workgroups can own (the per-panel launches are used)
-static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0)
+// tenants = 2: the plan of a filter that shares the GPU (gmw_shared = 1): at most half the CUs, so that two admitted launches are resident together
+static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int tenants = 1)
 {
     g.T = np / 64;
     g.Tp = (Tp > 0 && Tp < g.T) ? Tp : g.T;
+    g.tenants = tenants > 1 ? tenants : 1;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 2;
-    g.workers = srukf_gmw_persist_workers(g.T, g.Tp, cus - 1);  // one workgroup per CU (LDS), all of them resident
+    const int cap = cus / (tenants > 1 ? tenants : 1) - 1;    // one workgroup per CU (registers), all of them resident
+    g.workers = cap >= 1 ? srukf_gmw_persist_workers(g.T, g.Tp, cap) : -1;
     g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
     srukf_gmw_build_tiles(g.T, g.Tp, tk.data());
@@ -244,7 +247,8 @@ struct srukf_ctx {
     double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
     double red_fac_flop = 0, red_own_flop = 0;         // algorithmic flop of the rank-aware persistent launch: factorisation / owners' tiles of S^T S - U U^T
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
-    int gmw_shared = 0;                    // 1: the GPU is shared with other filters — never use the persistent launch (it needs all its workgroups resident)
+    int gmw_shared = 0;                    // 0: the filter has the GPU to itself; 1: shared with other filters — persistent launches of at most half the CUs behind
+                                           // the admission gate (k_gmw_gate); 2: one launch per panel (forced, or after an abandoned persistent launch)
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
     int clamp_frame_host = -1, clamp_row_host = -1;   // what the last SRUKF_ERR_CLAMP_PENDING was about (srukf_clamp_info)
@@ -415,7 +419,9 @@ static void shadow_rebuild(srukf_ctx* c)
 {
     if (c->red_r > 0 && c->shadowA) srukf_launch_rank_shadow(c->stream, c->d.n, c->d.np, c->red_r, c->S, c->red_perm, c->shadowA);
 }
-static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && !c->gmw_shared && c->gplan.workers >= 0; }
+static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c->gmw_shared != 2 && c->gplan.workers >= 0; }
+static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? 2 : 1; }
+static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? 2 : 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
 {
@@ -448,7 +454,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             // (kept rows below the head x all columns, K <= r and 2N): red_*_flop, update_null_set
             ProfScope ps(c, KC_GMW_PERSIST, c->red_fac_flop + c->red_own_flop, 8.0 * (2.0 * rr * n + (double)d.mp * n));
             srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
-                                     c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15);
+                                     c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c));
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
         srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
@@ -503,7 +509,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             for (int j0 = -64; j0 + 64 < np; j0 += 64) { fl += panel_flop(j0); by += panel_byte(j0); }
             ProfScope ps(c, KC_GMW_PERSIST, fl + syrk_flop * (1.0 - head_frac), by + syrk_byte * (1.0 - head_frac));
             if (fused) srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->G, c->gplan.pans, c->D, c->Wf, c->gplan.sync, c->gplan.tiles, c->gplan.ntiles,
-                                                c->gplan.workers, c->fs, c->S, c->Ut, ub, ue, 0, 0);
+                                                c->gplan.workers, c->fs, c->S, c->Ut, ub, ue, 0, 0, gate_limit(c));
             else launch_gmw_fast(c, c->G, c->S);
         } else {
             int pb = 0;
@@ -535,7 +541,7 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
         const int workers = c->debug_starve ? 0 : gp.workers;
-        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp, 0);
+        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp, 0, gate_limit(c));
         return;
     }
     // one launch per panel; rank-aware form: the step after the last pivoted panel still runs (it writes that panel's S rows)
@@ -637,9 +643,9 @@ static int update_null_set(srukf_ctx* c)
             }
             HIPCHK(c, hipMemcpy(c->red_perm, perm.data(), sizeof(int) * np, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(c->red_iperm, iperm.data(), sizeof(int) * np, hipMemcpyHostToDevice));
-            if (c->gplan_red.Tp != Tp || !c->gplan_red.pans) {
+            if (c->gplan_red.Tp != Tp || !c->gplan_red.pans || c->gplan_red.tenants != plan_tenants(c)) {
                 gmw_plan_destroy(c->gplan_red, c->stream);
-                const int rc = gmw_plan_create(c->gplan_red, np, c->stream, Tp);
+                const int rc = gmw_plan_create(c->gplan_red, np, c->stream, Tp, plan_tenants(c));
                 if (rc) { c->err = "rank-aware refactorisation: allocation failed"; return rc; }
             }
             c->red_r = r; c->red_Tp = Tp;
@@ -991,10 +997,10 @@ static int read_fs(srukf_ctx* c)
     HIPCHK(c, hipMemcpyAsync(c->hfs, c->fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->hfs->clamp_rows > 0 && c->hfs->clamp_frame == 0x7fffffff) c->hfs->clamp_frame = c->hfs->frame - 1;   // the run's last frame
-    if (c->hfs->gmw_aborts > 0 && !c->gmw_shared) {
+    if (c->hfs->gmw_aborts > 0 && c->gmw_shared != 2) {
         // a persistent launch did not get all its workgroups onto the GPU in time (somebody else is using it): the flagged
         // frame is repeated on the exact path like a clamp frame, and this filter stays with one launch per panel
-        c->gmw_shared = 1;
+        c->gmw_shared = 2;
         drop_graphs(c);
     }
     return SRUKF_OK;
@@ -1084,8 +1090,17 @@ int srukf_set_exclusive(srukf_ctx* c, int exclusive)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int shared = exclusive ? 0 : 1;
-    if (shared != c->gmw_shared) { c->gmw_shared = shared; drop_graphs(c); }
+    const int shared = exclusive == SRUKF_GPU_SHARED ? 1 : exclusive == SRUKF_GPU_SHARED_PER_PANEL ? 2 : 0;
+    if (shared == c->gmw_shared) return SRUKF_OK;
+    const int was = plan_tenants(c);
+    c->gmw_shared = shared;
+    drop_graphs(c);
+    if (plan_tenants(c) != was) {                              // the persistent launches keep to half the CUs / may use all of them again
+        gmw_plan_destroy(c->gplan, c->stream);
+        const int rc = gmw_plan_create(c->gplan, c->d.np, c->stream, 0, plan_tenants(c));
+        if (rc) { c->err = "set_exclusive: persistent GMW resources: allocation failed"; return rc; }
+        return update_null_set(c);                             // the rank-aware plan with the same limit
+    }
     return SRUKF_OK;
 }
 int srukf_set_storage(srukf_ctx* c, int storage)
@@ -1326,12 +1341,14 @@ static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     const bool own = c->own_stream;
     std::swap(*c, *c2);
     c->own_stream = own; c2->own_stream = false;
-    c->profiling = c2->profiling; c->use_graph = c2->use_graph; c->gmw_shared = c2->gmw_shared;
+    c->profiling = c2->profiling; c->use_graph = c2->use_graph;
+    const int shared = c2->gmw_shared;
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
     c2->profiling = false; c2->pev.clear();
     srukf_destroy(c2);
     c->phase = 0;
+    if (shared != c->gmw_shared) srukf_set_exclusive(c, shared == 1 ? SRUKF_GPU_SHARED : shared == 2 ? SRUKF_GPU_SHARED_PER_PANEL : SRUKF_GPU_EXCLUSIVE);
 }
 
 // deleteOneFeature, numeric part (SLAM.cpp:2637-2668): landmark id (0-based, state order) leaves the state.  The
@@ -1561,6 +1578,7 @@ int srukf_debug_starve_workers(srukf_ctx* c, int on)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;
     c->debug_starve = on ? 1 : 0;
+    drop_graphs(c);                                    // the captured frames contain one or the other launch sequence
     return SRUKF_OK;
 }
 
@@ -1645,7 +1663,7 @@ int srukf_gmw_host(int device, int n, const double* G, double* S_out, double* D_
         // the plan knows how many workgroups THIS device can keep resident (CU count); workers < 0: per-panel launches
         if (gmw_persist_mode()) { const int rc = gmw_plan_create(r.gp, np, st); if (rc) return rc; }
         if (gmw_persist_mode() && r.gp.workers >= 0) {
-            srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0, 0, 0);
+            srukf_launch_gmw_persist(st, n, np, epsilon, r.dG, r.gp.pans, r.dD, r.dS, r.gp.sync, r.gp.tiles, r.gp.ntiles, r.gp.workers, r.dFs, nullptr, nullptr, 0, 0, 0, 0, 0);
         } else {
             GH(srukf_dmalloc(&r.pan[0], srukf_gmw_panel_bytes())); GH(srukf_dmalloc(&r.pan[1], srukf_gmw_panel_bytes()));
             GH(hipMemset(r.pan[0], 0, srukf_gmw_panel_bytes())); GH(hipMemset(r.pan[1], 0, srukf_gmw_panel_bytes()));

@@ -430,12 +430,31 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
     }
 }
 
+// Admission of persistent launches when several filters share the GPU (srukf_set_exclusive(ctx, 0)): every such launch keeps to
+// half the CUs (GmwPlan) and is preceded on its stream by k_gmw_gate, which lets it start only while fewer than `limit` = 2 gated
+// launches are in flight on the device — so the launches that run together are always resident together, in whatever order the
+// hardware dispatches their workgroups (two partly resident launches holding each other's CUs would otherwise sit in the
+// bounded wait until it expires).  The gate is one wave that fits beside a resident factorisation workgroup (few registers, no
+// LDS), so it can always start; the last workgroup of a gated launch gives the slot back.
+__device__ int g_gmw_admitted = 0;
+__global__ void k_gmw_gate(const FrameScalars* __restrict__ fs, int limit)
+{
+    if (fs->frozen) return;                                    // the launch behind this gate returns at once as well
+    if (threadIdx.x != 0) return;
+    for (int spins = 0; spins < (1 << 22); spins++) {          // ~ 1 s: a slot leaked by a lost launch must not hang the stream for good
+        const int cur = __hip_atomic_load(&g_gmw_admitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur < limit && atomicCAS(&g_gmw_admitted, cur, cur + 1) == cur) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    atomicAdd(&g_gmw_admitted, 1);
+}
+
 template <bool MEM>
 __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int Tp, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
                                                      GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
                                                      FrameScalars* __restrict__ fs,
-                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows)
+                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows, int gated)
 {
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
@@ -496,6 +515,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gated) atomicSub(&g_gmw_admitted, 1);
         }
     }
 }
@@ -529,20 +549,21 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers)
     if (nt <= GMW_OWNED_MEM * max_workers) return max_workers;   // > GMW_OWNED_MAX tiles per worker: the memory-tile form
     return -1;
 }
-// S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G)
+// S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G); gate_limit > 0: behind k_gmw_gate
 void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
                               void* sync, const void* tiles, int ntiles, int workers, void* fs,
-                              const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows)
+                              const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit)
 {
+    if (gate_limit > 0) hipLaunchKernelGGL(k_gmw_gate, dim3(1), dim3(64), 0, st, (const FrameScalars*)fs, gate_limit);
     const int T = ld / 64;
     if (Tp <= 0 || Tp > T) Tp = T;
     if (krows <= 0 || krows > ld) krows = ld;
     if (workers > 0 && ntiles > GMW_OWNED_MAX * workers)
         hipLaunchKernelGGL(k_gmw_persist<true>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows);
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0);
     else
         hipLaunchKernelGGL(k_gmw_persist<false>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows);
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 }  // extern "C"

@@ -33,6 +33,7 @@ STATUS = {0: "SRUKF_OK", -1: "SRUKF_ERR_BAD_ARG", -2: "SRUKF_ERR_DIM_MISMATCH", 
           -7: "SRUKF_ERR_CLAMP_PENDING", -8: "SRUKF_ERR_NOMEM"}
 
 STORAGE_F64, STORAGE_F32, STORAGE_F32_MIXED = 0, 1, 2
+GPU_SHARED, GPU_EXCLUSIVE, GPU_SHARED_PER_PANEL = 0, 1, 2          # srukf_set_exclusive
 UPDATE_SEQUENTIAL, UPDATE_BATCHED = 0, 1
 NEED_REORDER, NEEDNOT_REORDER = 0, 1
 
@@ -265,9 +266,10 @@ class Filter:
         return out
 
     def set_exclusive(self, exclusive):
-        """True (default): the filter has the GPU to itself (one persistent refactorisation launch per frame);
-        False: several filters replay concurrently on this GPU (one launch per 64-row panel)."""
-        self._chk(self._lib.srukf_set_exclusive(self._h, 1 if exclusive else 0))
+        """True / GPU_EXCLUSIVE (default): the filter has the GPU to itself (one persistent refactorisation launch per frame that may
+        use every CU); False / GPU_SHARED: several filters replay concurrently on this GPU (persistent launches of half the CUs,
+        at most two admitted at a time); GPU_SHARED_PER_PANEL: one launch per 64-row panel."""
+        self._chk(self._lib.srukf_set_exclusive(self._h, int(exclusive)))
 
     def set_rank_aware(self, on):
         """Rank-aware refactorisation (default on): structurally null pivots are not factored."""

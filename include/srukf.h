@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define SRUKF_ABI_VERSION 4
+#define SRUKF_ABI_VERSION 5
+
 
 typedef enum srukf_status {
     SRUKF_OK                =  0,
@@ -177,11 +178,19 @@ int  srukf_get_match_patch(srukf_ctx* ctx, int k, unsigned char* out);
 /* Select the storage precision (default SRUKF_STORAGE_F64).  With SRUKF_STORAGE_F32 the state is rounded to float at
  * the end of every refactorisation (and by srukf_set_state); srukf_get_state returns those values widened to double,
  * srukf_get_state_f32 the float arrays themselves (X[n], S[n*n] row-major). */
-/* exclusive != 0 (default): this filter has the GPU to itself while it runs, and the refactorisation is ONE persistent
- * launch whose workgroups all have to be resident.  exclusive == 0: other filters / kernels share the GPU (several
- * contexts replaying concurrently): one launch per 64-row panel, no residency assumption.  A persistent launch that
- * cannot get its workgroups in time gives up (bounded waits), its frame is repeated on the exact path, and the context
- * switches to exclusive == 0 by itself.  No reference counterpart (the reference is single-threaded host code). */
+/* How the filter shares the GPU.  No reference counterpart (the reference is single-threaded host code).
+ * SRUKF_GPU_EXCLUSIVE (default, any value other than the two below): this filter has the GPU to itself while it runs; the
+ *   refactorisation is ONE persistent launch that may use every CU and whose workgroups all have to be resident.
+ * SRUKF_GPU_SHARED: several filters replay concurrently on this GPU (one context and stream each).  The persistent launch keeps
+ *   to half the CUs and starts behind an admission gate that lets at most two such launches of the process run at a time, so
+ *   the launches that run together are always resident together (measured at N = 200: one filter 4 330 frames/s, two 7 900,
+ *   three 10 000 aggregate).
+ * SRUKF_GPU_SHARED_PER_PANEL: one launch per 64-row panel, no residency assumption at all (other kernels of unknown size and
+ *   duration on the GPU).  A persistent launch that cannot get its workgroups in time gives up (bounded waits), its frame is
+ *   repeated on the exact path, and the context switches to this mode by itself. */
+#define SRUKF_GPU_SHARED 0
+#define SRUKF_GPU_EXCLUSIVE 1
+#define SRUKF_GPU_SHARED_PER_PANEL 2
 int  srukf_set_exclusive(srukf_ctx* ctx, int exclusive);
 /* Rank-aware refactorisation (default on).  The anchors of landmarks initialised in one batch are copies of one robot
  * position (SLAM.cpp:1223, 1247) and stay identical random variables for the life of the filter, so 3 (K - 1) pivots per

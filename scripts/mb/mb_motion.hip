@@ -18,7 +18,7 @@ int main()
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; rep++) {
-        hipEventRecord(a, st); for (int i = 0; i < 200; i++) srukf_launch_motion(st, d, w, p, X, S, sigR, Cmat, fs, nullptr, odo); hipEventRecord(b, st); hipEventSynchronize(b);
+        hipEventRecord(a, st); for (int i = 0; i < 200; i++) srukf_launch_motion(st, d, w, p, X, S, sigR, Cmat, fs, nullptr, odo, RankArgs{}); hipEventRecord(b, st); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b); printf("k_motion: %.2f us/launch\n", ms / 200 * 1000);
     }
     unsigned long long hs[32]; hipMemcpyFromSymbol(hs, HIP_SYMBOL(srukf_stamps), sizeof hs);

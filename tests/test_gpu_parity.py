@@ -544,15 +544,15 @@ def test_full_size_tolerance_study_n500(srukf, synth):
 
 
 def test_persistent_and_per_panel_refactor_agree(srukf, synth):
-    """The refactorisation runs as one persistent launch (default) or as one launch per 64-row panel
-    (set_exclusive(False): several filters on one GPU).  Step-wise API: same arithmetic in the same order, identical
-    results.  Replay: the persistent launch also forms most of S^T S - U U^T itself, in a different summation order
-    than k_syrk's split-K, so the two agree to rounding."""
+    """The refactorisation runs as one persistent launch (default), as a persistent launch of half the CUs behind the admission
+    gate (GPU_SHARED: several filters on one GPU) or as one launch per 64-row panel (GPU_SHARED_PER_PANEL).  Step-wise API: same
+    arithmetic in the same order, identical results.  Replay: the persistent launch also forms most of S^T S - U U^T itself, in a
+    different summation order than k_syrk's split-K, so persistent and per-panel agree to rounding."""
     p = synth.scene_params()
     for N, F in ((30, 4), (100, 3)):
         sc = synth.make_scene(N, F, seed=2, p=p)
         out, step = [], []
-        for exclusive in (True, False):
+        for exclusive in (srukf.GPU_EXCLUSIVE, srukf.GPU_SHARED_PER_PANEL, srukf.GPU_SHARED):
             f = srukf.Filter(N, p); f.set_exclusive(exclusive); f.set_state(sc["X0"], sc["S0"])
             f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
             t = f.run_frames(0, F)
@@ -567,6 +567,9 @@ def test_persistent_and_per_panel_refactor_agree(srukf, synth):
         np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-12)
         P0, P1 = out[0][2].T @ out[0][2], out[1][2].T @ out[1][2]
         np.testing.assert_allclose(P0, P1, rtol=0, atol=1e-15 + 1e-11 * np.abs(P1).max())
+        # the gated half-GPU form is the persistent kernel with another assignment of tiles to workers: the same numbers
+        np.testing.assert_array_equal(step[0][0], step[2][0]); np.testing.assert_array_equal(step[0][1], step[2][1])
+        np.testing.assert_array_equal(out[0][0], out[2][0]); np.testing.assert_array_equal(out[0][1], out[2][1])
 
 
 def test_persistent_launch_without_workers_falls_back(srukf, oracle, synth):

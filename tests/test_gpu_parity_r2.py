@@ -321,3 +321,31 @@ def test_rank_aware_follows_map_changes(srukf, oracle, synth):
     X4, S4 = f.get_state(); Xo4, So4 = o3.get_state()
     np.testing.assert_allclose(X4, Xo4, atol=1e-8)
     np.testing.assert_allclose(S4.T @ S4, So4.T @ So4, atol=1e-9)
+
+
+def test_three_filters_share_the_gpu(srukf, synth):
+    """Three filters replaying concurrently in GPU_SHARED mode (persistent launches of half the CUs, at most two admitted at a
+    time by k_gmw_gate): every one reproduces, bit for bit, what it computes alone with the GPU to itself, and nothing is flagged."""
+    p = synth.scene_params()
+    N, F, B = 100, 24, 3
+    scs = [synth.make_scene(N, F, seed=0, p=p, obs_seed=7000 + b) for b in range(B)]
+    alone = []
+    for sc in scs:
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        alone.append((f.run_frames(0, F),) + f.get_state()); f.close()
+    import torch
+    fs, ds = [], []
+    for sc in scs:
+        f = srukf.Filter(N, p); f.set_exclusive(srukf.GPU_SHARED); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        fs.append(f); ds.append(torch.zeros(F, 8, dtype=torch.float64, device="cuda"))
+    for k0 in range(0, F, 8):
+        for f, dt in zip(fs, ds):
+            f.run_frames_async(k0, 8, d_traj_ptr=dt.data_ptr() + 8 * 8 * k0)
+    for f in fs:
+        f.synchronize()
+    for f, dt, ref in zip(fs, ds, alone):
+        assert f.clamp_info() == (-1, -1)
+        X, S = f.get_state()
+        np.testing.assert_array_equal(dt.cpu().numpy(), ref[0])
+        np.testing.assert_array_equal(X, ref[1]); np.testing.assert_array_equal(S, ref[2])
+        f.close()
