@@ -1544,6 +1544,62 @@ int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_
     return rc;
 }
 
+// B filters (independent sequences: Monte-Carlo runs, several cameras) through the same block of staged frames, concurrently on one
+// GPU.  Every filter keeps its own context and stream; the frames are issued round-robin in chunks of two captured 8-frame graphs,
+// so that the filters' launches interleave on the device, then all are awaited.  Filters that were left in SRUKF_GPU_EXCLUSIVE are
+// switched to SRUKF_GPU_SHARED first (two exclusive persistent launches do not fit the GPU together).  A filter whose block holds
+// a flagged frame (theta clamp) is rerun alone through srukf_run_frames, which recovers by itself.
+// traj_host: [B][count][8] or null; status: per-filter return codes or null.  Returns the first error.
+int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, int mode, double* traj_host, int* status)
+{
+    if (!ctxs || B < 1 || count < 1) return SRUKF_ERR_BAD_ARG;
+    for (int b = 0; b < B; b++) if (!ctxs[b]) return SRUKF_ERR_BAD_ARG;
+    std::vector<double*> dt(B, nullptr);
+    std::vector<int> rcs(B, SRUKF_OK);
+    int rc = SRUKF_OK;
+    for (int b = 0; b < B && rc == SRUKF_OK; b++) {
+        srukf_ctx* c = ctxs[b];
+        if (B > 1 && c->gmw_shared == 0) rc = srukf_set_exclusive(c, SRUKF_GPU_SHARED);
+        if (rc == SRUKF_OK && hipSetDevice(c->device) != hipSuccess) rc = SRUKF_ERR_HIP;
+        if (rc == SRUKF_OK && srukf_dmalloc((void**)&dt[b], sizeof(double) * 8 * (size_t)count) != hipSuccess) { c->err = "run_frames_batch: out of device memory"; rc = SRUKF_ERR_NOMEM; }
+        if (rc == SRUKF_OK && !c->ckS) {                        // the state before the block, for the recovery of a flagged filter
+            const size_t np = c->d.np;
+            if (srukf_dmalloc((void**)&c->ckS, sizeof(double) * np * np) != hipSuccess || srukf_dmalloc((void**)&c->ckX, sizeof(double) * np) != hipSuccess) { c->err = "run_frames_batch: out of device memory (checkpoint)"; rc = SRUKF_ERR_NOMEM; }
+        }
+        if (rc == SRUKF_OK) {
+            const size_t np = c->d.np;
+            hipMemcpyAsync(c->ckS, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
+            hipMemcpyAsync(c->ckX, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
+        }
+    }
+    const int chunk = 2 * SRUKF_GRAPH_FRAMES;
+    for (int k0 = 0; k0 < count && rc == SRUKF_OK; k0 += chunk)
+        for (int b = 0; b < B && rc == SRUKF_OK; b++) {
+            rcs[b] = srukf_run_frames_async(ctxs[b], first + k0, std::min(chunk, count - k0), mode, dt[b] + (size_t)8 * k0);
+            if (rcs[b] != SRUKF_OK) rc = rcs[b];
+        }
+    for (int b = 0; b < B; b++) {
+        srukf_ctx* c = ctxs[b];
+        int r = srukf_synchronize(c);
+        if (rcs[b] == SRUKF_OK) rcs[b] = r;
+        if (rcs[b] == SRUKF_ERR_CLAMP_PENDING) {
+            // rewind this filter and let the synchronous form (checkpoint, exact path for the flagged frame) run its block alone
+            const size_t np = c->d.np;
+            hipMemcpyAsync(c->S, c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
+            hipMemcpyAsync(c->X, c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
+            quantize_state(c); shadow_rebuild(c);
+            std::vector<double> th((size_t)8 * count);
+            rcs[b] = srukf_run_frames(c, first, count, mode, th.data());
+            if (rcs[b] == SRUKF_OK && dt[b]) hipMemcpy(dt[b], th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice);
+        }
+        if (rcs[b] == SRUKF_OK && traj_host && dt[b]) hipMemcpy(traj_host + (size_t)b * 8 * count, dt[b], sizeof(double) * 8 * (size_t)count, hipMemcpyDeviceToHost);
+        if (rcs[b] != SRUKF_OK && rc == SRUKF_OK) rc = rcs[b];
+        if (dt[b]) srukf_dfree(dt[b]);
+        if (status) status[b] = rcs[b];
+    }
+    return rc;
+}
+
 // What the last SRUKF_ERR_CLAMP_PENDING of srukf_synchronize was about: the first flagged staged frame (frames before it
 // are valid) and the first flagged pivot row.  -1 / -1 if there was none.
 int srukf_clamp_info(srukf_ctx* c, int* frame, int* row)

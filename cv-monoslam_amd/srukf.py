@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_run_frames_batch", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_clamp_info", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -109,6 +109,7 @@ def load_library():
     L.srukf_set_storage.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_exclusive.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_rank_aware.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_run_frames_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.srukf_null_directions.argtypes = [C.c_void_p]
     L.srukf_get_state_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.srukf_stage_sequence.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
@@ -339,6 +340,19 @@ class Filter:
             self._chk(self._lib.srukf_profile_get(self._h, i, C.byref(name), C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
             out[name.value.decode()] = {"ms": ms.value, "launches": cnt.value, "alg_flops": fl.value, "alg_bytes": by.value}
         return out
+
+
+def run_frames_batch(filters, first, count, mode=UPDATE_BATCHED):
+    """B filters through the same block of staged frames concurrently on one GPU (srukf_run_frames_batch) -> traj[B, count, 8]."""
+    B = len(filters)
+    hs = (C.c_void_p * B)(*[f._h.value for f in filters])
+    traj = np.empty((B, count, 8))
+    st = (C.c_int * B)()
+    rc = load_library().srukf_run_frames_batch(hs, B, first, count, mode, _d(traj), st)
+    if rc != 0:
+        bad = [b for b in range(B) if st[b] != 0]
+        filters[bad[0] if bad else 0]._chk(rc)
+    return traj
 
 
 def gmw(G, eps=1e-13, force_slow=False, device=0):

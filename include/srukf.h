@@ -184,7 +184,9 @@ int  srukf_get_match_patch(srukf_ctx* ctx, int k, unsigned char* out);
  * SRUKF_GPU_SHARED: several filters replay concurrently on this GPU (one context and stream each).  The persistent launch keeps
  *   to half the CUs and starts behind an admission gate that lets at most two such launches of the process run at a time, so
  *   the launches that run together are always resident together (measured at N = 200: one filter 4 330 frames/s, two 7 900,
- *   three 10 000 aggregate).
+ *   three 10 400 aggregate).  Each filter's stream should have a hardware queue of its own: the ROCm runtime maps streams onto
+ *   GPU_MAX_HW_QUEUES = 4 queues by default, and streams that share one serialise — export GPU_MAX_HW_QUEUES=8 before the process
+ *   initialises HIP when it holds more than four streams.
  * SRUKF_GPU_SHARED_PER_PANEL: one launch per 64-row panel, no residency assumption at all (other kernels of unknown size and
  *   duration on the GPU).  A persistent launch that cannot get its workgroups in time gives up (bounded waits), its frame is
  *   repeated on the exact path, and the context switches to this mode by itself. */
@@ -231,6 +233,12 @@ int  srukf_run_frames(srukf_ctx* ctx, int first, int count, int mode, double* tr
  * the modified Cholesky: the frames BEFORE the first such frame are valid, that frame and the later ones are not
  * (srukf_clamp_info names it; restore the state the block started from and use srukf_run_frames or the step-wise API). */
 int  srukf_synchronize(srukf_ctx* ctx);
+/* B filters (independent sequences over the same frame range: the Monte-Carlo use, MonoSLAMView.cpp:526-572 once per run) replayed
+ * concurrently on one GPU: frames are issued round-robin in chunks so that the filters' launches interleave, then all are awaited;
+ * filters still in SRUKF_GPU_EXCLUSIVE are switched to SRUKF_GPU_SHARED.  A filter with a flagged frame in its block is rerun
+ * alone through srukf_run_frames.  ctxs[b] must have its own sequence staged (srukf_stage_sequence) and must live on the same
+ * device.  traj_host: [B][count][8] or NULL; status: [B] per-filter return codes or NULL.  Returns the first error. */
+int  srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, int mode, double* traj_host, int* status);
 /* First flagged staged frame / pivot row of the last SRUKF_ERR_CLAMP_PENDING (-1, -1: none).  Either may be NULL. */
 int  srukf_clamp_info(srukf_ctx* ctx, int* frame, int* row);
 

@@ -39,3 +39,17 @@ for B in Bs:
                        ("GPU_SHARED_PER_PANEL", srukf.GPU_SHARED_PER_PANEL)):
         v, fl = run(B, mode, 16)
         print(f"B={B} {name}: {v:.0f} frames/s aggregate, flagged filters {fl}", flush=True)
+
+# the C entry point for B filters against the Python loop above
+for B in (2, 3):
+    fs = []
+    for b in range(B):
+        sc = synth.make_scene(N, W + K, seed=0, p=synth.scene_params(), obs_seed=5000 + b)
+        f = srukf.Filter(N, sc["params"], device=0); f.set_exclusive(srukf.GPU_SHARED)
+        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"]); fs.append(f)
+    srukf.run_frames_batch(fs, 0, W)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        srukf.run_frames_batch(fs, W, K)
+        print(f"B={B} srukf_run_frames_batch rep {rep}: {B * K / (time.perf_counter() - t0):.0f} frames/s aggregate", flush=True)
+    for f in fs: f.close()

@@ -349,3 +349,14 @@ def test_three_filters_share_the_gpu(srukf, synth):
         np.testing.assert_array_equal(dt.cpu().numpy(), ref[0])
         np.testing.assert_array_equal(X, ref[1]); np.testing.assert_array_equal(S, ref[2])
         f.close()
+    # the same through the C entry point for B filters (srukf_run_frames_batch): filters created with the default (exclusive)
+    # setting are switched to the shared form by the call
+    fs = []
+    for sc in scs:
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"]); fs.append(f)
+    traj = srukf.run_frames_batch(fs, 0, F)
+    for b, (f, ref) in enumerate(zip(fs, alone)):
+        X, S = f.get_state()
+        np.testing.assert_array_equal(traj[b], ref[0])
+        np.testing.assert_array_equal(X, ref[1]); np.testing.assert_array_equal(S, ref[2])
+        f.close()
