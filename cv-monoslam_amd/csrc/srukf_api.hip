@@ -1026,6 +1026,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     HIPCHK(c, hipMemcpyAsync(c->zcur, hs, sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->mcur, hm, sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
+    bool exact_ran = false;
     seq_gain(c, c->zcur, c->mcur, false);
     // visibility is needed on the host only to skip no-op refactors in SEQUENTIAL mode
     if (reorder == SRUKF_NEED_REORDER) {
@@ -1041,6 +1042,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
         int rc = read_fs(c); if (rc) return rc;
         if (c->hfs->clamp_rows > 0) {
             // the reference's theta clamp would have been active: redo this refactor on the exact path
+            exact_ran = true;
             hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
             hipLaunchKernelGGL(k_refactor_reset, dim3((d.np + 255) / 256), dim3(256), 0, c->stream, d.np, c->theta, c->fs, 0);
             HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
@@ -1060,6 +1062,7 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
                 seq_refactor(c, m, m + 1, false, true, true, false);
                 int rc = read_fs(c); if (rc) return rc;
                 if (c->hfs->clamp_rows > 0) {
+                    exact_ran = true;
                     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
                     hipLaunchKernelGGL(k_refactor_reset, dim3((d.np + 255) / 256), dim3(256), 0, c->stream, d.np, c->theta, c->fs, 0);
                     HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
@@ -1070,9 +1073,10 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
             }
         }
     }
-    // rank-aware form: the reorder path and the exact column path write S without the permuted copy (and a reordered factor
-    // may have other null rows)
-    if (reorder == SRUKF_NEED_REORDER) { const int rc = update_null_set(c); if (rc) return rc; }
+    // rank-aware form: the reorder path and the exact column path write S without the permuted copy, and their factor may have
+    // other null rows (a frame that went to the exact path because a skipped direction was found not to be null must not meet the
+    // same null set again)
+    if (reorder == SRUKF_NEED_REORDER || exact_ran) { const int rc = update_null_set(c); if (rc) return rc; }
     else shadow_rebuild(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -1491,7 +1495,7 @@ static int run_staged_frame_exact(srukf_ctx* c, int frame, double* traj_row)
         ProfScope ps(c, KC_GMW_COL, 0, 0);
         for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
         quantize_state(c);
-        shadow_rebuild(c);
+        rc = update_null_set(c); if (rc) return rc;      // the null set is re-derived from the exact factor (see srukf_update)
     }
     srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
