@@ -1634,6 +1634,16 @@ int srukf_debug_allow_mixed(srukf_ctx* c, int on)
 }
 // Tests only: persistent factorisation launches of this context start WITHOUT their worker workgroups, as if another
 // process held the GPU — exercises the bounded waits and the fallback to per-panel launches.
+// Test hook: S[row][col] = value on the device, behind the back of everything that tracks S (the null set of the rank-aware
+// refactorisation, the permuted copy): the next frame has to notice by itself.
+int srukf_debug_poke_state(srukf_ctx* c, int row, int col, double value)
+{
+    if (!c || row < 0 || col < row || col >= c->d.n) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->S + (size_t)row * c->d.np + col, &value, sizeof(double), hipMemcpyHostToDevice));
+    return SRUKF_OK;
+}
 int srukf_debug_starve_workers(srukf_ctx* c, int on)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;

@@ -360,3 +360,29 @@ def test_three_filters_share_the_gpu(srukf, synth):
         np.testing.assert_array_equal(traj[b], ref[0])
         np.testing.assert_array_equal(X, ref[1]); np.testing.assert_array_equal(S, ref[2])
         f.close()
+
+
+def test_rank_aware_notices_a_direction_that_is_not_null(srukf, oracle, synth):
+    """A skipped direction that has energy after all (here: poked into S behind the filter's back, 1e-3 on the diagonal of a
+    duplicate anchor row) is caught by the per-frame check G_aa - sum Sp[k][a]^2 <= 1e-12: the refactorisation is flagged and
+    repeated on the exact column path, the null set is re-derived without that row, and the result is the oracle's for the
+    poked state.  (Step-wise API, which forms G from S itself; the replay path works from the permuted copy, which is in step
+    with S by construction — every writer of S goes through k_rank_expand or k_rank_shadow.)"""
+    p = synth.scene_params()
+    N, F = 50, 3
+    sc = synth.make_scene(N, F, seed=12, p=p)
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    nd = f.null_directions()
+    assert nd == 3 * (N - 1)
+    row = 6 * 7 + 1                                           # y anchor of landmark 7: a copy of landmark 0's
+    f.debug_poke_S(row, row, 1e-3)
+    assert f.null_directions() == nd                          # nobody told the filter
+    S0 = sc["S0"].copy(); S0[row, row] = 1e-3
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], S0)
+    for t in range(F):
+        f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); f.predict_measurement(); f.update(sc["z"][t], sc["matched"][t])
+        o.predict_motion(sc["odo"][t], sc["odo"][t + 1]); o.predict_measurement(); o.update(sc["z"][t], sc["matched"][t], 1, 0, 1)
+        assert f.null_directions() == nd - 1                  # noticed in the first frame: the row is factored from now on
+        X, S = f.get_state(); Xo, So = o.get_state()
+        np.testing.assert_allclose(X, Xo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(S.T @ S, So.T @ So, rtol=0, atol=1e-11)
