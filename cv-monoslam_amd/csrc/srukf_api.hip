@@ -245,6 +245,7 @@ struct srukf_ctx {
     int *red_perm = nullptr, *red_iperm = nullptr;     // permuted position <-> state index, kept indices first
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
     double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
+    int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
     double red_fac_flop = 0, red_own_flop = 0;         // algorithmic flop of the rank-aware persistent launch: factorisation / owners' tiles of S^T S - U U^T
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
     int gmw_shared = 0;                    // 0: the filter has the GPU to itself; 1: shared with other filters — persistent launches of at most half the CUs behind
@@ -414,6 +415,13 @@ static int rank_fused_mode()
     if (mode < 0) { const char* e = getenv("SRUKF_RANK_FUSED"); mode = (e && e[0] == '0') ? 0 : 1; }
     return mode;
 }
+// SRUKF_RANK_FOLD=0: the owners never form their tiles themselves in the rank-aware replay (k_syrk over all kept rows instead): A/B runs
+static int rank_fold_mode()
+{
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SRUKF_RANK_FOLD"); mode = (e && e[0] == '0') ? 0 : 1; }
+    return mode;
+}
 static double nnf(int n) { return (double)n; }
 static void shadow_rebuild(srukf_ctx* c)
 {
@@ -439,8 +447,11 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     // rank-aware form (srukf_rank.hip): permute the null directions to the end, pivot only the leading red_Tp panels
     const bool reduced = !slow && c->red_r > 0 && c->storage == SRUKF_STORAGE_F64;
     // ... and on the replay path directly in permuted order from the shadow copy (no full k_syrk, no permutation pass)
+    // (the owners' fold pays with about one tile per worker and T >= 16, as in the full-rank form: frames/s fold / k_syrk over the kept
+    //  rows: N = 100 7 360 / 7 610, N = 200 4 360 / 4 300, N = 300 — two tiles per worker — 2 400 / 2 580)
     const bool red_fused = reduced && c->shadowA && !keep_backup && ub == 0 && ue == d.mp && c->w.wc0 == c->w.wm0 && gmw_use_persist(c) &&
-                           c->gplan_red.workers >= 0 && c->gplan_red.ntiles <= 2 * c->gplan_red.workers && !c->debug_starve && gmw_fused_mode() && rank_fused_mode();
+                           c->gplan_red.workers >= 0 && c->gplan_red.ntiles <= c->gplan_red.workers + c->gplan_red.workers / 16 && c->gplan_red.T >= 16 &&
+                           !c->debug_starve && gmw_fused_mode() && rank_fused_mode() && rank_fold_mode();
     if (red_fused) {
         const double rr = c->red_r, hr = srukf_gmw_head_rows();
         {
@@ -455,6 +466,24 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             ProfScope ps(c, KC_GMW_PERSIST, c->red_fac_flop + c->red_own_flop, 8.0 * (2.0 * rr * n + (double)d.mp * n));
             srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
                                      c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c));
+        }
+        ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
+        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
+        return;
+    }
+    // ... or, where the owners cannot fold (memory tiles: more than two tiles per worker; one launch per panel), still in permuted
+    // order: k_syrk over the tiles of the kept rows only, K <= r, straight into Gp
+    const bool red_perm = reduced && !red_fused && !keep_backup && ub == 0 && ue == d.mp && c->shadowA && c->w.wc0 == c->w.wm0 && rank_fused_mode();
+    if (red_perm) {
+        const double rr = c->red_r, rp = 64.0 * c->red_Tp;
+        {
+            ProfScope ps(c, KC_SYRK, rr * rr * rr / 3.0 + rr * rr * (n - rr) + 2.0 * d.mp * (rr * n - rr * rr / 2.0) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * (rr * n + (double)d.mp * n + rp * n));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c));
+            c->dx_pending = false;
+        }
+        {
+            ProfScope ps(c, gmw_use_persist(c) && c->gplan_red.workers >= 0 ? KC_GMW_PERSIST : KC_GMW_TRAIL, c->red_fac_flop, 8.0 * 2.0 * rp * n);
+            launch_gmw_fast(c, c->Wf, c->G, true);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
         srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
@@ -659,6 +688,15 @@ static int update_null_set(srukf_ctx* c)
                     for (int J = I; J < T; J++)
                         for (int h = 0; h < 2; h++) c->red_own_flop += 2.0 * 32.0 * 64.0 * (fmin(64.0 * I + 32.0 * h + 32.0, kr) + c->d.mp) * (I == J ? 0.75 : 1.0);
             }
+            {
+                // k_syrk tiles of block rows < Tp in the XCD-aware order of the full table (build_tile_table)
+                std::vector<int> ts = build_tile_table(np / 32, np / 32, true, true, 0), tr;
+                for (size_t q = 0; q + 1 < ts.size(); q += 2) if (ts[q] >= 0 && ts[q] * 32 < 64 * Tp) { tr.push_back(ts[q]); tr.push_back(ts[q + 1]); }
+                if (c->red_syrk_tiles) srukf_dfree_on(c->red_syrk_tiles, c->stream);
+                c->red_syrk_tiles = nullptr; c->n_red_syrk_tiles = (int)tr.size() / 2;
+                HIPCHK(c, srukf_dmalloc(&c->red_syrk_tiles, sizeof(int) * tr.size()));
+                HIPCHK(c, hipMemcpy(c->red_syrk_tiles, tr.data(), sizeof(int) * tr.size(), hipMemcpyHostToDevice));
+            }
             if (!c->shadowA) {
                 HIPCHK(c, srukf_dmalloc(&c->shadowA, sizeof(double) * (size_t)np * np)); HIPCHK(c, srukf_dmalloc(&c->Utp, sizeof(double) * (size_t)c->d.mp * np));
                 HIPCHK(c, hipMemsetAsync(c->Utp, 0, sizeof(double) * (size_t)c->d.mp * np, c->stream));
@@ -783,7 +821,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph8) hipGraphDestroy(c->graph8);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->shadowA, c->Utp, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
