@@ -37,6 +37,7 @@ void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
+void srukf_launch_rank_round(hipStream_t, int, int, double*);
 int srukf_gmw_head_rows(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
@@ -431,6 +432,20 @@ static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c
 static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? 2 : 1; }
 static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? 2 : 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
+// Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
+// fp32 storage: S, X and the permuted copy are rounded to the stored values first, and the trajectory row is taken from those
+// (as the full-rank form does: quantize_state before the tail).
+static void rank_expand(srukf_ctx* c, bool frame_tail)
+{
+    const int n = c->d.n, np = c->d.np;
+    const bool f32 = c->storage == SRUKF_STORAGE_F32;
+    srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA);
+    if (f32) {
+        quantize_state(c);
+        srukf_launch_rank_round(c->stream, np, c->red_r, c->shadowA);
+        if (frame_tail) srukf_launch_traj(c->stream, c->d, c->X, c->S, c->fs, nullptr, 1);
+    }
+}
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
 {
     const KDims& d = c->d;
@@ -445,7 +460,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     // Measured (frames/s, fused against not fused): N = 200 2 965 / 2 910, N = 100 5 247 / 5 262, N = 50 9 256 / 9 465,
     // N = 300 (two tiles per worker, both to be computed first) 1 544 / 1 663 — so only with one tile per worker and T >= 16.
     // rank-aware form (srukf_rank.hip): permute the null directions to the end, pivot only the leading red_Tp panels
-    const bool reduced = !slow && c->red_r > 0 && c->storage == SRUKF_STORAGE_F64;
+    const bool reduced = !slow && c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED;
     // ... and on the replay path directly in permuted order from the shadow copy (no full k_syrk, no permutation pass)
     // (the owners' fold pays with about one tile per worker and T >= 16, as in the full-rank form: frames/s fold / k_syrk over the kept
     //  rows: N = 100 7 360 / 7 610, N = 200 4 360 / 4 300, N = 300 — two tiles per worker — 2 400 / 2 580)
@@ -468,7 +483,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
                                      c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c));
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
-        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
+        rank_expand(c, frame_tail);
         return;
     }
     // ... or, where the owners cannot fold (memory tiles: more than two tiles per worker; one launch per panel), still in permuted
@@ -486,7 +501,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
-        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
+        rank_expand(c, frame_tail);
         return;
     }
     const bool fused = !reduced && !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
@@ -525,7 +540,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * nn * nn);
-        srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, frame_tail ? 1 : 0, c->S, c->shadowA);
+        rank_expand(c, frame_tail);
         return;
     }
     if (!slow) {
@@ -1182,6 +1197,7 @@ int srukf_set_storage(srukf_ctx* c, int storage)
     if (storage != c->storage) drop_graphs(c);             // the captured frames do or do not contain the rounding pass / the fp32 contraction
     c->storage = storage;
     quantize_state(c);
+    shadow_rebuild(c);                                     // the permuted copy of the rank-aware form holds what S holds
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SRUKF_OK;
 }

@@ -133,7 +133,18 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     }
 }
 
+// fp32 storage: the permuted copy holds what the stored (float) state holds, like S after k_quantize
+__global__ __launch_bounds__(256) void k_rank_round(int ld, double* __restrict__ A)
+{
+    double* row = A + (size_t)blockIdx.x * ld;
+    for (int b = blockIdx.x + threadIdx.x; b < ld; b += 256) row[b] = (double)(float)row[b];
+}
+
 extern "C" {
+void srukf_launch_rank_round(hipStream_t st, int ld, int r, double* A)
+{
+    hipLaunchKernelGGL(k_rank_round, dim3(r), dim3(256), 0, st, ld, A);
+}
 void srukf_launch_row_energy(hipStream_t st, int n, int ld, const double* S, double* e)
 {
     hipLaunchKernelGGL(k_row_energy, dim3(n), dim3(256), 0, st, n, ld, S, e);
