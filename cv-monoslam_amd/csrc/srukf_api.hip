@@ -423,7 +423,6 @@ static int rank_fold_mode()
     if (mode < 0) { const char* e = getenv("SRUKF_RANK_FOLD"); mode = (e && e[0] == '0') ? 0 : 1; }
     return mode;
 }
-static double nnf(int n) { return (double)n; }
 static void shadow_rebuild(srukf_ctx* c)
 {
     if (c->red_r > 0 && c->shadowA) srukf_launch_rank_shadow(c->stream, c->d.n, c->d.np, c->red_r, c->S, c->red_perm, c->shadowA);
@@ -471,7 +470,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         const double rr = c->red_r, hr = srukf_gmw_head_rows();
         {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
-            ProfScope ps(c, KC_SYRK, 2.0 * hr * nnf(n) * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * ((hr + d.mp) * nnf(n) + (n - rr) * (rr + d.mp)));
+            ProfScope ps(c, KC_SYRK, 2.0 * hr * n * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * ((hr + d.mp) * n + (n - rr) * (rr + d.mp)));
             srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c));
             c->dx_pending = false;
         }
