@@ -47,12 +47,15 @@ __device__ __forceinline__ void dev_distort(const srukf_params& p, double ux, do
     const double ru = sqrt(xu * xu + yu * yu);
     const double ru2 = ru * ru;
     double rd = ru / (1 + k1 * ru * ru + k2 * (ru2 * ru2));                                              // 3184
+    double rprev = __builtin_nan("");                                                                   // 2-cycle between neighbouring doubles: see srukf_project
     for (int it = 0; it < p.newton_iters; it++) {
         const double rd2 = rd * rd, rd4 = rd2 * rd2;
         const double f = rd + k1 * (rd * rd2) + k2 * (rd * rd4) - ru;                                    // 3190
         const double ff = 1.0 + 3.0 * k1 * rd * rd + 5.0 * k2 * rd4;                                     // 3191
         const double rn = rd - f / ff;                                                                   // 3192
         if (rn == rd) break;
+        if (rn == rprev) { if ((p.newton_iters - it) & 1) rd = rn; break; }
+        rprev = rd;
         rd = rn;
     }
     const double rdsq = rd * rd;

@@ -122,14 +122,20 @@ __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, 
     const double ru = sqrt(xu * xu + yu * yu);
     const double ru2 = ru * ru;
     double rd = ru / (1.0 + k1 * ru2 + k2 * ru2 * ru2);
-    // 100 Newton iterations (3188-3193); leaving the loop once rd is a fixed point is bit-exact
-    // because every later iteration reproduces the same rd.
+    // 100 Newton iterations (3188-3193); leaving the loop once rd is a fixed point is bit-exact because every later iteration
+    // reproduces the same rd.  In floating point the iteration often does not reach a fixed point but ends in a 2-cycle between
+    // two neighbouring doubles (then all 100 iterations ran, on every wave that had one such lane: that was 40 % of k_project's
+    // time): once the new iterate equals the one before the current, the sequence alternates for good, and the value the
+    // reference holds after its last iteration follows from the parity of the iterations left.
+    double rprev = __builtin_nan("");
     for (int it = 0; it < p.newton_iters; it++) {
         const double rd2 = rd * rd;
         const double f  = rd + k1 * rd2 * rd + k2 * rd2 * rd2 * rd - ru;
         const double ff = 1.0 + 3.0 * k1 * rd2 + 5.0 * k2 * rd2 * rd2;
         const double rn = rd - f / ff;
         if (rn == rd) break;
+        if (rn == rprev) { if ((p.newton_iters - it) & 1) rd = rn; break; }
+        rprev = rd;
         rd = rn;
     }
     double d = 1.0 + k1 * rd * rd + k2 * rd * rd * rd * rd;
