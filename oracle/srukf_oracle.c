@@ -292,11 +292,18 @@ static void distort_rw(const orc_state *st, const srukf_params *p, double uvu_x,
     double ru = sqrt(xu * xu + yu * yu);                                          /* 3183 */
     double rd = ru / (1 + p->cam_k1 * ru * ru + p->cam_k2 * pow_di(ru, 4));          /* 3184 */
     int iters = p->newton_iters;                                                  /* 3186 */
+    double rd_prev = NAN;
     for (int i = 0; i < iters; i++) {                                             /* 3188-3193 */
         f  = rd + p->cam_k1 * pow_di(rd, 3) + p->cam_k2 * pow_di(rd, 5) - ru;
         ff = 1.0 + 3.0 * p->cam_k1 * rd * rd + 5.0 * p->cam_k2 * pow_di(rd, 4);
         double rd_new = rd - f / ff;
-        if (st && st->newton_early_exit && rd_new == rd) { rd = rd_new; break; }   /* fixed point: later iterations are idempotent */
+        if (st && st->newton_early_exit) {
+            if (rd_new == rd) { rd = rd_new; break; }                             /* fixed point: later iterations are idempotent */
+            /* 2-cycle between neighbouring doubles (the usual end of this iteration in floating point): the sequence alternates
+             * from here on, so the value after the last iteration follows from the parity of the iterations left */
+            if (rd_new == rd_prev) { if ((iters - i) & 1) rd = rd_new; break; }
+        }
+        rd_prev = rd;
         rd = rd_new;
     }
     double d = 1 + p->cam_k1 * rd * rd + p->cam_k2 * pow_di(rd, 4);                  /* 3195 */

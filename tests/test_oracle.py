@@ -34,6 +34,22 @@ def test_g2_projection_golden_and_numpy(oracle, golden, synth):
     assert np.allclose(g["uv"][1], g["uv"][2]) and 0 < g["uv"][1][0] < 0.1
 
 
+def test_newton_early_exit_is_bit_exact_on_random_points(oracle, synth):
+    """The 100 Newton iterations of distortOnePointRW (SLAM.cpp:3186-3193) either reach a fixed point or fall into a 2-cycle
+    between neighbouring doubles; both exits (the device's srukf_project takes them too) reproduce the full loop bit for bit."""
+    p = synth.default_params()
+    rng = np.random.default_rng(7)
+    M = 20000
+    feat = np.column_stack([rng.uniform(-2, 2, M), rng.uniform(-1, 1, M), rng.uniform(-2, 2, M), rng.uniform(-0.8, 0.8, M),
+                            rng.uniform(-0.5, 0.5, M), rng.uniform(0.05, 1.0, M)])
+    pos = np.column_stack([rng.uniform(-0.5, 0.5, M), rng.uniform(-0.2, 0.2, M), rng.uniform(-0.5, 0.5, M)])
+    psi = rng.uniform(-0.6, 0.6, M); err = rng.normal(0, 1.0, (M, 2))
+    full = oracle.project(p, feat, pos, psi, err, early_exit=0)
+    fast = oracle.project(p, feat, pos, psi, err, early_exit=1)
+    assert np.array_equal(full, fast)
+    assert (full != 0).any(axis=1).mean() > 0.2                         # a good share of the points is inside the image
+
+
 def test_projection_quirks(oracle, synth):
     p = synth.default_params()
     feat = np.array([[0, 0, 0, 0.05, -0.02, 1 / 3.0]])
