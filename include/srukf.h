@@ -183,8 +183,8 @@ int  srukf_get_match_patch(srukf_ctx* ctx, int k, unsigned char* out);
  *   refactorisation is ONE persistent launch that may use every CU and whose workgroups all have to be resident.
  * SRUKF_GPU_SHARED: several filters replay concurrently on this GPU (one context and stream each).  The persistent launch keeps
  *   to half the CUs and starts behind an admission gate that lets at most two such launches of the process run at a time, so
- *   the launches that run together are always resident together (measured at N = 200: one filter 4 330 frames/s, two 7 900,
- *   three 10 400 aggregate).  Each filter's stream should have a hardware queue of its own: the ROCm runtime maps streams onto
+ *   the launches that run together are always resident together (measured at N = 200: one filter 4 500 frames/s, two 8 000,
+ *   three 10 600 aggregate).  Each filter's stream should have a hardware queue of its own: the ROCm runtime maps streams onto
  *   GPU_MAX_HW_QUEUES = 4 queues by default, and streams that share one serialise — export GPU_MAX_HW_QUEUES=8 before the process
  *   initialises HIP when it holds more than four streams.
  * SRUKF_GPU_SHARED_PER_PANEL: one launch per 64-row panel, no residency assumption at all (other kernels of unknown size and
