@@ -106,6 +106,14 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; }
 }
 __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base = traj_base; }
+// start of a staged replay: frame counter, flags and trajectory base in one launch
+__global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* traj_base)
+{
+    fs->frame = frame;
+    fs->stat_count = 0;
+    fs->traj_base = traj_base;
+    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; }
+}
 
 // ---- NEED_REORDER helpers (GSLCholeskyUpdate, SLAM.cpp:2122-2138) -------------------------------
 // dst = P^T src P on the upper triangle of a symmetric matrix stored upper: dst[a][b] = src[ip[a]][ip[b]] (a <= b),
@@ -273,6 +281,7 @@ struct srukf_ctx {
     // one captured frame (BATCHED, staged inputs): replayed by srukf_run_frames_async
     hipGraph_t graph = nullptr, graph8 = nullptr;          // one frame / SRUKF_GRAPH_FRAMES frames
     hipGraphExec_t graph_exec = nullptr, graph8_exec = nullptr;
+    hipGraph_t graphN = nullptr; hipGraphExec_t graphN_exec = nullptr; int graphN_frames = 0;   // srukf_prepare_frames: a whole block of frames in ONE graph
     bool use_graph = true;
     // profiling
     bool profiling = false;
@@ -833,6 +842,8 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graph) hipGraphDestroy(c->graph);
     if (c->graph8_exec) hipGraphExecDestroy(c->graph8_exec);
     if (c->graph8) hipGraphDestroy(c->graph8);
+    if (c->graphN_exec) hipGraphExecDestroy(c->graphN_exec);
+    if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
                      c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
@@ -1141,6 +1152,9 @@ static void drop_graphs(srukf_ctx* c)
     if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     if (c->graph8_exec) { hipGraphExecDestroy(c->graph8_exec); c->graph8_exec = nullptr; }
     if (c->graph8) { hipGraphDestroy(c->graph8); c->graph8 = nullptr; }
+    if (c->graphN_exec) { hipGraphExecDestroy(c->graphN_exec); c->graphN_exec = nullptr; }
+    if (c->graphN) { hipGraphDestroy(c->graphN); c->graphN = nullptr; }
+    c->graphN_frames = 0;
 }
 int srukf_set_exclusive(srukf_ctx* c, int exclusive)
 {
@@ -1472,6 +1486,9 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
     if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     if (c->graph8_exec) { hipGraphExecDestroy(c->graph8_exec); c->graph8_exec = nullptr; }
     if (c->graph8) { hipGraphDestroy(c->graph8); c->graph8 = nullptr; }
+    if (c->graphN_exec) { hipGraphExecDestroy(c->graphN_exec); c->graphN_exec = nullptr; }
+    if (c->graphN) { hipGraphDestroy(c->graphN); c->graphN = nullptr; }
+    c->graphN_frames = 0;
     HIPCHK(c, srukf_dmalloc((void**)&c->odo_seq, sizeof(double) * 3 * (F + 1)));
     HIPCHK(c, srukf_dmalloc((void**)&c->z_seq, sizeof(double) * (size_t)F * 2 * N));
     HIPCHK(c, srukf_dmalloc((void**)&c->m_seq, sizeof(int) * (size_t)F * N));
@@ -1482,6 +1499,37 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
     return SRUKF_OK;
 }
 
+static void replay_one_frame(srukf_ctx* c)
+{
+    seq_predict_motion(c, nullptr);
+    seq_predict_measurement(c, true);
+    seq_gain(c, nullptr, nullptr, true);
+    seq_refactor(c, 0, c->d.mp, false, false, false, true);
+}
+static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec_t* ge)
+{
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int q = 0; q < nframes; q++) replay_one_frame(c);
+    HIPCHK(c, hipStreamEndCapture(c->stream, g));
+    HIPCHK(c, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+    return SRUKF_OK;
+}
+// A block of `count` staged frames as ONE captured graph for the next srukf_run_frames_async(ctx, *, count, ...) calls (the default
+// is graphs of 8 frames + single frames; between two graph launches the device idles for ~10 us, which shows in short blocks).
+// Nothing runs; the graph is dropped with the others whenever the launch sequence changes.  count <= 512.
+int srukf_prepare_frames(srukf_ctx* c, int count)
+{
+    if (!c || count < 1 || count > 512) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->use_graph || (c->graphN_exec && c->graphN_frames == count)) return SRUKF_OK;
+    if (c->graphN_exec) { hipGraphExecDestroy(c->graphN_exec); c->graphN_exec = nullptr; }
+    if (c->graphN) { hipGraphDestroy(c->graphN); c->graphN = nullptr; }
+    c->graphN_frames = 0;
+    const int rc = capture_frames(c, count, &c->graphN, &c->graphN_exec);
+    if (rc) return rc;
+    c->graphN_frames = count;
+    return SRUKF_OK;
+}
 int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double* d_traj)
 {
     if (!c || first < 0 || count < 1) return SRUKF_ERR_BAD_ARG;
@@ -1489,36 +1537,26 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     if (mode != SRUKF_UPDATE_BATCHED) { c->err = "run_frames_async supports BATCHED only (SEQUENTIAL needs a host check per column)"; return SRUKF_ERR_UNSUPPORTED; }
     HIPCHK(c, hipSetDevice(c->device));
     const KDims& d = c->d;
-    hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1);
     // traj rows are indexed by the absolute frame counter; offset so that frame `first` lands in row 0
     double* traj = d_traj ? d_traj - (size_t)8 * first : nullptr;
-    hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, traj);
-    auto one_frame = [&]() {
-        seq_predict_motion(c, nullptr);
-        seq_predict_measurement(c, true);
-        seq_gain(c, nullptr, nullptr, true);
-        seq_refactor(c, 0, d.mp, false, false, false, true);
-    };
+    hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1, traj);
     if (c->use_graph && !c->profiling) {
         // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
         // captured frame replays for all frames: the 45 launches cost one hipGraphLaunch on the host
         if (!c->graph_exec) {
-            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            one_frame();
-            HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
-            HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+            int rc = capture_frames(c, 1, &c->graph, &c->graph_exec); if (rc) return rc;
             // and a graph of SRUKF_GRAPH_FRAMES consecutive frames: one host launch per 8 frames keeps the host
             // ahead of the device when several filters share one host thread
-            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            for (int q = 0; q < SRUKF_GRAPH_FRAMES; q++) one_frame();
-            HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph8));
-            HIPCHK(c, hipGraphInstantiate(&c->graph8_exec, c->graph8, nullptr, nullptr, 0));
+            rc = capture_frames(c, SRUKF_GRAPH_FRAMES, &c->graph8, &c->graph8_exec); if (rc) return rc;
         }
-        int f = 0;
-        for (; f + SRUKF_GRAPH_FRAMES <= count; f += SRUKF_GRAPH_FRAMES) HIPCHK(c, hipGraphLaunch(c->graph8_exec, c->stream));
-        for (; f < count; f++) HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+        if (c->graphN_exec && c->graphN_frames == count) HIPCHK(c, hipGraphLaunch(c->graphN_exec, c->stream));   // srukf_prepare_frames
+        else {
+            int f = 0;
+            for (; f + SRUKF_GRAPH_FRAMES <= count; f += SRUKF_GRAPH_FRAMES) HIPCHK(c, hipGraphLaunch(c->graph8_exec, c->stream));
+            for (; f < count; f++) HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+        }
     } else {
-        for (int f = 0; f < count; f++) one_frame();
+        for (int f = 0; f < count; f++) replay_one_frame(c);
     }
     c->async_pending = true;
     c->phase = 0;

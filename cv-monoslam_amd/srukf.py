@@ -23,7 +23,7 @@ EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
-    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_run_frames_batch", "srukf_debug_poke_state", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
+    "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_run_frames_batch", "srukf_prepare_frames", "srukf_debug_poke_state", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_clamp_info", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
@@ -109,6 +109,7 @@ def load_library():
     L.srukf_set_storage.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_exclusive.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_rank_aware.argtypes = [C.c_void_p, C.c_int]
+    L.srukf_prepare_frames.argtypes = [C.c_void_p, C.c_int]
     L.srukf_debug_poke_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
     L.srukf_run_frames_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.srukf_null_directions.argtypes = [C.c_void_p]
@@ -305,6 +306,10 @@ class Filter:
         assert odo.shape == (F + 1, 3) and z.shape == (F, 2 * self.N) and m.shape == (F, self.N)
         self._chk(self._lib.srukf_stage_sequence(self._h, F, _d(odo), _d(z), _i(m)))
         self.F = F
+
+    def prepare_frames(self, count):
+        """Capture `count` staged frames as one graph for the following run_frames_async(*, count) calls (nothing runs)."""
+        self._chk(self._lib.srukf_prepare_frames(self._h, int(count)))
 
     def run_frames_async(self, first, count, mode=UPDATE_BATCHED, d_traj_ptr=None):
         self._chk(self._lib.srukf_run_frames_async(self._h, first, count, mode,

@@ -233,6 +233,10 @@ int  srukf_run_frames(srukf_ctx* ctx, int first, int count, int mode, double* tr
  * the modified Cholesky: the frames BEFORE the first such frame are valid, that frame and the later ones are not
  * (srukf_clamp_info names it; restore the state the block started from and use srukf_run_frames or the step-wise API). */
 int  srukf_synchronize(srukf_ctx* ctx);
+/* Optional: capture a block of `count` staged frames as ONE graph for the following srukf_run_frames_async calls with that count
+ * (default: graphs of 8 frames + single frames; the device idles ~10 us between two graph launches, which shows in short blocks).
+ * Nothing is executed.  1 <= count <= 512. */
+int  srukf_prepare_frames(srukf_ctx* ctx, int count);
 /* B filters (independent sequences over the same frame range: the Monte-Carlo use, MonoSLAMView.cpp:526-572 once per run) replayed
  * concurrently on one GPU: frames are issued round-robin in chunks so that the filters' launches interleave, then all are awaited;
  * filters still in SRUKF_GPU_EXCLUSIVE are switched to SRUKF_GPU_SHARED.  A filter with a flagged frame in its block is rerun
