@@ -386,3 +386,23 @@ def test_rank_aware_notices_a_direction_that_is_not_null(srukf, oracle, synth):
         X, S = f.get_state(); Xo, So = o.get_state()
         np.testing.assert_allclose(X, Xo, rtol=0, atol=1e-9)
         np.testing.assert_allclose(S.T @ S, So.T @ So, rtol=0, atol=1e-11)
+
+
+def test_prepared_block_graph_gives_the_same_frames(srukf, synth):
+    """srukf_prepare_frames: a block of frames captured as ONE graph replays to the bit what the 8-frame / single-frame graphs
+    and the eager launches compute; a later call with another count falls back to the default graphs."""
+    p = synth.scene_params()
+    N, F = 50, 27
+    sc = synth.make_scene(N, F, seed=3, p=p)
+    res = []
+    for prep in (0, 19):
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        if prep:
+            f.prepare_frames(prep)
+        import torch
+        dt = torch.zeros(F, 8, dtype=torch.float64, device="cuda")
+        f.run_frames_async(0, 19, d_traj_ptr=dt.data_ptr()); f.synchronize()            # the prepared count
+        f.run_frames_async(19, 8, d_traj_ptr=dt.data_ptr() + 8 * 8 * 19); f.synchronize()  # another count: default graphs
+        res.append((dt.cpu().numpy(),) + f.get_state()); f.close()
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
