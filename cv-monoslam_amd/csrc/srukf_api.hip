@@ -11,6 +11,7 @@
 #include <vector>
 #include <algorithm>
 #include <utility>
+#include <atomic>
 #include "srukf_device.h"
 #include "srukf_rank.h"
 
@@ -69,11 +70,12 @@ int srukf_app_tmpl_stride(void);
 // null stream it is ordered on; every free below happens after the streams that used the block have been synchronised.
 static void srukf_pool_init()
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
+    static std::atomic<unsigned long long> done_mask{0};       // one bit per device: every device's pool is set up once, by whichever thread gets there first
     int dev = 0; hipMemPool_t pool = nullptr;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    const unsigned long long bit = 1ull << dev;
+    if (done_mask.fetch_or(bit) & bit) return;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
         unsigned long long keep = ~0ull;
         hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
@@ -103,7 +105,7 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
     fs->frame = frame;
     fs->stat_count = 0;
     fs->traj_base = nullptr;
-    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; }
+    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
 }
 __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base = traj_base; }
 // start of a staged replay: frame counter, flags and trajectory base in one launch
@@ -112,7 +114,7 @@ __global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* 
     fs->frame = frame;
     fs->stat_count = 0;
     fs->traj_base = traj_base;
-    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; }
+    if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
 }
 
 // ---- NEED_REORDER helpers (GSLCholeskyUpdate, SLAM.cpp:2122-2138) -------------------------------
@@ -1159,6 +1161,7 @@ static void drop_graphs(srukf_ctx* c)
 int srukf_set_exclusive(srukf_ctx* c, int exclusive)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));                         // the plans below size themselves on the CURRENT device's CU count
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int shared = exclusive == SRUKF_GPU_SHARED ? 1 : exclusive == SRUKF_GPU_SHARED_PER_PANEL ? 2 : 0;
     if (shared == c->gmw_shared) return SRUKF_OK;
@@ -1413,6 +1416,8 @@ static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     std::swap(*c, *c2);
     c->own_stream = own; c2->own_stream = false;
     c->profiling = c2->profiling; c->use_graph = c2->use_graph;
+    // per-context switches the caller set on the handle survive the rebuild (before srukf_set_storage / update_null_set run on it)
+    c->rank_aware = c2->rank_aware; c->debug_allow_mixed = c2->debug_allow_mixed; c->debug_starve = c2->debug_starve;
     const int shared = c2->gmw_shared;
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
@@ -1510,7 +1515,9 @@ static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec
 {
     HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     for (int q = 0; q < nframes; q++) replay_one_frame(c);
+    const hipError_t launch_err = hipGetLastError();            // a failed launch inside the capture must not leave the stream capturing
     HIPCHK(c, hipStreamEndCapture(c->stream, g));
+    HIPCHK(c, launch_err);
     HIPCHK(c, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
     return SRUKF_OK;
 }
@@ -1522,7 +1529,7 @@ int srukf_prepare_frames(srukf_ctx* c, int count)
     if (!c || count < 1 || count > 512) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->use_graph || (c->graphN_exec && c->graphN_frames == count)) return SRUKF_OK;
-    if (c->graphN_exec) { hipGraphExecDestroy(c->graphN_exec); c->graphN_exec = nullptr; }
+    if (c->graphN_exec) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipGraphExecDestroy(c->graphN_exec); c->graphN_exec = nullptr; }   // a launch of the old one may still be in flight
     if (c->graphN) { hipGraphDestroy(c->graphN); c->graphN = nullptr; }
     c->graphN_frames = 0;
     const int rc = capture_frames(c, count, &c->graphN, &c->graphN_exec);
@@ -1654,8 +1661,8 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
     int rc = SRUKF_OK;
     for (int b = 0; b < B && rc == SRUKF_OK; b++) {
         srukf_ctx* c = ctxs[b];
-        if (B > 1 && c->gmw_shared == 0) rc = srukf_set_exclusive(c, SRUKF_GPU_SHARED);
-        if (rc == SRUKF_OK && hipSetDevice(c->device) != hipSuccess) rc = SRUKF_ERR_HIP;
+        if (hipSetDevice(c->device) != hipSuccess) rc = SRUKF_ERR_HIP;
+        if (rc == SRUKF_OK && B > 1 && c->gmw_shared == 0) rc = srukf_set_exclusive(c, SRUKF_GPU_SHARED);
         if (rc == SRUKF_OK && srukf_dmalloc((void**)&dt[b], sizeof(double) * 8 * (size_t)count) != hipSuccess) { c->err = "run_frames_batch: out of device memory"; rc = SRUKF_ERR_NOMEM; }
         if (rc == SRUKF_OK && !c->ckS) {                        // the state before the block, for the recovery of a flagged filter
             const size_t np = c->d.np;

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
         }
     }
     // ---- control (SLAM.cpp:1444-1458) ----
+    bool freeze = false;
     if (tid == 0) {
         const double* o = odo_pair ? odo_pair : (odo_seq + 3 * fs->frame);
         double ut[3], mt[3];
@@ -109,11 +110,14 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
         // staged replay: the previous frame's refactorisation was flagged (theta clamp / abandoned launch) -> remember which
         if (!odo_pair && fs->clamp_rows > 0) {
             if (fs->clamp_frame == 0x7fffffff) fs->clamp_frame = fs->frame - 1;
-            fs->frozen = 1;                                    // the rest of this frame and all later frames of the run return at once
+            freeze = true;
         }
         if (odo_pair) fs->frozen = 0;                          // step-wise API: the host has taken over
     }
     __syncthreads();
+    // written only now: every wave has read the flag at the top before it reached this barrier, so the early return there is
+    // uniform over the workgroup.  The rest of this frame and all later frames of the run return at once.
+    if (freeze) fs->frozen = 1;
     const double rot1 = sh[0], trans = sh[1], rot2 = sh[2];
     const double xr[4] = { sh[6], sh[7], sh[8], sh[9] };
     const double crot2 = sh[10], srot2 = sh[11];

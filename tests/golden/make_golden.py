@@ -98,7 +98,33 @@ def g6_trajectory():
                 clamps_seq=np.array(list(o.clamp_stats().values())), clamps_bat=np.array(list(o2.clamp_stats().values())))
 
 
+def g7_sequential(N, F, seed):
+    """The reference's own structure (2M refactors per frame, SLAM.cpp:2066-2095, 2116-2154) at the benchmark sizes: what the
+    BATCHED device path (one refactor per frame) is held to.  N = 200: one frame is ~3 minutes of single-thread CPU.
+    The full P (11.6 MB at N = 200) is not stored: the state, diag P, the robot columns of P, every landmark's 6 x 6 block
+    and P V for 16 seeded +-1 probe vectors are (an error matrix E shows in E V with |E V| >= |E|max for almost every V)."""
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=seed, p=p)
+    o = O.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    traj = o.run_frames(sc["odo"], sc["z"], sc["matched"], O.Oracle.SEQUENTIAL)
+    X, S = o.get_state()
+    P = S.T @ S
+    n = 6 * N + 4
+    V = np.random.default_rng(700 + N).choice([-1.0, 1.0], size=(n, 16))
+    blocks = np.stack([P[6 * k:6 * k + 6, 6 * k:6 * k + 6] for k in range(N)])
+    return dict(N=N, F=F, seed=seed, traj=traj, X=X, P_diag=np.diag(P).copy(), P_robot_cols=P[:, n - 4:].copy(), P_blocks=blocks, V=V, PV=P @ V,
+                P_absmax=np.abs(P).max(), clamps=np.array(list(o.clamp_stats().values())))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        # separate (slow) target:  python tests/golden/make_golden.py g7 [n50|n200]
+        which = sys.argv[2:] or ["n50", "n200"]
+        if "n50" in which:
+            np.savez_compressed(os.path.join(OUT, "g7_sequential_n50.npz"), **g7_sequential(50, 2, 71))
+        if "n200" in which:
+            np.savez_compressed(os.path.join(OUT, "g7_sequential_n200.npz"), **g7_sequential(200, 1, 72))
+        sys.exit(0)
     np.savez_compressed(os.path.join(OUT, "g1_weights.npz"), table=g1_weights())
     np.savez_compressed(os.path.join(OUT, "g2_projection.npz"), **g2_projection())
     np.savez_compressed(os.path.join(OUT, "g3_gmw.npz"), **g3_gmw())
