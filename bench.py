@@ -108,7 +108,23 @@ def spawn_ranks(nproc, argv, timeout=None):
     return r.returncode, line
 
 
-def launch_selftest(rank, world):
+def collectives_check(timeout=240):
+    """The RCCL calls of the N-rank path (init_process_group("nccl"), broadcast of the map, barrier, max all-reduce, all-gather of the
+    trajectories) executed once on THIS box: a short `--gpus 1 --force-dist` run in child processes (torch.distributed.run -> one
+    rank).  Never fails the line: the outcome is reported."""
+    try:
+        rc, line = spawn_ranks(1, ["--gpus", "1", "--force-dist", "--steps", "8", "--warmup", "2", "--profile-frames", "4", "--no-cpu-baseline",
+                                   "--sequences-per-gpu", "0"], timeout=timeout)
+        if rc != 0 or not line:
+            return {"ok": False, "returncode": rc}
+        d = json.loads(line)
+        return {"ok": d.get("collectives") == "nccl" and d.get("n_gpus") == 1, "collectives": d.get("collectives"), "n_gpus": d.get("n_gpus"),
+                "frames_per_s": d.get("value"), "how": "python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --force-dist (child processes)"}
+    except Exception as e:                                     # noqa: BLE001 - a report, not a gate
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"}
+
+
+def launch_selftest(rank, world, force=False):
     """`--launch-selftest`: the launcher and every collective of the N-rank run on the gloo backend with CPU
     tensors and NO filter (tests/test_distributed_cpu.py; this container has no GPU).  Exercises: spawn, rendezvous,
     broadcast of rank 0's map, max-over-ranks of the wall time, all-gather of the trajectories, one JSON line whose
@@ -117,15 +133,16 @@ def launch_selftest(rank, world):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    if world > 1:
+    use_dist = world > 1 or force                              # --force-dist: one rank goes through the same calls
+    if use_dist:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     n = 16
     sc = {"X0": np.full(n, 1.0 + rank), "S0": np.triu(np.full((n, n), 2.0 + rank))}
-    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, torch.device("cpu"))
+    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, torch.device("cpu"), force=use_dist)
     same = bool((X0 == 1.0).all() and (S0 == torch.triu(torch.full((n, n), 2.0, dtype=torch.float64))).all())
     traj = torch.full((3, 8), float(rank), dtype=torch.float64)
     tt = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         allt = [torch.empty_like(traj) for _ in range(world)]
@@ -136,8 +153,8 @@ def launch_selftest(rank, world):
     ok = same and [float(t[0, 0]) for t in allt] == [float(r) for r in range(world)]
     if rank == 0:
         print(json.dumps({"metric": "srukf_updates_per_sec", "value": None, "unit": "frames/s", "n_gpus": seen,
-                          "selftest": True, "collectives_ok": ok, "wall_max": float(tt.item()), "scaling": "weak"}))
-    if world > 1:
+                          "selftest": True, "collectives_ok": ok, "collectives": (dist.get_backend() if use_dist else None), "wall_max": float(tt.item()), "scaling": "weak"}))
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -148,14 +165,14 @@ def build_inputs(synth, N, F, rank, map_seed=0):
     return synth.make_scene(N, F, seed=map_seed, p=synth.scene_params(), obs_seed=1000 + rank)
 
 
-def broadcast_map(torch, dist, sc, n, rank, world, device):
+def broadcast_map(torch, dist, sc, n, rank, world, device, force=False):
     """RCCL broadcast of the shared initial map (X0: n doubles, S0: n*n doubles) from rank 0."""
     X = torch.empty(n, dtype=torch.float64, device=device)
     S = torch.empty(n, n, dtype=torch.float64, device=device)
     if rank == 0:
         X.copy_(torch.from_numpy(sc["X0"]))
         S.copy_(torch.from_numpy(np.ascontiguousarray(sc["S0"])))
-    if world > 1:
+    if world > 1 or force:
         dist.broadcast(X, src=0)
         dist.broadcast(S, src=0)
     return X, S
@@ -276,9 +293,14 @@ def main():
                     help="extra measurement: B concurrent independent sequences on one GPU (0 = skip)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="CPU/gloo check of the N-rank launcher and collectives only (no filter, no GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="go through torch.distributed.run -> init_process_group('nccl') -> broadcast / all-reduce / all-gather even with ONE rank "
+                         "(the only way the RCCL calls of the N-rank path execute on a 1-GPU box)")
+    ap.add_argument("--no-collectives-check", action="store_true",
+                    help="skip the short --force-dist child run whose outcome the default 1-GPU line reports as `collectives_check`")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become the launcher.  Nothing in this process has touched torch / HIP yet.
         rc, line = spawn_ranks(args.gpus, sys.argv[1:])
         if line:
@@ -290,7 +312,7 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
     if args.launch_selftest:
-        raise SystemExit(launch_selftest(rank, world))
+        raise SystemExit(launch_selftest(rank, world, args.force_dist))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -301,15 +323,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist                    # --force-dist: the collectives run with one rank too
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     N, K, W, PF = args.landmarks, args.steps, args.warmup, args.profile_frames
     n = 6 * N + 4
     F = W + K + PF + 4
     sc = build_inputs(synth, N, F, rank)
-    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, device)
+    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, device, force=use_dist)
 
     # a dedicated HIP stream shared by torch (events, barriers) and the filter (kernel launches):
     # torch.cuda.Event only sees work on the stream it is recorded on
@@ -321,7 +345,7 @@ def main():
     traj = torch.zeros(F, 8, dtype=torch.float64, device=device)
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -355,12 +379,12 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     tt = torch.tensor([wall], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wall_max = float(tt.item())
 
     # gather trajectories (end-of-run all-gather, nothing per frame)
-    if world > 1:
+    if use_dist:
         allt = [torch.empty_like(traj) for _ in range(world)]
         dist.all_gather(allt, traj)
     else:
@@ -398,6 +422,7 @@ def main():
             "frame_alg_gflop": sum(v["alg_flops"] for v in prof.values()) / PF / 1e9,
             "frame_full_rank_gflop": w_alg(N) / 1e9,
             "frame_mfma_frac": sum(v["alg_flops"] for v in prof.values()) / PF * (K / wall_max) / (FP64_MFMA_PEAK_TFLOPS * 1e12),
+            "collectives": (dist.get_backend() if use_dist else None),     # "nccl" = RCCL: broadcast of the map, barrier, max all-reduce, all-gather all ran
             "null_directions_skipped": f.null_directions(),
             "device_ms_per_step": dev_ms / K,
             "pose_rmse_vs_truth_m": pose_rmse_truth,
@@ -435,8 +460,10 @@ def main():
                                    "reference_structure_1_thread": out["value"] / cb["faithful_value"]}
             out["pose_rmse_vs_oracle_m"] = float(np.sqrt(np.mean((gt[:, :2] - otraj[:, :2]) ** 2)))
             out["max_abs_dP_robot_vs_oracle"] = float(np.abs(gt[:, 4:] - otraj[:, 4:]).max())
+        if world == 1 and not use_dist and not args.no_collectives_check:
+            out["collectives_check"] = collectives_check()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

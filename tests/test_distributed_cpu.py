@@ -60,3 +60,14 @@ def test_bench_gpus_flag_fails_in_the_children_without_gpus():
         return
     assert r.returncode != 0
     assert "no CPU fallback" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_force_dist_one_rank_goes_through_the_collectives():
+    """`--gpus 1 --force-dist`: the launcher starts ONE rank and that rank still initialises the process group and runs the
+    broadcast / barrier / all-reduce / all-gather (gloo here; the -m gpu twin of this test runs the same with nccl = RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--launch-selftest"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["collectives_ok"] and d["collectives"] == "gloo"

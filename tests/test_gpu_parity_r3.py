@@ -51,3 +51,21 @@ def test_map_changes_keep_the_context_switches(srukf, synth):
     assert f.null_directions() > 0
     f.delete_landmark(0)
     assert f.null_directions() > 0
+
+
+def test_bench_force_dist_runs_the_rccl_collectives_with_one_rank():
+    """`bench.py --gpus 1 --force-dist`: torch.distributed.run -> one rank -> init_process_group("nccl") -> broadcast of the map ->
+    barrier -> max all-reduce -> all-gather of the trajectories.  On a 1-GPU box this is the only way the RCCL calls of the
+    N-rank path execute at all.  Fresh child processes; nothing is re-exec'ed."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "6", "--warmup", "2",
+                        "--profile-frames", "4", "--no-cpu-baseline", "--sequences-per-gpu", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["collectives"] == "nccl" and d["steps"] == 6
+    assert d["value"] > 100 and d["pose_rmse_vs_truth_m"] < 1e-3
