@@ -45,8 +45,9 @@ void CSLAM::initializeParameters()
     m_frame.stop = m_frame.start + CAPACITY;                                       // 244-246
     m_frame.index = m_frame.start;
     m_frame.counter = 1;
-    m_odoCounter = 0; m_showCounter = 1;
+    m_odoCounter = 0; m_showCounter = 1; ID = 1;                                   // 248
     m_nMapFeatures = m_nPredicts = m_nMatches = m_nAddings = 0;
+    m_nDeletes = m_nStores = 0; m_deleteID.clear(); isAdding = false;
     m_frameTime = m_totalTime = 0;
     mapStore.clear(); relinkMap();
 }
@@ -73,7 +74,8 @@ bool CSLAM::setMap(int N, const double* X, const double* S, const double* px, in
     const int n = 6 * N + 4;
     m_X_k.create(n, 1); m_S_k.create(n, n); m_P_k.create(n, n);
     mapStore.assign(N, PointsMap()); relinkMap();
-    for (int k = 0; k < N; k++) { map[k].ID = k + 1; if (px) { map[k].initPixel.x = px[2 * k]; map[k].initPixel.y = px[2 * k + 1]; } }
+    ID = 1;
+    for (int k = 0; k < N; k++) { map[k].ID = ID++; if (px) { map[k].initPixel.x = px[2 * k]; map[k].initPixel.y = px[2 * k + 1]; } }
     m_nMapFeatures = N;
     m_nAddings = n_added;    // 0 = steady state: FLAG_4_NEEDNOT_REORDER (SLAM.cpp:2083-2090)
     if (n_added > 0 && !check(srukf_set_new_landmarks(ctx_, n_added))) return false;                           // m_nFilters, 758-766
@@ -91,7 +93,7 @@ bool CSLAM::integrateFeaturesInformation(int K, const double* kp)
     if (!check(srukf_add_landmarks(ctx_, K, kp))) return false;
     const int N = m_nMapFeatures + K, n = 6 * N + 4;
     m_X_k.create(n, 1); m_S_k.create(n, n); m_P_k.create(n, n);
-    for (int k = 0; k < K; k++) { PointsMap pm; pm.ID = m_nMapFeatures + k + 1; pm.initPixel.x = kp[2 * k]; pm.initPixel.y = kp[2 * k + 1]; mapStore.push_back(pm); }
+    for (int k = 0; k < K; k++) { PointsMap pm; pm.ID = ID++; pm.initPixel.x = kp[2 * k]; pm.initPixel.y = kp[2 * k + 1]; mapStore.push_back(pm); }
     relinkMap();
     m_nMapFeatures = N;                                                                                         // 766
     m_nAddings = K;                                                                                             // 758-765 (m_nFilters = m_nAddings = counter)
@@ -135,7 +137,7 @@ bool CSLAM::dataAssociationOnDevice(const unsigned char* gray)
 }
 
 // ---- display accessors -----------------------------------------------------------------------------------------
-bool CSLAM::updateFeaturesInformation()
+bool CSLAM::refreshFeaturesDisplay()
 {
     const int N = m_nMapFeatures;
     if (!ctx_ || N == 0) return true;
@@ -146,6 +148,57 @@ bool CSLAM::updateFeaturesInformation()
         map[k].xyz.x = xyz[3 * k]; map[k].xyz.y = xyz[3 * k + 1]; map[k].xyz.z = xyz[3 * k + 2];
         for (int e = 0; e < 9; e++) { map[k].cov[e] = cov[9 * (size_t)k + e]; c.data[e] = map[k].cov[e]; }
         get3DdisplayInformation(map[k].axis, map[k].sigma, c);                                                 // 2575
+    }
+    return true;
+}
+
+// SLAM.cpp:2397-2621.  m_P_k = S^T S (2404) is what refreshMirrors / the device accessors stand for.
+bool CSLAM::updateFeaturesInformation()
+{
+    if (!m_nMapFeatures || !ctx_) return true;                                                                  // 2399-2402
+    if (!check(srukf_get_state(ctx_, m_X_k.data.data(), nullptr))) return false;
+    if (!refreshFeaturesDisplay()) return false;                 // xyz / cov / axis / sigma from the posterior (2566-2567; also what an archived landmark takes along, 2528-2529)
+    const double imageWidth = m_params.image_w, imageHeight = m_params.image_h;
+    m_nDeletes = 0; m_nStores = 0; m_deleteID.clear();                                                           // 2419-2422
+    int id = 0;
+    PointsMap* map_p = map;
+    while (NULL != map_p) {                                                                                      // 2425
+        const int dim = m_X_k.rows;
+        const double zi = m_X_k.at(6 * id + 2, 0), theta = m_X_k.at(6 * id + 3, 0), phi = m_X_k.at(6 * id + 4, 0), rho = m_X_k.at(6 * id + 5, 0);
+        const double Hlr_z = rho * (zi - m_X_k.at(dim - 2, 0)) + cos(phi) * cos(theta);                          // 2435
+        const double px = map_p->predictLocation.x, py = map_p->predictLocation.y, dpx = imageWidth - px, dpy = imageHeight - py;
+        const bool unmatched = map_p->nPredictTimes > 2 * map_p->nMatchTimes && map_p->nPredictTimes >= 10;
+        const bool predBorder = px < DIST_2_BORDER || py < DIST_2_BORDER || dpx < DIST_2_BORDER || dpy < DIST_2_BORDER;
+        bool isDelete = unmatched || rho < 0.01 || Hlr_z < 0.0 || predBorder;                                    // 2443-2446
+        bool matchBorder = false;
+        if (map_p->isMatching) {                                                                                 // 2448-2459
+            const double mx = map_p->matchLocation.x, my = map_p->matchLocation.y;
+            matchBorder = mx < DIST_2_BORDER || my < DIST_2_BORDER || imageWidth - mx < DIST_2_BORDER || imageHeight - my < DIST_2_BORDER;
+            isDelete = isDelete || matchBorder;
+        }
+        if (isDelete) {
+            bool isNeedStore = false;
+            if (unmatched || rho < 0.01 || Hlr_z < 0.0) m_nPredicts--;                                           // 2465-2488
+            else if (predBorder) { m_nPredicts--; if (map_p->isMatching) { isNeedStore = true; m_nStores++; m_nMatches--; } }      // 2489-2502
+            else if (matchBorder) { isNeedStore = true; m_nStores++; m_nPredicts--; m_nMatches--; }              // 2503-2512
+            m_deleteID.push_back(map_p->ID);                                                                     // 2514
+            if (isNeedStore) {                                                                                   // 2516-2532
+                FeatureInfo fi;
+                fi.ID = map_p->ID; fi.isLoop = map_p->isLoop; fi.nPredictTimes = map_p->nPredictTimes; fi.nMatchTimes = map_p->nMatchTimes;
+                fi.initXYZ = map_p->xyz; fi.initPixel = map_p->initPixel;
+                for (int e = 0; e < 6; e++) fi.state[e] = m_X_k.at(6 * id + e, 0);
+                fi.position = map_p->xyz; memcpy(fi.cov, map_p->cov, sizeof fi.cov); fi.axis = map_p->axis; fi.sigma = map_p->sigma;
+                m_featuresAllInfo.push_back(fi);
+            }
+            if (!deleteOneFeature(id)) return false;                                                             // 2554 (m_nDeletes++, m_nMapFeatures--: 2662-2664)
+            m_nDeletes++;
+            map_p = (id < m_nMapFeatures) ? &mapStore[id] : nullptr;                                             // 2555-2570: the node now at position id
+        } else {
+            map_p->isVisible = false;                                                                            // 2598
+        }
+        if (id == m_nMapFeatures || !map_p) break;                                                               // 2607-2615 (a NULL node is dereferenced there)
+        id++;
+        map_p = map_p->next;
     }
     return true;
 }
@@ -258,10 +311,23 @@ bool CSLAM::loadOdometryData(const std::string& path)
         }
         return true;
     };
+    for (int skip = 1; skip < m_frame.start; skip++) if (!one(0)) break;                                       // 372-395: the origin is line m_frame.start
     if (!one(0)) { fclose(f); lastError = "empty odometry file"; return false; }
     m_odoCounter = 1;
+    // 397: the robot heading starts at the first sample's heading
+    if (m_X_k.rows >= 4) {
+        m_X_k.at(m_X_k.rows - 1, 0) = m_odoTheta.at(1, 0);
+        if (ctx_) {
+            const int dim = m_X_k.rows;
+            std::vector<double> X(dim), S((size_t)dim * dim);
+            if (!check(srukf_get_state(ctx_, X.data(), S.data()))) { fclose(f); return false; }
+            X[dim - 1] = m_odoTheta.at(1, 0);
+            if (!check(srukf_set_state(ctx_, X.data(), S.data()))) { fclose(f); return false; }
+            if (m_nAddings > 0 && !check(srukf_set_new_landmarks(ctx_, m_nAddings))) { fclose(f); return false; }
+        }
+    }
     m_odoTheta.at(2, 0) = 0;
-    while (m_odoCounter <= CAPACITY) {
+    for (int i = 0; i < m_frame.stop - m_frame.start && m_odoCounter <= CAPACITY; i++) {                       // 400
         if (!one(m_odoCounter)) break;
         bool ok = true;
         while (std::fabs(m_odoXY[2 * m_odoCounter] - m_odoXY[2 * m_odoCounter - 2]) < MIN_STEP_X &&
@@ -286,7 +352,7 @@ bool CSLAM::loadOdometryData(const std::string& path)
 bool CSLAM::redirection()
 {
     const int c = m_frame.counter, n = m_X_k.rows;
-    if (m_nMapFeatures > 0 && !updateFeaturesInformation()) return false;                                      // xyz / cov / axis / sigma of every landmark
+    if (m_nMapFeatures > 0 && !refreshFeaturesDisplay()) return false;                                         // xyz / cov / axis / sigma of every landmark
     if (!check(srukf_get_state(ctx_, m_X_k.data.data(), nullptr))) return false;
     int id = 0;
     for (const PointsMap* map_p = map; NULL != map_p; map_p = map_p->next, id++) {                             // 1357-1378
@@ -418,10 +484,16 @@ void CSLAM::SLAM()
     predictMeasurement();
     if (dataAssociation) dataAssociation(*this);                                                               // loadPictures + dataAssociation (95-97)
     KalmanUpdate();
-    refreshMirrors();                                                                                          // updateFeaturesInformation: m_P_k (2404)
+    updateFeaturesInformation();                                                                               // deletion policy + display refresh (2397-2621)
+    refreshMirrors();                                                                                          // m_P_k (2404), m_X_k, m_S_k
     updateRobotInformation();
     recordRobotInformation();
-    m_nAddings = 0;                                                                                            // addFeatures (552-554)
+    m_nAddings = 0;                                                                                            // addFeatures (552-562)
+    if ((m_nMatches < m_minNUM || isAdding) && addFeatures) {                                                  // 556: the host detects, the facade joint-initialises
+        std::vector<double> keyPoints;
+        const int K = addFeatures(*this, keyPoints);
+        if (K > 0) integrateFeaturesInformation(K, keyPoints.data());
+    }
     m_frame.counter++;                                                                                         // stopTimer 142-151
     m_frameTime = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     m_totalTime += m_frameTime;

@@ -112,9 +112,16 @@ public:
     bool dataAssociationOnDevice(const unsigned char* gray);
 
     // ---- display accessors (what OpenGlDisplay.cpp:449-583 reads per paint) ------------------------------
-    // updateFeaturesInformation's numeric part (SLAM.cpp:2566-2580): xyz, axis, sigma of every landmark of `map`, from
-    // ONE device call (srukf_get_landmarks_cartesian) instead of a pass over the n x n m_P_k per landmark
+    // updateFeaturesInformation (SLAM.cpp:2397-2621), as SLAM() calls it after KalmanUpdate: the deletion policy (2443-2460:
+    // nPredictTimes > 2 nMatchTimes with >= 10 predictions, rho < 0.01, Hlr_z < 0, predicted or matched pixel within
+    // DIST_2_BORDER of the image border) -> deleteOneFeature, landmarks that leave while matched are archived in
+    // m_featuresAllInfo (2516-2532); the landmarks that stay get xyz / axis / sigma refreshed (2566-2580) and isVisible
+    // cleared (2598).  The loop keeps the reference's traversal: the node that moves into a deleted node's place is not
+    // examined in the same call (2554-2570, 2607-2615).
     bool updateFeaturesInformation();
+    // the display part alone (2566-2580): xyz, cov, axis, sigma of every landmark of `map`, from ONE device call
+    // (srukf_get_landmarks_cartesian) instead of a pass over the n x n m_P_k per landmark
+    bool refreshFeaturesDisplay();
     // getFeatureCartesianInformation (2721-2751): xyz and cov (3x3) of landmark id from the last refresh; sr (the 6x6
     // diagonal block of m_S_k) only when fullCovariance mirrors are on, otherwise left empty
     void getFeatureCartesianInformation(Point3d& xyz, Mat& sr, Mat& cov, const int& id) const;
@@ -146,6 +153,12 @@ public:
     srukf_params m_params;               // the tunables of SLAM.cpp:172-198, 221-224, 329-337
     int    m_updateMode = SRUKF_UPDATE_BATCHED;
     int    m_nMapFeatures = 0, m_nPredicts = 0, m_nMatches = 0, m_nAddings = 0, m_odoCounter = 0, m_showCounter = 1;
+    int    m_nDeletes = 0, m_nStores = 0;    // landmarks deleted / archived by the last updateFeaturesInformation (2419-2420)
+    std::vector<int> m_deleteID;             // their IDs (m_deleteID, SLAM.h:278)
+    int    ID = 1;                           // running landmark ID (SLAM.h:202, SLAM.cpp:248, 912)
+    int    m_minNUM = 5;                     // addFeatures when fewer landmarks matched (SLAM.cpp:179, 556)
+    bool   isAdding = false;                 // forces addFeatures (SLAM.cpp:268, 556)
+    int    DIST_2_BORDER = 20;               // SLAM.cpp:48
     double m_frameTime = 0, m_totalTime = 0;
     std::vector<double> m_odoXY, m_path; // 2*(CAPACITY+1) each (SLAM.h:188-189)
     Mat    m_odoTheta;                   // 3 x (CAPACITY+1): index, theta, redirection flag (SLAM.cpp:235)

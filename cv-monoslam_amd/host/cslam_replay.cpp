@@ -5,6 +5,11 @@
 // redirect=<counter>: flags that odometry sample as a heading jump (what loadOdometryData does for |dtheta| > 45 deg,
 //   SLAM.cpp:438-445), so that predictMotion takes the redirection restart (1354-1428); the host's addFeatures callback
 //   "detects" the landmarks where the flagged frame's image shows them.
+// extra=<file>: a map that changes mid-sequence.  File: int32 K, int32 f_starve, int32 keep, double uv_new[K][2], double z_new[F][2K].
+//   In frame f_starve (0-based) only the first `keep` landmarks of the map are matched, so m_nMatches < m_minNUM and SLAM() calls
+//   the addFeatures slot (SLAM.cpp:552-562), which "detects" the K key points uv_new; from then on landmark ID N + 1 + j is measured at
+//   z_new[frame][2j..].  Landmarks leave through the deletion policy of updateFeaturesInformation (2443-2460).  Every map change is
+//   printed as an `event` line.
 // scene.bin: int32 N, int32 F, double a1..a4, double X0[n], double S0[n*n], double z[F][2N]
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +36,16 @@ int main(int argc, char** argv)
     if (argc > 5 && !strcmp(argv[5], "sequential")) SLAM.m_updateMode = SRUKF_UPDATE_SEQUENTIAL;
     int redirect = 0;
     for (int a = 5; a < argc; a++) if (!strncmp(argv[a], "redirect=", 9)) redirect = atoi(argv[a] + 9);
+    int K_new = 0, f_starve = -1, keep = 0;
+    std::vector<double> uv_new, z_new;
+    for (int a = 5; a < argc; a++) if (!strncmp(argv[a], "extra=", 6)) {
+        FILE* e = fopen(argv[a] + 6, "rb");
+        if (!e) { perror(argv[a] + 6); return 2; }
+        if (fread(&K_new, 4, 1, e) != 1 || fread(&f_starve, 4, 1, e) != 1 || fread(&keep, 4, 1, e) != 1) return 2;
+        uv_new.resize(2 * (size_t)K_new); z_new.resize((size_t)F * 2 * K_new);
+        if (fread(uv_new.data(), 8, uv_new.size(), e) != uv_new.size() || fread(z_new.data(), 8, z_new.size(), e) != z_new.size()) { fprintf(stderr, "short extra file\n"); return 2; }
+        fclose(e);
+    }
     if (!SLAM.setMap(N, X0.data(), S0.data(), nullptr)) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
     SLAM.MIN_STEP_X = SLAM.MIN_STEP_Y = 0.0;             // the synthetic odometry is already one pose per frame: keep every sample
     if (!SLAM.loadOdometryData(argv[2])) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
@@ -39,13 +54,21 @@ int main(int argc, char** argv)
     remove(argv[3]);
     SLAM.dataAssociation = [&](monoslam::CSLAM& s) {        // stands in for loadPictures + dataAssociation
         const int fr = s.m_frame.counter - 1;
-        for (int k = 0; k < N; k++) {
-            monoslam::PointsMap& p = s.map[k];
-            p.isMatching = p.isVisible;
-            p.matchLocation.x = z[(size_t)fr * 2 * N + 2 * k];
-            p.matchLocation.y = z[(size_t)fr * 2 * N + 2 * k + 1];
+        int pos = 0;
+        for (monoslam::PointsMap* mp = s.map; NULL != mp; mp = mp->next, pos++) {      // by landmark ID: the map may have changed
+            monoslam::PointsMap& p = *mp;
+            const double* zz = p.ID <= N ? &z[(size_t)fr * 2 * N + 2 * (p.ID - 1)] : &z_new[(size_t)fr * 2 * K_new + 2 * (p.ID - N - 1)];
+            p.isMatching = p.isVisible && !(fr == f_starve && pos >= keep);
+            p.matchLocation.x = zz[0];
+            p.matchLocation.y = zz[1];
         }
     };
+    if (K_new > 0)
+        SLAM.addFeatures = [&](monoslam::CSLAM& s, std::vector<double>& kp) {         // detectAndfilteringFeatures stand-in
+            kp = uv_new;
+            printf("event frame %d add %d\n", s.m_frame.counter - 1, K_new);
+            return K_new;
+        };
     if (redirect > 0) {
         SLAM.m_odoTheta.at(2, redirect) = 1;
         SLAM.addFeatures = [&](monoslam::CSLAM& s, std::vector<double>& kp) {     // detectAndfilteringFeatures stand-in
@@ -58,6 +81,7 @@ int main(int argc, char** argv)
     const int steps = redirect > 0 ? F - 1 : F;             // the restart consumes one odometry sample (1424-1425)
     for (int fr = 0; fr < steps; fr++) {                    // OnBnClickedAuto loop, MonoSLAMView.cpp:526-572
         SLAM.SLAM();
+        for (int q = 0; q < SLAM.m_nDeletes; q++) printf("event frame %d delete %d\n", fr, SLAM.m_deleteID[q]);
         if (!SLAM.lastError.empty()) { fprintf(stderr, "frame %d: %s\n", fr, SLAM.lastError.c_str()); return 1; }
         const int nn = SLAM.m_X_k.rows;
         for (int e = 0; e < 4; e++) traj[8 * fr + e] = SLAM.m_X_k.at(nn - 4 + e, 0);
@@ -68,7 +92,7 @@ int main(int argc, char** argv)
     fwrite(traj.data(), 8, traj.size(), o);
     fclose(o);
     // what the OpenGL view reads per paint (OpenGlDisplay.cpp:449-583): xyz, cov, ellipsoid axes of every landmark
-    if (!SLAM.updateFeaturesInformation()) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+    if (!SLAM.refreshFeaturesDisplay()) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
     {
         std::string fn = std::string(argv[4]) + ".features";
         FILE* ff = fopen(fn.c_str(), "wb");
