@@ -57,7 +57,9 @@ int main(int argc, char** argv)
         int pos = 0;
         for (monoslam::PointsMap* mp = s.map; NULL != mp; mp = mp->next, pos++) {      // by landmark ID: the map may have changed
             monoslam::PointsMap& p = *mp;
-            const double* zz = p.ID <= N ? &z[(size_t)fr * 2 * N + 2 * (p.ID - 1)] : &z_new[(size_t)fr * 2 * K_new + 2 * (p.ID - N - 1)];
+            // IDs run on (SLAM.cpp:912): 1..N = the scene's landmarks, N+1.. = the `extra` key points; after a redirection restart
+            // the scene's landmarks come back under new IDs, in the same order
+            const double* zz = (K_new > 0 && p.ID > N) ? &z_new[(size_t)fr * 2 * K_new + 2 * (p.ID - N - 1)] : &z[(size_t)fr * 2 * N + 2 * ((p.ID - 1) % N)];
             p.isMatching = p.isVisible && !(fr == f_starve && pos >= keep);
             p.matchLocation.x = zz[0];
             p.matchLocation.y = zz[1];

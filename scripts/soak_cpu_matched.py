@@ -22,29 +22,37 @@ m = O.Matched(N, p, threads); m.set_state(sc["X0"], sc["S0"])
 traj = np.full((F, 8), np.nan)
 first_fb, fb_prev, run, t0 = None, 0, 0, time.time()
 stopped = None
+MARKS = (100, 500, 1000, 1500, 1649, 2000, 2500, 3000)
+null = [6 * k + c for k in range(1, N) for c in range(3)]
+null_at = {}
+
+
+def null_stats():
+    X, S = m.get_state(); e = np.sum(S * S, axis=1); d = np.diag(S)
+    return dict(max_row_energy=float(e[null].max()), max_offdiag=float(np.abs(S[null] - np.diag(d)[null]).max()), min_diag=float(d.min()))
 for f in range(F):
     traj[f] = m.run_frames(sc["odo"][f:f + 2], sc["z"][f:f + 1], sc["matched"][f:f + 1])[0]
     fb = m.clamp_fallbacks()
     if fb > fb_prev:
         if first_fb is None:
             first_fb = f
-            X, S = m.get_state(); e = np.sum(S * S, axis=1); d = np.diag(S)
-            null = [6 * k + c for k in range(1, N) for c in range(3)]
-            null_info = dict(max_row_energy=float(e[null].max()), max_offdiag=float(np.abs(S[null] - np.diag(d)[null]).max()), min_diag=float(d.min()))
+            null_info = null_stats()
         run += 1
     else:
         run = 0
     fb_prev = fb
+    if f + 1 in MARKS:
+        null_at[str(f + 1)] = null_stats()
     if run >= max_fallbacks:
         stopped = f; break
     if f % 100 == 99:
         print(f"frame {f + 1}: {(f + 1) / (time.time() - t0):.1f} frames/s, fallbacks {fb}, pose err vs truth {np.abs(traj[f, :2] - sc['odo'][f + 1, :2]).max():.2e}", flush=True)
 done = (stopped + 1) if stopped is not None else F
 err = np.abs(traj[:done, :2] - sc["odo"][1:done + 1, :2]).max(axis=1)
-marks = [q for q in (100, 500, 1000, 1500, 1649, 2000, 2500, 3000) if q <= done]
+marks = [q for q in MARKS if q <= done]
 out = dict(N=N, frames_requested=F, frames_run=done, threads=m.threads, isa=m.isa, seconds=time.time() - t0,
            first_theta_clamp_frame=first_fb, clamp_fallbacks=fb_prev, stopped_after_consecutive_fallbacks=stopped is not None,
-           null_rows_at_first_clamp=null_info if first_fb is not None else None,
+           null_rows_at_first_clamp=null_info if first_fb is not None else None, null_rows_at=null_at,
            pose_at={str(q): traj[q - 1, :4].tolist() for q in marks}, P_robot_at={str(q): traj[q - 1, 4:].tolist() for q in marks},
            pose_err_vs_truth_at={str(q): float(err[q - 1]) for q in marks}, pose_err_vs_truth_max=float(err.max()),
            what="oracle/srukf_matched.c, full-rank form (every pivot factored, null pivots end at EPSILON), scene seed 0 = bench.py's")
