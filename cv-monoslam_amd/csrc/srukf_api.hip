@@ -21,13 +21,14 @@ void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const doub
 void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
-                       const double*, const int*, const int*, FrameScalars*, double*, double*, const double*, RankArgs);
+                       const double*, const int*, const int*, FrameScalars*, double*, double*, const double*, RankArgs, const double*, double*);
+void srukf_launch_project_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs);
 int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int, KWeights, MeasArgs);
-void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*, RankArgs);
+void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*, RankArgs, const double*);
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const FrameScalars*);
 int srukf_gmw_panel_bytes(void);
 int srukf_gmw_sync_bytes(int T);
@@ -56,7 +57,7 @@ int srukf_mixed_build_tasks(int np, int ue, short* out_tasks, int* out_tiles, in
 size_t srukf_mixed_part_bytes(int ntasks);
 void srukf_launch_cvt_f32(hipStream_t, size_t, const double*, float*);
 void srukf_launch_cvt_robot_cols(hipStream_t, int, int, const double*, float*);
-void srukf_launch_gain_dx(hipStream_t, int, int, const double*, double*);
+void srukf_launch_gain_dx(hipStream_t, int, int, const double*, double*, const double*);
 void srukf_launch_syrk32(hipStream_t, int, int, int, const float*, const float*, const void*, int, const void*, int, float*, double*, void*);
 int srukf_app_patch_stride(void);
 int srukf_app_tmpl_stride(void);
@@ -100,9 +101,16 @@ __global__ void k_refactor_reset(int np, unsigned long long* theta_bits, FrameSc
     if (i < np) theta_bits[i] = 0ull;
     if (i == 0 && reset_stats) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
 }
+// staged sequence: what srukf_prepare_control needs to prepare the control of a frame on the device
+__global__ void k_set_seq(FrameScalars* fs, const double* odo_seq, int seqF, double a1, double a2, double a3, double a4)
+{
+    fs->odo_seq = odo_seq; fs->seqF = seqF;
+    fs->a[0] = a1; fs->a[1] = a2; fs->a[2] = a3; fs->a[3] = a4;
+}
 __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
 {
     fs->frame = frame;
+    srukf_prepare_control(fs);
     fs->stat_count = 0;
     fs->traj_base = nullptr;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
@@ -112,6 +120,7 @@ __global__ void k_set_traj(FrameScalars* fs, double* traj_base) { fs->traj_base 
 __global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* traj_base)
 {
     fs->frame = frame;
+    srukf_prepare_control(fs);                                 // the first frame's control (k_project_motion); later ones by the frame tails
     fs->stat_count = 0;
     fs->traj_base = traj_base;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
@@ -212,13 +221,15 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
         hipStreamSynchronize(st) != hipSuccess) { gmw_plan_destroy(g, st); return SRUKF_ERR_HIP; }
     return SRUKF_OK;
 }
-// 1 = one persistent launch per factorisation (default), 0 = one launch per 64-row panel (SRUKF_GMW_PERSIST=0: A/B runs)
-static int gmw_persist_mode()
-{
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SRUKF_GMW_PERSIST"); mode = (e && e[0] == '0') ? 0 : 1; }
-    return mode;
-}
+// A/B switches of srukf_debug_set (process-wide; measurement and test knobs, all 1 in the product):
+//   gmw_persist  1 = one persistent launch per factorisation, 0 = one launch per 64-row panel
+//   gmw_fused    0 = the persistent launch reads every tile from G (k_syrk computes all of them)
+//   rank_fused   0 = the rank-aware form always goes through the full k_syrk + permutation pass
+//   rank_fold    0 = the owners never form their tiles themselves in the rank-aware replay (k_syrk over all kept rows instead)
+//   rank_aware   0 = no context looks for structurally null directions (per filter: srukf_set_rank_aware)
+//   graphs       0 = contexts created from now on launch eagerly (profilers with --pmc; per filter: key "use_graph")
+static int g_dbg_gmw_persist = 1, g_dbg_gmw_fused = 1, g_dbg_rank_fused = 1, g_dbg_rank_fold = 1, g_dbg_rank_aware = 1, g_dbg_graphs = 1;
+static int gmw_persist_mode() { return g_dbg_gmw_persist; }
 
 struct srukf_ctx {
     int device = 0;
@@ -235,6 +246,7 @@ struct srukf_ctx {
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
     bool dx_pending = false;               // k_gain left slice partials of dX that the next k_syrk must add to X
+    bool xr1_pending = false;              // replay path: the robot mean after the motion step waits in fs->Xr1 for the same launch
     // NEED_REORDER (frames that follow a landmark addition): K_new = m_nFilters, permutation between the normal and the
     // disordered layout (getPermutationMatrix, SLAM.cpp:1303-1334), disordered factor
     int K_new = 0;
@@ -262,6 +274,7 @@ struct srukf_ctx {
     int gmw_shared = 0;                    // 0: the filter has the GPU to itself; 1: shared with other filters — persistent launches of at most half the CUs behind
                                            // the admission gate (k_gmw_gate); 2: one launch per panel (forced, or after an abandoned persistent launch)
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
+    int dbg_fused_motion = 1;              // srukf_debug_set "fused_motion": replay path with the motion step inside the projection launch (k_project_motion)
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
     int clamp_frame_host = -1, clamp_row_host = -1;   // what the last SRUKF_ERR_CLAMP_PENDING was about (srukf_clamp_info)
     double *ckS = nullptr, *ckX = nullptr; // srukf_run_frames: state before the block of frames in flight (recovery from a theta-clamp frame)
@@ -388,8 +401,24 @@ static void quantize_state(srukf_ctx* c)
 static RankArgs rank_args(const srukf_ctx* c)
 {
     RankArgs ra = {};
-    if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.r = c->red_r; }
+    if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.perm = c->red_perm; ra.r = c->red_r; }
     return ra;
+}
+// fs->Xr1 for the launch that applies the pending state update (and only once)
+static const double* take_xr1(srukf_ctx* c)
+{
+    if (!c->xr1_pending) return nullptr;
+    c->xr1_pending = false;
+    return (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1));
+}
+// Replay path: motion step + projection of all sigma points in ONE launch (k_project_motion): workgroup 0 is the motion step,
+// whose results wait beside the state (fs->Xr1, Cmat) until k_gain / the dX job commit them.
+static void seq_predict_fused(srukf_ctx* c)
+{
+    const KDims& d = c->d;
+    ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N + 60.0 * d.L, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N + 8.0 * d.L + 8.0 * d.n));
+    srukf_launch_project_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
+    c->xr1_pending = true;
 }
 static void seq_predict_motion(srukf_ctx* c, const double* odo_pair_dev)
 {
@@ -413,27 +442,9 @@ static void seq_predict_measurement(srukf_ctx* c, bool fused_stats)
 // one refactorisation  S <- gmw(S^T S - U[ub:ue] U[ub:ue]^T);  slow = column-by-column path.
 // need_reset: the gamma/xi accumulators were not just cleared by k_gain (SEQUENTIAL mode, fallbacks).
 // frame_tail: the check kernel also records the trajectory row and advances the staged frame counter.
-// SRUKF_GMW_FUSED=0: the persistent launch reads every tile from G (k_syrk computes all of them): A/B runs
-static int gmw_fused_mode()
-{
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SRUKF_GMW_FUSED"); mode = (e && e[0] == '0') ? 0 : 1; }
-    return mode;
-}
-// SRUKF_RANK_FUSED=0: the rank-aware form always goes through the full k_syrk + permutation pass: A/B runs
-static int rank_fused_mode()
-{
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SRUKF_RANK_FUSED"); mode = (e && e[0] == '0') ? 0 : 1; }
-    return mode;
-}
-// SRUKF_RANK_FOLD=0: the owners never form their tiles themselves in the rank-aware replay (k_syrk over all kept rows instead): A/B runs
-static int rank_fold_mode()
-{
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SRUKF_RANK_FOLD"); mode = (e && e[0] == '0') ? 0 : 1; }
-    return mode;
-}
+static int gmw_fused_mode() { return g_dbg_gmw_fused; }
+static int rank_fused_mode() { return g_dbg_rank_fused; }
+static int rank_fold_mode() { return g_dbg_rank_fold; }
 static void shadow_rebuild(srukf_ctx* c)
 {
     if (c->red_r > 0 && c->shadowA) srukf_launch_rank_shadow(c->stream, c->d.n, c->d.np, c->red_r, c->S, c->red_perm, c->shadowA);
@@ -482,7 +493,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
             ProfScope ps(c, KC_SYRK, 2.0 * hr * n * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * ((hr + d.mp) * n + (n - rr) * (rr + d.mp)));
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -503,7 +514,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         const double rr = c->red_r, rp = 64.0 * c->red_Tp;
         {
             ProfScope ps(c, KC_SYRK, rr * rr * rr / 3.0 + rr * rr * (n - rr) + 2.0 * d.mp * (rr * n - rr * rr / 2.0) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * (rr * n + (double)d.mp * n + rp * n));
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -523,7 +534,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     if (c->storage == SRUKF_STORAGE_F32_MIXED && ub == 0 && ue == d.mp) {
         // mixed precision: the fp32 state S32 and U^T rounded once, products on the fp32 matrix pipe, chunk sums in FP64
         ProfScope ps(c, KC_SYRK, syrk_flop, 4.0 * (nn * nn + (double)(ue - ub) * nn) + 8.0 * nn * nn / 2);
-        if (c->dx_pending) srukf_launch_gain_dx(c->stream, n, np, c->dxp, c->X);
+        if (c->dx_pending) srukf_launch_gain_dx(c->stream, n, np, c->dxp, c->X, take_xr1(c));
         c->dx_pending = false;
         srukf_launch_cvt_f32(c->stream, (size_t)d.mp * np, c->Ut, c->U32);
         srukf_launch_cvt_robot_cols(c->stream, n, np, c->S, c->S32);          // the motion step's columns, computed after the state was rounded
@@ -531,7 +542,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     } else {
         ProfScope ps(c, KC_SYRK, syrk_flop * head_frac, syrk_byte * head_frac);
         srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, fused ? c->syrk_head_tiles : c->syrk_tiles,
-                          fused ? c->n_syrk_head_tiles : c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{});
+                          fused ? c->n_syrk_head_tiles : c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{}, take_xr1(c));
         c->dx_pending = false;
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
@@ -629,13 +640,13 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
     const size_t bytes = sizeof(double) * (size_t)np * np;
     if (!c->Sdis) { if (srukf_dmalloc((void**)&c->Sdis, bytes) != hipSuccess) { c->err = "out of device memory (NEED_REORDER buffer)"; return SRUKF_ERR_NOMEM; } }
     hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
-    srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{});
+    srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{}, take_xr1(c));
     c->dx_pending = false;
     for (int stage = 0; stage < 2; stage++) {
         double* out = stage == 0 ? c->Sdis : c->S;
         if (stage == 1) {
             hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
-            srukf_launch_syrk(c->stream, d, c->Sdis, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{});
+            srukf_launch_syrk(c->stream, d, c->Sdis, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{}, nullptr);
         }
         for (int slow = 0; slow < 2; slow++) {
             hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, 0, 1);
@@ -651,31 +662,33 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
     quantize_state(c);
     return SRUKF_OK;
 }
-static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats)
+// fused_motion: the frame's motion step ran inside k_project_motion: the statistics take the robot mean from fs->Xr1, k_gain commits Cmat
+static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false)
 {
     const KDims& d = c->d;
     {
         const double nn = d.n;
         ProfScope ps(c, KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
         MeasArgs ms = {};
-        if (fused_stats) ms = MeasArgs{ c->X, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32 };
+        const double* xrob = fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
+        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32 };
         srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
-        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c));
+        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
+                          fused_motion ? c->Cmat : nullptr, c->S);
         c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
 }
 
 // Which directions of the state are structurally null (srukf_rank.hip)?  Called whenever a state arrives from outside
-// (srukf_set_state*, map changes): row energies of S on the device, the lists on the host.  SRUKF_RANK_AWARE=0 switches it off.
+// (srukf_set_state*, map changes): row energies of S on the device, the lists on the host.  srukf_debug_set(0, "rank_aware", 0) switches it off.
 static void drop_graphs(srukf_ctx* c);
 #define SRUKF_NULL_ENERGY 1e-12
 static int update_null_set(srukf_ctx* c)
 {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("SRUKF_RANK_AWARE"); enabled = (e && e[0] == '0') ? 0 : 1; }
+    const int enabled = g_dbg_rank_aware;
     const int n = c->d.n, np = c->d.np, T = np / 64;
     const int was = c->red_r;
     c->red_r = 0;
@@ -779,7 +792,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     }
     srukf_ctx* c = new srukf_ctx();
     c->device = device; c->p = *p;
-    { const char* e = getenv("SRUKF_NO_GRAPH"); if (e && e[0] == '1') c->use_graph = false; }   // eager launches (profilers)
+    if (!g_dbg_graphs) c->use_graph = false;                 // eager launches (profilers): srukf_debug_set(0, "graphs", 0)
     memset(c->prof_ms, 0, sizeof c->prof_ms); memset(c->prof_n, 0, sizeof c->prof_n);
     memset(c->prof_flops, 0, sizeof c->prof_flops); memset(c->prof_bytes, 0, sizeof c->prof_bytes);
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
@@ -1014,7 +1027,7 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     if (!c || !P) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{});
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{}, nullptr);
     HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) { const double v = c->hstage[(size_t)r * np + cc]; P[(size_t)r * n + cc] = v; P[(size_t)cc * n + r] = v; }
@@ -1448,7 +1461,7 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     if (srukf_dmalloc((void**)&d_map, sizeof(int) * nn) != hipSuccess) { srukf_destroy(c2); c->err = "delete_landmark: out of device memory"; return SRUKF_ERR_NOMEM; }
     hipMemcpy(d_map, map.data(), sizeof(int) * nn, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
-    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{});   // P = S^T S
+    srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{}, nullptr);   // P = S^T S
     hipLaunchKernelGGL(k_gather, dim3((ldn + 255) / 256), dim3(256), 0, c->stream, nn, ldn, c->X, c2->X, d_map);
     for (int slow = 0; slow < 2; slow++) {
         hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c2->fs, 0, 1);
@@ -1501,14 +1514,22 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
     HIPCHK(c, hipMemcpy(c->z_seq, z, sizeof(double) * (size_t)F * 2 * N, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->m_seq, matched, sizeof(int) * (size_t)F * N, hipMemcpyHostToDevice));
     c->seqF = F;
+    hipLaunchKernelGGL(k_set_seq, dim3(1), dim3(1), 0, c->stream, c->fs, c->odo_seq, F, c->p.a1, c->p.a2, c->p.a3, c->p.a4);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SRUKF_OK;
 }
 
+// srukf_debug_set(ctx, "fused_motion", 0): the replay keeps k_motion and k_project as two launches (A/B runs)
 static void replay_one_frame(srukf_ctx* c)
 {
-    seq_predict_motion(c, nullptr);
-    seq_predict_measurement(c, true);
-    seq_gain(c, nullptr, nullptr, true);
+    if (c->dbg_fused_motion) {
+        seq_predict_fused(c);
+        seq_gain(c, nullptr, nullptr, true, true);
+    } else {
+        seq_predict_motion(c, nullptr);
+        seq_predict_measurement(c, true);
+        seq_gain(c, nullptr, nullptr, true);
+    }
     seq_refactor(c, 0, c->d.mp, false, false, false, true);
 }
 static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec_t* ge)
@@ -1740,6 +1761,29 @@ int srukf_debug_poke_state(srukf_ctx* c, int row, int col, double value)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->S + (size_t)row * c->d.np + col, &value, sizeof(double), hipMemcpyHostToDevice));
+    return SRUKF_OK;
+}
+// Measurement / test switches behind ONE entry point (none of them is needed to use the library; all default to the product
+// path).  ctx may be NULL for the process-wide keys listed above g_dbg_*; per-context keys: "use_graph" (0: eager launches),
+// "fused_motion" (0: the replay keeps k_motion and k_project as two launches).  Captured graphs are dropped.
+int srukf_debug_set(srukf_ctx* c, const char* key, int value)
+{
+    if (!key) return SRUKF_ERR_BAD_ARG;
+    struct { const char* k; int* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
+                                                    { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs } };
+    for (auto& g : globals)
+        if (!strcmp(key, g.k)) {
+            *g.v = value ? 1 : 0;
+            if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); drop_graphs(c); if (!strcmp(key, "rank_aware")) return update_null_set(c); }
+            return SRUKF_OK;
+        }
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!strcmp(key, "use_graph")) c->use_graph = value != 0;
+    else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value ? 1 : 0;
+    else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
+    drop_graphs(c);
     return SRUKF_OK;
 }
 int srukf_debug_starve_workers(srukf_ctx* c, int on)

@@ -45,10 +45,57 @@ struct FrameScalars {
     int gmw_aborts;            // persistent GMW launches abandoned on an expired wait (their frames are flagged like clamp rows)
     int clamp_frame;           // staged replay: index of the FIRST frame whose refactorisation was flagged (0x7fffffff: none).  Set by
                                // the k_motion of the following frame (or by the host at the end of a run): frames before it are valid
+    // ---- replay path (k_project_motion): the motion step rides on the projection launch ----
+    double Xr1[4];             // robot mean after the motion step; the dX job of the k_syrk launch commits it (X_robot = Xr1 + dX)
+    double ctl[8];             // control of the frame `frame` (rot1, trans, rot2, cos rot2, sin rot2, Mt[0..2]; SLAM.cpp:1444-1458), prepared by
+                               // whoever sets or advances `frame` (srukf_prepare_control), so that no projection thread waits on the odometry
+    const double* odo_seq;     // staged odometry (3 doubles per pose) and its frame count, a1..a4: what srukf_prepare_control needs
+    double a[4];
+    int seqF;
     int frozen;                // staged replay: a frame was flagged -> k_motion and the persistent factorisation of the later frames of the run
                                // return at once (three quarters of a frame's time; the other kernels would pay a memory round trip per launch
                                // for the test); cleared with the clamp counters (k_set_frame) and by the step-wise API
 };
+
+// control from two odometry poses (SLAM.cpp:1444-1458): Ut = (rot1, trans, rot2), Mt = control-noise sigmas
+__device__ __forceinline__ void srukf_motion_control_a(const double (&a)[4], const double* o, double (&ut)[3], double (&mt)[3])
+{
+    const double dx = o[3] - o[0], dy = o[4] - o[1];
+    const double rot1 = atan2(dy, dx) - o[2];
+    const double trans = sqrt(dy * dy + dx * dx);
+    const double rot2 = o[5] - o[2] - rot1;
+    ut[0] = rot1; ut[1] = trans; ut[2] = rot2;
+    mt[0] = a[0] * rot1 * rot1 + a[1] * trans * trans;
+    mt[1] = a[2] * trans * trans + a[3] * rot1 * rot1 + a[3] * rot2 * rot2;
+    mt[2] = a[0] * rot2 * rot2 + a[1] * trans * trans;
+}
+// fs->ctl for the staged frame fs->frame (one thread; call after `frame` was set or advanced)
+__device__ __forceinline__ void srukf_prepare_control(FrameScalars* fs)
+{
+    const double* os = fs->odo_seq;
+    const int f = fs->frame;
+    if (!os || f < 0 || f >= fs->seqF) return;
+    double ut[3], mt[3];
+    const double a[4] = { fs->a[0], fs->a[1], fs->a[2], fs->a[3] };
+    srukf_motion_control_a(a, os + 3 * f, ut, mt);
+    fs->ctl[0] = ut[0]; fs->ctl[1] = ut[1]; fs->ctl[2] = ut[2];
+    fs->ctl[3] = cos(ut[2]); fs->ctl[4] = sin(ut[2]);
+    fs->ctl[5] = mt[0]; fs->ctl[6] = mt[1]; fs->ctl[7] = mt[2];
+}
+
+// sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1: VALU only, no LDS traffic); every lane of the row gets the total
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_mov_f64<0x128>(v); v += dpp_mov_f64<0x124>(v); v += dpp_mov_f64<0x122>(v); v += dpp_mov_f64<0x121>(v);
+    return v;
+}
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -149,19 +196,22 @@ __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, 
 
 // ---- state update X += sum of the k_gain slice partials (fixed order): 256 state rows per workgroup ----
 #define GAIN_SLICES 32
-__device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job)
+// xr1 (replay path, may be null): the robot mean after the motion step, which k_project_motion left beside X because the
+// projection threads of its launch were still reading the mean before it
+__device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job, const double* xr1 = nullptr)
 {
     const int r = job * 256 + threadIdx.x;
     if (r >= n) return;
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < GAIN_SLICES; u++) acc += dxp[(size_t)u * np + r];
-    X[r] += acc;
+    const double x = (xr1 && r >= n - 4) ? xr1[r - (n - 4)] : X[r];
+    X[r] = x + acc;
 }
 
 // measurement-statistics work attached to a k_pxy launch (replay path): Z == null -> none
 struct MeasArgs {
-    const double* X; const double* sigR; const double* Z; double* part;
+    const double* X; const double* xrob; const double* sigR; const double* Z; double* part;   // xrob: robot mean after the motion step (4 doubles)
     double* h; double* Si; int* vis; double* PxyR;
     FrameScalars* fs; int gx;                                  // gx = (N + 31) / 32 landmark groups
 };

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
     const int nstat = ms.Z ? MEAS_SLICES * ms.gx : 0;         // statistics jobs first: they start with the launch, the tiles fill in behind
     if ((int)blockIdx.x < nstat) {
         const int job = blockIdx.x;
-        meas_partial_job<true>(d, w, ms.X, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm);
+        meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm);
         __shared__ int last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's device-scope stores have landed ...
         __syncthreads();                                       // ... and so have the whole workgroup's, before the count
@@ -80,12 +80,12 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
                                               int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
                                               const int2* __restrict__ tiles, int ntiles, const double* __restrict__ dxp, double* __restrict__ X,
-                                              int krows, int ndx, const RankArgs ra)
+                                              int krows, int ndx, const RankArgs ra, const double* __restrict__ xr1)
 {
     // workgroups past the tile list: the state update X += sum_k K_k (z_k - h_k) left over by k_gain, then (rank-aware replay)
     // the diagonal of G at the dropped positions
     if ((int)blockIdx.x >= ntiles + ndx) { srukf_rank_gdiag_job(d.n, d.np, ue, ra, &fs->gmax_bits, blockIdx.x - ntiles - ndx); return; }
-    if ((int)blockIdx.x >= ntiles) { srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles); return; }
+    if ((int)blockIdx.x >= ntiles) { srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles, xr1); return; }
     __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int2 tl = tiles[blockIdx.x];  // upper-triangle tiles only, XCD-aware order
@@ -427,6 +427,7 @@ __global__ __launch_bounds__(256) void k_gmw_check(int n, int ld, const double* 
                 t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
             }
             fs->frame += 1;
+            srukf_prepare_control(fs);                         // control of the next staged frame (k_project_motion)
         }
         return;
     }
@@ -517,12 +518,12 @@ void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S
 // dxp != null: (n + 255)/256 extra workgroups apply the pending state update
 // ra.A != null (rank-aware replay): S / Ut are the permuted operands, ceil((n - r) / 16) more workgroups form the dropped diagonal
 void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs,
-                       const void* tiles, int ntiles, const double* dxp, double* X, RankArgs ra)
+                       const void* tiles, int ntiles, const double* dxp, double* X, RankArgs ra, const double* xr1)
 {
     const int ndx = dxp ? (d.n + 255) / 256 : 0;
     const int krows = ra.A ? min(d.np, (ra.r + 15) & ~15) : d.np;
     const int extra = ndx + (ra.A ? (d.n - ra.r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS : 0);
-    hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X, krows, ndx, ra);
+    hipLaunchKernelGGL(k_syrk, dim3(ntiles + extra), dim3(256), 0, st, d, S, Ut, ub, ue, G, fs, (const int2*)tiles, ntiles, dxp, X, krows, ndx, ra, xr1);
 }
 // 64-row panel step; j0 = -64 factors the first 64x64 region only (one workgroup)
 void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, double* G, const void* cur, void* nxt, double* D, double* Sout,

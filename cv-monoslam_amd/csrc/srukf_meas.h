@@ -9,7 +9,8 @@
 #define MEAS_SM_DOUBLES (8 * 32 * MEAS_NS)
 // one workgroup: 32 landmarks (bx) x one of MEAS_SLICES row slices (by); smem: MEAS_SM_DOUBLES doubles of LDS
 template <bool COHERENT>
-__device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights& w, const double* __restrict__ X,
+// xrob: the robot mean AFTER the motion step (X + n - 4, or fs->Xr1 in the replay path where X still holds the mean before it)
+__device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights& w, const double* __restrict__ xrob,
                                                  const double* __restrict__ sigR, const double* __restrict__ Z,
                                                  double* __restrict__ part /* [MEAS_SLICES][MEAS_NS][mp/2] */, int bx, int by, double* smem)
 {
@@ -17,13 +18,13 @@ __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights&
     const int lx = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int k = bx * 32 + lx;
     const int kk = (k < d.N) ? k : 0;
-    const int L = d.L, mp = d.mp, n = d.n;
+    const int L = d.L, mp = d.mp;
     const int rows = (L + MEAS_SLICES - 1) / MEAS_SLICES;
     const int c_beg = by * rows, c_end = min(L, c_beg + rows);
     const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * kk);
     double xr[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) xr[e] = X[n - 4 + e];
+    for (int e = 0; e < 4; e++) xr[e] = xrob[e];
     double s[MEAS_NS];
 #pragma unroll
     for (int q = 0; q < MEAS_NS; q++) s[q] = 0.0;

@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void k_syrk32_reduce(int n, int np, const int2
 }
 
 // the state update X += sum_k K_k (z_k - h_k) that k_gain left in slices (k_syrk adds it in its spare workgroups; here its own launch)
-__global__ __launch_bounds__(256) void k_gain_dx(int n, int np, const double* __restrict__ dxp, double* __restrict__ X)
+__global__ __launch_bounds__(256) void k_gain_dx(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, const double* __restrict__ xr1)
 {
-    srukf_gain_dx_job(n, np, dxp, X, blockIdx.x);
+    srukf_gain_dx_job(n, np, dxp, X, blockIdx.x, xr1);
 }
 
 // The motion step rewrites the last four columns of the FP64 working copy of S after the state was rounded (k_motion:
@@ -195,9 +195,9 @@ void srukf_launch_cvt_f32(hipStream_t st, size_t count, const double* src, float
 {
     hipLaunchKernelGGL(k_cvt_f32, dim3((unsigned)((count / 4 + 255) / 256 + 1)), dim3(256), 0, st, count, src, dst);
 }
-void srukf_launch_gain_dx(hipStream_t st, int n, int np, const double* dxp, double* X)
+void srukf_launch_gain_dx(hipStream_t st, int n, int np, const double* dxp, double* X, const double* xr1)
 {
-    hipLaunchKernelGGL(k_gain_dx, dim3((n + 255) / 256), dim3(256), 0, st, n, np, dxp, X);
+    hipLaunchKernelGGL(k_gain_dx, dim3((n + 255) / 256), dim3(256), 0, st, n, np, dxp, X, xr1);
 }
 void srukf_launch_cvt_robot_cols(hipStream_t st, int n, int np, const double* S, float* S32)
 {

@@ -34,21 +34,15 @@ __device__ __forceinline__ void srukf_motion_centre(const MotionCtl& m, const do
     s0[0] = xr[0] + m.trans * cs; s0[1] = xr[1] + m.trans * sn; s0[2] = xr[2] + 0.0; s0[3] = xr[3] + (m.rot1 + m.rot2);
     c0s = cs * m.crot2 - sn * m.srot2; s0s = sn * m.crot2 + cs * m.srot2;
 }
-// control from two odometry poses (SLAM.cpp:1444-1458): Ut = (rot1, trans, rot2), Mt = control-noise sigmas
+// control from two odometry poses (SLAM.cpp:1444-1458): srukf_motion_control_a in srukf_device.h
 __device__ __forceinline__ void srukf_motion_control(const srukf_params& p, const double* o, double (&ut)[3], double (&mt)[3])
 {
-    const double dx = o[3] - o[0], dy = o[4] - o[1];
-    const double rot1 = atan2(dy, dx) - o[2];
-    const double trans = sqrt(dy * dy + dx * dx);
-    const double rot2 = o[5] - o[2] - rot1;
-    ut[0] = rot1; ut[1] = trans; ut[2] = rot2;
-    mt[0] = p.a1 * rot1 * rot1 + p.a2 * trans * trans;
-    mt[1] = p.a3 * trans * trans + p.a4 * rot1 * rot1 + p.a4 * rot2 * rot2;
-    mt[2] = p.a1 * rot2 * rot2 + p.a2 * trans * trans;
+    const double a[4] = { p.a1, p.a2, p.a3, p.a4 };
+    srukf_motion_control_a(a, o, ut, mt);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_motion: predictMotion numeric tail (SLAM.cpp:1430-1465) fused:
+// Motion step: predictMotion numeric tail (SLAM.cpp:1430-1465) fused:
 //   control Ut/Mt from two odometry poses (1444-1458);
 //   robot rows of all L sigma points through the odometry model (generateSigmaPoints 1148-1162
 //   restricted to rows n-4..n-1 and the control-noise rows, passSigmaThroughMotionFunction
@@ -61,50 +55,83 @@ __device__ __forceinline__ void srukf_motion_control(const srukf_params& p, cons
 //   (backward stable for P = S^T S, which is what the filter consumes; its rows equal the
 //   Householder R's up to sign).  Only the last four columns of S are rewritten: O(n) instead of
 //   the reference's 2n^2(2Na - n/3) flop Householder QR (DESIGN.md "Motion step").
-// One workgroup of 512 threads, one pass over the sigma directions, ONE block reduction.
+// One workgroup of 512 threads, one pass over the sigma directions, ONE block reduction (16-lane DPP rows, then 32 row sums
+// per value through LDS: fixed order, 3.6 KB of LDS instead of a 57 KB tree).
+//
+// REPLAY = false: k_motion, the step-wise API (odometry pair from the host) and the exact path: results go straight into X, S.
+// REPLAY = true : workgroup 0 of k_project_motion (staged replay).  The projection threads of the same launch evaluate the
+//   robot part of their own sigma points from the state BEFORE the motion step, so nothing they read may change under
+//   them: the new robot mean goes to fs->Xr1 and the new last four columns of S to Cm (n x 4; k_gain commits them, the dX
+//   job of the k_syrk launch adds the update to Xr1).  The control comes from fs->ctl (srukf_prepare_control).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_params p,
-                                                double* __restrict__ X, double* __restrict__ S,
-                                                double* __restrict__ sigR, double* __restrict__ Cmat,
-                                                FrameScalars* __restrict__ fs,
-                                                const double* __restrict__ odo_seq, const double* odo_pair, const RankArgs ra)
+#define MOTION_SM_DOUBLES (14 * 32 + 16 + 24)
+template <bool REPLAY>
+__device__ __forceinline__ void motion_body(const KDims& d, const KWeights& w, const srukf_params& p,
+                                            double* __restrict__ X, double* __restrict__ S,
+                                            double* __restrict__ sigR, double* __restrict__ Cm,
+                                            FrameScalars* __restrict__ fs,
+                                            const double* __restrict__ odo_seq, const double* odo_pair, const RankArgs& ra, double* smem)
 {
-    __shared__ double red[16];
-    __shared__ double sh[24];
-    __shared__ double part[14][512];
-    __shared__ double part2[14][33];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    double (*part)[32] = (double (*)[32])smem;                 // [14][32]
+    double* red = smem + 14 * 32;                              // [16]
+    double* sh = red + 16;                                     // [24]
+    const int tid = threadIdx.x;
     const int n = d.n, Na = d.Na, L = d.L, ld = d.np;
     if (!odo_pair && fs->frozen) return;                       // staged replay behind a flagged frame: nothing to compute from
 
     STAMP(0);
+    // Replay path with the rank-aware form: the directions are walked in PERMUTED order — kept rows (positions < r, read from the
+    // permuted copy A), then the five noise rows, then the structurally null rows.  A null row of S has nothing in the robot
+    // columns, so both its sigma points are the centre point, bit for bit: they are filled in without the two sincos — half of
+    // all directions — and, walked in this order, whole waves do nothing else.
+    const bool permuted = REPLAY && ra.A != nullptr;
+    if constexpr (REPLAY) __builtin_amdgcn_s_setprio(3);        // this workgroup shares its CU with projection waves: the chain goes first
     // the S rows of this thread's directions are requested before the control block: their round trip then overlaps
     // thread 0's dependent chain  frame counter -> odometry pair  instead of following it
-    constexpr int MAXIT = 4;                                   // the first 4 * 512 directions; the rest load in the loop
+    // prefetched slots: step-wise API the first 3 * 512 directions (N <= 254); replay only the first 512 (in permuted order the
+    // later passes are mostly fills, and the kernel shares its register budget with the projection threads); the rest load in the loop
+    constexpr int MAXIT = REPLAY ? 1 : 3;
     double2 pre[MAXIT][2];
-    int prow[MAXIT];                                           // rank-aware replay: row of the shadow copy that mirrors S row i (or none)
-#pragma unroll
-    for (int it = 0; it < MAXIT; it++) {
-        const int i = tid + it * 512;
-        pre[it][0] = make_double2(0.0, 0.0); pre[it][1] = make_double2(0.0, 0.0);
-        prow[it] = (ra.A && i < n - 4) ? ra.iperm[i] : 0x7fffffff;
+    int pidx[MAXIT];                                           // direction (row of the augmented sqrt matrix) of this slot; -1: none
+    int prow[MAXIT];                                           // step-wise API, rank-aware: row of the shadow copy that mirrors S row i (or none)
+    bool pnull[MAXIT];                                         // structurally null row: fill only
+    auto slot = [&](const int pos, int& i, int& arow, bool& isnull, double2& u0, double2& u1) {
+        u0 = make_double2(0.0, 0.0); u1 = u0; arow = 0x7fffffff; isnull = false; i = -1;
+        if (pos >= Na) return;
+        if (permuted) {
+            if (pos < ra.r) {
+                i = ra.perm[pos];
+                const double* ap = ra.A + (size_t)pos * ld + (ra.r - 4);       // r - 4 may be odd: four 8-byte loads
+                u0 = make_double2(ap[0], ap[1]); u1 = make_double2(ap[2], ap[3]);
+            } else if (pos < ra.r + 5) i = n + (pos - ra.r);
+            else { i = ra.perm[pos - 5]; isnull = true; }
+            return;
+        }
+        i = pos;
+        arow = (ra.A && i < n - 4) ? ra.iperm[i] : 0x7fffffff;
         if (i < n) {
             // S[i][n-4..n-1]: 16-byte aligned (n-4 = 6N is even, ld a multiple of 64); the strictly lower
             // triangle of S is kept zero, so rows inside the robot block need no masking
             const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4));
-            pre[it][0] = sp2[0]; pre[it][1] = sp2[1];
+            u0 = sp2[0]; u1 = sp2[1];
         }
-    }
+    };
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) slot(tid + it * 512, pidx[it], prow[it], pnull[it], pre[it][0], pre[it][1]);
     // ---- control (SLAM.cpp:1444-1458) ----
     bool freeze = false;
     if (tid == 0) {
-        const double* o = odo_pair ? odo_pair : (odo_seq + 3 * fs->frame);
-        double ut[3], mt[3];
-        srukf_motion_control(p, o, ut, mt);
-        const double rot2 = ut[2];
-        for (int q = 0; q < 3; q++) { sh[q] = ut[q]; sh[3 + q] = mt[q]; }
+        if constexpr (REPLAY) {
+            for (int q = 0; q < 3; q++) { sh[q] = fs->ctl[q]; sh[3 + q] = fs->ctl[5 + q]; }
+            sh[10] = fs->ctl[3]; sh[11] = fs->ctl[4];
+        } else {
+            const double* o = odo_pair ? odo_pair : (odo_seq + 3 * fs->frame);
+            double ut[3], mt[3];
+            srukf_motion_control(p, o, ut, mt);
+            for (int q = 0; q < 3; q++) { sh[q] = ut[q]; sh[3 + q] = mt[q]; }
+            sh[10] = cos(ut[2]); sh[11] = sin(ut[2]);
+        }
         for (int q = 0; q < 4; q++) sh[6 + q] = X[n - 4 + q];
-        sh[10] = cos(rot2); sh[11] = sin(rot2);
         for (int q = 0; q < 3; q++) { fs->Ut[q] = sh[q]; fs->Mt[q] = sh[3 + q]; }
         for (int q = 0; q < 4; q++) fs->Xr0[q] = sh[6 + q];
         // staged replay: the previous frame's refactorisation was flagged (theta clamp / abandoned launch) -> remember which
@@ -121,6 +148,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
     const double rot1 = sh[0], trans = sh[1], rot2 = sh[2];
     const double xr[4] = { sh[6], sh[7], sh[8], sh[9] };
     const double crot2 = sh[10], srot2 = sh[11];
+    const double mts[3] = { sh[3], sh[4], sh[5] };
 
     STAMP(1);
     // ---- one fused pass over the Na sigma directions: each thread takes direction i, reads row i of the
@@ -145,7 +173,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
         if (i < n) {
             srow[0] = u0.x; srow[1] = u0.y; srow[2] = u1.x; srow[3] = u1.y;
         } else if (i < n + 3) {
-            mnoise[i - n] = sh[3 + (i - n)];                   // control-noise rows (sr = blockdiag(S, Mt, Qt))
+            mnoise[i - n] = mts[i - n];                        // control-noise rows (sr = blockdiag(S, Mt, Qt))
         }
         double dev[2][4];
 #pragma unroll
@@ -158,14 +186,22 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
             o[1] = make_double4(c2, s2, 0.0, 0.0);
 #pragma unroll
             for (int e = 0; e < 4; e++) { acc[e] += w.wi * r[e]; dev[sg][e] = r[e] - s0[e]; }
+            if constexpr (REPLAY) __builtin_amdgcn_sched_barrier(0);   // one sigma point after the other: the kernel shares its register budget with the projection threads
         }
         if (i < n - 4) {
             double c[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) { S[(size_t)i * ld + (n - 4 + e)] = k2 * (dev[0][e] - dev[1][e]); c[e] = k2 * (dev[0][e] + dev[1][e]); }
-            if (arow < ra.r) {
+            for (int e = 0; e < 4; e++) c[e] = k2 * (dev[0][e] + dev[1][e]);
+            if constexpr (REPLAY) {
+                *reinterpret_cast<double4*>(Cm + (size_t)i * 4) = make_double4(k2 * (dev[0][0] - dev[1][0]), k2 * (dev[0][1] - dev[1][1]),
+                                                                               k2 * (dev[0][2] - dev[1][2]), k2 * (dev[0][3] - dev[1][3]));
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; e++) ra.A[(size_t)arow * ld + (ra.r - 4 + e)] = k2 * (dev[0][e] - dev[1][e]);
+                for (int e = 0; e < 4; e++) S[(size_t)i * ld + (n - 4 + e)] = k2 * (dev[0][e] - dev[1][e]);
+                if (arow < ra.r) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ra.A[(size_t)arow * ld + (ra.r - 4 + e)] = k2 * (dev[0][e] - dev[1][e]);
+                }
             }
             int q = 4;
 #pragma unroll
@@ -180,33 +216,40 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
                 for (int b = a; b < 4; b++) acc[q++] += (w.wi_sr * dev[0][a]) * (w.wi_sr * dev[0][b]) + (w.wi_sr * dev[1][a]) * (w.wi_sr * dev[1][b]);
         }
     };
+    // a structurally null row: srukf_motion_point with a zero row IS srukf_motion_centre (same operations on the same values)
+    auto fill = [&](const int i) {
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) {
+            double4* o = reinterpret_cast<double4*>(sigR + (size_t)(1 + sg * Na + i) * 8);
+            o[0] = make_double4(s0[0], s0[1], s0[2], s0[3]);
+            o[1] = make_double4(c0s, s0s, 0.0, 0.0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[e] += w.wi * s0[e];
+        }
+        *reinterpret_cast<double4*>(Cm + (size_t)i * 4) = make_double4(0.0, 0.0, 0.0, 0.0);
+    };
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
-        const int i = tid + it * 512;
-        if (i < Na) direction(i, pre[it][0], pre[it][1], prow[it]);
+        if (pidx[it] < 0) continue;
+        if (pnull[it]) fill(pidx[it]); else direction(pidx[it], pre[it][0], pre[it][1], prow[it]);
     }
-    for (int i = tid + MAXIT * 512; i < Na; i += 512) {         // more than 2048 directions (N > 339): plain loads
-        double2 u0 = make_double2(0.0, 0.0), u1 = u0;
-        if (i < n) { const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4)); u0 = sp2[0]; u1 = sp2[1]; }
-        direction(i, u0, u1, (ra.A && i < n - 4) ? ra.iperm[i] : 0x7fffffff);
+    for (int pos = tid + MAXIT * 512; pos < Na; pos += 512) {   // the slots that were not prefetched: plain loads
+        int i, arow; bool isnull; double2 u0, u1;
+        slot(pos, i, arow, isnull, u0, u1);
+        if (isnull) fill(i); else direction(i, u0, u1, arow);
     }
     STAMP(2);
-    // block reduction through LDS only (wave shuffles of 14 doubles cost more LDS-pipeline time than this tree):
-    // [14][512] partials -> 14 x 32 threads sum 16 each -> 14 threads sum 32 each; fixed order => deterministic
+    // block reduction in fixed order (deterministic): 16-lane DPP rows on the VALU, then the 32 row sums of each value by one thread
 #pragma unroll
-    for (int q = 0; q < 14; q++) part[q][tid] = acc[q];
-    __syncthreads();
-    if (tid < 14 * 32) {
-        const int q = tid >> 5, u = tid & 31;
-        double t = 0.0;
+    for (int q = 0; q < 14; q++) acc[q] = row16_sum(acc[q]);
+    if ((tid & 15) == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) t += part[q][u + 32 * e];
-        part2[q][u] = t;
+        for (int q = 0; q < 14; q++) part[q][tid >> 4] = acc[q];
     }
     __syncthreads();
     if (tid < 14) {
         double t = 0.0;
-        for (int e = 0; e < 32; e++) t += part2[tid][e];
+        for (int e = 0; e < 32; e++) t += part[tid][e];
         red[tid] = t;
     }
     __syncthreads();
@@ -214,7 +257,7 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
     for (int q = 0; q < 14; q++) acc[q] = red[q];
     STAMP(3);
     if (tid < 4) {
-        X[n - 4 + tid] = acc[tid];                                               // 1531
+        if constexpr (REPLAY) fs->Xr1[tid] = acc[tid]; else X[n - 4 + tid] = acc[tid];   // 1531
         // rs[e] = sum_c wc_c (sigma_c[e] - X[e]) with the covariance weights (wc0 for the centre): the constant
         // k_meas_final needs to re-centre the robot rows of Pxy on the mean h.
         //   sum_c wc_c sigma_c = mean + (wc0 - wm0) sigma_0,  sum_c wc_c = wc0 + 2 Na wi
@@ -239,25 +282,41 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
                 R[a][b] = (raa > 0.0) ? v / raa : 0.0;
             }
         }
-        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = R[a][b];
-        if (ra.A) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) ra.A[(size_t)(ra.r - 4 + a) * ld + (ra.r - 4 + b)] = R[a][b];
+        if constexpr (REPLAY) {
+            for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) Cm[(size_t)(n - 4 + a) * 4 + b] = R[a][b];
+        } else {
+            for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) S[(size_t)(n - 4 + a) * ld + (n - 4 + b)] = R[a][b];
+            if (ra.A) for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) ra.A[(size_t)(ra.r - 4 + a) * ld + (ra.r - 4 + b)] = R[a][b];
+        }
     }
     STAMP(5);
 }
+__global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_params p,
+                                                double* __restrict__ X, double* __restrict__ S,
+                                                double* __restrict__ sigR, double* __restrict__ Cmat,
+                                                FrameScalars* __restrict__ fs,
+                                                const double* __restrict__ odo_seq, const double* odo_pair, const RankArgs ra)
+{
+    __shared__ double sm[MOTION_SM_DOUBLES];
+    motion_body<false>(d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair, ra, sm);
+}
 
 // ------------------------------------------------------------------------------------------------
-// k_project: passSigmaThroughMesaurementFunction (SLAM.cpp:1615-1674).  Thread (k, ii): landmark
-// k and sigma "direction" ii: ii = 0 is the centre column, ii >= 1 handles the +/- pair built
-// from row i = ii-1 of the augmented sqrt matrix, so every S row is read once and
-// DZ[i] = Z[1+i] - Z[1+Na+i] falls out for the cross-covariance contraction.
+// Projection: passSigmaThroughMesaurementFunction (SLAM.cpp:1615-1674).  Flat item g = (direction ii, landmark k):
+// ii = 0 is the centre column, ii >= 1 handles the +/- pair built from row i = ii-1 of the augmented sqrt matrix, so
+// every S row is read once and DZ[i] = Z[1+i] - Z[1+Na+i] falls out for the cross-covariance contraction.
+// INLINE_ROBOT = false (k_project): the robot part of every sigma point comes from the table sigR (k_motion ran before).
+// INLINE_ROBOT = true (k_project_motion): the thread pushes the robot rows of its two sigma points through the motion
+//   model itself — the same device functions on the same inputs as the motion workgroup, so the same bits as its table —
+//   from the state before the motion step and the prepared control fs->ctl; it waits for nothing.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_params p,
-                                                 const double* __restrict__ X, const double* __restrict__ S,
-                                                 const double* __restrict__ sigR,
-                                                 double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs)
+template <bool INLINE_ROBOT>
+__device__ __forceinline__ void project_item(const int g, const KDims& d, const KWeights& w, const srukf_params& p,
+                                             const double* __restrict__ X, const double* __restrict__ S,
+                                             const double* __restrict__ sigR,
+                                             double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs)
 {
     // flat (direction, landmark) index: no idle lanes when N is not a multiple of the wave size (N = 200: 78 % -> 100 %)
-    const int g = blockIdx.x * 256 + threadIdx.x;
     const int ii = g / d.N, k = g - ii * d.N;
     const int n = d.n, Na = d.Na, ld = d.np, mp = d.mp;
     if (ii > d.Na) return;
@@ -265,38 +324,85 @@ __global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_para
     double base[6];
 #pragma unroll
     for (int e = 0; e < 6; e++) base[e] = X[6 * k + e];
+    MotionCtl mc = { 0, 0, 0, 1, 0 };
+    double xr[4] = { 0, 0, 0, 0 }, mts[3] = { 0, 0, 0 };
+    if constexpr (INLINE_ROBOT) {
+        mc.rot1 = fs->ctl[0]; mc.trans = fs->ctl[1]; mc.rot2 = fs->ctl[2]; mc.crot2 = fs->ctl[3]; mc.srot2 = fs->ctl[4];
+#pragma unroll
+        for (int e = 0; e < 3; e++) mts[e] = fs->ctl[5 + e];
+#pragma unroll
+        for (int e = 0; e < 4; e++) xr[e] = X[n - 4 + e];
+    }
 
     if (ii == 0) {
-        const double* r = sigR;
         double ox, oy;
-        srukf_project(p, f1, f2, base, r[0], r[1], r[2], r[4], r[5], 0.0, 0.0, ox, oy);
+        if constexpr (INLINE_ROBOT) {
+            double s0[4], c0s, s0s;
+            srukf_motion_centre(mc, xr, s0, c0s, s0s);
+            srukf_project(p, f1, f2, base, s0[0], s0[1], s0[2], c0s, s0s, 0.0, 0.0, ox, oy);
+        } else {
+            const double* r = sigR;
+            srukf_project(p, f1, f2, base, r[0], r[1], r[2], r[4], r[5], 0.0, 0.0, ox, oy);
+        }
         *reinterpret_cast<double2*>(Z + 2 * k) = make_double2(ox, oy);
         return;
     }
     const int i = ii - 1;
     double dev[6] = { 0, 0, 0, 0, 0, 0 };
+    double srow[4] = { 0, 0, 0, 0 }, mnoise[3] = { 0, 0, 0 };
     if (i < n) {
 #pragma unroll
         for (int e = 0; e < 6; e++) { const int col = 6 * k + e; dev[e] = (col >= i) ? S[(size_t)i * ld + col] : 0.0; }
+        if constexpr (INLINE_ROBOT) {
+            const double2* sp2 = reinterpret_cast<const double2*>(S + (size_t)i * ld + (n - 4));
+            const double2 u0 = sp2[0], u1 = sp2[1];
+            srow[0] = u0.x; srow[1] = u0.y; srow[2] = u1.x; srow[3] = u1.y;
+        }
+    } else if (INLINE_ROBOT && i < n + 3) {
+        mnoise[i - n] = mts[i - n];
     }
     double e0 = 0.0, e1 = 0.0;                       // pixel-noise sigma rows n+3, n+4 (Qt on the sqrt diagonal)
     if (i == n + 3) e0 = p.sigma_measure; else if (i == n + 4) e1 = p.sigma_measure;
     double zp[2], zm[2];
 #pragma unroll
     for (int sgn = 0; sgn < 2; sgn++) {
-        const double g = sgn ? -w.gamma : w.gamma;
+        const double gq = sgn ? -w.gamma : w.gamma;
         const int c = sgn ? (1 + Na + i) : (1 + i);
         double feat[6];
 #pragma unroll
-        for (int e = 0; e < 6; e++) feat[e] = base[e] * 1 + dev[e] * g + 0;     // addWeighted, 1159-1160
-        const double* r = sigR + (size_t)c * 8;
-        const double q0 = 0.0 * 1 + e0 * g + 0, q1 = 0.0 * 1 + e1 * g + 0;
+        for (int e = 0; e < 6; e++) feat[e] = base[e] * 1 + dev[e] * gq + 0;     // addWeighted, 1159-1160
+        const double q0 = 0.0 * 1 + e0 * gq + 0, q1 = 0.0 * 1 + e1 * gq + 0;
         double ox, oy;
-        srukf_project(p, f1, f2, feat, r[0], r[1], r[2], r[4], r[5], q0, q1, ox, oy);
+        if constexpr (INLINE_ROBOT) {
+            double r[4], c2, s2;
+            srukf_motion_point(mc, xr, srow, mnoise, gq, r, c2, s2);
+            srukf_project(p, f1, f2, feat, r[0], r[1], r[2], c2, s2, q0, q1, ox, oy);
+        } else {
+            const double* r = sigR + (size_t)c * 8;
+            srukf_project(p, f1, f2, feat, r[0], r[1], r[2], r[4], r[5], q0, q1, ox, oy);
+        }
         *reinterpret_cast<double2*>(Z + (size_t)c * mp + 2 * k) = make_double2(ox, oy);
         if (sgn) { zm[0] = ox; zm[1] = oy; } else { zp[0] = ox; zp[1] = oy; }
     }
     if (i < n) *reinterpret_cast<double2*>(DZ + (size_t)i * mp + 2 * k) = make_double2(zp[0] - zm[0], zp[1] - zm[1]);
+}
+__global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_params p,
+                                                 const double* __restrict__ X, const double* __restrict__ S,
+                                                 const double* __restrict__ sigR,
+                                                 double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs)
+{
+    project_item<false>(blockIdx.x * 256 + threadIdx.x, d, w, p, X, S, sigR, Z, DZ, fs);
+}
+// Replay path: workgroup 0 is the motion step of the frame (a one-workgroup latency chain of ~14 us that the whole GPU used to
+// wait for), every other workgroup projects 512 (direction, landmark) items and needs nothing from it.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_project_motion(KDims d, KWeights w, srukf_params p,
+                                                        double* __restrict__ X, double* __restrict__ S,
+                                                        double* __restrict__ sigR, double* __restrict__ Cm,
+                                                        double* __restrict__ Z, double* __restrict__ DZ, FrameScalars* __restrict__ fs, const RankArgs ra)
+{
+    __shared__ double sm[MOTION_SM_DOUBLES];
+    if (blockIdx.x == 0) { motion_body<true>(d, w, p, X, S, sigR, Cm, fs, nullptr, nullptr, ra, sm); return; }
+    project_item<true>((blockIdx.x - 1) * 512 + threadIdx.x, d, w, p, X, S, sigR, Z, DZ, fs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,7 +421,7 @@ __global__ __launch_bounds__(256) void k_meas_partial(KDims d, KWeights w, const
                                                       const double* __restrict__ sigR, const double* __restrict__ Z, double* __restrict__ part)
 {
     __shared__ double sm[MEAS_SM_DOUBLES];
-    meas_partial_job<false>(d, w, X, sigR, Z, part, blockIdx.x, blockIdx.y, sm);
+    meas_partial_job<false>(d, w, X + d.n - 4, sigR, Z, part, blockIdx.x, blockIdx.y, sm);
 }
 __global__ __launch_bounds__(256) void k_meas_final(KDims d, KWeights w, const double* __restrict__ X, const double* __restrict__ sigR,
                                                     const double* __restrict__ Z, const double* __restrict__ part,
@@ -341,13 +447,26 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               const double* __restrict__ Si, const int* __restrict__ vis,
                                               const double* __restrict__ h, const double* __restrict__ z_seq,
                                               const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
-                                              FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra)
+                                              FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra,
+                                              const double* __restrict__ Cm, double* __restrict__ S)
 {
     __shared__ double red[4][64];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
     const int rl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int r = blockIdx.x * 64 + rl;
     const int n = d.n, ld = d.np, mp = d.mp, N = d.N;
+    // replay path: the motion step of this frame (workgroup 0 of k_project_motion) left the new last four columns of S in Cm —
+    // the projection threads of its launch were reading the old ones.  Committed here, one row per thread, before the
+    // k_syrk launch reads them: R12 rows (r < n-4), R22 rows (the robot block); the permuted copy of the rank-aware form too.
+    if (Cm && blockIdx.y == 0 && sl == 0 && r < n) {
+        const double4 v = *reinterpret_cast<const double4*>(Cm + (size_t)r * 4);
+        *reinterpret_cast<double2*>(S + (size_t)r * ld + (n - 4)) = make_double2(v.x, v.y);
+        *reinterpret_cast<double2*>(S + (size_t)r * ld + (n - 2)) = make_double2(v.z, v.w);
+        if (ra.A) {
+            const int arow = (r < n - 4) ? ra.iperm[r] : ra.r - 4 + (r - (n - 4));
+            if (arow < ra.r) { double* o = ra.A + (size_t)arow * ld + (ra.r - 4); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+        }
+    }
     const double* z = z_cur ? z_cur : (z_seq + (size_t)fs->frame * 2 * N);
     const int* mt = m_cur ? m_cur : (m_seq + (size_t)fs->frame * N);
     const double sc = w.wi * w.gamma;
@@ -478,7 +597,7 @@ __global__ __launch_bounds__(256) void k_traj(KDims d, const double* __restrict_
             for (int e = 0; e < 4; e++) t[e] = X[n - 4 + e];
             t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
         }
-        if (advance) fs->frame += 1;
+        if (advance) { fs->frame += 1; srukf_prepare_control(fs); }
     }
 }
 
@@ -550,6 +669,12 @@ void srukf_launch_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, do
 {
     hipLaunchKernelGGL(k_motion, dim3(1), dim3(512), 0, st, d, w, p, X, S, sigR, Cmat, fs, odo_seq, odo_pair, ra);
 }
+void srukf_launch_project_motion(hipStream_t st, KDims d, KWeights w, srukf_params p, double* X, double* S, double* sigR, double* Cm,
+                                 double* Z, double* DZ, FrameScalars* fs, RankArgs ra)
+{
+    dim3 grid(1 + ((d.Na + 1) * d.N + 511) / 512);
+    hipLaunchKernelGGL(k_project_motion, grid, dim3(512), 0, st, d, w, p, X, S, sigR, Cm, Z, DZ, fs, ra);
+}
 void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
                           double* Z, double* DZ, const FrameScalars* fs)
 {
@@ -565,9 +690,9 @@ void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* 
 int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
-                       FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra)
+                       FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra, const double* Cm, double* S)
 {
-    hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra);
+    hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra, Cm, S);
     if (w.wc0 != w.wm0)
         hipLaunchKernelGGL(k_gain_center, dim3(d.np / 256 + 1), dim3(256), 0, st, d, w, Ut, Z, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
 }

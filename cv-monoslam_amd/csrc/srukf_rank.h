@@ -8,6 +8,7 @@ struct RankArgs {
     double* Utp;           // U^T with permuted columns
     double* gdiag;         // [ld] diagonal of G at the dropped positions (permuted index)
     const int* iperm;      // state index -> permuted position
+    const int* perm;       // permuted position -> state index
     int r;                 // kept pivots (robot last: positions r-4 .. r-1)
 };
 

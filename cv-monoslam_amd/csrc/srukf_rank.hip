@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                 t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
             }
             fs->frame += 1;
+            srukf_prepare_control(fs);                         // control of the next staged frame (k_project_motion)
         }
         return;
     }

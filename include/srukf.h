@@ -266,6 +266,11 @@ int  srukf_debug_starve_workers(srukf_ctx* ctx, int on);
  * diverges; scripts/mixed_eps_study.py documents exactly that). */
 int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
 
+/* Measurement / test switches, not for hosts (every one defaults to the product path).  Process-wide keys (ctx may be NULL):
+ * "gmw_persist", "gmw_fused", "rank_fused", "rank_fold", "rank_aware", "graphs" (0: contexts created afterwards launch eagerly,
+ * which rocprofv3 --pmc needs); per-context keys: "use_graph", "fused_motion".  See srukf_api.hip. */
+int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
+
 /* Problem sizes of a context: N, n, Na, L. */
 int  srukf_dims(const srukf_ctx* ctx, int* N, int* n, int* Na, int* L);
 

@@ -186,7 +186,15 @@ def test_step_api_equals_staged_replay(srukf, synth):
     b = srukf.Filter(20, p); b.set_state(sc["X0"], sc["S0"]); b.stage_sequence(sc["odo"], sc["z"], sc["matched"])
     b.run_frames(0, 6)
     Xa, Sa = a.get_state(); Xb, Sb = b.get_state()
-    assert np.array_equal(Xa, Xb) and np.array_equal(Sa, Sb)       # same kernels, same order: bit-identical (also across graph replay)
+    # The replay runs the motion step inside the projection launch (k_project_motion: other reduction order, the control prepared
+    # by the previous frame's tail), so the two paths agree to rounding, not bit for bit; the replay against itself — eager
+    # launches or any graph — stays bit-identical (test_prepared_block_graph_gives_the_same_frames).
+    np.testing.assert_allclose(Xa, Xb, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Sa.T @ Sa, Sb.T @ Sb, rtol=0, atol=1e-15)
+    c = srukf.Filter(20, p); c.set_state(sc["X0"], sc["S0"]); c.stage_sequence(sc["odo"], sc["z"], sc["matched"]); c.debug_set("fused_motion", 0)
+    c.run_frames(0, 6)
+    Xc, Sc = c.get_state()
+    assert np.array_equal(Xa, Xc) and np.array_equal(Sa, Sc)       # with the two-launch form: same kernels, same order: bit-identical
 
 
 def test_row_sign_invariance(srukf, synth):
