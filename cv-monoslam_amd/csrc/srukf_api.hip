@@ -450,8 +450,10 @@ static void shadow_rebuild(srukf_ctx* c)
     if (c->red_r > 0 && c->shadowA) srukf_launch_rank_shadow(c->stream, c->d.n, c->d.np, c->red_r, c->S, c->red_perm, c->shadowA);
 }
 static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c->gmw_shared != 2 && c->gplan.workers >= 0; }
-static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? 2 : 1; }
-static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? 2 : 0; }
+// SRUKF_GPU_SHARED: how many persistent launches share the GPU (each keeps to 1 / tenants of the CUs; the gate admits that many)
+static int g_dbg_shared_tenants = 2;
+static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants : 1; }
+static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants : 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
 // fp32 storage: S, X and the permuted copy are rounded to the stored values first, and the trajectory row is taken from those
@@ -606,7 +608,9 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
         const int workers = c->debug_starve ? 0 : gp.workers;
-        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp, 0, gate_limit(c));
+        // (krows: where the kept pivots end — the last pivoted panel is not factored beyond them)
+        srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp,
+                                 reduced ? ((c->red_r + 15) & ~15) : 0, gate_limit(c));
         return;
     }
     // one launch per panel; rank-aware form: the step after the last pivoted panel still runs (it writes that panel's S rows)
@@ -1771,6 +1775,11 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     if (!key) return SRUKF_ERR_BAD_ARG;
     struct { const char* k; int* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs } };
+    if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
+        if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;
+        g_dbg_shared_tenants = value;
+        return SRUKF_OK;
+    }
     for (auto& g : globals)
         if (!strcmp(key, g.k)) {
             *g.v = value ? 1 : 0;

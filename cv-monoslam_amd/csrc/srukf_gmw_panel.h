@@ -89,6 +89,8 @@ __device__ __forceinline__ void stage32_tri_globalB(d4 (&acc)[2][2], const doubl
 // after the tile store — the persistent kernel raises the tile's flag there, before the S rows nobody waits for.
 // early2: the whole panel buffer is known to be complete already (a worker that is behind): the second half's operands
 // are requested together with the first half's — one memory round trip per step instead of two.
+// rows32: the panel has only its first 32 pivots (the rank-aware form's last pivoted panel when the kept pivots end there) and the
+// tile's own values are not needed: the call ends after the first half with the S rows j0 .. j0+31.
 // acc: this wave's 32x32 quadrant.  load_tile / store_tile: read it from / write it back to G (the persistent kernel
 // keeps a tile in registers from its first update to its last).
 // DEV: G tiles are exchanged with other workgroups of the SAME launch (agent-scope accesses).  The panel buffer is read
@@ -100,7 +102,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                                                 const GmwPanel64* cur, double* __restrict__ Sout,
                                                 double (*Lr)[G64_LS], double (*Wc)[G64_LS], int tid, d4 (&acc)[2][2],
                                                 bool load_tile, bool store_tile, WaitHalf&& wait_half, WaitFull&& wait_full, Stored&& stored,
-                                                bool early2 = false)
+                                                bool early2 = false, bool rows32 = false)
 {
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -170,6 +172,12 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
         for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int t = 0; t < 4; t++) dr[q][t] = (which == 0) ? cur->rD[16 * q + lk + 4 * t] : 0.0;
+        if (rows32 && !early2) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
+        }
         zero_acc(W1);
         // W1 = T1 G1 (T1 unit lower triangular: output rows 0..15 only see k < 16)
 #pragma unroll
@@ -201,6 +209,22 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                     if (which == 0) { Lr[jj][cc] = w1 * dr[a][t]; if (diagblk) Wc[jj][cc] = w1; }
                     else Wc[jj][cc] = w1;
                 }
+    }
+    if (rows32) {
+        // the panel ends after its first 32 pivots: S rows j0 .. j0+31 of this wave's half slab, nothing else
+        if (write_s) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int jj = 16 * a + lk + 4 * t;
+                        if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = W1[a][b][t] * sqr[a][t];
+                    }
+        }
+        __syncthreads();                                       // the LDS slabs may be rewritten by the caller's next step
+        return true;
     }
     __syncthreads();
     if (live) {

@@ -95,7 +95,7 @@ __device__ __forceinline__ void gmw_stage_tile(double (*dst)[G64_LS], const doub
 __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                   double* __restrict__ Dall, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
                                                   double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg, double* xreg, double* keepreg,
-                                                  int* okp, int* halfcnt, int* stageok, int tid)
+                                                  int* okp, int* halfcnt, int* stageok, int tid, int klim)
 {
     const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int qa = wv >> 1, qb = wv & 1;
@@ -114,6 +114,9 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
     for (int p = 0; p < Tp; p++) {
         const int j0 = 64 * (p - 1), base = 64 * p;
         const bool first = (p == 0);
+        // rank-aware form: the kept pivots end inside the last pivoted panel.  When they end in its first half (klim <= base + 32)
+        // the second 32-pivot factor would work on null directions only (rows nobody reads): it is not run — ~4 us of the chain.
+        const bool half_only = (p == Tp - 1) && (Tp < T) && (klim <= base + 32);
         GmwPanel64* nxt = pans + p;
         if (wv0) GMW_TS(sy, p, 0);
         // operands staged in LDS by waves 1 / 3 during factor 2 of the previous panel: Lr = tile (p-1, p) (rows of the
@@ -243,7 +246,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
         }
         __syncthreads();
         // ---- C2: quarter of X11 -= E'^T W1d -> Xm of factor 2 ----
-        {
+        if (!half_only) {
             d4 x;
 #pragma unroll
             for (int t = 0; t < 4; t++) x[t] = X11[16 * qa + lk + 4 * t][16 * qb + lr];
@@ -264,8 +267,9 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
         // free: wave 1 is the only reader of Lr's E' corner, wave 3 of Wc's W1d corner, both in rows 0..31 which they
         // overwrite themselves.  Waiting for those loads also waits for the wave's earlier stores, so after the closing
         // barrier the panel buffer is complete in memory and panel_ready can be raised at once.
-        if (wv0) { gmw_cols_pivot_wave(ws2, eps, lane); GMW_TS(sy, p + 64, 0); }
+        if (wv0) { if (!half_only) gmw_cols_pivot_wave(ws2, eps, lane); GMW_TS(sy, p + 64, 0); }
         else if (wvu == 2) {
+            if (!half_only) {
             // this wave has slack while it follows the pivots: it asks early whether the owners of the two tiles of the NEXT
             // panel have finished them (normally yes) and tells the others through LDS — saves every wave the ~1 us poll
             // round trip at the end of the iteration
@@ -278,6 +282,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
                 if (p == 0 || gmw_uniform64(fa) >= ebase + p) stageok[0] = 1;
                 if (p == 0 || gmw_uniform64(fb) >= ebase + p) stageok[1] = 1;
             });
+            }
         } else {
             const int c4 = (lane & 7) * 4;
             if (wv1) {
@@ -309,7 +314,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
                 }
             }
             gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD);
-            gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32);
+            if (!half_only) gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32);
             if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
         }
         if (p + 1 < Tp) {
@@ -339,14 +344,16 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
 }
 
 // Worker side of one update step of an owned tile; returns false when a wait expired.
-struct GmwOwned { int I, J, nsteps; bool computed; };
+// kfirst: first panel step the owner takes part in.  passon: a tile of row block Tp of the rank-aware form — its own values are never used, it only
+// turns the LAST pivoted panel into S rows for its columns, so it joins at that step (kfirst = Tp - 1), neither loads nor stores a tile and raises no flag.
+struct GmwOwned { int I, J, nsteps; bool computed; int kfirst; bool passon; };
 struct KDimsLite { int n, ld; };
 // memtile: the tile lives in G between the steps (k_gmw_persist<true>: a worker owns more tiles than accumulator sets would
 // fit): it is read at the start of every step and written back at the end — by the same lanes, with agent-scope accesses, so
 // every lane sees its own earlier stores.
 __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, const GmwOwned& tl, d4 (&acc)[2][2], double* __restrict__ G,
                                                GmwPanel64* pans, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
-                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid, bool memtile = false)
+                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid, bool memtile = false, bool rows32 = false)
 {
     unsigned long long* ver = gmw_sync_ver(sy);
     // the two row-panel tiles (k, I), (k, J) are finished (k updates each) — both flags, and the panel flag, in one round
@@ -373,7 +380,8 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
     const bool behind = *okp == 2;
     const bool last = k == tl.nsteps - 1;
     __syncthreads();                                           // *okp is rewritten by the panel waits below
-    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, memtile || (k == 0 && !tl.computed), memtile || last,
+    return gmw_tile_update<true>(n, ld, 64 * k, tl.I - k - 1, tl.J - k - 1, G, pans + k, Sout, Lr, Wc, tid, acc, !tl.passon && (memtile || (k == 0 && !tl.computed)),
+                                 !tl.passon && (memtile || last),
         [&] {
             if (!behind) { if (wv0) *okp = gmw_wait_ge(&sy->half_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort); }
             __syncthreads();
@@ -384,8 +392,8 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
             __syncthreads();
             return *okp != 0;
         },
-        [&] { if (last) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); },
-        behind);
+        [&] { if (last && !tl.passon) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); },
+        behind, rows32 && tl.passon);
 }
 
 // k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any), both kept in accumulator
@@ -466,11 +474,12 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     if (fs->frozen) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
     const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
     if (blockIdx.x == 0) {
-        gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid);
+        gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid, krows);
     } else {
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
         const int workers = gridDim.x - 1, w = blockIdx.x - 1;
         bool good = true;
+        const bool half_last = (Tp < T) && (krows <= 64 * (Tp - 1) + 32);     // the pivot stops after the first half of the last pivoted panel (gmw_pivot_persist)
         if constexpr (MEM) {
             int kmax = 0;
             for (int m = 0; m < GMW_OWNED_MEM; m++) if (w + m * workers < ntiles) kmax = max(kmax, (int)tiles[w + m * workers].nsteps);
@@ -480,27 +489,28 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
                     if (ti >= ntiles) break;
                     const GmwTile t = tiles[ti];
                     if (k >= t.nsteps) continue;
-                    const GmwOwned tm = { t.I, t.J, t.nsteps, false };
+                    if (k < t.pad) continue;
+                    const GmwOwned tm = { t.I, t.J, t.nsteps, false, t.pad, Tp < T && t.I == Tp };
                     d4 accm[2][2];
                     zero_acc(accm);
-                    good = gmw_owner_step(n, ld, T, k, tm, accm, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, true);
+                    good = gmw_owner_step(n, ld, T, k, tm, accm, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, true, half_last && k == Tp - 1);
                 }
         } else {
-        GmwOwned ta = { 0, 0, 0, false }, tb = { 0, 0, 0, false };
-        if (w < ntiles) { const GmwTile t = tiles[w]; ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; }
-        if (w + workers < ntiles) { const GmwTile t = tiles[w + workers]; tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; }
+        GmwOwned ta = { 0, 0, 0, false, 0, false }, tb = { 0, 0, 0, false, 0, false };
+        if (w < ntiles) { const GmwTile t = tiles[w]; ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; ta.kfirst = t.pad; ta.passon = Tp < T && t.I == Tp; }
+        if (w + workers < ntiles) { const GmwTile t = tiles[w + workers]; tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; tb.kfirst = t.pad; tb.passon = Tp < T && t.I == Tp; }
         d4 acca[2][2], accb[2][2];
         zero_acc(acca); zero_acc(accb);
         if (S0) {
             const KDimsLite dl = { n, ld };
             // (rank-aware form: block row Tp only passes the last pivoted panel's factor rows on; its own values are never used)
-            if (ta.nsteps > 0 && ta.I >= GMW_HEAD_ROWS) { if (ta.I < Tp) gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid, krows); ta.computed = true; }
-            if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { if (tb.I < Tp) gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid, krows); tb.computed = true; }
+            if (ta.nsteps > 0 && ta.I >= GMW_HEAD_ROWS) { if (!ta.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid, krows); ta.computed = true; }
+            if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { if (!tb.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid, krows); tb.computed = true; }
         }
         const int kmax = max(ta.nsteps, tb.nsteps);
         for (int k = 0; k < kmax && good; k++) {
-            if (k < ta.nsteps) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
-            if (good && k < tb.nsteps) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid);
+            if (k < ta.nsteps && k >= ta.kfirst) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1);
+            if (good && k < tb.nsteps && k >= tb.kfirst) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1);
         }
         }
         if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -534,7 +544,8 @@ int srukf_gmw_build_tiles(int T, int Tp, short* out)
         for (int J = I; J < T; J++) {
             const int ns = (I == J && I < Tp) ? I - 1 : I;      // the pivot applies the last update of the diagonal tiles it factors
             if (ns < 1) continue;
-            if (out) { out[4 * cnt] = (short)I; out[4 * cnt + 1] = (short)J; out[4 * cnt + 2] = (short)ns; out[4 * cnt + 3] = 0; }
+            // row block Tp of the rank-aware form only passes the last pivoted panel's factor rows on: it joins at that step
+            if (out) { out[4 * cnt] = (short)I; out[4 * cnt + 1] = (short)J; out[4 * cnt + 2] = (short)ns; out[4 * cnt + 3] = (short)((Tp < T && I == Tp) ? Tp - 1 : 0); }
             cnt++;
         }
     return cnt;
