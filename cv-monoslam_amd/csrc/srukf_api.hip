@@ -37,7 +37,9 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double);
+void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs);
+void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
 void srukf_launch_rank_round(hipStream_t, int, int, double*);
 int srukf_gmw_head_rows(void);
@@ -274,7 +276,8 @@ struct srukf_ctx {
     int gmw_shared = 0;                    // 0: the filter has the GPU to itself; 1: shared with other filters — persistent launches of at most half the CUs behind
                                            // the admission gate (k_gmw_gate); 2: one launch per panel (forced, or after an abandoned persistent launch)
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
-    int dbg_fused_motion = 1;              // srukf_debug_set "fused_motion": replay path with the motion step inside the projection launch (k_project_motion)
+    int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
+                                           // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
     int clamp_frame_host = -1, clamp_row_host = -1;   // what the last SRUKF_ERR_CLAMP_PENDING was about (srukf_clamp_info)
     double *ckS = nullptr, *ckX = nullptr; // srukf_run_frames: state before the block of frames in flight (recovery from a theta-clamp frame)
@@ -398,9 +401,10 @@ static void quantize_state(srukf_ctx* c)
         hipLaunchKernelGGL(k_quantize, dim3(c->d.n + 1), dim3(256), 0, c->stream, c->d.n, c->d.np, c->S, c->X, c->S32, c->X32);
 }
 // rank-aware replay form: what k_motion / k_gain / k_syrk carry along (all null when the shadow copy does not exist)
-static RankArgs rank_args(const srukf_ctx* c)
+static RankArgs rank_args(const srukf_ctx* c, bool prep_next = false)
 {
     RankArgs ra = {};
+    ra.prep_next = prep_next ? 1 : 0;
     if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.perm = c->red_perm; ra.r = c->red_r; }
     return ra;
 }
@@ -413,11 +417,12 @@ static const double* take_xr1(srukf_ctx* c)
 }
 // Replay path: motion step + projection of all sigma points in ONE launch (k_project_motion): workgroup 0 is the motion step,
 // whose results wait beside the state (fs->Xr1, Cmat) until k_gain / the dX job commit them.
-static void seq_predict_fused(srukf_ctx* c)
+static void seq_predict_fused(srukf_ctx* c, int mode)
 {
     const KDims& d = c->d;
     ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N + 60.0 * d.L, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N + 8.0 * d.L + 8.0 * d.n));
-    srukf_launch_project_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
+    if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
+    else srukf_launch_project_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
     c->xr1_pending = true;
 }
 static void seq_predict_motion(srukf_ctx* c, const double* odo_pair_dev)
@@ -458,18 +463,34 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
 // fp32 storage: S, X and the permuted copy are rounded to the stored values first, and the trajectory row is taken from those
 // (as the full-rank form does: quantize_state before the tail).
-static void rank_expand(srukf_ctx* c, bool frame_tail)
+// table: "table" mode of the replay — the tail also prepares the next frame's table of robot poses (k_rank_expand)
+static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false)
 {
     const int n = c->d.n, np = c->d.np;
     const bool f32 = c->storage == SRUKF_STORAGE_F32;
-    srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA);
+    srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
+                             (table && frame_tail && !f32) ? c->sigR : nullptr, c->w.gamma);
     if (f32) {
         quantize_state(c);
         srukf_launch_rank_round(c->stream, np, c->red_r, c->shadowA);
         if (frame_tail) srukf_launch_traj(c->stream, c->d, c->X, c->S, c->fs, nullptr, 1);
     }
 }
-static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail)
+// the rank-aware replay whose owners form their tiles of S^T S - U U^T themselves (seq_refactor below): what a whole staged frame takes
+static bool replay_red_fused(const srukf_ctx* c)
+{
+    return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && gmw_use_persist(c) &&
+           c->gplan_red.workers >= 0 && c->gplan_red.ntiles <= c->gplan_red.workers + c->gplan_red.workers / 16 && c->gplan_red.T >= 16 &&
+           !c->debug_starve && gmw_fused_mode() && rank_fused_mode() && rank_fold_mode();
+}
+// 0: k_motion + k_project; 1: k_project_motion (motion workgroup + projection with the robot part inline); 2: "table" (k_project_table: the
+// previous frame's tail prepared the robot part of every sigma point) — only where the tail is k_rank_expand on fp64 storage
+static int replay_motion_mode(const srukf_ctx* c)
+{
+    if (c->dbg_fused_motion == 2 && !(replay_red_fused(c) && c->storage == SRUKF_STORAGE_F64)) return 1;
+    return c->dbg_fused_motion;
+}
+static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false)
 {
     const KDims& d = c->d;
     const int np = d.np, n = d.n;
@@ -487,15 +508,13 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     // ... and on the replay path directly in permuted order from the shadow copy (no full k_syrk, no permutation pass)
     // (the owners' fold pays with about one tile per worker and T >= 16, as in the full-rank form: frames/s fold / k_syrk over the kept
     //  rows: N = 100 7 360 / 7 610, N = 200 4 360 / 4 300, N = 300 — two tiles per worker — 2 400 / 2 580)
-    const bool red_fused = reduced && c->shadowA && !keep_backup && ub == 0 && ue == d.mp && c->w.wc0 == c->w.wm0 && gmw_use_persist(c) &&
-                           c->gplan_red.workers >= 0 && c->gplan_red.ntiles <= c->gplan_red.workers + c->gplan_red.workers / 16 && c->gplan_red.T >= 16 &&
-                           !c->debug_starve && gmw_fused_mode() && rank_fused_mode() && rank_fold_mode();
+    const bool red_fused = reduced && !keep_backup && ub == 0 && ue == d.mp && replay_red_fused(c);
     if (red_fused) {
         const double rr = c->red_r, hr = srukf_gmw_head_rows();
         {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
             ProfScope ps(c, KC_SYRK, 2.0 * hr * n * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * ((hr + d.mp) * n + (n - rr) * (rr + d.mp)));
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c), take_xr1(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -506,7 +525,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
                                      c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c));
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
-        rank_expand(c, frame_tail);
+        rank_expand(c, frame_tail, table);
         return;
     }
     // ... or, where the owners cannot fold (memory tiles: more than two tiles per worker; one launch per panel), still in permuted
@@ -1526,15 +1545,16 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
 // srukf_debug_set(ctx, "fused_motion", 0): the replay keeps k_motion and k_project as two launches (A/B runs)
 static void replay_one_frame(srukf_ctx* c)
 {
-    if (c->dbg_fused_motion) {
-        seq_predict_fused(c);
+    const int mode = replay_motion_mode(c);
+    if (mode) {
+        seq_predict_fused(c, mode);
         seq_gain(c, nullptr, nullptr, true, true);
     } else {
         seq_predict_motion(c, nullptr);
         seq_predict_measurement(c, true);
         seq_gain(c, nullptr, nullptr, true);
     }
-    seq_refactor(c, 0, c->d.mp, false, false, false, true);
+    seq_refactor(c, 0, c->d.mp, false, false, false, true, mode == 2);
 }
 static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec_t* ge)
 {
@@ -1572,6 +1592,8 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     // traj rows are indexed by the absolute frame counter; offset so that frame `first` lands in row 0
     double* traj = d_traj ? d_traj - (size_t)8 * first : nullptr;
     hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1, traj);
+    // "table" mode: the first frame's table of robot poses (the frames after it get theirs from their predecessor's tail)
+    if (replay_motion_mode(c) == 2) srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs);
     if (c->use_graph && !c->profiling) {
         // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
         // captured frame replays for all frames: the 45 launches cost one hipGraphLaunch on the host
@@ -1790,7 +1812,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!strcmp(key, "use_graph")) c->use_graph = value != 0;
-    else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value ? 1 : 0;
+    else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);
     return SRUKF_OK;

@@ -52,6 +52,7 @@ struct FrameScalars {
     const double* odo_seq;     // staged odometry (3 doubles per pose) and its frame count, a1..a4: what srukf_prepare_control needs
     double a[4];
     int seqF;
+    int ctl_next_valid;        // "table" mode: k_gain prepared fs->ctl for frame + 1 (0: the staged sequence ends with this frame)
     int frozen;                // staged replay: a frame was flagged -> k_motion and the persistent factorisation of the later frames of the run
                                // return at once (three quarters of a frame's time; the other kernels would pay a memory round trip per launch
                                // for the test); cleared with the clamp counters (k_set_frame) and by the step-wise API
@@ -69,19 +70,21 @@ __device__ __forceinline__ void srukf_motion_control_a(const double (&a)[4], con
     mt[1] = a[2] * trans * trans + a[3] * rot1 * rot1 + a[3] * rot2 * rot2;
     mt[2] = a[0] * rot2 * rot2 + a[1] * trans * trans;
 }
-// fs->ctl for the staged frame fs->frame (one thread; call after `frame` was set or advanced)
-__device__ __forceinline__ void srukf_prepare_control(FrameScalars* fs)
+// fs->ctl for the staged frame f (one thread); false: no such frame
+__device__ __forceinline__ bool srukf_prepare_control(FrameScalars* fs, int f)
 {
     const double* os = fs->odo_seq;
-    const int f = fs->frame;
-    if (!os || f < 0 || f >= fs->seqF) return;
+    if (!os || f < 0 || f >= fs->seqF) return false;
     double ut[3], mt[3];
     const double a[4] = { fs->a[0], fs->a[1], fs->a[2], fs->a[3] };
     srukf_motion_control_a(a, os + 3 * f, ut, mt);
     fs->ctl[0] = ut[0]; fs->ctl[1] = ut[1]; fs->ctl[2] = ut[2];
     fs->ctl[3] = cos(ut[2]); fs->ctl[4] = sin(ut[2]);
     fs->ctl[5] = mt[0]; fs->ctl[6] = mt[1]; fs->ctl[7] = mt[2];
+    return true;
 }
+// ... for the frame the counter stands at (call after `frame` was set or advanced)
+__device__ __forceinline__ void srukf_prepare_control(FrameScalars* fs) { srukf_prepare_control(fs, fs->frame); }
 
 // sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1: VALU only, no LDS traffic); every lane of the row gets the total
 template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v)

@@ -85,7 +85,11 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
     // workgroups past the tile list: the state update X += sum_k K_k (z_k - h_k) left over by k_gain, then (rank-aware replay)
     // the diagonal of G at the dropped positions
     if ((int)blockIdx.x >= ntiles + ndx) { srukf_rank_gdiag_job(d.n, d.np, ue, ra, &fs->gmax_bits, blockIdx.x - ntiles - ndx); return; }
-    if ((int)blockIdx.x >= ntiles) { srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles, xr1); return; }
+    if ((int)blockIdx.x >= ntiles) {
+        if (ra.prep_next && (int)blockIdx.x == ntiles && threadIdx.x == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
+        srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles, xr1);
+        return;
+    }
     __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int2 tl = tiles[blockIdx.x];  // upper-triangle tiles only, XCD-aware order

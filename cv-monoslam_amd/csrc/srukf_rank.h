@@ -10,6 +10,8 @@ struct RankArgs {
     const int* iperm;      // state index -> permuted position
     const int* perm;       // permuted position -> state index
     int r;                 // kept pivots (robot last: positions r-4 .. r-1)
+    int prep_next;         // "table" mode of the replay: the k_syrk launch also prepares the NEXT frame's control in fs->ctl (this frame's motion
+                           // step has consumed it; the tail that needs it must not read the frame counter it advances itself)
 };
 
 // gdiag[a] = sum_{k<r} A[k][a]^2 - sum_{m<mu} Utp[m][a]^2 for 16 dropped positions a = r + 16 blk .. (16 columns x 16 row lanes,

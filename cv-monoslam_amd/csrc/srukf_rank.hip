@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include "srukf_device.h"
 #include "srukf_rank.h"
+#include "srukf_motion.h"
 
 // A[a][b] = S[perm[a]][perm[b]] for a < r (the kept rows in permuted column order), zero rows below
 __global__ __launch_bounds__(256) void k_rank_shadow(int n, int ld, int r, const double* __restrict__ S, const int* __restrict__ perm, double* __restrict__ A)
@@ -62,11 +63,41 @@ __global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* 
 __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
                                                      const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
                                                      FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
-                                                     double* __restrict__ A)
+                                                     double* __restrict__ A, double* __restrict__ sigR, double gamma)
 {
     __shared__ double red[16 * 3];
     const int j = blockIdx.x;
+    // "Table" mode of the replay (sigR != null): the workgroup that writes row j of S also pushes the NEXT frame's two sigma points
+    // of direction j through the motion model — robot part only: pose before the step X[n-4..], the row's entries in the robot
+    // columns, the control k_gain prepared in fs->ctl — and leaves them in the table the next k_project_table launch reads.
+    // Two lanes per workgroup, hidden behind the row copy; the frame tail does the centre point and the five noise rows.
+    const int Na = n + 5;
+    const bool table = sigR && fs->ctl_next_valid && !fs->frozen;
+    auto table_rows = [&](const int i, const int sg, const double (&srow)[4], const double (&mnoise)[3]) {
+        const MotionCtl mc = { fs->ctl[0], fs->ctl[1], fs->ctl[2], fs->ctl[3], fs->ctl[4] };
+        const double xr[4] = { X[n - 4], X[n - 3], X[n - 2], X[n - 1] };
+        double rr[4], c2, s2;
+        srukf_motion_point(mc, xr, srow, mnoise, sg ? -gamma : gamma, rr, c2, s2);
+        double4* o = reinterpret_cast<double4*>(sigR + (size_t)(1 + sg * Na + i) * 8);
+        o[0] = make_double4(rr[0], rr[1], rr[2], rr[3]); o[1] = make_double4(c2, s2, 0.0, 0.0);
+    };
     if (j == n) {
+        if (table && threadIdx.x < 11) {
+            const double zero4[4] = { 0, 0, 0, 0 };
+            if (threadIdx.x == 0) {
+                const MotionCtl mc = { fs->ctl[0], fs->ctl[1], fs->ctl[2], fs->ctl[3], fs->ctl[4] };
+                const double xr[4] = { X[n - 4], X[n - 3], X[n - 2], X[n - 1] };
+                double s0[4], c0s, s0s;
+                srukf_motion_centre(mc, xr, s0, c0s, s0s);
+                double4* o = reinterpret_cast<double4*>(sigR);
+                o[0] = make_double4(s0[0], s0[1], s0[2], s0[3]); o[1] = make_double4(c0s, s0s, 0.0, 0.0);
+            } else {
+                const int q = (threadIdx.x - 1) >> 1, sg = (threadIdx.x - 1) & 1;       // noise row n + q (control noise: q < 3)
+                double mnoise[3] = { 0, 0, 0 };
+                if (q < 3) mnoise[q] = fs->ctl[5 + q];
+                table_rows(n + q, sg, zero4, mnoise);
+            }
+        }
         // frame tail: RobotPath.txt row (SLAM.cpp:3549-3556) with P = S^T S restricted to the robot x / y block (2404): the
         // dropped rows have no entry in the robot columns
         const int bx = iperm[n - 4], by = iperm[n - 3];
@@ -84,7 +115,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                 t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
             }
             fs->frame += 1;
-            srukf_prepare_control(fs);                         // control of the next staged frame (k_project_motion)
+            if (!sigR) srukf_prepare_control(fs);              // control of the next staged frame (k_project_motion); "table" mode: k_gain did it
         }
         return;
     }
@@ -103,6 +134,15 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     }
     const int a = iperm[j];
     double* out = S + (size_t)j * ld;
+    if (table && threadIdx.x < 2) {
+        double srow[4] = { 0, 0, 0, 0 };
+        const double zero3[3] = { 0, 0, 0 };
+        if (a < r) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) srow[e] = (r - 4 + e >= a) ? Sp[(size_t)a * ld + (r - 4 + e)] : 0.0;    // the robot columns: permuted positions r-4 .. r-1
+        }
+        table_rows(j, threadIdx.x, srow, zero3);
+    }
     if (a >= r) {                                              // dropped direction: what the reference's clamp leaves
         for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == j) ? sqrt(eps) : 0.0;
         return;
@@ -155,9 +195,10 @@ void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, cons
     hipLaunchKernelGGL(k_rank_diag, dim3((n + 255) / 256), dim3(256), 0, st, n, ld, G, perm, gdiag);
 }
 void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
-                              const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A)
+                              const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A, double* sigR, double gamma)
 {
-    hipLaunchKernelGGL(k_rank_expand, dim3(n + 1 + (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS), dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A);
+    hipLaunchKernelGGL(k_rank_expand, dim3(n + 1 + (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS), dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A,
+                       sigR, gamma);
 }
 void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
 {

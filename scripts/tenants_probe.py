@@ -1,5 +1,6 @@
 """Aggregate frames/s of B filters in SRUKF_GPU_SHARED at N = 200 against the number of persistent launches that share the GPU."""
-import sys, time
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ".")
 import numpy as np
 import __graft_entry__ as ge

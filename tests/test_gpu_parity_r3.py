@@ -69,3 +69,25 @@ def test_bench_force_dist_runs_the_rccl_collectives_with_one_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["collectives"] == "nccl" and d["steps"] == 6
     assert d["value"] > 100 and d["pose_rmse_vs_truth_m"] < 1e-3
+
+
+@pytest.mark.parametrize("N", [20, 200])
+def test_replay_motion_modes_agree(srukf, synth, N):
+    """The three forms of the replay's motion step — its own launch (k_motion, as in the step-wise API), inside the projection launch
+    (k_project_motion), and "table" mode (the previous frame's tail prepares the robot part of every sigma point, k_project_table
+    reduces it; rank-aware replay at N = 200, falls back to the second form at N = 20) — are the same arithmetic in different
+    orders: trajectories and states agree to rounding, over a run that is split into two calls."""
+    p = synth.scene_params()
+    F = 12
+    sc = synth.make_scene(N, F, seed=4, p=p)
+    res = []
+    for mode in (0, 1, 2):
+        f = srukf.Filter(N, p); f.debug_set("fused_motion", mode); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        traj = np.vstack([f.run_frames(0, 5), f.run_frames(5, F - 5)])
+        X, S = f.get_state()
+        res.append((traj, X, S.T @ S))
+    for traj, X, P in res[1:]:
+        np.testing.assert_allclose(traj[:, :4], res[0][0][:, :4], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(traj[:, 4:], res[0][0][:, 4:], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(X, res[0][1], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(P, res[0][2], rtol=0, atol=1e-14)
