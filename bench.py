@@ -296,6 +296,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="go through torch.distributed.run -> init_process_group('nccl') -> broadcast / all-reduce / all-gather even with ONE rank "
                          "(the only way the RCCL calls of the N-rank path execute on a 1-GPU box)")
+    ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 --pmc passes need it)")
     ap.add_argument("--no-collectives-check", action="store_true",
                     help="skip the short --force-dist child run whose outcome the default 1-GPU line reports as `collectives_check`")
     args = ap.parse_args()
@@ -321,6 +322,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.eager:
+        srukf.debug_set_global("graphs", 0)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist                    # --force-dist: the collectives run with one rank too

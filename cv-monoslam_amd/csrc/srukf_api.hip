@@ -21,13 +21,18 @@ void srukf_launch_project(hipStream_t, KDims, KWeights, srukf_params, const doub
 void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const double*, const double*, double*, double*, double*, int*, double*);
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
-                       const double*, const int*, const int*, FrameScalars*, double*, double*, const double*, RankArgs, const double*, double*);
+                       const double*, const int*, const int*, FrameScalars*, double*, double*, const double*, RankArgs, const double*, double*,
+                       const double*, int, const double*, double);
 void srukf_launch_project_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs);
 int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int, KWeights, MeasArgs);
+void srukf_launch_pxy2(hipStream_t, KDims, const double*, const double*, double*, double*, const void*, int, int, KWeights, MeasArgs);
+int srukf_pxy2_build_tiles(int mp, int np, int kr, int* out);
+int srukf_pxy2_split_groups(void);
+extern int g_pxy2_skip;
 void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*, RankArgs, const double*);
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const FrameScalars*);
 int srukf_gmw_panel_bytes(void);
@@ -114,6 +119,7 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
     fs->frame = frame;
     srukf_prepare_control(fs);
     fs->stat_count = 0;
+    for (int q = 0; q < 64; q++) fs->stat_cnt[q] = 0;
     fs->traj_base = nullptr;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
 }
@@ -124,6 +130,7 @@ __global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* 
     fs->frame = frame;
     srukf_prepare_control(fs);                                 // the first frame's control (k_project_motion); later ones by the frame tails
     fs->stat_count = 0;
+    for (int q = 0; q < 64; q++) fs->stat_cnt[q] = 0;
     fs->traj_base = traj_base;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
 }
@@ -270,6 +277,7 @@ struct srukf_ctx {
     int *red_perm = nullptr, *red_iperm = nullptr;     // permuted position <-> state index, kept indices first
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
     double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
+    double* P1 = nullptr; int* pxy2_tiles = nullptr; int n_pxy2_tiles = 0, pxy2_split_b0 = 0;   // "table" mode: k_pxy2's second K half, its tile list
     int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
     double red_fac_flop = 0, red_own_flop = 0;         // algorithmic flop of the rank-aware persistent launch: factorisation / owners' tiles of S^T S - U U^T
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
@@ -278,6 +286,7 @@ struct srukf_ctx {
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
                                            // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
+    int dbg_pxy2 = 1;                      // srukf_debug_set "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
     int clamp_frame_host = -1, clamp_row_host = -1;   // what the last SRUKF_ERR_CLAMP_PENDING was about (srukf_clamp_info)
     double *ckS = nullptr, *ckX = nullptr; // srukf_run_frames: state before the block of frames in flight (recovery from a theta-clamp frame)
@@ -401,10 +410,10 @@ static void quantize_state(srukf_ctx* c)
         hipLaunchKernelGGL(k_quantize, dim3(c->d.n + 1), dim3(256), 0, c->stream, c->d.n, c->d.np, c->S, c->X, c->S32, c->X32);
 }
 // rank-aware replay form: what k_motion / k_gain / k_syrk carry along (all null when the shadow copy does not exist)
-static RankArgs rank_args(const srukf_ctx* c, bool prep_next = false)
+static RankArgs rank_args(const srukf_ctx* c, bool prep_next = false, bool dzperm = false)
 {
     RankArgs ra = {};
-    ra.prep_next = prep_next ? 1 : 0;
+    ra.prep_next = prep_next ? 1 : 0; ra.dzperm = dzperm ? 1 : 0;
     if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.perm = c->red_perm; ra.r = c->red_r; }
     return ra;
 }
@@ -421,7 +430,7 @@ static void seq_predict_fused(srukf_ctx* c, int mode)
 {
     const KDims& d = c->d;
     ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N + 60.0 * d.L, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N + 8.0 * d.L + 8.0 * d.n));
-    if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
+    if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c, false, c->dbg_pxy2 != 0));
     else srukf_launch_project_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
     c->xr1_pending = true;
 }
@@ -686,7 +695,8 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
     return SRUKF_OK;
 }
 // fused_motion: the frame's motion step ran inside k_project_motion: the statistics take the robot mean from fs->Xr1, k_gain commits Cmat
-static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false)
+// table: "table" mode of the replay — the product on the permuted operands (k_pxy2), k_gain takes it from there
+static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false)
 {
     const KDims& d = c->d;
     {
@@ -695,12 +705,13 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
         MeasArgs ms = {};
         const double* xrob = fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
         if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32 };
-        srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
+        if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
+        else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
         srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
-                          fused_motion ? c->Cmat : nullptr, c->S);
+                          fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ, sqrt(c->p.epsilon));
         c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
 }
@@ -761,6 +772,21 @@ static int update_null_set(srukf_ctx* c)
             if (!c->shadowA) {
                 HIPCHK(c, srukf_dmalloc(&c->shadowA, sizeof(double) * (size_t)np * np)); HIPCHK(c, srukf_dmalloc(&c->Utp, sizeof(double) * (size_t)c->d.mp * np));
                 HIPCHK(c, hipMemsetAsync(c->Utp, 0, sizeof(double) * (size_t)c->d.mp * np, c->stream));
+                HIPCHK(c, srukf_dmalloc(&c->P1, sizeof(double) * (size_t)c->d.mp * np));
+                HIPCHK(c, hipMemsetAsync(c->P1, 0, sizeof(double) * (size_t)c->d.mp * np, c->stream));
+            }
+            {
+                // k_pxy2 ("table" mode): 64 x 64 tiles of the permuted product, K ends at the kept rows, long K ranges in two halves
+                const int kr = (r + 15) & ~15;
+                const int nt = srukf_pxy2_build_tiles(c->d.mp, np, kr, nullptr);
+                std::vector<int> tl((size_t)4 * nt);
+                srukf_pxy2_build_tiles(c->d.mp, np, kr, tl.data());
+                if (c->pxy2_tiles) srukf_dfree_on(c->pxy2_tiles, c->stream);
+                c->pxy2_tiles = nullptr; c->n_pxy2_tiles = nt;
+                HIPCHK(c, srukf_dmalloc(&c->pxy2_tiles, sizeof(int) * tl.size()));
+                HIPCHK(c, hipMemcpy(c->pxy2_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
+                c->pxy2_split_b0 = np;                            // first permuted column whose K range is cut in two
+                for (int bt = 0; bt < np / 64; bt++) if (std::min(4 * (bt + 1), ((kr + 63) / 64) * 4) >= srukf_pxy2_split_groups()) { c->pxy2_split_b0 = 64 * bt; break; }
             }
             shadow_rebuild(c);
         }
@@ -884,7 +910,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -1548,7 +1574,7 @@ static void replay_one_frame(srukf_ctx* c)
     const int mode = replay_motion_mode(c);
     if (mode) {
         seq_predict_fused(c, mode);
-        seq_gain(c, nullptr, nullptr, true, true);
+        seq_gain(c, nullptr, nullptr, true, true, mode == 2 && c->dbg_pxy2);
     } else {
         seq_predict_motion(c, nullptr);
         seq_predict_measurement(c, true);
@@ -1797,6 +1823,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     if (!key) return SRUKF_ERR_BAD_ARG;
     struct { const char* k; int* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs } };
+    if (!strcmp(key, "pxy2_skip")) { g_pxy2_skip = value & 3; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }   // timing only: results are garbage
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
         if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;
         g_dbg_shared_tenants = value;
@@ -1812,6 +1839,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!strcmp(key, "use_graph")) c->use_graph = value != 0;
+    else if (!strcmp(key, "pxy2")) c->dbg_pxy2 = value ? 1 : 0;
     else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);

@@ -40,7 +40,9 @@ struct FrameScalars {
     int clamp_rows;            // rows where the GMW theta clamp would have been active
     int clamp_first;           // first such row
     int frame;                 // frame counter for staged sequences
-    int stat_count;            // measurement-statistics slices finished in the current k_pxy launch (last one runs the final pass)
+    int stat_count;            // (unused since round 3: per-group counters below)
+    int stat_cnt[64];          // measurement-statistics jobs finished per landmark group of 32 in the current contraction launch: the last one
+                               // of a group runs its final pass
     double* traj_base;         // device trajectory buffer of the current replay (row = absolute frame), or null
     int gmw_aborts;            // persistent GMW launches abandoned on an expired wait (their frames are flagged like clamp rows)
     int clamp_frame;           // staged replay: index of the FIRST frame whose refactorisation was flagged (0x7fffffff: none).  Set by

@@ -13,6 +13,24 @@
 #include "srukf_gmw_cols.h"
 #include "srukf_meas.h"
 
+// A statistics job that rides on a contraction launch has stored its partial sums: the LAST of the MEAS_SLICES jobs of a landmark
+// group (device-scope counter per group) runs that group's final pass with its whole workgroup.  (One last workgroup for all
+// landmarks, 208 dependent loads per thread, was an 8 us tail on the launch's critical path.)
+__device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w, const MeasArgs& ms, int bx, double* shm)
+{
+    __shared__ int last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's device-scope stores have landed ...
+    __syncthreads();                                           // ... and so have the whole workgroup's, before the count
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(&ms.fs->stat_cnt[bx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (done == MEAS_SLICES - 1);
+        if (last) __hip_atomic_store(&ms.fs->stat_cnt[bx], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next frame
+    }
+    __syncthreads();
+    if (!last) return;
+    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_pxy: landmark rows of all cross covariances in one contraction
 //   Ut[c][r] = sum_{i <= r, i < n} DZ[i][c] * S[i][r]          c < 2N (mp padded), r < np
@@ -32,17 +50,7 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
     if ((int)blockIdx.x < nstat) {
         const int job = blockIdx.x;
         meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm);
-        __shared__ int last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's device-scope stores have landed ...
-        __syncthreads();                                       // ... and so have the whole workgroup's, before the count
-        if (threadIdx.x == 0) {
-            const int done = __hip_atomic_fetch_add(&ms.fs->stat_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (done == ms.gx * MEAS_SLICES - 1);
-            if (last) __hip_atomic_store(&ms.fs->stat_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next frame
-        }
-        __syncthreads();
-        if (!last) return;
-        for (int k = threadIdx.x; k < d.N; k += 256) meas_final_one<true>(d, w, ms.X, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, k);
+        meas_job_done(d, w, ms, job % ms.gx, shm);
         return;
     }
     double (*red)[64][17] = (double (*)[64][17])shm;
@@ -67,6 +75,109 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 Ut[(size_t)(m0 + 16 * a + lk + 4 * t) * d.np + n0 + 16 * b + lr] = acc[a][b][t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pxy2: the same contraction for the rank-aware replay in "table" mode, on the PERMUTED operands:
+//   P[m][b] = sum_{a <= b, a < r} DZp[a][m] * A[a][b]            m < mp, b < np (permuted column), a = permuted row
+// DZp = DZ with its rows in permuted order (k_project_table writes it so), A = the kept rows of S in permuted column order.  The
+// structurally null rows of S (sqrt(EPSILON) e_i) are not in A: their contribution, sqrt(EPSILON) DZ[i][m] to column i only, is
+// added by k_gain.  K ends at r instead of n.
+// k_pxy moves 158 MB from L2 to the CUs per launch (one fragment load per MFMA and lane) and is bound there (6.3 TB/s, 25 us).
+// Here a workgroup owns a 64 x 64 tile of P; each 16-row K group of both operand slabs goes global -> registers -> LDS ONCE per
+// workgroup (double buffered, one barrier per group) and feeds all four waves (32 x 32 sub-tile each): 16 MB from L2.  To fill
+// the GPU the long K ranges are cut in two halves that go to two workgroups; the second half lands in P1 and k_gain adds the two
+// (a + b in a fixed order: deterministic, no atomics).  The measurement statistics ride along as in k_pxy.
+// tiles[w] = (mt, bt, half, halves).
+// ------------------------------------------------------------------------------------------------
+#define PXY2_LS 80
+// 512 threads: EIGHT waves, two per SIMD — a single wave per SIMD issues FP64 MFMAs at 44 % of the rate (34 of 78 TFLOP/s,
+// scripts/mb/mb_mfma_f64.hip; the four-wave form of this kernel took 20.6 us for its 8.5 us of MFMA).  Waves w and w + 4 share a
+// 32 x 32 sub-tile and take k-steps 0-1 / 2-3 of every group; the upper four hand their accumulators over through LDS at the end.
+__global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
+                                              const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms, int skip)
+{
+    __shared__ double shm[2 * 2 * 16 * PXY2_LS];               // [buf][A|B][k][PXY2_LS]; >= MEAS_SM_DOUBLES (statistics scratch), >= 4 x 64 x 17 (hand-over)
+    static_assert(2 * 2 * 16 * PXY2_LS >= MEAS_SM_DOUBLES && 2 * 2 * 16 * PXY2_LS >= 4 * 64 * 17, "scratch");
+    const int nstat = ms.Z ? MEAS_SLICES * ms.gx : 0;         // statistics jobs first: they start with the launch, the tiles fill in behind
+    if ((int)blockIdx.x < nstat) {
+        if ((skip & 1) || threadIdx.x >= 256) return;          // (skip: measurement runs of one half of the launch alone, srukf_debug_set "pxy2_skip")
+        const int job = blockIdx.x;                            // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
+        meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm);
+        meas_job_done(d, w, ms, job % ms.gx, shm);
+        return;
+    }
+    const int4 tl = tiles[blockIdx.x - nstat];
+    if (tl.x < 0 || (skip & 2)) return;                        // empty slot of the XCD-aware list
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = 64 * tl.x, b0 = 64 * tl.y;
+    // A[a][b] = 0 for a > b and for a >= r.  Every range is a whole number of FOUR-group rounds (kr is rounded up to 64 rows — the
+    // rows of A behind the kept ones are zero — and the cut falls on a multiple of four): the rounds below are straight-line code
+    const int ng = min(4 * (tl.y + 1), ((kr + 63) >> 6) << 2);
+    const int gh = (ng / 2) & ~3;
+    const int g0 = (tl.w == 2 && tl.z == 1) ? gh : 0, g1 = (tl.w == 2 && tl.z == 0) ? gh : ng;
+    double (*sA)[16][PXY2_LS] = (double (*)[16][PXY2_LS])shm;                          // sA[buf][k][m]
+    double (*sB)[16][PXY2_LS] = (double (*)[16][PXY2_LS])(shm + 2 * 16 * PXY2_LS);     // sB[buf][k][b]
+    // staging: thread t carries row t >> 5 of the group, two doubles at column 2 (t & 31), of both slabs
+    const int srow = tid >> 5, scol = (tid & 31) * 2;
+    const double* gA = DZp + (size_t)srow * d.mp + m0 + scol;
+    const double* gB = A + (size_t)srow * d.np + b0 + scol;
+    // The slab rows of FOUR groups are in flight at any time (a register ring): nothing else hides the ~2 us a load takes under
+    // this kernel's own traffic, and one group of MFMAs covers 0.2-0.4 us (a single group of look-ahead measured 57 us for the launch).
+    d2 ra[4], rb[4];                                        // (ext vectors: a ring of HIP_vector_type structs ends up in scratch)
+#pragma unroll
+    for (int u = 0; u < 4; u++) { ra[u] = *(const d2*)(gA + (size_t)(16 * (g0 + u)) * d.mp); rb[u] = *(const d2*)(gB + (size_t)(16 * (g0 + u)) * d.np); }
+    *(d2*)&sA[0][srow][scol] = ra[0]; *(d2*)&sB[0][srow][scol] = rb[0];
+    __syncthreads();
+    d4 acc[2][2];
+    zero_acc(acc);
+    const int mo = 32 * ((wv >> 1) & 1), bo = 32 * (wv & 1), kh = 8 * (wv >> 2);
+    for (int gb = g0; gb < g1; gb += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = gb + u;
+            const int buf = u & 1;                             // (g - g0) & 1: gb - g0 is a multiple of 4
+            // slot u held group g, which went to LDS at the end of the previous step: free for group g + 4.  Unconditional (the
+            // last round re-reads the last group): a conditional load makes the compiler wait for ALL loads before every LDS write
+            const int gn = min(g + 4, g1 - 1);
+            ra[u] = *(const d2*)(gA + (size_t)(16 * gn) * d.mp); rb[u] = *(const d2*)(gB + (size_t)(16 * gn) * d.np);
+            double fa0[2], fa1[2], fb0[2], fb1[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                fa0[ks] = sA[buf][kh + 4 * ks + lk][mo + lr]; fa1[ks] = sA[buf][kh + 4 * ks + lk][mo + 16 + lr];
+                fb0[ks] = sB[buf][kh + 4 * ks + lk][bo + lr]; fb1[ks] = sB[buf][kh + 4 * ks + lk][bo + 16 + lr];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[ks], fb0[ks], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[ks], fb1[ks], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[ks], fb0[ks], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[ks], fb1[ks], acc[1][1], 0, 0, 0);
+            }
+            *(d2*)&sA[buf ^ 1][srow][scol] = ra[(u + 1) & 3]; *(d2*)&sB[buf ^ 1][srow][scol] = rb[(u + 1) & 3];
+            __syncthreads();
+        }
+    }
+    // hand-over: waves 4..7 -> LDS -> waves 0..3 (fixed order: lower K steps + upper K steps)
+    double (*ho)[64][17] = (double (*)[64][17])shm;
+    if (wv >= 4) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) ho[wv - 4][lane][(a * 2 + b) * 4 + t] = acc[a][b][t];
+    }
+    __syncthreads();
+    if (wv >= 4) return;
+    double* P = (tl.w == 2 && tl.z == 1) ? P1 : P0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                P[(size_t)(m0 + mo + 16 * a + lk + 4 * t) * d.np + b0 + bo + 16 * b + lr] = acc[a][b][t] + ho[wv][lane][(a * 2 + b) * 4 + t];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -519,6 +630,51 @@ void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S
     const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
     hipLaunchKernelGGL(k_pxy, dim3(ntiles + extra), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles, ntiles, w, ms);
 }
+int g_pxy2_skip = 0;
+void srukf_launch_pxy2(hipStream_t st, KDims d, const double* DZp, const double* A, double* P0, double* P1, const void* tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
+{
+    const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
+    hipLaunchKernelGGL(k_pxy2, dim3(ntiles + extra), dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms, g_pxy2_skip);
+}
+// host-side tile list of k_pxy2 (4 ints per workgroup: mt, bt, half, halves; mt < 0: empty slot).  K ranges of at least PXY2_SPLIT
+// groups are cut in two.  XCD-aware: workgroup w runs on XCD w % 8 (round-robin dispatch; the statistics jobs in front of the
+// list are a multiple of 8), and each XCD has its own L2 — so all mp / 64 tiles that contract the same slab of A (one (bt, half)
+// pair: 0.16-0.33 MB) go to ONE XCD, pairs are dealt to the XCDs longest first onto the least loaded one, and each XCD walks its
+// pairs longest first.  (In plain bt-major order every slab of A was fetched by seven XCDs: 72 MB from the Infinity Cache per launch.)
+// Returns the number of slots; out may be null.
+#define PXY2_SPLIT 16
+int srukf_pxy2_build_tiles(int mp, int np, int kr, int* out)
+{
+    const int ngmax = ((kr + 63) / 64) * 4, nmt = mp / 64;
+    struct Pair { int bt, h, halves, groups; };
+    Pair pairs[2 * 64]; int npairs = 0;
+    for (int bt = np / 64 - 1; bt >= 0 && npairs + 2 <= 2 * 64; bt--) {
+        const int ng = (4 * (bt + 1) < ngmax) ? 4 * (bt + 1) : ngmax;
+        const int halves = ng >= PXY2_SPLIT ? 2 : 1, gh = (ng / 2) & ~3;
+        for (int h = 0; h < halves; h++) pairs[npairs++] = { bt, h, halves, halves == 1 ? ng : (h == 0 ? gh : ng - gh) };
+    }
+    for (int a = 1; a < npairs; a++) { const Pair t = pairs[a]; int b = a; while (b > 0 && pairs[b - 1].groups < t.groups) { pairs[b] = pairs[b - 1]; b--; } pairs[b] = t; }   // longest first
+    int load[8] = { 0 }, cnt[8] = { 0 }, lst[8][2 * 64];
+    for (int a = 0; a < npairs; a++) {
+        int x = 0;
+        for (int q = 1; q < 8; q++) if (load[q] < load[x]) x = q;
+        lst[x][cnt[x]++] = a; load[x] += pairs[a].groups;
+    }
+    int maxlen = 0;
+    for (int x = 0; x < 8; x++) maxlen = cnt[x] * nmt > maxlen ? cnt[x] * nmt : maxlen;
+    if (out) {
+        for (int q = 0; q < maxlen * 8; q++) { out[4 * q] = -1; out[4 * q + 1] = 0; out[4 * q + 2] = 0; out[4 * q + 3] = 1; }
+        for (int x = 0; x < 8; x++)
+            for (int a = 0; a < cnt[x]; a++)
+                for (int mt = 0; mt < nmt; mt++) {
+                    const Pair& pr = pairs[lst[x][a]];
+                    int* o = out + 4 * ((a * nmt + mt) * 8 + x);
+                    o[0] = mt; o[1] = pr.bt; o[2] = pr.h; o[3] = pr.halves;
+                }
+    }
+    return maxlen * 8;
+}
+int srukf_pxy2_split_groups(void) { return PXY2_SPLIT; }
 // dxp != null: (n + 255)/256 extra workgroups apply the pending state update
 // ra.A != null (rank-aware replay): S / Ut are the permuted operands, ceil((n - r) / 16) more workgroups form the dropped diagonal
 void srukf_launch_syrk(hipStream_t st, KDims d, const double* S, const double* Ut, int ub, int ue, double* G, FrameScalars* fs,

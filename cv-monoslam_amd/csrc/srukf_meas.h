@@ -6,7 +6,8 @@
 
 #define MEAS_SLICES 16
 #define MEAS_NS 13
-#define MEAS_SM_DOUBLES (8 * 32 * MEAS_NS)
+#define MEAS_CHUNK 10                                  // rows of Z per thread and chunk: all of them in flight at once
+#define MEAS_SM_DOUBLES (8 * 32 * MEAS_NS + 8 * MEAS_CHUNK * 4)
 // one workgroup: 32 landmarks (bx) x one of MEAS_SLICES row slices (by); smem: MEAS_SM_DOUBLES doubles of LDS
 template <bool COHERENT>
 // xrob: the robot mean AFTER the motion step (X + n - 4, or fs->Xr1 in the replay path where X still holds the mean before it)
@@ -28,16 +29,37 @@ __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights&
     double s[MEAS_NS];
 #pragma unroll
     for (int q = 0; q < MEAS_NS; q++) s[q] = 0.0;
-    for (int c = c_beg + sl; c < c_end; c += 8) {
-        const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
-        const double* r = sigR + (size_t)c * 8;
-        const double dx = z.x - z0.x, dy = z.y - z0.y;
-        const double wt = (c == 0) ? w.wc0 : w.wi;
-        s[0] += dx; s[1] += dy;
-        const double a = w.wi_sr * dx, b = w.wi_sr * dy;
-        s[2] += a * a; s[3] += a * b; s[4] += b * b;
+    // The job walks its rows in chunks of 8 x MEAS_CHUNK: the robot parts of the chunk's sigma points (32 B each, the same for all
+    // 32 landmarks) are staged in LDS by one coalesced pass, then every thread requests ALL its MEAS_CHUNK rows of Z before it
+    // touches the first — one memory round trip per chunk (one row per trip was a round trip per row: 9.8 us per job, the long
+    // pole of the launch the statistics ride on).
+    double (*rs)[4] = (double (*)[4])(smem + 8 * 32 * MEAS_NS);
+    for (int cb = c_beg; cb < c_end; cb += 8 * MEAS_CHUNK) {
+        const int cn = min(8 * MEAS_CHUNK, c_end - cb);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cn * 4; e += 256) rs[e >> 2][e & 3] = sigR[(size_t)(cb + (e >> 2)) * 8 + (e & 3)];
+        double2 zz[MEAS_CHUNK];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); s[5 + e] += dr * dx; s[9 + e] += dr * dy; }
+        for (int u = 0; u < MEAS_CHUNK; u++) {
+            const int c = min(cb + sl + 8 * u, c_end - 1);
+            zz[u] = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MEAS_CHUNK; u++) {
+            const int c = cb + sl + 8 * u;
+            if (c < c_end) {
+                const double2 z = zz[u];
+                const double* r = rs[sl + 8 * u];
+                const double dx = z.x - z0.x, dy = z.y - z0.y;
+                const double wt = (c == 0) ? w.wc0 : w.wi;
+                s[0] += dx; s[1] += dy;
+                const double a = w.wi_sr * dx, b = w.wi_sr * dy;
+                s[2] += a * a; s[3] += a * b; s[4] += b * b;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); s[5 + e] += dr * dx; s[9 + e] += dr * dy; }
+            }
+        }
     }
 #pragma unroll
     for (int q = 0; q < MEAS_NS; q++) sm[sl][lx][q] = s[q];
@@ -58,6 +80,21 @@ __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights&
     }
 }
 
+// The MEAS_SLICES partial sums of one value of landmark k in the fixed order both forms of the final pass use: slice pairs first,
+// then the eight pair sums one after the other.
+template <bool COHERENT>
+__device__ __forceinline__ double meas_slice_pair(const double* __restrict__ part, int half, int k, int q, int pr)
+{
+    const double* s0 = &part[((size_t)(2 * pr) * MEAS_NS + q) * half + k];
+    const double* s1 = &part[((size_t)(2 * pr + 1) * MEAS_NS + q) * half + k];
+    if (COHERENT) return __hip_atomic_load(s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + __hip_atomic_load(s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *s0 + *s1;
+}
+// landmark k, given the reduced sums t[]: h, Si, visible, PxyR
+__device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
+                                                const double* __restrict__ Z, const double (&t)[MEAS_NS],
+                                                double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
+                                                double* __restrict__ PxyR, int k);
 // landmark k: reduce the slices, finish h, Si, visible, PxyR
 template <bool COHERENT>
 __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w, const double* __restrict__ X, const double* __restrict__ sigR,
@@ -65,17 +102,51 @@ __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w
                                                double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
                                                double* __restrict__ PxyR, int k)
 {
-    const int mp = d.mp, half = mp / 2, n = d.n;
+    static_assert(MEAS_SLICES == 16, "eight slice pairs");
+    const int half = d.mp / 2;
     double t[MEAS_NS];
 #pragma unroll
     for (int q = 0; q < MEAS_NS; q++) {
         double acc = 0.0;
-        for (int u = 0; u < MEAS_SLICES; u++) {
-            const double* src = &part[((size_t)u * MEAS_NS + q) * half + k];
-            acc += COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
-        }
+        for (int pr = 0; pr < MEAS_SLICES / 2; pr++) acc += meas_slice_pair<COHERENT>(part, half, k, q, pr);
         t[q] = acc;
     }
+    meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k);
+}
+// One landmark group (32 landmarks) by a whole workgroup of 256 threads: thread (landmark l, pair p) sums its slice pair of all
+// 13 values, the pair sums meet in LDS (sm: MEAS_SM_DOUBLES doubles), 32 threads finish.  Same summation order as meas_final_one.
+__device__ __forceinline__ void meas_final_group(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
+                                                 const double* __restrict__ Z, const double* __restrict__ part,
+                                                 double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
+                                                 double* __restrict__ PxyR, int bx, double* smem)
+{
+    double (*sm)[32][MEAS_NS] = (double (*)[32][MEAS_NS])smem;
+    const int lx = threadIdx.x & 31, pr = threadIdx.x >> 5;
+    const int k = bx * 32 + lx, half = d.mp / 2;
+    __syncthreads();                                           // the partial job's use of the scratch is over
+    if (k < d.N) {
+#pragma unroll
+        for (int q = 0; q < MEAS_NS; q++) sm[pr][lx][q] = meas_slice_pair<true>(part, half, k, q, pr);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && k < d.N) {
+        double t[MEAS_NS];
+#pragma unroll
+        for (int q = 0; q < MEAS_NS; q++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += sm[u][lx][q];
+            t[q] = acc;
+        }
+        meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k);
+    }
+}
+__device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
+                                                const double* __restrict__ Z, const double (&t)[MEAS_NS],
+                                                double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
+                                                double* __restrict__ PxyR, int k)
+{
+    const int mp = d.mp;
     const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * k);
     // h = wm0*Z0 + wi*sum_{c>=1} Z_c = Z0*(wm0 + 2Na*wi) + wi*sum (Z_c - Z0)      (SLAM.cpp:1678-1681)
     const double wsum = w.wm0 + 2.0 * d.Na * w.wi;

@@ -397,7 +397,8 @@ template <bool INLINE_ROBOT>
 __device__ __forceinline__ void project_item(const int g, const KDims& d, const KWeights& w, const srukf_params& p,
                                              const double* __restrict__ X, const double* __restrict__ S,
                                              const double* __restrict__ sigR,
-                                             double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs)
+                                             double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs,
+                                             const int* __restrict__ dzperm = nullptr)
 {
     // flat (direction, landmark) index: no idle lanes when N is not a multiple of the wave size (N = 200: 78 % -> 100 %)
     const int ii = g / d.N, k = g - ii * d.N;
@@ -467,7 +468,8 @@ __device__ __forceinline__ void project_item(const int g, const KDims& d, const 
         *reinterpret_cast<double2*>(Z + (size_t)c * mp + 2 * k) = make_double2(ox, oy);
         if (sgn) { zm[0] = ox; zm[1] = oy; } else { zp[0] = ox; zp[1] = oy; }
     }
-    if (i < n) *reinterpret_cast<double2*>(DZ + (size_t)i * mp + 2 * k) = make_double2(zp[0] - zm[0], zp[1] - zm[1]);
+    // dzperm ("table" mode): the rows of DZ in the permuted order of the rank-aware form, the K order of k_pxy2
+    if (i < n) *reinterpret_cast<double2*>(DZ + (size_t)(dzperm ? dzperm[i] : i) * mp + 2 * k) = make_double2(zp[0] - zm[0], zp[1] - zm[1]);
 }
 __global__ __launch_bounds__(256) void k_project(KDims d, KWeights w, srukf_params p,
                                                  const double* __restrict__ X, const double* __restrict__ S,
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 {
     __shared__ double sm[MOTION_SM_DOUBLES];
     if (blockIdx.x == 0) { motion_reduce_body<256>(d, w, X, S, sigR, Cm, fs, ra, sm); return; }
-    project_item<false>((blockIdx.x - 1) * 256 + threadIdx.x, d, w, p, X, S, sigR, Z, DZ, fs);
+    project_item<false>((blockIdx.x - 1) * 256 + threadIdx.x, d, w, p, X, S, sigR, Z, DZ, fs, ra.dzperm ? ra.iperm : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               const double* __restrict__ h, const double* __restrict__ z_seq,
                                               const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
                                               FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra,
-                                              const double* __restrict__ Cm, double* __restrict__ S)
+                                              const double* __restrict__ Cm, double* __restrict__ S,
+                                              const double* __restrict__ P1, int split_b0, const double* __restrict__ DZp, double sqeps)
 {
     __shared__ double red[4][64];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
@@ -593,7 +596,14 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
             double u0 = 0.0, u1 = 0.0;
             if (lon[q] && r < n) {
                 double p0, p1;
-                if (r < n - 4) {
+                if (r < n - 4 && P1) {
+                    // "table" mode: the raw product arrives in permuted columns (k_pxy2): first K half in Utp, second in P1 where the
+                    // range was cut; a structurally null row of S contributes sqrt(EPSILON) DZ[r] to its own column only
+                    double q0 = ra.Utp[(size_t)(2 * k) * ld + rp], q1 = ra.Utp[(size_t)(2 * k + 1) * ld + rp];
+                    if (rp >= split_b0) { q0 += P1[(size_t)(2 * k) * ld + rp]; q1 += P1[(size_t)(2 * k + 1) * ld + rp]; }
+                    if (rp >= ra.r) { q0 += sqeps * DZp[(size_t)rp * mp + 2 * k]; q1 += sqeps * DZp[(size_t)rp * mp + 2 * k + 1]; }
+                    p0 = sc * q0; p1 = sc * q1;
+                } else if (r < n - 4) {
                     p0 = sc * Ut[(size_t)(2 * k) * ld + r];
                     p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
                 } else {
@@ -794,9 +804,11 @@ void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* 
 int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
-                       FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra, const double* Cm, double* S)
+                       FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra, const double* Cm, double* S,
+                       const double* P1, int split_b0, const double* DZp, double sqeps)
 {
-    hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra, Cm, S);
+    hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra, Cm, S,
+                       P1, split_b0, DZp, sqeps);
     if (w.wc0 != w.wm0)
         hipLaunchKernelGGL(k_gain_center, dim3(d.np / 256 + 1), dim3(256), 0, st, d, w, Ut, Z, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
 }

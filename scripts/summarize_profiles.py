@@ -34,7 +34,7 @@ def agg(path):
 
 
 f, w = agg(fetch), agg(write)
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches: SRUKF_NO_GRAPH=1), bench.py N=200",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches: bench.py --eager), bench.py N=200",
        "unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     if not k.startswith("k_"):
