@@ -114,7 +114,7 @@ def collectives_check(timeout=240):
     rank).  Never fails the line: the outcome is reported."""
     try:
         rc, line = spawn_ranks(1, ["--gpus", "1", "--force-dist", "--steps", "8", "--warmup", "2", "--profile-frames", "4", "--no-cpu-baseline",
-                                   "--sequences-per-gpu", "0"], timeout=timeout)
+                                   "--sequences-per-gpu", "0", "--no-configs4"], timeout=timeout)
         if rc != 0 or not line:
             return {"ok": False, "returncode": rc}
         d = json.loads(line)
@@ -259,6 +259,46 @@ def cpu_baseline(synth, sc, N, frames, matched_frames=24):
     }, traj
 
 
+def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
+    """BASELINE configs[4] observed by the driver: N = 500 landmarks (n = 3004), fp32 STORAGE of the filter state (X and S live as float
+    between frames, every frame computes in fp64 from exactly what fp32 holds: srukf_set_storage), same synthetic scene family, K frames
+    of graph replay after W warm-up frames; its own roofline object for the dominant kernel (eager leg of PF frames with HIP events)."""
+    sc = synth.make_scene(N, 4 + PF + W + K, seed=0, p=synth.scene_params())
+    f = srukf.Filter(N, sc["params"], device=local)
+    f.set_state(sc["X0"], sc["S0"])
+    f.set_storage(srukf.STORAGE_F32)
+    f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    f.set_profiling(1)
+    f.run_frames_async(0, 4); f.synchronize(); f.profile_reset()
+    f.run_frames_async(4, PF); f.synchronize()
+    prof = f.profile(); f.set_profiling(0)
+    f.prepare_frames(K)
+    f.run_frames_async(4 + PF, W); f.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f.run_frames_async(4 + PF + W, K); f.synchronize()
+    dt = time.perf_counter() - t0
+    pose, _ = f.get_robot()
+    err = float(np.abs(np.asarray(pose)[:2] - sc["odo"][4 + PF + W + K, :2]).max())
+    dom = max((k for k in prof if prof[k]["launches"]), key=lambda k: prof[k]["ms"])
+    d = prof[dom]
+    avg_s = d["ms"] / d["launches"] * 1e-3
+    fl, by = d["alg_flops"] / d["launches"], d["alg_bytes"] / d["launches"]
+    if fl / max(by, 1.0) > FP64_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+        roof = {"bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof.update({"traffic": None, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches_per_frame": d["launches"] / PF})
+    out = {"workload": f"BASELINE configs[4]: {N} landmarks (n={6 * N + 4}), fp32 storage of X / S between frames, fp64 arithmetic, one GPU",
+           "value": K / dt, "unit": "frames/s", "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "dtype": "f64 (state stored as f32)",
+           "roofline": roof, "null_directions_skipped": f.null_directions(), "pose_err_vs_truth_m": err,
+           "kernels_us_per_frame": {k: round(v["ms"] / PF * 1e3, 1) for k, v in prof.items() if v["launches"]},
+           "note": "the mixed-precision sqrt(S) downdate of configs[4] (SRUKF_STORAGE_F32_MIXED) is refused below epsilon = 1e-9: DESIGN.md, row g"}
+    f.close()
+    return out
+
+
 def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local):
     """B independent sequences (Monte-Carlo runs: same map, own measurement noise) on ONE GPU, one
     context + HIP stream each, frames replayed concurrently.  Returns aggregate frames/s."""
@@ -296,6 +336,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="go through torch.distributed.run -> init_process_group('nccl') -> broadcast / all-reduce / all-gather even with ONE rank "
                          "(the only way the RCCL calls of the N-rank path execute on a 1-GPU box)")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the N = 500 / fp32-storage leg (BASELINE configs[4]) of the 1-GPU line")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 --pmc passes need it)")
     ap.add_argument("--no-collectives-check", action="store_true",
                     help="skip the short --force-dist child run whose outcome the default 1-GPU line reports as `collectives_check`")
@@ -437,6 +478,8 @@ def main():
                 torch, synth, srukf, N, B, min(K, 100), 10, local),
                 "note": "B independent Monte-Carlo sequences replayed concurrently on one GPU (one context/stream each, SRUKF_GPU_SHARED: "
                         "persistent launches of half the CUs, at most two admitted at a time); not the headline value"}
+        if world == 1 and not args.no_configs4:
+            out["configs4"] = configs4_leg(torch, synth, srukf, local)
         if world == 1 and not args.no_cpu_baseline:
             cb, otraj = cpu_baseline(synth, sc, N, args.cpu_frames)
             g = srukf.Filter(N, sc["params"], device=local)
