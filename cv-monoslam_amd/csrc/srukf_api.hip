@@ -43,8 +43,8 @@ void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, dou
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double);
-void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs);
-void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*);
+void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
+void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
 void srukf_launch_rank_round(hipStream_t, int, int, double*);
 int srukf_gmw_head_rows(void);
@@ -278,6 +278,7 @@ struct srukf_ctx {
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
     double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
     double* P1 = nullptr; int* pxy2_tiles = nullptr; int n_pxy2_tiles = 0, pxy2_split_b0 = 0;   // "table" mode: k_pxy2's second K half, its tile list
+    int* nskip = nullptr; int ns_full = 0, ns_null = 0, ns_rows = 0;   // NullSkip lists (srukf_device.h): [dirs | nulls | rows] in one buffer
     int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
     double red_fac_flop = 0, red_own_flop = 0;         // algorithmic flop of the rank-aware persistent launch: factorisation / owners' tiles of S^T S - U U^T
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
@@ -286,6 +287,7 @@ struct srukf_ctx {
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
                                            // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
+    int dbg_nullskip = 1;                  // srukf_debug_set "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
     int dbg_pxy2 = 1;                      // srukf_debug_set "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
     int clamp_frame_host = -1, clamp_row_host = -1;   // what the last SRUKF_ERR_CLAMP_PENDING was about (srukf_clamp_info)
@@ -417,6 +419,16 @@ static RankArgs rank_args(const srukf_ctx* c, bool prep_next = false, bool dzper
     if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.perm = c->red_perm; ra.r = c->red_r; }
     return ra;
 }
+// NullSkip of the "table" mode (all null: every direction is projected and read in full)
+static NullSkip null_skip(const srukf_ctx* c)
+{
+    NullSkip ns = {};
+    if (c->dbg_nullskip && c->dbg_pxy2 && c->nskip && c->red_r > 0) {
+        ns.dirs = c->nskip; ns.nulls = c->nskip + c->ns_full; ns.rows = c->nskip + c->ns_full + c->ns_null;
+        ns.nfull = c->ns_full; ns.nnull = c->ns_null; ns.nrows = c->ns_rows; ns.iperm = c->red_iperm; ns.r = c->red_r;
+    }
+    return ns;
+}
 // fs->Xr1 for the launch that applies the pending state update (and only once)
 static const double* take_xr1(srukf_ctx* c)
 {
@@ -430,7 +442,7 @@ static void seq_predict_fused(srukf_ctx* c, int mode)
 {
     const KDims& d = c->d;
     ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N + 60.0 * d.L, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N + 8.0 * d.L + 8.0 * d.n));
-    if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c, false, c->dbg_pxy2 != 0));
+    if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c, false, c->dbg_pxy2 != 0), null_skip(c));
     else srukf_launch_project_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
     c->xr1_pending = true;
 }
@@ -704,7 +716,7 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
         ProfScope ps(c, KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
         MeasArgs ms = {};
         const double* xrob = fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
-        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32 };
+        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{} };
         if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
         else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
     }
@@ -785,6 +797,21 @@ static int update_null_set(srukf_ctx* c)
                 c->pxy2_tiles = nullptr; c->n_pxy2_tiles = nt;
                 HIPCHK(c, srukf_dmalloc(&c->pxy2_tiles, sizeof(int) * tl.size()));
                 HIPCHK(c, hipMemcpy(c->pxy2_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
+                {
+                    // NullSkip: which directions are projected for all landmarks, which only for their own, which rows of Z the statistics walk
+                    std::vector<int> dirs, nulls, rows;
+                    const int Na = n + 5;
+                    for (int i = 0; i < Na; i++) ((i >= n || i < 2 || iperm[i] < r) ? dirs : nulls).push_back(i);
+                    rows.push_back(0);
+                    for (int i : dirs) rows.push_back(1 + i);
+                    for (int i : dirs) rows.push_back(1 + Na + i);
+                    std::vector<int> all(dirs); all.insert(all.end(), nulls.begin(), nulls.end()); all.insert(all.end(), rows.begin(), rows.end());
+                    if (c->nskip) srukf_dfree_on(c->nskip, c->stream);
+                    c->nskip = nullptr;
+                    HIPCHK(c, srukf_dmalloc(&c->nskip, sizeof(int) * all.size()));
+                    HIPCHK(c, hipMemcpy(c->nskip, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice));
+                    c->ns_full = (int)dirs.size(); c->ns_null = (int)nulls.size(); c->ns_rows = (int)rows.size();
+                }
                 c->pxy2_split_b0 = np;                            // first permuted column whose K range is cut in two
                 for (int bt = 0; bt < np / 64; bt++) if (std::min(4 * (bt + 1), ((kr + 63) / 64) * 4) >= srukf_pxy2_split_groups()) { c->pxy2_split_b0 = 64 * bt; break; }
             }
@@ -910,7 +937,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -1619,7 +1646,7 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     double* traj = d_traj ? d_traj - (size_t)8 * first : nullptr;
     hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1, traj);
     // "table" mode: the first frame's table of robot poses (the frames after it get theirs from their predecessor's tail)
-    if (replay_motion_mode(c) == 2) srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs);
+    if (replay_motion_mode(c) == 2) srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs, c->red_iperm, c->red_r);
     if (c->use_graph && !c->profiling) {
         // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
         // captured frame replays for all frames: the 45 launches cost one hipGraphLaunch on the host
@@ -1840,6 +1867,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!strcmp(key, "pxy2")) c->dbg_pxy2 = value ? 1 : 0;
+    else if (!strcmp(key, "nullskip")) c->dbg_nullskip = value ? 1 : 0;
     else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);

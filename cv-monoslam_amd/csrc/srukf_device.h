@@ -215,10 +215,19 @@ __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* _
 }
 
 // measurement-statistics work attached to a k_pxy launch (replay path): Z == null -> none
+// "Table" mode of the rank-aware replay: a structurally null row of S (sqrt(EPSILON) e_i, nothing in the robot columns) moves ONE landmark
+// only, by sqrt(EPSILON) gamma in one anchor coordinate — for every other landmark both its sigma points project exactly where the centre
+// point does (same function, same inputs), so their Z rows equal Z_0, their DZ entries are 0 and their terms in every statistic are
+// exact zeros.  They are neither projected nor read: dirs = the directions that are projected for all landmarks (kept rows, the noise
+// rows, and rows 0 / 1, whose Z rows the Si factor names explicitly), nulls = the others (one item each: their own landmark i / 6),
+// rows = the rows of Z the statistics walk (0, then 1 + i and 1 + Na + i of every direction in dirs).  All null: every direction is full.
+struct NullSkip { const int* dirs; const int* nulls; const int* rows; int nfull, nnull, nrows; const int* iperm; int r; };
+
 struct MeasArgs {
     const double* X; const double* xrob; const double* sigR; const double* Z; double* part;   // xrob: robot mean after the motion step (4 doubles)
     double* h; double* Si; int* vis; double* PxyR;
     FrameScalars* fs; int gx;                                  // gx = (N + 31) / 32 landmark groups
+    NullSkip ns;                                               // ns.rows != null: the statistics walk that row list (+ every landmark's own null rows)
 };
 
 // ---- agent-scope (device-coherent) accesses: data handed from one workgroup to another INSIDE a launch ----

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
     if ((int)blockIdx.x < nstat) {
         if ((skip & 1) || threadIdx.x >= 256) return;          // (skip: measurement runs of one half of the launch alone, srukf_debug_set "pxy2_skip")
         const int job = blockIdx.x;                            // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
-        meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm);
+        meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm, ms.ns);
         meas_job_done(d, w, ms, job % ms.gx, shm);
         return;
     }

@@ -9,17 +9,20 @@
 #define MEAS_CHUNK 10                                  // rows of Z per thread and chunk: all of them in flight at once
 #define MEAS_SM_DOUBLES (8 * 32 * MEAS_NS + 8 * MEAS_CHUNK * 4)
 // one workgroup: 32 landmarks (bx) x one of MEAS_SLICES row slices (by); smem: MEAS_SM_DOUBLES doubles of LDS
-template <bool COHERENT>
 // xrob: the robot mean AFTER the motion step (X + n - 4, or fs->Xr1 in the replay path where X still holds the mean before it)
+// ns.rows != null (NullSkip, srukf_device.h): the job's rows are a slice of that list instead of a slice of 0 .. L-1, and slice 0 adds,
+// for each of its landmarks, the six rows of the landmark's own structurally null directions (all other null rows are exact zeros).
+template <bool COHERENT>
 __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights& w, const double* __restrict__ xrob,
                                                  const double* __restrict__ sigR, const double* __restrict__ Z,
-                                                 double* __restrict__ part /* [MEAS_SLICES][MEAS_NS][mp/2] */, int bx, int by, double* smem)
+                                                 double* __restrict__ part /* [MEAS_SLICES][MEAS_NS][mp/2] */, int bx, int by, double* smem,
+                                                 const NullSkip ns = NullSkip{})
 {
     double (*sm)[32][MEAS_NS] = (double (*)[32][MEAS_NS])smem;
     const int lx = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int k = bx * 32 + lx;
     const int kk = (k < d.N) ? k : 0;
-    const int L = d.L, mp = d.mp;
+    const int L = ns.rows ? ns.nrows : d.L, mp = d.mp;          // (list positions when a row list is given)
     const int rows = (L + MEAS_SLICES - 1) / MEAS_SLICES;
     const int c_beg = by * rows, c_end = min(L, c_beg + rows);
     const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * kk);
@@ -37,11 +40,14 @@ __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights&
     for (int cb = c_beg; cb < c_end; cb += 8 * MEAS_CHUNK) {
         const int cn = min(8 * MEAS_CHUNK, c_end - cb);
         __syncthreads();
-        for (int e = threadIdx.x; e < cn * 4; e += 256) rs[e >> 2][e & 3] = sigR[(size_t)(cb + (e >> 2)) * 8 + (e & 3)];
+        for (int e = threadIdx.x; e < cn * 4; e += 256) {
+            const int cp = cb + (e >> 2), c = ns.rows ? ns.rows[cp] : cp;
+            rs[e >> 2][e & 3] = sigR[(size_t)c * 8 + (e & 3)];
+        }
         double2 zz[MEAS_CHUNK];
 #pragma unroll
         for (int u = 0; u < MEAS_CHUNK; u++) {
-            const int c = min(cb + sl + 8 * u, c_end - 1);
+            const int cp = min(cb + sl + 8 * u, c_end - 1), c = ns.rows ? ns.rows[cp] : cp;
             zz[u] = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
         }
         __syncthreads();
@@ -52,13 +58,29 @@ __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights&
                 const double2 z = zz[u];
                 const double* r = rs[sl + 8 * u];
                 const double dx = z.x - z0.x, dy = z.y - z0.y;
-                const double wt = (c == 0) ? w.wc0 : w.wi;
+                const double wt = (c == 0) ? w.wc0 : w.wi;                 // (list position 0 is row 0 as well)
                 s[0] += dx; s[1] += dy;
                 const double a = w.wi_sr * dx, b = w.wi_sr * dy;
                 s[2] += a * a; s[3] += a * b; s[4] += b * b;
 #pragma unroll
                 for (int e = 0; e < 4; e++) { const double dr = wt * (r[e] - xr[e]); s[5 + e] += dr * dx; s[9 + e] += dr * dy; }
             }
+        }
+    }
+    if (ns.rows && by == 0 && sl < 6 && k < d.N) {
+        // the landmark's own null directions (anchor coordinates 6 k + e): sub-slice sl takes (e, sign) = (sl >> 1, sl & 1)
+        const int i = 6 * k + (sl >> 1);
+        if (i >= 2 && ns.iperm[i] >= ns.r) {
+            const int c = 1 + (sl & 1) * d.Na + i;
+            const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * k);
+            const double4 rr = *reinterpret_cast<const double4*>(sigR + (size_t)c * 8);
+            const double r[4] = { rr.x, rr.y, rr.z, rr.w };
+            const double dx = z.x - z0.x, dy = z.y - z0.y;
+            s[0] += dx; s[1] += dy;
+            const double a = w.wi_sr * dx, b = w.wi_sr * dy;
+            s[2] += a * a; s[3] += a * b; s[4] += b * b;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const double dr = w.wi * (r[e] - xr[e]); s[5 + e] += dr * dx; s[9 + e] += dr * dy; }
         }
     }
 #pragma unroll

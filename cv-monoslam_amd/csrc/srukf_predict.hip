@@ -344,7 +344,7 @@ __device__ __forceinline__ void motion_reduce_body(const KDims& d, const KWeight
 // The table of robot poses for ALL directions from the state as it stands (S in state order): the first frame of a staged run in
 // "table" mode, whose predecessor's tail did not prepare it.  One thread per direction, thread 0 also the centre point.
 __global__ __launch_bounds__(256) void k_sigr_rows(KDims d, KWeights w, const double* __restrict__ X, const double* __restrict__ S,
-                                                   double* __restrict__ sigR, const FrameScalars* __restrict__ fs)
+                                                   double* __restrict__ sigR, const FrameScalars* __restrict__ fs, const int* __restrict__ iperm, int rkeep)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = d.n, Na = d.Na, ld = d.np;
@@ -365,10 +365,12 @@ __global__ __launch_bounds__(256) void k_sigr_rows(KDims d, KWeights w, const do
         const double2 u0 = sp2[0], u1 = sp2[1];
         srow[0] = u0.x; srow[1] = u0.y; srow[2] = u1.x; srow[3] = u1.y;
     } else if (i < n + 3) mnoise[i - n] = fs->ctl[5 + (i - n)];
+    const bool isnull = i < n && iperm[i] >= rkeep;             // a structurally null row: both points ARE the centre point (same bits: NullSkip rests on it)
 #pragma unroll
     for (int sg = 0; sg < 2; sg++) {
         double r[4], c2, s2;
-        srukf_motion_point(mc, xr, srow, mnoise, sg ? -w.gamma : w.gamma, r, c2, s2);
+        if (isnull) { srukf_motion_centre(mc, xr, r, c2, s2); }
+        else srukf_motion_point(mc, xr, srow, mnoise, sg ? -w.gamma : w.gamma, r, c2, s2);
         double4* o = reinterpret_cast<double4*>(sigR + (size_t)(1 + sg * Na + i) * 8);
         o[0] = make_double4(r[0], r[1], r[2], r[3]); o[1] = make_double4(c2, s2, 0.0, 0.0);
     }
@@ -394,6 +396,12 @@ __global__ __launch_bounds__(512) void k_motion(KDims d, KWeights w, srukf_param
 //   from the state before the motion step and the prepared control fs->ctl; it waits for nothing.
 // ------------------------------------------------------------------------------------------------
 template <bool INLINE_ROBOT>
+__device__ __forceinline__ void project_dir(const int ii, const int k, const KDims& d, const KWeights& w, const srukf_params& p,
+                                            const double* __restrict__ X, const double* __restrict__ S,
+                                            const double* __restrict__ sigR,
+                                            double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs,
+                                            const int* __restrict__ dzperm);
+template <bool INLINE_ROBOT>
 __device__ __forceinline__ void project_item(const int g, const KDims& d, const KWeights& w, const srukf_params& p,
                                              const double* __restrict__ X, const double* __restrict__ S,
                                              const double* __restrict__ sigR,
@@ -402,8 +410,18 @@ __device__ __forceinline__ void project_item(const int g, const KDims& d, const 
 {
     // flat (direction, landmark) index: no idle lanes when N is not a multiple of the wave size (N = 200: 78 % -> 100 %)
     const int ii = g / d.N, k = g - ii * d.N;
-    const int n = d.n, Na = d.Na, ld = d.np, mp = d.mp;
     if (ii > d.Na) return;
+    project_dir<INLINE_ROBOT>(ii, k, d, w, p, X, S, sigR, Z, DZ, fs, dzperm);
+}
+// landmark k under direction ii (0: the centre point, ii >= 1: the +/- pair of row ii - 1 of the augmented sqrt matrix)
+template <bool INLINE_ROBOT>
+__device__ __forceinline__ void project_dir(const int ii, const int k, const KDims& d, const KWeights& w, const srukf_params& p,
+                                            const double* __restrict__ X, const double* __restrict__ S,
+                                            const double* __restrict__ sigR,
+                                            double* __restrict__ Z, double* __restrict__ DZ, const FrameScalars* __restrict__ fs,
+                                            const int* __restrict__ dzperm)
+{
+    const int n = d.n, Na = d.Na, ld = d.np, mp = d.mp;
     const double f1 = p.cam_f / p.cam_dx, f2 = p.cam_f / p.cam_dy;
     double base[6];
 #pragma unroll
@@ -494,11 +512,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_project_table(KDims d, KWeights w, srukf_params p,
                                                        double* __restrict__ X, double* __restrict__ S,
                                                        double* __restrict__ sigR, double* __restrict__ Cm,
-                                                       double* __restrict__ Z, double* __restrict__ DZ, FrameScalars* __restrict__ fs, const RankArgs ra)
+                                                       double* __restrict__ Z, double* __restrict__ DZ, FrameScalars* __restrict__ fs, const RankArgs ra,
+                                                       const NullSkip ns)
 {
     __shared__ double sm[MOTION_SM_DOUBLES];
     if (blockIdx.x == 0) { motion_reduce_body<256>(d, w, X, S, sigR, Cm, fs, ra, sm); return; }
-    project_item<false>((blockIdx.x - 1) * 256 + threadIdx.x, d, w, p, X, S, sigR, Z, DZ, fs, ra.dzperm ? ra.iperm : nullptr);
+    const int g = (blockIdx.x - 1) * 256 + threadIdx.x;
+    const int* dzperm = ra.dzperm ? ra.iperm : nullptr;
+    if (!ns.dirs) { project_item<false>(g, d, w, p, X, S, sigR, Z, DZ, fs, dzperm); return; }
+    // NullSkip (srukf_device.h): the full directions x all landmarks, then one item per structurally null direction (its own landmark)
+    const int nf = (1 + ns.nfull) * d.N;                        // the centre point first
+    if (g < nf) { const int q = g / d.N; project_dir<false>(q ? 1 + ns.dirs[q - 1] : 0, g - q * d.N, d, w, p, X, S, sigR, Z, DZ, fs, dzperm); }
+    else if (g - nf < ns.nnull) { const int i = ns.nulls[g - nf]; project_dir<false>(1 + i, i / 6, d, w, p, X, S, sigR, Z, DZ, fs, dzperm); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -601,7 +626,8 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                     // range was cut; a structurally null row of S contributes sqrt(EPSILON) DZ[r] to its own column only
                     double q0 = ra.Utp[(size_t)(2 * k) * ld + rp], q1 = ra.Utp[(size_t)(2 * k + 1) * ld + rp];
                     if (rp >= split_b0) { q0 += P1[(size_t)(2 * k) * ld + rp]; q1 += P1[(size_t)(2 * k + 1) * ld + rp]; }
-                    if (rp >= ra.r) { q0 += sqeps * DZp[(size_t)rp * mp + 2 * k]; q1 += sqeps * DZp[(size_t)rp * mp + 2 * k + 1]; }
+                    // (its DZ row is zero outside its own landmark r / 6 — exactly, see NullSkip — and may not even be written there)
+                    if (rp >= ra.r && k == r / 6) { q0 += sqeps * DZp[(size_t)rp * mp + 2 * k]; q1 += sqeps * DZp[(size_t)rp * mp + 2 * k + 1]; }
                     p0 = sc * q0; p1 = sc * q1;
                 } else if (r < n - 4) {
                     p0 = sc * Ut[(size_t)(2 * k) * ld + r];
@@ -780,14 +806,15 @@ void srukf_launch_project_motion(hipStream_t st, KDims d, KWeights w, srukf_para
     hipLaunchKernelGGL(k_project_motion, grid, dim3(512), 0, st, d, w, p, X, S, sigR, Cm, Z, DZ, fs, ra);
 }
 void srukf_launch_project_table(hipStream_t st, KDims d, KWeights w, srukf_params p, double* X, double* S, double* sigR, double* Cm,
-                                double* Z, double* DZ, FrameScalars* fs, RankArgs ra)
+                                double* Z, double* DZ, FrameScalars* fs, RankArgs ra, NullSkip ns)
 {
-    dim3 grid(1 + ((d.Na + 1) * d.N + 255) / 256);
-    hipLaunchKernelGGL(k_project_table, grid, dim3(256), 0, st, d, w, p, X, S, sigR, Cm, Z, DZ, fs, ra);
+    const int items = ns.dirs ? (1 + ns.nfull) * d.N + ns.nnull : (d.Na + 1) * d.N;
+    dim3 grid(1 + (items + 255) / 256);
+    hipLaunchKernelGGL(k_project_table, grid, dim3(256), 0, st, d, w, p, X, S, sigR, Cm, Z, DZ, fs, ra, ns);
 }
-void srukf_launch_sigr_rows(hipStream_t st, KDims d, KWeights w, const double* X, const double* S, double* sigR, const FrameScalars* fs)
+void srukf_launch_sigr_rows(hipStream_t st, KDims d, KWeights w, const double* X, const double* S, double* sigR, const FrameScalars* fs, const int* iperm, int rkeep)
 {
-    hipLaunchKernelGGL(k_sigr_rows, dim3((d.Na + 255) / 256), dim3(256), 0, st, d, w, X, S, sigR, fs);
+    hipLaunchKernelGGL(k_sigr_rows, dim3((d.Na + 255) / 256), dim3(256), 0, st, d, w, X, S, sigR, fs, iperm, rkeep);
 }
 void srukf_launch_project(hipStream_t st, KDims d, KWeights w, srukf_params p, const double* X, const double* S, const double* sigR,
                           double* Z, double* DZ, const FrameScalars* fs)

@@ -73,11 +73,12 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     // Two lanes per workgroup, hidden behind the row copy; the frame tail does the centre point and the five noise rows.
     const int Na = n + 5;
     const bool table = sigR && fs->ctl_next_valid && !fs->frozen;
-    auto table_rows = [&](const int i, const int sg, const double (&srow)[4], const double (&mnoise)[3]) {
+    auto table_rows = [&](const int i, const int sg, const double (&srow)[4], const double (&mnoise)[3], const bool isnull) {
         const MotionCtl mc = { fs->ctl[0], fs->ctl[1], fs->ctl[2], fs->ctl[3], fs->ctl[4] };
         const double xr[4] = { X[n - 4], X[n - 3], X[n - 2], X[n - 1] };
         double rr[4], c2, s2;
-        srukf_motion_point(mc, xr, srow, mnoise, sg ? -gamma : gamma, rr, c2, s2);
+        if (isnull) srukf_motion_centre(mc, xr, rr, c2, s2);    // a structurally null row: both points ARE the centre point (same bits: NullSkip rests on it)
+        else srukf_motion_point(mc, xr, srow, mnoise, sg ? -gamma : gamma, rr, c2, s2);
         double4* o = reinterpret_cast<double4*>(sigR + (size_t)(1 + sg * Na + i) * 8);
         o[0] = make_double4(rr[0], rr[1], rr[2], rr[3]); o[1] = make_double4(c2, s2, 0.0, 0.0);
     };
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                 const int q = (threadIdx.x - 1) >> 1, sg = (threadIdx.x - 1) & 1;       // noise row n + q (control noise: q < 3)
                 double mnoise[3] = { 0, 0, 0 };
                 if (q < 3) mnoise[q] = fs->ctl[5 + q];
-                table_rows(n + q, sg, zero4, mnoise);
+                table_rows(n + q, sg, zero4, mnoise, false);
             }
         }
         // frame tail: RobotPath.txt row (SLAM.cpp:3549-3556) with P = S^T S restricted to the robot x / y block (2404): the
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
 #pragma unroll
             for (int e = 0; e < 4; e++) srow[e] = (r - 4 + e >= a) ? Sp[(size_t)a * ld + (r - 4 + e)] : 0.0;    // the robot columns: permuted positions r-4 .. r-1
         }
-        table_rows(j, threadIdx.x, srow, zero3);
+        table_rows(j, threadIdx.x, srow, zero3, a >= r);
     }
     if (a >= r) {                                              // dropped direction: what the reference's clamp leaves
         for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == j) ? sqrt(eps) : 0.0;
