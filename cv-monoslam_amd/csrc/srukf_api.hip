@@ -48,6 +48,7 @@ void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const d
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
 void srukf_launch_rank_round(hipStream_t, int, int, double*);
 int srukf_gmw_head_rows(void);
+int srukf_gmw_head_extra_diag(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
@@ -196,6 +197,7 @@ static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_st
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
+static int g_dbg_shared_slack = 0;      // SRUKF_GPU_SHARED: CUs each tenant leaves free (srukf_debug_set "shared_slack")
 struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1, tenants = 1; };
 static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 {
@@ -213,7 +215,7 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     g.tenants = tenants > 1 ? tenants : 1;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 2;
-    const int cap = cus / (tenants > 1 ? tenants : 1) - 1;    // one workgroup per CU (registers), all of them resident
+    const int cap = cus / (tenants > 1 ? tenants : 1) - 1 - (tenants > 1 ? g_dbg_shared_slack : 0);    // one workgroup per CU (registers), all of them resident
     g.workers = cap >= 1 ? srukf_gmw_persist_workers(g.T, g.Tp, cap) : -1;
     g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
@@ -897,7 +899,11 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
         ALLOC(c->syrk_tiles, ts.size()); ALLOC(c->pxy_tiles, tp.size());
         // the same order, restricted to the tile rows the persistent launch does not compute itself
         std::vector<int> th;
-        for (size_t q = 0; q + 1 < ts.size(); q += 2) if (ts[q] >= 0 && ts[q] * 32 < srukf_gmw_head_rows()) { th.push_back(ts[q]); th.push_back(ts[q + 1]); }
+        // ... plus the diagonal 64 x 64 tile right behind them (srukf_gmw_head_extra_diag): the pivot workgroup needs it, with one panel
+        // update applied, at the end of its second panel — its owner would still be forming it then
+        const int hd = srukf_gmw_head_rows(), hx = srukf_gmw_head_extra_diag() ? hd + 64 : hd;
+        for (size_t q = 0; q + 1 < ts.size(); q += 2)
+            if (ts[q] >= 0 && (ts[q] * 32 < hd || (ts[q] * 32 < hx && ts[q + 1] * 32 < hx))) { th.push_back(ts[q]); th.push_back(ts[q + 1]); }
         c->n_syrk_head_tiles = (int)th.size() / 2;
         ALLOC(c->syrk_head_tiles, th.size() ? th.size() : 2);
         if (!th.empty() && hipMemcpyAsync(c->syrk_head_tiles, th.data(), sizeof(int) * th.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
@@ -1851,6 +1857,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     struct { const char* k; int* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs } };
     if (!strcmp(key, "pxy2_skip")) { g_pxy2_skip = value & 3; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }   // timing only: results are garbage
+    if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
         if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;
         g_dbg_shared_tenants = value;
@@ -1871,6 +1878,22 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);
+    return SRUKF_OK;
+}
+// Diagnostic read-out of the device-resident frame scalars (synchronises the stream): "gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts"
+int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
+{
+    if (!c || !key || !value) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->hfs, c->fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!strcmp(key, "gmw_aborts")) *value = c->hfs->gmw_aborts;
+    else if (!strcmp(key, "clamp_rows")) *value = c->hfs->clamp_rows;
+    else if (!strcmp(key, "frame")) *value = c->hfs->frame;
+    else if (!strcmp(key, "frozen")) *value = c->hfs->frozen;
+    else if (!strcmp(key, "gate_timeouts")) *value = c->hfs->gate_timeouts;
+    else if (!strcmp(key, "gmw_shared")) *value = c->gmw_shared;
+    else return SRUKF_ERR_BAD_ARG;
     return SRUKF_OK;
 }
 int srukf_debug_starve_workers(srukf_ctx* c, int on)

@@ -54,6 +54,7 @@ struct FrameScalars {
     const double* odo_seq;     // staged odometry (3 doubles per pose) and its frame count, a1..a4: what srukf_prepare_control needs
     double a[4];
     int seqF;
+    int gate_timeouts;         // k_gmw_gate gave up waiting for a slot (SRUKF_GPU_SHARED) and went ahead: reported, never silent
     int ctl_next_valid;        // "table" mode: k_gain prepared fs->ctl for frame + 1 (0: the staged sequence ends with this frame)
     int frozen;                // staged replay: a frame was flagged -> k_motion and the persistent factorisation of the later frames of the run
                                // return at once (three quarters of a frame's time; the other kernels would pay a memory round trip per launch

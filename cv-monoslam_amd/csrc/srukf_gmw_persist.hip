@@ -412,6 +412,11 @@ struct GmwTile { short I, J, nsteps, pad; };
 // microseconds instead of ~37).  The owner of tile (I, J) needs 12.5 + 1.7 I us for it and has ~12 I us until somebody waits
 // for the tile.  S0 must not be the buffer the factor is written to (Sout).
 #define GMW_HEAD_ROWS 2
+// ... except the diagonal tile (GMW_HEAD_ROWS, GMW_HEAD_ROWS), which k_syrk forms as well: the pivot workgroup needs it — one panel
+// update applied — at the end of its second panel, 28 us into the launch, and an owner that first has to form it (16 us) and then
+// apply panel 0 publishes it ~10 us too late (time stamps of scripts/mb/dbg_persist: the second panel's iteration took 23.5 us instead of 13.9).
+#define GMW_HEAD_EXTRA_DIAG 1
+__device__ __forceinline__ bool gmw_owner_computes(int I, int J) { return I >= GMW_HEAD_ROWS && !(GMW_HEAD_EXTRA_DIAG && I == GMW_HEAD_ROWS && J == GMW_HEAD_ROWS); }
 __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
                                                int I, int J, d4 (&acc)[2][2], FrameScalars* __restrict__ fs, int tid, int krows)
 {
@@ -445,7 +450,7 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
 // bounded wait until it expires).  The gate is one wave that fits beside a resident factorisation workgroup (few registers, no
 // LDS), so it can always start; the last workgroup of a gated launch gives the slot back.
 __device__ int g_gmw_admitted = 0;
-__global__ void k_gmw_gate(const FrameScalars* __restrict__ fs, int limit)
+__global__ void k_gmw_gate(FrameScalars* __restrict__ fs, int limit)
 {
     if (fs->frozen) return;                                    // the launch behind this gate returns at once as well
     if (threadIdx.x != 0) return;
@@ -455,6 +460,7 @@ __global__ void k_gmw_gate(const FrameScalars* __restrict__ fs, int limit)
         __builtin_amdgcn_s_sleep(8);
     }
     atomicAdd(&g_gmw_admitted, 1);
+    atomicAdd(&fs->gate_timeouts, 1);
 }
 
 template <bool MEM>
@@ -504,8 +510,8 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         if (S0) {
             const KDimsLite dl = { n, ld };
             // (rank-aware form: block row Tp only passes the last pivoted panel's factor rows on; its own values are never used)
-            if (ta.nsteps > 0 && ta.I >= GMW_HEAD_ROWS) { if (!ta.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid, krows); ta.computed = true; }
-            if (tb.nsteps > 0 && tb.I >= GMW_HEAD_ROWS) { if (!tb.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid, krows); tb.computed = true; }
+            if (ta.nsteps > 0 && gmw_owner_computes(ta.I, ta.J)) { if (!ta.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid, krows); ta.computed = true; }
+            if (tb.nsteps > 0 && gmw_owner_computes(tb.I, tb.J)) { if (!tb.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid, krows); tb.computed = true; }
         }
         const int kmax = max(ta.nsteps, tb.nsteps);
         for (int k = 0; k < kmax && good; k++) {
@@ -565,7 +571,7 @@ void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double*
                               void* sync, const void* tiles, int ntiles, int workers, void* fs,
                               const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit)
 {
-    if (gate_limit > 0) hipLaunchKernelGGL(k_gmw_gate, dim3(1), dim3(64), 0, st, (const FrameScalars*)fs, gate_limit);
+    if (gate_limit > 0) hipLaunchKernelGGL(k_gmw_gate, dim3(1), dim3(64), 0, st, (FrameScalars*)fs, gate_limit);
     const int T = ld / 64;
     if (Tp <= 0 || Tp > T) Tp = T;
     if (krows <= 0 || krows > ld) krows = ld;
@@ -577,4 +583,5 @@ void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double*
                            (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
+int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }
 }  // extern "C"

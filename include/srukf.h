@@ -270,6 +270,8 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  * "gmw_persist", "gmw_fused", "rank_fused", "rank_fold", "rank_aware", "graphs" (0: contexts created afterwards launch eagerly,
  * which rocprofv3 --pmc needs); per-context keys: "use_graph", "fused_motion".  See srukf_api.hip. */
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
+/* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared"). */
+int  srukf_debug_get(srukf_ctx* ctx, const char* key, long long* value);
 
 /* Problem sizes of a context: N, n, Na, L. */
 int  srukf_dims(const srukf_ctx* ctx, int* N, int* n, int* Na, int* L);
