@@ -901,7 +901,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
         std::vector<int> th;
         // ... plus the diagonal 64 x 64 tile right behind them (srukf_gmw_head_extra_diag): the pivot workgroup needs it, with one panel
         // update applied, at the end of its second panel — its owner would still be forming it then
-        const int hd = srukf_gmw_head_rows(), hx = srukf_gmw_head_extra_diag() ? hd + 64 : hd;
+        const int hd = srukf_gmw_head_rows(), hx = hd + 64 * srukf_gmw_head_extra_diag();
         for (size_t q = 0; q + 1 < ts.size(); q += 2)
             if (ts[q] >= 0 && (ts[q] * 32 < hd || (ts[q] * 32 < hx && ts[q + 1] * 32 < hx))) { th.push_back(ts[q]); th.push_back(ts[q + 1]); }
         c->n_syrk_head_tiles = (int)th.size() / 2;
@@ -1878,6 +1878,21 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);
+    return SRUKF_OK;
+}
+// Diagnostic builds only (make EXTRA=-DSRUKF_GMW_DBG): host-visible time stamps of the persistent factorisation launch of THIS context's rank-aware
+// plan (GMW_TS in srukf_gmw_persist.hip).  buf receives 4096 unsigned long longs: [2048 + 8 p + slot] = s_memrealtime (10 ns ticks) of pivot iteration p.
+int srukf_debug_gmw_stamps(srukf_ctx* c, unsigned long long* buf)
+{
+    if (!c) return SRUKF_ERR_BAD_ARG;
+    static unsigned long long* hbuf = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    GmwPlan& g = c->red_r > 0 ? c->gplan_red : c->gplan;
+    if (!g.sync) return SRUKF_ERR_SEQUENCE;
+    if (!hbuf) { HIPCHK(c, hipHostMalloc((void**)&hbuf, 8 * 4096, hipHostMallocCoherent)); memset(hbuf, 0, 8 * 4096); }
+    if (buf) memcpy(buf, hbuf, 8 * 4096);
+    HIPCHK(c, hipMemcpy((char*)g.sync + offsetof(GmwSync, dbg), &hbuf, 8, hipMemcpyHostToDevice));      // armed for the launches that follow
     return SRUKF_OK;
 }
 // Diagnostic read-out of the device-resident frame scalars (synchronises the stream): "gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts"

@@ -293,18 +293,24 @@ template <int J0, int J1, bool DEV> __device__ __forceinline__ void gmw_out_grou
     *(d4*)&Sout[(size_t)(j0 + j) * ld + j0 + c0] = v;
 }
 // Two output waves (which = 0 / 1) take alternate groups, so the last group starts the moment its rows exist.
-template <bool DEV = false>
+// before_last(): called once, before the wave's last group — the persistent kernel requests the flag of the tile it stages next
+// there, so that the flag's round trip runs under the last group instead of after it.
+struct GmwNoHook { __device__ __forceinline__ void operator()() const {} };
+template <bool DEV = false, class Hook = GmwNoHook>
 __device__ __forceinline__ void gmw_cols_out_wave(const GmwColsLds& w, int which, int lane, int n, int ld, int j0,
                                                   double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
-                                                  double* __restrict__ Dall, double* __restrict__ Sout, double* lsq = nullptr, double* lrc = nullptr)
+                                                  double* __restrict__ Dall, double* __restrict__ Sout, double* lsq = nullptr, double* lrc = nullptr,
+                                                  Hook&& before_last = Hook())
 {
     const unsigned dv = lds_off(w.Dv);
     if (which == 0) {
         gmw_out_group<0, 8, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
         gmw_out_group<16, 24, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        before_last();
         gmw_out_group<28, 32, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     } else {
         gmw_out_group<8, 16, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        before_last();
         gmw_out_group<24, 28, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     }
 }

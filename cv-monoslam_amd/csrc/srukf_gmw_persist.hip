@@ -267,6 +267,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
         // free: wave 1 is the only reader of Lr's E' corner, wave 3 of Wc's W1d corner, both in rows 0..31 which they
         // overwrite themselves.  Waiting for those loads also waits for the wave's earlier stores, so after the closing
         // barrier the panel buffer is complete in memory and panel_ready can be raised at once.
+        unsigned long long early = 0;                          // waves 1 / 3: the flag of the tile they stage next, requested under their last output group
         if (wv0) { if (!half_only) gmw_cols_pivot_wave(ws2, eps, lane); GMW_TS(sy, p + 64, 0); }
         else if (wvu == 2) {
             if (!half_only) {
@@ -314,14 +315,16 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
                 }
             }
             gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD);
-            if (!half_only) gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32);
+            if (!half_only) gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32,
+                                                    [&] { if (p >= 1 && p + 1 < Tp) early = __hip_atomic_load(&ver[(size_t)(wv1 ? p : p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
             if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
         }
         if (p + 1 < Tp) {
             const bool tileA = wvu < 2;                        // waves 0, 1: tile (p, p+1) -> Lr;  waves 2, 3: tile (p+1, p+1) -> Wc
             const int tr = tileA ? p : p + 1, r0 = (wvu & 1) ? 0 : 32;
             if (wv1) GMW_TS(sy, p, 5);
-            const bool ready = p == 0 || __builtin_amdgcn_readfirstlane(stageok[tileA ? 0 : 1]) != 0 || gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
+            const bool ready = p == 0 || gmw_uniform64(early) >= ebase + p || __builtin_amdgcn_readfirstlane(stageok[tileA ? 0 : 1]) != 0 ||
+                               gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
             if (wv1) GMW_TS(sy, p, 6);
             if (!ready) *okp = 0;
             else {
@@ -415,8 +418,9 @@ struct GmwTile { short I, J, nsteps, pad; };
 // ... except the diagonal tile (GMW_HEAD_ROWS, GMW_HEAD_ROWS), which k_syrk forms as well: the pivot workgroup needs it — one panel
 // update applied — at the end of its second panel, 28 us into the launch, and an owner that first has to form it (16 us) and then
 // apply panel 0 publishes it ~10 us too late (time stamps of scripts/mb/dbg_persist: the second panel's iteration took 23.5 us instead of 13.9).
-#define GMW_HEAD_EXTRA_DIAG 1
-__device__ __forceinline__ bool gmw_owner_computes(int I, int J) { return I >= GMW_HEAD_ROWS && !(GMW_HEAD_EXTRA_DIAG && I == GMW_HEAD_ROWS && J == GMW_HEAD_ROWS); }
+// GMW_HEAD_EXTRA_DIAG = 2: the 2 x 2 block of tiles behind the head rows, (2,2), (2,3), (3,3) — the third panel's iteration still waited ~2 us for (3,3).
+#define GMW_HEAD_EXTRA_DIAG 2
+__device__ __forceinline__ bool gmw_owner_computes(int I, int J) { return I >= GMW_HEAD_ROWS && !(I < GMW_HEAD_ROWS + GMW_HEAD_EXTRA_DIAG && J < GMW_HEAD_ROWS + GMW_HEAD_EXTRA_DIAG); }
 __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
                                                int I, int J, d4 (&acc)[2][2], FrameScalars* __restrict__ fs, int tid, int krows)
 {

@@ -272,6 +272,8 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
 /* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared"). */
 int  srukf_debug_get(srukf_ctx* ctx, const char* key, long long* value);
+/* Diagnostic builds (-DSRUKF_GMW_DBG) only: arms / reads the time stamps of the persistent factorisation launch (4096 values). */
+int  srukf_debug_gmw_stamps(srukf_ctx* ctx, unsigned long long* buf);
 
 /* Problem sizes of a context: N, n, Na, L. */
 int  srukf_dims(const srukf_ctx* ctx, int* N, int* n, int* Na, int* L);

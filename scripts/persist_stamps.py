@@ -1,0 +1,35 @@
+"""Per-panel timeline of k_gmw_persist inside the REAL replay at N landmarks (diagnostic build of the library: the script builds
+cv-monoslam_amd/libsrukf_hip_dbg.so with -DSRUKF_GMW_DBG on the GPU box, loads it instead of the product library, replays frames and
+prints the pivot workgroup's time stamps of the last frame).  Ticks are 10 ns (s_memrealtime)."""
+import os, subprocess, sys
+sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+csrc = os.path.join(ROOT, "cv-monoslam_amd", "csrc")
+dbgdir = os.path.join(ROOT, "gpurun_out", "dbgobj"); os.makedirs(dbgdir, exist_ok=True)
+srcs = ["srukf_api", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank"]
+flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -DSRUKF_GMW_DBG -w".split()
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-c", f"{csrc}/{s}.hip", "-o", f"{dbgdir}/{s}.o"]) for s in srcs]
+assert all(p.wait() == 0 for p in procs)
+lib = os.path.join(dbgdir, "libsrukf_hip_dbg.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [f"{dbgdir}/{s}.o" for s in srcs])
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package(); synth, srukf = pkg.synth, pkg.srukf
+srukf.LIB_PATH = lib                                  # the diagnostic build instead of the product library (nothing has been loaded yet)
+assert srukf._lib is None
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+p = synth.scene_params(); F = 60
+sc = synth.make_scene(N, F, seed=0, p=p)
+f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+f.run_frames(0, 20)
+f.debug_gmw_stamps()                                   # arm
+f.run_frames(20, 20)
+st = f.debug_gmw_stamps()
+Tp = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+print("p: afterA afterB afterF1 afterC1 | poll_begin poll_end | pivot_done w1_done w3_done | iter_end | since prev start")
+prev = None
+for pnl in range(Tp):
+    t = st[2048 + 8 * pnl: 2048 + 8 * pnl + 8].astype(np.int64); u = st[2048 + 8 * (pnl + 64): 2048 + 8 * (pnl + 64) + 8].astype(np.int64)
+    d = lambda x: int(x - t[0]) if x else -1
+    print(f"p={pnl:02d}: {d(t[1]):6d} {d(t[2]):6d} {d(t[3]):6d} {d(t[4]):6d} | {d(t[5]):6d} {d(t[6]):6d} | {d(u[0]):6d} {d(u[1]):6d} {d(u[2]):6d} | {d(t[7]):6d} | {int(t[0] - prev) if prev is not None else 0}")
+    prev = t[0]
