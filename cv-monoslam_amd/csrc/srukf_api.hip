@@ -120,6 +120,7 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
     fs->frame = frame;
     srukf_prepare_control(fs);
     fs->stat_count = 0;
+    fs->const_rows_ok = 0; fs->const_rows_pending = 0;         // whatever happened to S since the last staged frame: its first tail writes every row again
     for (int q = 0; q < 64; q++) fs->stat_cnt[q] = 0;
     fs->traj_base = nullptr;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
@@ -131,6 +132,7 @@ __global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* 
     fs->frame = frame;
     srukf_prepare_control(fs);                                 // the first frame's control (k_project_motion); later ones by the frame tails
     fs->stat_count = 0;
+    fs->const_rows_ok = 0; fs->const_rows_pending = 0;         // whatever happened to S since the last staged frame: its first tail writes every row again
     for (int q = 0; q < 64; q++) fs->stat_cnt[q] = 0;
     fs->traj_base = traj_base;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }

@@ -54,6 +54,8 @@ struct FrameScalars {
     const double* odo_seq;     // staged odometry (3 doubles per pose) and its frame count, a1..a4: what srukf_prepare_control needs
     double a[4];
     int seqF;
+    int const_rows_ok, const_rows_pending;   // "table" mode: the structurally null rows of S already hold sqrt(EPSILON) e_k (k_rank_expand skips them); pending: as of the
+                               // launch that is running — promoted by the next frame's first launch, so that no workgroup of the writing launch sees it
     int gate_timeouts;         // k_gmw_gate gave up waiting for a slot (SRUKF_GPU_SHARED) and went ahead: reported, never silent
     int ctl_next_valid;        // "table" mode: k_gain prepared fs->ctl for frame + 1 (0: the staged sequence ends with this frame)
     int frozen;                // staged replay: a frame was flagged -> k_motion and the persistent factorisation of the later frames of the run

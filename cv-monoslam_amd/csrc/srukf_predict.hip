@@ -291,6 +291,7 @@ __device__ __forceinline__ void motion_reduce_body(const KDims& d, const KWeight
     __builtin_amdgcn_s_setprio(3);
     bool freeze = false;
     if (tid == 0) {
+        fs->const_rows_ok = fs->const_rows_pending;            // the previous frame's tail has written the constant rows of S: its successors may skip them
         for (int q = 0; q < 3; q++) { fs->Ut[q] = fs->ctl[q]; fs->Mt[q] = fs->ctl[5 + q]; }
         for (int q = 0; q < 4; q++) fs->Xr0[q] = X[n - 4 + q];
         if (fs->clamp_rows > 0) {                              // the previous frame's refactorisation was flagged -> remember which
@@ -640,8 +641,10 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                 u1 = p0 * lk[q][1] + p1 * lk[q][3];
                 dx += u0 * lk[q][4] + u1 * lk[q][5];
             }
-            Ut[(size_t)(2 * k) * ld + r] = u0;
-            Ut[(size_t)(2 * k + 1) * ld + r] = u1;
+            if (!P1) {                                         // ("table" mode consumes U^T in permuted columns only)
+                Ut[(size_t)(2 * k) * ld + r] = u0;
+                Ut[(size_t)(2 * k + 1) * ld + r] = u1;
+            }
             if (ra.Utp) { ra.Utp[(size_t)(2 * k) * ld + rp] = u0; ra.Utp[(size_t)(2 * k + 1) * ld + rp] = u1; }
         }
     }

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                 t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
             }
             fs->frame += 1;
+            fs->const_rows_pending = 1;                         // this launch wrote (or found) every structurally null row of S as sqrt(EPSILON) e_k
             if (!sigR) srukf_prepare_control(fs);              // control of the next staged frame (k_project_motion); "table" mode: k_gain did it
         }
         return;
@@ -145,19 +146,24 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         table_rows(j, threadIdx.x, srow, zero3, a >= r);
     }
     if (a >= r) {                                              // dropped direction: what the reference's clamp leaves
+        // the same row every frame: written by the first frame of a staged run only (fs->const_rows_ok: set for the frames after it
+        // by the next launch, cleared by k_set_run / k_set_frame; whoever else rewrites S goes through one of those first)
+        if (sigR && fs->const_rows_ok) return;
         for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == j) ? sqrt(eps) : 0.0;
         return;
     }
     const double* src = Sp + (size_t)a * ld;
     double mx = 0.0;
-    for (int c = threadIdx.x; c < ld; c += 256) {
+    // columns left of the diagonal hold zeros in S (every writer keeps the strictly lower triangle zero) and in the permuted copy:
+    // only the row's upper part is written ("table" mode; the other callers rewrite the whole row as before)
+    for (int c = (sigR ? (j & ~3) : 0) + threadIdx.x; c < ld; c += 256) {
         double v = 0.0;
         if (c >= j && c < n) { v = src[iperm[c]]; if (c > j) mx = fmax(mx, fabs(v)); }
         out[c] = v;
     }
     if (A) {
         double* sh = A + (size_t)a * ld;
-        for (int b = threadIdx.x; b < ld; b += 256) sh[b] = (b >= a && b < n) ? src[b] : 0.0;
+        for (int b = (sigR ? (a & ~3) : 0) + threadIdx.x; b < ld; b += 256) sh[b] = (b >= a && b < n) ? src[b] : 0.0;
     }
     // theta clamp of the reference evaluated afterwards, as k_gmw_check does (SLAM.cpp:2204-2211, 2264-2285)
     mx = wave_max(mx);
