@@ -40,6 +40,7 @@ int srukf_gmw_sync_bytes(int T);
 int srukf_gmw_build_tiles(int T, int Tp, short* out);
 int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
+void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double);
@@ -291,6 +292,7 @@ struct srukf_ctx {
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
                                            // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
+    int dbg_head_fold = 1;                 // srukf_debug_set "head_fold": exclusive rank-aware replay without the k_syrk launch (helper workgroups of the persistent launch)
     int dbg_nullskip = 1;                  // srukf_debug_set "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
     int dbg_pxy2 = 1;                      // srukf_debug_set "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
@@ -298,7 +300,7 @@ struct srukf_ctx {
     double *ckS = nullptr, *ckX = nullptr; // srukf_run_frames: state before the block of frames in flight (recovery from a theta-clamp frame)
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
     int *syrk_head_tiles = nullptr;                    // k_syrk tiles of the first srukf_gmw_head_rows() rows only (fused refactor)
-    int n_syrk_tiles = 0, n_pxy_tiles = 0, n_syrk_head_tiles = 0;
+    int n_syrk_tiles = 0, n_pxy_tiles = 0, n_syrk_head_tiles = 0, n_syrk_head_crit = 0;
     FrameScalars* fs = nullptr;
     // staged sequence
     int seqF = 0;
@@ -536,18 +538,29 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     const bool red_fused = reduced && !keep_backup && ub == 0 && ue == d.mp && replay_red_fused(c);
     if (red_fused) {
         const double rr = c->red_r, hr = srukf_gmw_head_rows();
-        {
+        const double head_flop = 2.0 * hr * n * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), head_byte = 8.0 * ((hr + d.mp) * n + (n - rr) * (rr + d.mp));
+        // head fold (a filter that has the GPU to itself): the head tiles, the pending X += dX and the dropped diagonal are helper
+        // workgroups of the persistent launch instead of a k_syrk launch in front of it (srukf_debug_set "head_fold", 0: two launches)
+        const bool head_fold = c->dbg_head_fold && c->gmw_shared == 0;
+        if (!head_fold) {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
-            ProfScope ps(c, KC_SYRK, 2.0 * hr * n * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * ((hr + d.mp) * n + (n - rr) * (rr + d.mp)));
+            ProfScope ps(c, KC_SYRK, head_flop, head_byte);
             srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table), take_xr1(c));
             c->dx_pending = false;
         }
         {
             // factorisation of the leading red_Tp panels (all n columns carried along) + the owners' tiles of S^T S - U U^T
             // (kept rows below the head x all columns, K <= r and 2N): red_*_flop, update_null_set
-            ProfScope ps(c, KC_GMW_PERSIST, c->red_fac_flop + c->red_own_flop, 8.0 * (2.0 * rr * n + (double)d.mp * n));
-            srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
-                                     c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c));
+            ProfScope ps(c, KC_GMW_PERSIST, c->red_fac_flop + c->red_own_flop + (head_fold ? head_flop : 0.0), 8.0 * (2.0 * rr * n + (double)d.mp * n));
+            HeadArgs ha = {};
+            if (head_fold) {
+                ha.tiles = (const int2*)c->syrk_head_tiles; ha.ntiles = c->n_syrk_head_tiles; ha.ncrit = c->n_syrk_head_crit;
+                ha.dxp = c->dx_pending ? c->dxp : nullptr; ha.X = c->X; ha.xr1 = take_xr1(c); ha.ndx = c->dx_pending ? (n + 255) / 256 : 0;
+                ha.ra = rank_args(c, table); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
+                c->dx_pending = false;
+            }
+            srukf_launch_gmw_persist_head(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
+                                          c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c), head_fold ? &ha : nullptr);
         }
         ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
         rank_expand(c, frame_tail, table);
@@ -904,8 +917,15 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
         // ... plus the diagonal 64 x 64 tile right behind them (srukf_gmw_head_extra_diag): the pivot workgroup needs it, with one panel
         // update applied, at the end of its second panel — its owner would still be forming it then
         const int hd = srukf_gmw_head_rows(), hx = hd + 64 * srukf_gmw_head_extra_diag();
-        for (size_t q = 0; q + 1 < ts.size(); q += 2)
-            if (ts[q] >= 0 && (ts[q] * 32 < hd || (ts[q] * 32 < hx && ts[q + 1] * 32 < hx))) { th.push_back(ts[q]); th.push_back(ts[q + 1]); }
+        // (the tiles of the leading 128 x 128 block first: the pivot workgroup waits for nothing else before its first panel — head fold)
+        for (int pass = 0; pass < 2; pass++)
+            for (size_t q = 0; q + 1 < ts.size(); q += 2) {
+                if (!(ts[q] >= 0 && (ts[q] * 32 < hd || (ts[q] * 32 < hx && ts[q + 1] * 32 < hx)))) continue;
+                const bool crit = ts[q] * 32 < 128 && ts[q + 1] * 32 < 128;
+                if (crit == (pass == 0)) { th.push_back(ts[q]); th.push_back(ts[q + 1]); }
+            }
+        c->n_syrk_head_crit = 0;
+        for (size_t q = 0; q + 1 < th.size(); q += 2) if (th[q] * 32 < 128 && th[q + 1] * 32 < 128) c->n_syrk_head_crit++;
         c->n_syrk_head_tiles = (int)th.size() / 2;
         ALLOC(c->syrk_head_tiles, th.size() ? th.size() : 2);
         if (!th.empty() && hipMemcpyAsync(c->syrk_head_tiles, th.data(), sizeof(int) * th.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
@@ -1877,6 +1897,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     if (!strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!strcmp(key, "pxy2")) c->dbg_pxy2 = value ? 1 : 0;
     else if (!strcmp(key, "nullskip")) c->dbg_nullskip = value ? 1 : 0;
+    else if (!strcmp(key, "head_fold")) c->dbg_head_fold = value ? 1 : 0;
     else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);

@@ -257,7 +257,9 @@ struct GmwSync {
     unsigned int exited;             // workgroups that have left the current launch
     int abort;                       // a bounded wait expired: everybody leaves, the frame is flagged for the exact path
     unsigned long long* dbg;         // diagnostic builds: host-visible progress markers (null in the product)
-    unsigned long long pad[61];
+    unsigned int head_done;          // head fold: 32 x 32 tiles of the head rows of S^T S - U U^T finished by the helper workgroups of this launch
+    unsigned int head_crit;          // ... and the first ha.ncrit of them: what the pivot needs before its first panel
+    unsigned long long pad[60];
     unsigned long long panel_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];  // copy c at [c * STRIDE]: (epoch << SHIFT) + panels published
     unsigned long long half_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];   // same for the first half of a panel buffer (Tt1, E, pivots of sub-panel 1)
     // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)

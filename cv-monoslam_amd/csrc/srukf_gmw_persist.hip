@@ -6,6 +6,7 @@
 #include "srukf_tiles.h"
 #include "srukf_gmw_cols.h"
 #include "srukf_gmw_panel.h"
+#include "srukf_rank.h"
 
 // ------------------------------------------------------------------------------------------------
 // Persistent form: the whole factorisation in ONE launch (k_gmw_persist).
@@ -467,12 +468,63 @@ __global__ void k_gmw_gate(FrameScalars* __restrict__ fs, int limit)
     atomicAdd(&fs->gate_timeouts, 1);
 }
 
+// ---- head fold (exclusive replay of the rank-aware form) -------------------------------------------------------------------------
+// What the k_syrk launch in front of the factorisation used to do rides on the persistent launch as HELPER workgroups in front of
+// the pivot and the workers (blockIdx >= 1 + workers): the 32 x 32 tiles of the head rows of S^T S - U U^T (4-way split-K over the waves, as
+// in k_syrk), the pending state update X += dX, the diagonal of the dropped positions.  Helpers are short (~5 us) and come first in
+// dispatch order; the pivot and every worker's first step wait for sy->head_done == ha.ntiles.  One launch and its boundary (~13 us)
+// less per frame, ~6 us more inside this one.
+__device__ __forceinline__ void gmw_head_tile_job(int n, int ld, int krows, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
+                                                  int2 tl, double* __restrict__ G, FrameScalars* __restrict__ fs, double* smem, int tid)
+{
+    if (tl.x < 0) return;
+    double (*red)[64][17] = (double (*)[64][17])smem;
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = tl.x * 32, n0 = tl.y * 32;
+    d4 acc[2][2];
+    zero_acc(acc);
+    const int ke = min(m0 + 32, krows);
+    const int ngs = ke >> 4, ngu = (u1 - u0) >> 4, ng = ngs + ngu;
+    const int g0 = (ng * wv) >> 2, g1 = (ng * (wv + 1)) >> 2;
+    if (g0 < ngs) tile32_tn<false>(acc, S0, ld, S0, ld, m0, n0, g0 << 4, min(g1, ngs) << 4, lane);
+    if (g1 > ngs) tile32_tn<true>(acc, Ut0, ld, Ut0, ld, m0, n0, u0 + ((max(g0, ngs) - ngs) << 4), u0 + ((g1 - ngs) << 4), lane);
+    splitk_reduce(acc, red, wv, lane);
+    if (wv != 0) return;
+    double gmax = 0.0, xmax = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
+                const double v = acc[a][b][t];
+                st_dev(&G[(size_t)r * ld + c], v);             // read by other workgroups of this launch
+                if (r < n && c < n) { if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v); }
+            }
+    gmax = wave_max(gmax); xmax = wave_max(xmax);
+    if (lane == 0) {
+        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
+    }
+}
+__device__ __forceinline__ bool gmw_wait_head(const unsigned int* cnt, unsigned int want, const int* abort_flag)
+{
+    for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= want) return true;
+        if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
 template <bool MEM>
 __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int Tp, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
                                                      GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
                                                      FrameScalars* __restrict__ fs,
-                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows, int gated)
+                                                     const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows, int gated,
+                                                     const HeadArgs ha)
 {
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
@@ -483,11 +535,35 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     const int tid = threadIdx.x;
     if (fs->frozen) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
     const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
-    if (blockIdx.x == 0) {
-        gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid, krows);
+    const int nhelp = ha.ntiles + ha.ndx + ha.ngd;             // head fold: helper workgroups BEHIND the pivot and the workers (0 without it)
+    const int nmain = (int)gridDim.x - nhelp;                  // 1 + workers: dispatched first, so that the owners start forming their tiles at once
+    const int role = (int)blockIdx.x < nmain ? (int)blockIdx.x : -1;      // -1: helper, 0: pivot, > 0: worker role - 1
+    if (role < 0) {
+        const int hb = (int)blockIdx.x - nmain;
+        if (hb < ha.ntiles) {
+            gmw_head_tile_job(n, ld, krows, S0, Ut0, u0, u1, ha.tiles[hb], G, fs, &Lr[0][0], tid);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tile stores have landed ...
+            __syncthreads();
+            // the list starts with the ha.ncrit tiles the pivot needs before its first panel ((0,0), (0,1), (1,1) in 64 x 64 terms)
+            if (tid == 0) __hip_atomic_fetch_add(hb < ha.ncrit ? &sy->head_crit : &sy->head_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (hb < ha.ntiles + ha.ndx) {
+            const int job = hb - ha.ntiles;
+            if (ha.ra.prep_next && job == 0 && tid == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
+            srukf_gain_dx_job(n, ld, ha.dxp, ha.X, job, ha.xr1);
+        } else srukf_rank_gdiag_job(n, ld, u1, ha.ra, &fs->gmax_bits, hb - ha.ntiles - ha.ndx);
+    } else if (role == 0) {
+        bool head_ok = true;
+        if (ha.ntiles > 0) {                                   // region R_0 and the two tiles behind it come from the helpers of this launch
+            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) ok = gmw_wait_head(&sy->head_crit, (unsigned)ha.ncrit, &sy->abort) ? 1 : 0;
+            __syncthreads();
+            head_ok = ok != 0;
+            __syncthreads();
+        }
+        if (head_ok) gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid, krows);
+        else if (tid == 0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
-        const int workers = gridDim.x - 1, w = blockIdx.x - 1;
+        const int workers = nmain - 1, w = role - 1;
         bool good = true;
         const bool half_last = (Tp < T) && (krows <= 64 * (Tp - 1) + 32);     // the pivot stops after the first half of the last pivoted panel (gmw_pivot_persist)
         if constexpr (MEM) {
@@ -517,6 +593,12 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             if (ta.nsteps > 0 && gmw_owner_computes(ta.I, ta.J)) { if (!ta.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, ta.I, ta.J, acca, fs, tid, krows); ta.computed = true; }
             if (tb.nsteps > 0 && gmw_owner_computes(tb.I, tb.J)) { if (!tb.passon) gmw_owner_syrk(dl, S0, Ut0, u0, u1, tb.I, tb.J, accb, fs, tid, krows); tb.computed = true; }
         }
+        if (ha.ntiles > 0) {                                   // step 0 reads the head rows of G (and a row-1 / 2 x 2-block tile is loaded from there)
+            if (wv0) ok = (gmw_wait_head(&sy->head_crit, (unsigned)ha.ncrit, &sy->abort) && gmw_wait_head(&sy->head_done, (unsigned)(ha.ntiles - ha.ncrit), &sy->abort)) ? 1 : 0;
+            __syncthreads();
+            good = ok != 0;
+            __syncthreads();
+        }
         const int kmax = max(ta.nsteps, tb.nsteps);
         for (int k = 0; k < kmax && good; k++) {
             if (k < ta.nsteps && k >= ta.kfirst) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1);
@@ -534,6 +616,8 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
             __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->head_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->head_crit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gated) atomicSub(&g_gmw_admitted, 1);
         }
@@ -571,20 +655,29 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers)
     return -1;
 }
 // S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G); gate_limit > 0: behind k_gmw_gate
-void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
-                              void* sync, const void* tiles, int ntiles, int workers, void* fs,
-                              const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit)
+void srukf_launch_gmw_persist_head(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
+                                   void* sync, const void* tiles, int ntiles, int workers, void* fs,
+                                   const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit, const HeadArgs* hap)
 {
     if (gate_limit > 0) hipLaunchKernelGGL(k_gmw_gate, dim3(1), dim3(64), 0, st, (FrameScalars*)fs, gate_limit);
     const int T = ld / 64;
     if (Tp <= 0 || Tp > T) Tp = T;
     if (krows <= 0 || krows > ld) krows = ld;
+    HeadArgs ha = {};
+    if (hap) ha = *hap;
+    const int nhelp = ha.ntiles + ha.ndx + ha.ngd;
     if (workers > 0 && ntiles > GMW_OWNED_MAX * workers)
         hipLaunchKernelGGL(k_gmw_persist<true>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0);
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, HeadArgs{});
     else
-        hipLaunchKernelGGL(k_gmw_persist<false>, dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_gmw_persist<false>, dim3(nhelp + 1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, ha);
+}
+void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
+                              void* sync, const void* tiles, int ntiles, int workers, void* fs,
+                              const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit)
+{
+    srukf_launch_gmw_persist_head(st, n, ld, eps, G, pans, D, Sout, sync, tiles, ntiles, workers, fs, S0, Ut0, u0, u1, Tp, krows, gate_limit, nullptr);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }

@@ -15,6 +15,15 @@ struct RankArgs {
                            // step has consumed it; the tail that needs it must not read the frame counter it advances itself)
 };
 
+// Head fold of the persistent factorisation launch (srukf_gmw_persist.hip): what its helper workgroups take over from k_syrk.
+struct HeadArgs {
+    const int2* tiles; int ntiles;                             // k_syrk's head tile list (row tile, col tile); the first ncrit: rows / columns < 128
+    int ncrit;
+    const double* dxp; double* X; const double* xr1; int ndx;  // dX slice partials -> X (srukf_gain_dx_job), ndx jobs
+    int ngd;                                                   // dropped-diagonal jobs (srukf_rank_gdiag_job)
+    RankArgs ra;
+};
+
 // gdiag[a] = sum_{k<r} A[k][a]^2 - sum_{m<mu} Utp[m][a]^2 for 16 dropped positions a = r + 16 blk .. (16 columns x 16 row lanes,
 // eight independent loads in flight per lane: a plain loop is one memory round trip per iteration); also feeds
 // gamma = max diag(G) of the GMW bound (SLAM.cpp:2204-2211).  256 threads.

@@ -91,3 +91,19 @@ def test_replay_motion_modes_agree(srukf, synth, N):
         np.testing.assert_allclose(traj[:, 4:], res[0][0][:, 4:], rtol=0, atol=1e-14)
         np.testing.assert_allclose(X, res[0][1], rtol=0, atol=2e-10)      # weakly observed directions carry the rounding differences of twelve frames
         np.testing.assert_allclose(P, res[0][2], rtol=0, atol=1e-12)
+
+
+def test_head_fold_is_the_same_arithmetic(srukf, synth):
+    """Exclusive rank-aware replay at N = 200: the head tiles of S^T S - U U^T, the pending state update and the dropped diagonal as
+    helper workgroups of the persistent factorisation launch (head fold, default) against the k_syrk launch in front of it: the
+    same tile routine in the same summation order, so the trajectories and the states are bit-identical."""
+    p = synth.scene_params()
+    N, F = 200, 10
+    sc = synth.make_scene(N, F, seed=6, p=p)
+    res = []
+    for fold in (1, 0):
+        f = srukf.Filter(N, p); f.debug_set("head_fold", fold); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        traj = f.run_frames(0, F)
+        X, S = f.get_state()
+        res.append((traj, X, S))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
