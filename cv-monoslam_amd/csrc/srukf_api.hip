@@ -193,9 +193,10 @@ static thread_local double* g_spare_stage = nullptr;       // one pinned staging
 static thread_local size_t g_spare_stage_bytes = 0;
 
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_SYRK, KC_GMW_TRAIL, KC_GMW_PERSIST, KC_GMW_CHECK,
-              KC_GMW_COL, KC_MISC, KC_COUNT };
+              KC_GMW_COL, KC_RANK_EXPAND, KC_PROJECT_MOTION, KC_PROJECT_TABLE, KC_PXY2, KC_MISC, KC_COUNT };
 static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_stats", "k_pxy", "k_gain", "k_syrk",
-                                             "k_gmw_step64", "k_gmw_persist", "k_gmw_check", "k_gmw_col", "misc" };
+                                             "k_gmw_step64", "k_gmw_persist", "k_gmw_check", "k_gmw_col", "k_rank_expand", "k_project_motion", "k_project_table", "k_pxy2",
+                                             "misc" };
 
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
@@ -447,7 +448,7 @@ static const double* take_xr1(srukf_ctx* c)
 static void seq_predict_fused(srukf_ctx* c, int mode)
 {
     const KDims& d = c->d;
-    ProfScope ps(c, KC_PROJECT, 2.0 * 60.0 * d.Na * d.N + 60.0 * d.L, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N + 8.0 * d.L + 8.0 * d.n));
+    ProfScope ps(c, mode == 2 ? KC_PROJECT_TABLE : KC_PROJECT_MOTION, 2.0 * 60.0 * d.Na * d.N + 60.0 * d.L, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N + 8.0 * d.L + 8.0 * d.n));
     if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c, false, c->dbg_pxy2 != 0), null_skip(c));
     else srukf_launch_project_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
     c->xr1_pending = true;
@@ -562,7 +563,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             srukf_launch_gmw_persist_head(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
                                           c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c), head_fold ? &ha : nullptr);
         }
-        ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
+        ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
         rank_expand(c, frame_tail, table);
         return;
     }
@@ -580,7 +581,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             ProfScope ps(c, gmw_use_persist(c) && c->gplan_red.workers >= 0 ? KC_GMW_PERSIST : KC_GMW_TRAIL, c->red_fac_flop, 8.0 * 2.0 * rp * n);
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
-        ProfScope ps(c, KC_GMW_CHECK, 0, 8.0 * 2.5 * (double)n * n);
+        ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
         rank_expand(c, frame_tail);
         return;
     }
@@ -730,7 +731,7 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
     const KDims& d = c->d;
     {
         const double nn = d.n;
-        ProfScope ps(c, KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
+        ProfScope ps(c, table ? KC_PXY2 : KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
         MeasArgs ms = {};
         const double* xrob = fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
         if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{} };
