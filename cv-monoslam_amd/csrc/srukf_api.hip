@@ -14,6 +14,7 @@
 #include <atomic>
 #include "srukf_device.h"
 #include "srukf_rank.h"
+#include "srukf_tail.h"
 
 extern "C" {
 void srukf_launch_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, FrameScalars*, const double*, const double*, RankArgs);
@@ -40,10 +41,10 @@ int srukf_gmw_sync_bytes(int T);
 int srukf_gmw_build_tiles(int T, int Tp, short* out);
 int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
-void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
+void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*, const TailArgs*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, double*);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
@@ -202,7 +203,7 @@ struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
 static int g_dbg_shared_slack = 0;      // SRUKF_GPU_SHARED: CUs each tenant leaves free (srukf_debug_set "shared_slack")
-struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1, tenants = 1; };
+struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1, tenants = 1, cus = 0; };
 static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 {
     if (g.pans) srukf_dfree_on(g.pans, st);
@@ -219,6 +220,7 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     g.tenants = tenants > 1 ? tenants : 1;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 2;
+    g.cus = cus;
     const int cap = cus / (tenants > 1 ? tenants : 1) - 1 - (tenants > 1 ? g_dbg_shared_slack : 0);    // one workgroup per CU (registers), all of them resident
     g.workers = cap >= 1 ? srukf_gmw_persist_workers(g.T, g.Tp, cap) : -1;
     g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
@@ -293,6 +295,11 @@ struct srukf_ctx {
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
                                            // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
+    int dbg_tail_fold = 0;                 // srukf_debug_set "tail_fold" 1: the helpers of the persistent launch also project the NEXT frame's sigma points (srukf_tail.h: built,
+                                           // bit-identical, NOT faster — the jobs cost the pivot chain what the projection launch cost); 0 (default): k_project_table
+    TailArgs* d_tail = nullptr;            // ... their arguments (device copy, rebuilt with the null set)
+    int tail_jobs = 0; bool tail_ok = false;
+    int dbg_tail_cap = 0;                  // srukf_debug_set "tail_cap": at most this many helper workgroups (0: every CU the pivot and the workers leave free)
     int dbg_head_fold = 1;                 // srukf_debug_set "head_fold": exclusive rank-aware replay without the k_syrk launch (helper workgroups of the persistent launch)
     int dbg_nullskip = 1;                  // srukf_debug_set "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
     int dbg_pxy2 = 1;                      // srukf_debug_set "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
@@ -492,12 +499,13 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
 // fp32 storage: S, X and the permuted copy are rounded to the stored values first, and the trajectory row is taken from those
 // (as the full-rank form does: quantize_state before the tail).
 // table: "table" mode of the replay — the tail also prepares the next frame's table of robot poses (k_rank_expand)
-static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false)
+// tail: "tail" mode — the persistent launch has prepared that table (and projected the next frame): the tail runs the next frame's motion reduction instead
+static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool tail = false)
 {
     const int n = c->d.n, np = c->d.np;
     const bool f32 = c->storage == SRUKF_STORAGE_F32;
     srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
-                             (table && frame_tail && !f32) ? c->sigR : nullptr, c->w.gamma);
+                             (table && frame_tail && !f32) ? c->sigR : nullptr, c->w.gamma, (tail && table && frame_tail && !f32) ? 1 : 0, c->d, c->w, c->Cmat);
     if (f32) {
         quantize_state(c);
         srukf_launch_rank_round(c->stream, np, c->red_r, c->shadowA);
@@ -518,7 +526,16 @@ static int replay_motion_mode(const srukf_ctx* c)
     if (c->dbg_fused_motion == 2 && !(replay_red_fused(c) && c->storage == SRUKF_STORAGE_F64)) return 1;
     return c->dbg_fused_motion;
 }
-static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false)
+// "tail" mode on top of "table" mode: the helper workgroups of the persistent launch (head fold) stay and project the NEXT frame's sigma points
+// while the factorisation runs (srukf_tail.h); a frame is then k_pxy2, k_gain, k_gmw_persist, k_rank_expand, and only a run's first frame has a
+// projection launch.  Needs the head fold (a filter that has the GPU to itself) and a useful number of CUs beside the pivot and the workers.
+static int tail_helpers(const srukf_ctx* c) { const int fr = c->gplan_red.cus - 1 - c->gplan_red.workers; return c->dbg_tail_cap > 0 ? std::min(fr, c->dbg_tail_cap) : fr; }
+static bool replay_tail_mode(const srukf_ctx* c)
+{
+    return replay_motion_mode(c) == 2 && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->dbg_head_fold && c->gmw_shared == 0 && c->dbg_tail_fold && !(c->dbg_tail_fold & 16) && c->d_tail && c->tail_ok &&
+           c->red_Tp <= GMW_TAIL_PANELS && tail_helpers(c) >= 32;
+}
+static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false, bool tail = false)
 {
     const KDims& d = c->d;
     const int np = d.np, n = d.n;
@@ -558,13 +575,18 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
                 ha.tiles = (const int2*)c->syrk_head_tiles; ha.ntiles = c->n_syrk_head_tiles; ha.ncrit = c->n_syrk_head_crit;
                 ha.dxp = c->dx_pending ? c->dxp : nullptr; ha.X = c->X; ha.xr1 = take_xr1(c); ha.ndx = c->dx_pending ? (n + 255) / 256 : 0;
                 ha.ra = rank_args(c, table); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
+                // helper workgroups: one per CU the pivot and the workers leave free (they share a job queue), never more than there are jobs
+                // (tail fold: they share a job queue; otherwise one workgroup per job)
+                const int nhead = ha.ntiles + ha.ndx + ha.ngd;
+                ha.nhelp = (tail || (c->dbg_tail_fold & 16)) ? std::max(1, std::min(tail_helpers(c), nhead + c->tail_jobs)) : nhead;
                 c->dx_pending = false;
             }
             srukf_launch_gmw_persist_head(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
-                                          c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c), head_fold ? &ha : nullptr);
+                                          c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c), head_fold ? &ha : nullptr,
+                                          (head_fold && (tail || (c->dbg_tail_fold & 16))) ? c->d_tail : nullptr);
         }
         ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
-        rank_expand(c, frame_tail, table);
+        rank_expand(c, frame_tail, table, head_fold && tail);
         return;
     }
     // ... or, where the owners cannot fold (memory tiles: more than two tiles per worker; one launch per panel), still in permuted
@@ -726,7 +748,7 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
 }
 // fused_motion: the frame's motion step ran inside k_project_motion: the statistics take the robot mean from fs->Xr1, k_gain commits Cmat
 // table: "table" mode of the replay — the product on the permuted operands (k_pxy2), k_gain takes it from there
-static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false)
+static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false)
 {
     const KDims& d = c->d;
     {
@@ -734,7 +756,7 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
         ProfScope ps(c, table ? KC_PXY2 : KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
         MeasArgs ms = {};
         const double* xrob = fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
-        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{} };
+        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{}, preamble ? 1 : 0 };
         if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
         else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
     }
@@ -829,6 +851,17 @@ static int update_null_set(srukf_ctx* c)
                     HIPCHK(c, srukf_dmalloc(&c->nskip, sizeof(int) * all.size()));
                     HIPCHK(c, hipMemcpy(c->nskip, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice));
                     c->ns_full = (int)dirs.size(); c->ns_null = (int)nulls.size(); c->ns_rows = (int)rows.size();
+                    // tail fold (srukf_tail.h): what the helpers of the persistent launch need to project the next frame
+                    TailArgs ta = {};
+                    ta.on = c->dbg_tail_fold > 1 ? c->dbg_tail_fold : 1; ta.N = c->d.N; ta.n = n; ta.Na = Na; ta.mp = c->d.mp; ta.r = r; ta.nnull = c->ns_null; ta.nchunk = (c->d.N + TAIL_LM - 1) / TAIL_LM;
+                    ta.p = c->p; ta.w = c->w; ta.X = c->X; ta.sigR = c->sigR; ta.Z = c->Z; ta.DZ = c->DZ;
+                    ta.perm = c->red_perm; ta.iperm = c->red_iperm; ta.nulls = c->nskip + c->ns_full;
+                    if (!c->d_tail) HIPCHK(c, srukf_dmalloc((void**)&c->d_tail, sizeof(TailArgs)));
+                    HIPCHK(c, hipMemcpy(c->d_tail, &ta, sizeof ta, hipMemcpyHostToDevice));
+                    c->tail_jobs = tail_jobs_total(ta);
+                    // (directions 0 and 1 are projected for every landmark even when they are structurally null — the Si factor names their Z rows —
+                    //  and the tail jobs only do that for kept rows: such a state stays with k_project_table)
+                    c->tail_ok = iperm[0] < r && iperm[1] < r;
                 }
                 c->pxy2_split_b0 = np;                            // first permuted column whose K range is cut in two
                 for (int bt = 0; bt < np / 64; bt++) if (std::min(4 * (bt + 1), ((kr + 63) / 64) * 4) >= srukf_pxy2_split_groups()) { c->pxy2_split_b0 = 64 * bt; break; }
@@ -966,7 +999,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->d_tail, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -1628,7 +1661,12 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
 static void replay_one_frame(srukf_ctx* c)
 {
     const int mode = replay_motion_mode(c);
-    if (mode) {
+    const bool tail = replay_tail_mode(c);
+    if (tail) {
+        // the previous frame's launches (or, for a run's first frame, run_frames_async) projected this frame and ran its motion reduction
+        c->xr1_pending = true;
+        seq_gain(c, nullptr, nullptr, true, true, true, true);
+    } else if (mode) {
         seq_predict_fused(c, mode);
         seq_gain(c, nullptr, nullptr, true, true, mode == 2 && c->dbg_pxy2);
     } else {
@@ -1636,7 +1674,7 @@ static void replay_one_frame(srukf_ctx* c)
         seq_predict_measurement(c, true);
         seq_gain(c, nullptr, nullptr, true);
     }
-    seq_refactor(c, 0, c->d.mp, false, false, false, true, mode == 2);
+    seq_refactor(c, 0, c->d.mp, false, false, false, true, mode == 2, tail);
 }
 static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec_t* ge)
 {
@@ -1676,6 +1714,9 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1, traj);
     // "table" mode: the first frame's table of robot poses (the frames after it get theirs from their predecessor's tail)
     if (replay_motion_mode(c) == 2) srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs, c->red_iperm, c->red_r);
+    // "tail" mode: ... and the first frame's projection + motion reduction (k_project_table); every later frame is projected inside its
+    // predecessor's factorisation launch
+    if (replay_tail_mode(c)) seq_predict_fused(c, 2);
     if (c->use_graph && !c->profiling) {
         // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
         // captured frame replays for all frames: the 45 launches cost one hipGraphLaunch on the host
@@ -1899,6 +1940,11 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "pxy2")) c->dbg_pxy2 = value ? 1 : 0;
     else if (!strcmp(key, "nullskip")) c->dbg_nullskip = value ? 1 : 0;
     else if (!strcmp(key, "head_fold")) c->dbg_head_fold = value ? 1 : 0;
+    else if (!strcmp(key, "tail_cap")) c->dbg_tail_cap = value < 0 ? 0 : value;
+    else if (!strcmp(key, "tail_fold")) {
+        c->dbg_tail_fold = value < 0 ? 0 : value > 31 ? 31 : value;    // > 1: timing only (2: no projection jobs; + 4 / + 8: pivot / worker rows with plain stores): the NEXT frame is garbage
+        if (c->d_tail) { const int on = c->dbg_tail_fold ? c->dbg_tail_fold : 1; HIPCHK(c, hipMemcpy((char*)c->d_tail + offsetof(TailArgs, on), &on, sizeof on, hipMemcpyHostToDevice)); }
+    }
     else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);
@@ -1933,6 +1979,29 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     else if (!strcmp(key, "gate_timeouts")) *value = c->hfs->gate_timeouts;
     else if (!strcmp(key, "gmw_shared")) *value = c->gmw_shared;
     else return SRUKF_ERR_BAD_ARG;
+    return SRUKF_OK;
+}
+// Diagnostic copy of a device work buffer (synchronises the stream): "Z" (L x mp), "DZ" (np x mp), "sigR" ((L + 1) x 8), "Cmat" (n x 4),
+// "Xr1" (4), "Utp" / "P1" (mp x np), "h" (2N), "Si" (4N).  count doubles from the start of the buffer.
+int srukf_debug_copy(srukf_ctx* c, const char* key, double* out, long long count)
+{
+    if (!c || !key || !out || count < 0) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const KDims& d = c->d;
+    const double* src = nullptr; long long cap = 0;
+    if (!strcmp(key, "Z")) { src = c->Z; cap = (long long)d.L * d.mp; }
+    else if (!strcmp(key, "DZ")) { src = c->DZ; cap = (long long)d.np * d.mp; }
+    else if (!strcmp(key, "sigR")) { src = c->sigR; cap = (long long)(d.L + 1) * 8; }
+    else if (!strcmp(key, "Cmat")) { src = c->Cmat; cap = (long long)d.n * 4; }
+    else if (!strcmp(key, "Xr1")) { src = (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)); cap = 4; }
+    else if (!strcmp(key, "Utp")) { src = c->Utp; cap = c->Utp ? (long long)d.mp * d.np : 0; }
+    else if (!strcmp(key, "P1")) { src = c->P1; cap = c->P1 ? (long long)d.mp * d.np : 0; }
+    else if (!strcmp(key, "h")) { src = c->h; cap = 2LL * d.N; }
+    else if (!strcmp(key, "Si")) { src = c->Si; cap = 4LL * d.N; }
+    else return SRUKF_ERR_BAD_ARG;
+    if (!src || count > cap) return SRUKF_ERR_DIM_MISMATCH;
+    HIPCHK(c, hipMemcpy(out, src, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
     return SRUKF_OK;
 }
 int srukf_debug_starve_workers(srukf_ctx* c, int on)

@@ -75,17 +75,26 @@ __device__ __forceinline__ void srukf_motion_control_a(const double (&a)[4], con
     mt[1] = a[2] * trans * trans + a[3] * rot1 * rot1 + a[3] * rot2 * rot2;
     mt[2] = a[0] * rot2 * rot2 + a[1] * trans * trans;
 }
-// fs->ctl for the staged frame f (one thread); false: no such frame
-__device__ __forceinline__ bool srukf_prepare_control(FrameScalars* fs, int f)
+// control of the staged frame f as fs->ctl holds it (rot1, trans, rot2, cos rot2, sin rot2, Mt[0..2]); false: no such frame
+__device__ __forceinline__ bool srukf_control_values(const FrameScalars* fs, int f, double (&ctl)[8])
 {
     const double* os = fs->odo_seq;
     if (!os || f < 0 || f >= fs->seqF) return false;
     double ut[3], mt[3];
     const double a[4] = { fs->a[0], fs->a[1], fs->a[2], fs->a[3] };
     srukf_motion_control_a(a, os + 3 * f, ut, mt);
-    fs->ctl[0] = ut[0]; fs->ctl[1] = ut[1]; fs->ctl[2] = ut[2];
-    fs->ctl[3] = cos(ut[2]); fs->ctl[4] = sin(ut[2]);
-    fs->ctl[5] = mt[0]; fs->ctl[6] = mt[1]; fs->ctl[7] = mt[2];
+    ctl[0] = ut[0]; ctl[1] = ut[1]; ctl[2] = ut[2];
+    ctl[3] = cos(ut[2]); ctl[4] = sin(ut[2]);
+    ctl[5] = mt[0]; ctl[6] = mt[1]; ctl[7] = mt[2];
+    return true;
+}
+// fs->ctl for the staged frame f (one thread); false: no such frame
+__device__ __forceinline__ bool srukf_prepare_control(FrameScalars* fs, int f)
+{
+    double ctl[8];
+    if (!srukf_control_values(fs, f, ctl)) return false;
+#pragma unroll
+    for (int q = 0; q < 8; q++) fs->ctl[q] = ctl[q];
     return true;
 }
 // ... for the frame the counter stands at (call after `frame` was set or advanced)
@@ -143,25 +152,30 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
 // ---- camera model (device restatement of SLAM.cpp:1634-1674, 3177-3213, 3250-3347) ----------
 // feat = (xi yi zi theta phi rho), robot = (x y z), cs/sn = cos/sin of robot theta,
 // err = pixel-noise sigma rows.  Returns uvd = (x, y) = Z[2k], Z[2k+1].
+// Every fused multiply-add of this function is written out and the compiler's own contraction is off: which products it fuses
+// depends on the code around an inlined call, and the same sigma point projected by two kernels (k_project_table; the tail jobs of
+// the persistent launch, srukf_tail.h) must give the same bits.
 __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, double f2,
                                               const double feat[6], double px, double py, double pz,
                                               double cs, double sn, double e0, double e1,
                                               double& ox, double& oy)
 {
+#pragma clang fp contract(off)
     const double xi = feat[0], yi = feat[1], zi = feat[2], th = feat[3], ph = feat[4], rho = feat[5];
     double sth, cth, sph, cph;
     sincos(th, &sth, &cth);
     sincos(ph, &sph, &cph);
     const double ir = 1.0 / rho;
     // coordinatesState2World, SLAM.cpp:3272-3275
-    const double hx = xi + ir * cph * sth - px;
-    const double hy = yi - ir * sph - py;
-    const double hz = zi + ir * cph * cth - pz;
+    const double ic = ir * cph;
+    const double hx = fma(ic, sth, xi) - px;
+    const double hy = fma(-ir, sph, yi) - py;
+    const double hz = fma(ic, cth, zi) - pz;
     // Rcw = Rwc.inv() (SLAM.cpp:1642-1643): closed-form cofactor inverse, det = c^2 + s^2
-    const double det = cs * cs + sn * sn;
+    const double det = fma(cs, cs, sn * sn);
     const double id = 1.0 / det;
-    const double rx = (cs * id) * hx + (sn * id) * hy;        // coordinatesWorld2Camera, 3292
-    const double ry = (-sn * id) * hx + (cs * id) * hy;
+    const double rx = fma(cs * id, hx, (sn * id) * hy);       // coordinatesWorld2Camera, 3292
+    const double ry = fma(-sn * id, hx, (cs * id) * hy);
     const double rz = (det * id) * hz;
     double ux, uy;
     if (rz == 0.0) { ux = 0.0; uy = 0.0; }                    // coordinatesCamera2Image, 3331-3335
@@ -174,26 +188,27 @@ __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, 
     const double k1 = p.cam_k1, k2 = p.cam_k2;
     const double xu = (ux - p.cam_cx) * p.cam_dx;
     const double yu = (uy - p.cam_cy) * p.cam_dy;
-    const double ru = sqrt(xu * xu + yu * yu);
+    const double ru = sqrt(fma(xu, xu, yu * yu));
     const double ru2 = ru * ru;
-    double rd = ru / (1.0 + k1 * ru2 + k2 * ru2 * ru2);
+    double rd = ru / fma(k2 * ru2, ru2, fma(k1, ru2, 1.0));
     // 100 Newton iterations (3188-3193); leaving the loop once rd is a fixed point is bit-exact because every later iteration
     // reproduces the same rd.  In floating point the iteration often does not reach a fixed point but ends in a 2-cycle between
     // two neighbouring doubles (then all 100 iterations ran, on every wave that had one such lane: that was 40 % of k_project's
     // time): once the new iterate equals the one before the current, the sequence alternates for good, and the value the
     // reference holds after its last iteration follows from the parity of the iterations left.
     double rprev = __builtin_nan("");
+    const double k1_3 = 3.0 * k1, k2_5 = 5.0 * k2;
     for (int it = 0; it < p.newton_iters; it++) {
         const double rd2 = rd * rd;
-        const double f  = rd + k1 * rd2 * rd + k2 * rd2 * rd2 * rd - ru;
-        const double ff = 1.0 + 3.0 * k1 * rd2 + 5.0 * k2 * rd2 * rd2;
+        const double f  = fma(k2 * rd2 * rd2, rd, fma(k1 * rd2, rd, rd)) - ru;
+        const double ff = fma(k2_5 * rd2, rd2, fma(k1_3, rd2, 1.0));
         const double rn = rd - f / ff;
         if (rn == rd) break;
         if (rn == rprev) { if ((p.newton_iters - it) & 1) rd = rn; break; }
         rprev = rd;
         rd = rn;
     }
-    double d = 1.0 + k1 * rd * rd + k2 * rd * rd * rd * rd;
+    double d = fma(k2 * rd * rd * rd, rd, fma(k1 * rd, rd, 1.0));
     if (d == 0.0) d = p.epsilon;
     const double vx = p.cam_cx + (xu / d) / p.cam_dx;
     const double vy = p.cam_cy + (yu / d) / p.cam_dy;
@@ -202,10 +217,31 @@ __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, 
     oy = vis ? vy : 0.0;
 }
 
+// generateSigmaPoints' addWeighted (SLAM.cpp:1159-1160: src1 * 1 + src2 * (+-gamma) + 0) on a landmark's six entries and the two pixel-noise rows
+__device__ __forceinline__ void srukf_sigma_feat(const double (&base)[6], const double (&dev)[6], double e0, double e1, double gq,
+                                                 double (&feat)[6], double& q0, double& q1)
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 6; e++) feat[e] = fma(dev[e], gq, base[e] * 1) + 0;
+    q0 = fma(e0, gq, 0.0 * 1) + 0; q1 = fma(e1, gq, 0.0 * 1) + 0;
+}
+// One sigma point of a direction (generateSigmaPoints' addWeighted, SLAM.cpp:1159-1160, on the landmark's six entries and the two
+// pixel-noise rows), projected; r = its robot part (x, y, z, theta, cos theta, sin theta).  gq = +gamma / -gamma.
+__device__ __forceinline__ void srukf_project_sigma(const srukf_params& p, double f1, double f2, const double (&base)[6], const double (&dev)[6],
+                                                    double e0, double e1, double gq, const double* r, double& ox, double& oy)
+{
+    double feat[6], q0, q1;
+    srukf_sigma_feat(base, dev, e0, e1, gq, feat, q0, q1);
+    srukf_project(p, f1, f2, feat, r[0], r[1], r[2], r[4], r[5], q0, q1, ox, oy);
+}
+
 // ---- state update X += sum of the k_gain slice partials (fixed order): 256 state rows per workgroup ----
 #define GAIN_SLICES 32
 // xr1 (replay path, may be null): the robot mean after the motion step, which k_project_motion left beside X because the
 // projection threads of its launch were still reading the mean before it
+// DEV: the new state is read by other workgroups of the SAME launch (tail jobs of the persistent factorisation): agent-scope store
+template <bool DEV = false>
 __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job, const double* xr1 = nullptr)
 {
     const int r = job * 256 + threadIdx.x;
@@ -214,7 +250,7 @@ __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* _
 #pragma unroll
     for (int u = 0; u < GAIN_SLICES; u++) acc += dxp[(size_t)u * np + r];
     const double x = (xr1 && r >= n - 4) ? xr1[r - (n - 4)] : X[r];
-    X[r] = x + acc;
+    if constexpr (DEV) __hip_atomic_store(&X[r], x + acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else X[r] = x + acc;
 }
 
 // measurement-statistics work attached to a k_pxy launch (replay path): Z == null -> none
@@ -231,6 +267,7 @@ struct MeasArgs {
     double* h; double* Si; int* vis; double* PxyR;
     FrameScalars* fs; int gx;                                  // gx = (N + 31) / 32 landmark groups
     NullSkip ns;                                               // ns.rows != null: the statistics walk that row list (+ every landmark's own null rows)
+    int preamble;                                              // "tail" mode: k_pxy2 is the frame's first launch -> its first thread runs srukf_frame_preamble
 };
 
 // ---- agent-scope (device-coherent) accesses: data handed from one workgroup to another INSIDE a launch ----
@@ -240,6 +277,13 @@ struct MeasArgs {
 __device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <bool DEV> __device__ __forceinline__ double ld_g(const double* p) { if constexpr (DEV) return ld_dev(p); else return *p; }
+// 32 bytes, write-through, as two 128-bit stores (the atomic builtins stop at 64 bits): factor rows that tail jobs of the same launch read
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_d4_wt(double* p, d4 v)
+{
+    union { d4 d; u4v u[2]; } c; c.d = v;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(p), "v"(c.u[0]), "v"(c.u[1]) : "memory");
+}
 template <bool DEV> __device__ __forceinline__ void st_d4(double* p, d4 v)
 {
     if constexpr (DEV) { st_dev(p, v[0]); st_dev(p + 1, v[1]); st_dev(p + 2, v[2]); st_dev(p + 3, v[3]); }
@@ -252,6 +296,7 @@ template <bool DEV> __device__ __forceinline__ void st_d4(double* p, d4 v)
 #define GMW_EPOCH_SHIFT 12
 #define GMW_FLAG_COPIES 16          // the two panel flags are polled by every worker at once: one copy per 16 workgroups,
 #define GMW_FLAG_STRIDE 512         // 4 KB apart (unsigned long longs), so that the polls do not all queue on one memory channel
+#define GMW_TAIL_PANELS 32         // the tail fold serves factorisations of at most this many pivoted panels
 struct GmwSync {
     unsigned long long epoch;        // run counter (starts at 1)
     unsigned int exited;             // workgroups that have left the current launch
@@ -259,7 +304,11 @@ struct GmwSync {
     unsigned long long* dbg;         // diagnostic builds: host-visible progress markers (null in the product)
     unsigned int head_done;          // head fold: 32 x 32 tiles of the head rows of S^T S - U U^T finished by the helper workgroups of this launch
     unsigned int head_crit;          // ... and the first ha.ncrit of them: what the pivot needs before its first panel
-    unsigned long long pad[60];
+    // tail fold (srukf_tail.h): the helper workgroups stay, take their jobs from a queue and project the NEXT frame's sigma points row panel by row panel
+    unsigned int job_next;           // next job of the helpers' queue
+    unsigned int dx_done;            // state-update jobs finished (X is final)
+    unsigned int rows_done[GMW_TAIL_PANELS];   // per pivoted panel: writers of its factor rows (Sout) that have finished: complete at T - p
+    unsigned long long pad[59 - GMW_TAIL_PANELS / 2];
     unsigned long long panel_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];  // copy c at [c * STRIDE]: (epoch << SHIFT) + panels published
     unsigned long long half_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];   // same for the first half of a panel buffer (Tt1, E, pivots of sub-panel 1)
     // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)

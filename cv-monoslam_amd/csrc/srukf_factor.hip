@@ -12,6 +12,7 @@
 #include "srukf_rank.h"
 #include "srukf_gmw_cols.h"
 #include "srukf_meas.h"
+#include "srukf_motion_reduce.h"
 
 // A statistics job that rides on a contraction launch has stored its partial sums: the LAST of the MEAS_SLICES jobs of a landmark
 // group (device-scope counter per group) runs that group's final pass with its whole workgroup.  (One last workgroup for all
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
     __shared__ double shm[2 * 2 * 16 * PXY2_LS];               // [buf][A|B][k][PXY2_LS]; >= MEAS_SM_DOUBLES (statistics scratch), >= 4 x 64 x 17 (hand-over)
     static_assert(2 * 2 * 16 * PXY2_LS >= MEAS_SM_DOUBLES && 2 * 2 * 16 * PXY2_LS >= 4 * 64 * 17, "scratch");
     const int nstat = ms.Z ? MEAS_SLICES * ms.gx : 0;         // statistics jobs first: they start with the launch, the tiles fill in behind
+    if (ms.preamble && blockIdx.x == 0 && threadIdx.x == 0) srukf_frame_preamble(ms.fs);   // "tail" mode: nothing of this frame runs before this launch
     if ((int)blockIdx.x < nstat) {
         if ((skip & 1) || threadIdx.x >= 256) return;          // (skip: measurement runs of one half of the launch alone, srukf_debug_set "pxy2_skip")
         const int job = blockIdx.x;                            // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)

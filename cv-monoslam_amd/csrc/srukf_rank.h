@@ -21,6 +21,7 @@ struct HeadArgs {
     int ncrit;
     const double* dxp; double* X; const double* xr1; int ndx;  // dX slice partials -> X (srukf_gain_dx_job), ndx jobs
     int ngd;                                                   // dropped-diagonal jobs (srukf_rank_gdiag_job)
+    int nhelp;                                                 // helper workgroups in the grid: they share one job queue (<= the CUs the pivot and the workers leave free)
     RankArgs ra;
 };
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
     "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
     "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_run_frames_batch", "srukf_prepare_frames", "srukf_debug_poke_state", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
-    "srukf_clamp_info", "srukf_debug_set", "srukf_debug_get", "srukf_debug_gmw_stamps", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
+    "srukf_clamp_info", "srukf_debug_set", "srukf_debug_get", "srukf_debug_copy", "srukf_debug_gmw_stamps", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
 
@@ -122,6 +122,7 @@ def load_library():
     L.srukf_debug_starve_workers.argtypes = [C.c_void_p, C.c_int]
     L.srukf_debug_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.srukf_debug_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
+    L.srukf_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_longlong]
     L.srukf_debug_gmw_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.srukf_debug_allow_mixed.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -344,6 +345,12 @@ class Filter:
         v = C.c_longlong()
         self._chk(self._lib.srukf_debug_get(self._h, key.encode(), C.byref(v)))
         return v.value
+
+    def debug_copy(self, key, count):
+        """Diagnostic copy of the first `count` doubles of a device work buffer ("Z", "DZ", "sigR", "Cmat", "Xr1", "Utp", "P1", "h", "Si")."""
+        out = np.empty(int(count), dtype=np.float64)
+        self._chk(self._lib.srukf_debug_copy(self._h, key.encode(), out.ctypes.data_as(C.POINTER(C.c_double)), int(count)))
+        return out
 
     def debug_gmw_stamps(self):
         """Diagnostic builds only: the time stamps the persistent launch left since the last call (and arms the next launches)."""

@@ -272,6 +272,9 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
 /* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared"). */
 int  srukf_debug_get(srukf_ctx* ctx, const char* key, long long* value);
+/* Diagnostic copy of a device work buffer (tests compare the launch sequences stage by stage): key = "Z", "DZ", "sigR", "Cmat", "Xr1",
+ * "Utp", "P1", "h", "Si"; `count` doubles from the start of the buffer. */
+int  srukf_debug_copy(srukf_ctx* ctx, const char* key, double* out, long long count);
 /* Diagnostic builds (-DSRUKF_GMW_DBG) only: arms / reads the time stamps of the persistent factorisation launch (4096 values). */
 int  srukf_debug_gmw_stamps(srukf_ctx* ctx, unsigned long long* buf);
 

@@ -20,7 +20,9 @@ assert srukf._lib is None
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 p = synth.scene_params(); F = 60
 sc = synth.make_scene(N, F, seed=0, p=p)
-f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+f = srukf.Filter(N, p)
+if len(sys.argv) > 3: f.debug_set("tail_fold", int(sys.argv[3]))
+f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
 f.run_frames(0, 20)
 f.debug_gmw_stamps()                                   # arm
 f.run_frames(20, 20)
@@ -33,3 +35,10 @@ for pnl in range(Tp):
     d = lambda x: int(x - t[0]) if x else -1
     print(f"p={pnl:02d}: {d(t[1]):6d} {d(t[2]):6d} {d(t[3]):6d} {d(t[4]):6d} | {d(t[5]):6d} {d(t[6]):6d} | {d(u[0]):6d} {d(u[1]):6d} {d(u[2]):6d} | {d(t[7]):6d} | {int(t[0] - prev) if prev is not None else 0}")
     prev = t[0]
+
+g = lambda p_, s_: int(st[2048 + 8 * p_ + s_])
+t0 = g(128, 0)
+print("pivot: entry 0, head ready %d, loop end %d   (ticks of 10 ns since the pivot's entry)" % (g(128, 1) - t0, g(128, 2) - t0))
+for nm, q in (("first worker", 129), ("last worker", 130)):
+    print(f"{nm}: entry {g(q, 0) - t0}, own tiles formed {g(q, 1) - t0}, head seen {g(q, 2) - t0}, done {g(q, 3) - t0}")
+print("first helper: entry %d, out %d; last helper (by index) out %d" % (g(131, 0) - t0, g(131, 1) - t0, g(131, 2) - t0))

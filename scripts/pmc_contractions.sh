@@ -17,6 +17,6 @@ for q in (1, 2, 3):
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         c = per[k][r["Counter_Name"]]; c[0] += 1; c[1] += float(r["Counter_Value"])
-    for k in ("k_pxy", "k_syrk", "k_project", "k_gmw_persist<false>", "k_gain", "k_rank_expand"):
+    for k in ("k_pxy", "k_syrk", "k_project", "k_gmw_persist<false, false>", "k_gain", "k_rank_expand"):
         if k in per: print(q, k, {c: round(v[1] / v[0]) for c, v in per[k].items()})
 PY
