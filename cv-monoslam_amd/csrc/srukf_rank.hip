@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* 
 // One workgroup per state row j, one for the frame tail, and one per 16 dropped indices for the null-direction check.
 // Sp: factor rows in permuted order (row a < r valid for columns b >= a), D: pivots in permuted order, perm[a] = state index at
 // permuted position a, iperm = inverse.  A (may be null): the shadow copy of the kept rows in permuted order.
+// TAIL: the instance whose frame-tail workgroup also runs the next frame's motion reduction ("tail" mode; 82 instead of 59 VGPRs: the default instance carries none of it)
+template <bool TAIL>
 __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
                                                      const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
                                                      FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
@@ -69,14 +71,14 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
 {
     __shared__ double red[16 * 3];
     // the frame-tail workgroup comes first in dispatch order ("tail" mode: it carries the next frame's motion reduction, a one-workgroup chain)
-    const int j = (blockIdx.x == 0) ? n : ((int)blockIdx.x <= n ? (int)blockIdx.x - 1 : (int)blockIdx.x);
+    const int j = !TAIL ? (int)blockIdx.x : (blockIdx.x == 0) ? n : ((int)blockIdx.x <= n ? (int)blockIdx.x - 1 : (int)blockIdx.x);
     // "Table" mode of the replay (sigR != null): the workgroup that writes row j of S also pushes the NEXT frame's two sigma points
     // of direction j through the motion model — robot part only: pose before the step X[n-4..], the row's entries in the robot
     // columns, the control k_gain prepared in fs->ctl — and leaves them in the table the next k_project_table launch reads.
     // Two lanes per workgroup, hidden behind the row copy; the frame tail does the centre point and the five noise rows.
     const int Na = n + 5;
     // tailmode: the persistent launch in front of this one has written the whole table already (tail fold, srukf_tail.h)
-    const bool table = sigR && !tailmode && fs->ctl_next_valid && !fs->frozen;
+    const bool table = sigR && !(TAIL && tailmode) && fs->ctl_next_valid && !fs->frozen;
     auto table_rows = [&](const int i, const int sg, const double (&srow)[4], const double (&mnoise)[3], const bool isnull) {
         const MotionCtl mc = { fs->ctl[0], fs->ctl[1], fs->ctl[2], fs->ctl[3], fs->ctl[4] };
         const double xr[4] = { X[n - 4], X[n - 3], X[n - 2], X[n - 1] };
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
             fs->const_rows_pending = 1;                         // this launch wrote (or found) every structurally null row of S as sqrt(EPSILON) e_k
             if (!sigR) srukf_prepare_control(fs);              // control of the next staged frame (k_project_motion); "table" mode: k_gain did it
         }
-        if (sigR && tailmode) {
+        if constexpr (TAIL) if (sigR && tailmode) {
             // "tail" mode: the next frame's sigma points are projected and its table of robot poses is complete -> its motion step
             // (sums over the table, srukf_motion_reduce.h) runs here, and the frame starts with k_pxy2.  Results wait in fs->Xr1 / Cm.
             __shared__ double msm[MOTION_SM_DOUBLES];
@@ -216,8 +218,9 @@ void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, 
                               const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A, double* sigR, double gamma,
                               int tailmode, KDims d, KWeights w, double* Cm)
 {
-    hipLaunchKernelGGL(k_rank_expand, dim3(n + 1 + (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS), dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A,
-                       sigR, gamma, tailmode, d, w, Cm);
+    const dim3 grid(n + 1 + (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS);
+    if (tailmode) hipLaunchKernelGGL(k_rank_expand<true>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm);
+    else hipLaunchKernelGGL(k_rank_expand<false>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm);
 }
 void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
 {
