@@ -213,6 +213,48 @@ static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 }
 // workers = -1 afterwards: the matrix has more tiles than resident workgroups can own (the per-panel launches are used)
 // tenants = 2: the plan of a filter that shares the GPU (gmw_shared = 1): at most half the CUs, so that two admitted launches are resident together
+// XCD-aware order of the tile list when every worker owns ONE tile (srukf_debug_set "tile_xcd", default on).  Workgroup b runs on XCD b % 8, and
+// in the fused replay the owner of tile (I, J) streams the operand columns of blocks I and J through its XCD's L2: with the tiles dealt out in
+// list order every XCD touches every column block (8 copies of the 9.8 MB operand set through 4 MB L2s — the 17 bandwidth-bound us at the head
+// of the launch).  Here the tiles whose owners compute them are cut into 8 compact 2D regions (two bands of block rows x four ranges of block
+// columns), one per XCD; the others (head rows, pass-on row) fill the XCDs up to equal counts.  Which worker owns which tile changes nothing else.
+static int g_dbg_tile_xcd = 1;
+static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles, int workers, int T, int Tp)
+{
+    if (!g_dbg_tile_xcd || ntiles > workers || ntiles < 16) return;
+    struct Tl { short v[4]; };
+    std::vector<Tl> comp, rest;
+    const int h0 = srukf_gmw_head_rows() / 64, hx = h0 + srukf_gmw_head_extra_diag();
+    for (int q = 0; q < ntiles; q++) {
+        Tl t; for (int e = 0; e < 4; e++) t.v[e] = tk[4 * q + e];
+        const int I = t.v[0], J = t.v[1];
+        const bool computes = I >= h0 && !(I < hx && J < hx) && !(Tp < T && I == Tp);
+        (computes ? comp : rest).push_back(t);
+    }
+    if (comp.size() < 16) return;
+    // two bands of block rows with about half of the computed tiles each, each band in J-major order cut into four ranges
+    std::sort(comp.begin(), comp.end(), [](const Tl& a, const Tl& b) { return a.v[0] != b.v[0] ? a.v[0] < b.v[0] : a.v[1] < b.v[1]; });
+    size_t cut = comp.size() / 2;
+    while (cut < comp.size() && cut > 0 && comp[cut].v[0] == comp[cut - 1].v[0]) cut++;      // bands end at row boundaries
+    std::vector<std::vector<Tl>> grp(8);
+    for (int band = 0; band < 2; band++) {
+        std::vector<Tl> b(comp.begin() + (band ? cut : 0), band ? comp.end() : comp.begin() + cut);
+        std::sort(b.begin(), b.end(), [](const Tl& x, const Tl& y) { return x.v[1] != y.v[1] ? x.v[1] < y.v[1] : x.v[0] < y.v[0]; });
+        for (size_t q = 0; q < b.size(); q++) grp[4 * band + std::min<size_t>(3, q * 4 / b.size())].push_back(b[q]);
+    }
+    // positions of XCD x: list index w with (w + 1) % 8 == x (blockIdx = w + 1: the pivot is workgroup 0)
+    int cap[8] = { 0 };
+    for (int w = 0; w < ntiles; w++) cap[(w + 1) % 8]++;
+    std::vector<Tl> spill(rest);
+    for (int x = 0; x < 8; x++) while ((int)grp[x].size() > cap[x]) { spill.push_back(grp[x].back()); grp[x].pop_back(); }
+    for (int x = 0; x < 8; x++) while ((int)grp[x].size() < cap[x] && !spill.empty()) { grp[x].push_back(spill.back()); spill.pop_back(); }
+    size_t pos[8] = { 0 };
+    for (int w = 0; w < ntiles; w++) {
+        const int x = (w + 1) % 8;
+        const Tl t = grp[x][pos[x]++];
+        for (int e = 0; e < 4; e++) tk[4 * w + e] = t.v[e];
+    }
+}
 static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int tenants = 1)
 {
     g.T = np / 64;
@@ -226,6 +268,7 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
     srukf_gmw_build_tiles(g.T, g.Tp, tk.data());
+    gmw_tiles_xcd_order(tk, g.ntiles, g.workers, g.T, g.Tp);
     const size_t sync_bytes = (size_t)srukf_gmw_sync_bytes(g.T);
     if (srukf_dmalloc_on(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
         srukf_dmalloc_on(&g.sync, sync_bytes, st) != hipSuccess ||
@@ -1919,7 +1962,8 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
 {
     if (!key) return SRUKF_ERR_BAD_ARG;
     struct { const char* k; int* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
-                                                    { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs } };
+                                                    { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs },
+                                                    { "tile_xcd", &g_dbg_tile_xcd } };      // tile_xcd: applies to plans built afterwards (set it before the state)
     if (!strcmp(key, "pxy2_skip")) { g_pxy2_skip = value & 3; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }   // timing only: results are garbage
     if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards

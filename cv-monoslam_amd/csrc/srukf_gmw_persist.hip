@@ -486,7 +486,7 @@ __global__ void k_gmw_gate(FrameScalars* __restrict__ fs, int limit)
 // dispatch order; the pivot and every worker's first step wait for sy->head_done == ha.ntiles.  One launch and its boundary (~13 us)
 // less per frame, ~6 us more inside this one.
 __device__ __forceinline__ void gmw_head_tile_job(int n, int ld, int krows, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
-                                                  int2 tl, double* __restrict__ G, FrameScalars* __restrict__ fs, double* smem, int tid)
+                                                  int2 tl, double* __restrict__ G, FrameScalars* __restrict__ fs, double* smem, int tid, GmwSync* sy = nullptr, bool stamp = false)
 {
     if (tl.x < 0) return;
     double (*red)[64][17] = (double (*)[64][17])smem;
@@ -500,8 +500,12 @@ __device__ __forceinline__ void gmw_head_tile_job(int n, int ld, int krows, cons
     // (a helper wave has its SIMD to itself, like an owner: three groups of loads in flight — with one group of look-ahead the critical
     //  tiles took 18 us under the owners' operand traffic, and the pivot's first panel waits for them; same summation order)
     if (g0 < ngs) tile32_tn_deep<false>(acc, S0, ld, S0, ld, m0, n0, g0 << 4, min(g1, ngs) << 4, lane);
+    if (stamp && wv == 0) GMW_TS(sy, 132, 1);
     if (g1 > ngs) tile32_tn_deep<true>(acc, Ut0, ld, Ut0, ld, m0, n0, u0 + ((max(g0, ngs) - ngs) << 4), u0 + ((g1 - ngs) << 4), lane);
+    if (stamp && wv == 0) GMW_TS(sy, 132, 2);
+    if (stamp && wv == 3) GMW_TS(sy, 132, 6);
     splitk_reduce(acc, red, wv, lane);
+    if (stamp && wv == 0) GMW_TS(sy, 132, 3);
     if (wv != 0) return;
     double gmax = 0.0, xmax = 0.0;
 #pragma unroll
@@ -547,11 +551,29 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     __shared__ double keepreg[1024 + 64 + 64];
     __shared__ int ok, halfcnt, stageok[2];
     const int tid = threadIdx.x;
-    if (fs->frozen) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
-    const unsigned long long ebase = sy->epoch << GMW_EPOCH_SHIFT;      // written by the previous launch's last workgroup
     const int nhelp = ha.nhelp;                                // head fold: helper workgroups BEHIND the pivot and the workers (0 without it)
     const int nmain = (int)gridDim.x - nhelp;                  // 1 + workers: dispatched first, so that the owners start forming their tiles at once
     const int role = (int)blockIdx.x < nmain ? (int)blockIdx.x : -1;      // -1: helper, 0: pivot, > 0: worker role - 1
+    // What a role needs first — its entry of the tile list — is requested TOGETHER with the frozen flag and the epoch: a round trip in a freshly
+    // launched grid is ~2 us (cold TLB and L2, 256 workgroups asking at once), and flag -> list entry -> operands was a chain of three of them in front
+    // of the critical head tiles (time stamps: 7.5 us before the first MFMA).  The asm pins all four loads in front of the first use.
+    int2 mytile = make_int2(-1, -1);
+    unsigned long long t01 = 0, t23 = 0;                       // GmwTile entries (4 shorts each) of a worker's two tiles
+    if (!MEM) {
+        if (role < 0) { const int hb = (int)blockIdx.x - nmain; if (!(TAIL && tap != nullptr) && hb < ha.ntiles) mytile = ha.tiles[hb]; }
+        else if (role > 0) {
+            const unsigned long long* tq = (const unsigned long long*)tiles;
+            if (role - 1 < ntiles) t01 = tq[role - 1];
+            if (role - 1 + nmain - 1 < ntiles) t23 = tq[role - 1 + nmain - 1];
+        }
+    }
+    int frozen_now = fs->frozen;
+    unsigned long long epoch_now = sy->epoch;                  // written by the previous launch's last workgroup
+    asm volatile("" : "+v"(mytile.x), "+v"(mytile.y), "+v"(t01), "+v"(t23), "+v"(frozen_now), "+v"(epoch_now));
+    if (frozen_now) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
+    const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
+    // (Letting the critical head tiles go first — every other role sleeping 1 .. 5 us before its first operand loads — was measured: 195.5 us per
+    //  frame without, 196.8 / 197.2 / 198.6 / 199.0 / 203.8 with 0.9 / 1.7 / 2.6 / 3.4 / 5.1 us: every chain of the launch is critical.)
     const bool tail = TAIL && tap != nullptr && fs->odo_seq && fs->frame + 1 < fs->seqF;   // (there is a next staged frame)                       // tail fold: the args live in device memory (a by-value copy costs every role ~200 SGPR spills)
     // (measurement only, srukf_debug_set "tail_fold" with bits 4 / 8: the pivot's / the workers' rows with plain stores and no counting)
     const int tail_on = (TAIL && tail) ? tap->on : 0;
@@ -582,9 +604,12 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             } else if (pass) break;
             if (job >= njobs) break;
             if (job < ha.ntiles) {
-                gmw_head_tile_job(n, ld, krows, S0, Ut0, u0, u1, ha.tiles[job], G, fs, &Lr[0][0], tid);
+                if (job == 0) GMW_TS(sy, 132, 0);
+                gmw_head_tile_job(n, ld, krows, S0, Ut0, u0, u1, (TAIL && tap != nullptr) ? ha.tiles[job] : mytile, G, fs, &Lr[0][0], tid, sy, job == 0);
+                if (job == 0) GMW_TS(sy, 132, 4);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tile stores have landed ...
                 __syncthreads();
+                if (job == 0) GMW_TS(sy, 132, 5);
                 // the list starts with the ha.ncrit tiles the pivot needs before its first panel ((0,0), (0,1), (1,1) in 64 x 64 terms)
                 if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(job < ha.ncrit ? &sy->head_crit : &sy->head_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             } else if (job < ha.ntiles + ha.ndx) {
@@ -640,8 +665,9 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
                 }
         } else {
         GmwOwned ta = { 0, 0, 0, false, 0, false }, tb = { 0, 0, 0, false, 0, false };
-        if (w < ntiles) { const GmwTile t = tiles[w]; ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; ta.kfirst = t.pad; ta.passon = Tp < T && t.I == Tp; }
-        if (w + workers < ntiles) { const GmwTile t = tiles[w + workers]; tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; tb.kfirst = t.pad; tb.passon = Tp < T && t.I == Tp; }
+        auto entry = [](unsigned long long q) { GmwTile t; t.I = (short)(q & 0xffff); t.J = (short)((q >> 16) & 0xffff); t.nsteps = (short)((q >> 32) & 0xffff); t.pad = (short)((q >> 48) & 0xffff); return t; };
+        if (w < ntiles) { const GmwTile t = entry(t01); ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; ta.kfirst = t.pad; ta.passon = Tp < T && t.I == Tp; }
+        if (w + workers < ntiles) { const GmwTile t = entry(t23); tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; tb.kfirst = t.pad; tb.passon = Tp < T && t.I == Tp; }
         d4 acca[2][2], accb[2][2];
         zero_acc(acca); zero_acc(accb);
         if (role == 1) GMW_TS(sy, 129, 0);
