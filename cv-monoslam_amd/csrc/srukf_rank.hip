@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* 
     if (a < n) { const int j = perm[a]; gdiag[a] = G[(size_t)j * ld + j]; }
 }
 
-// One workgroup per state row j, one for the frame tail, and one per 16 dropped indices for the null-direction check.
+// One workgroup per row (permuted position a; state row perm[a]), one for the frame tail, and one per 16 dropped indices for the null-direction check.
 // Sp: factor rows in permuted order (row a < r valid for columns b >= a), D: pivots in permuted order, perm[a] = state index at
 // permuted position a, iperm = inverse.  A (may be null): the shadow copy of the kept rows in permuted order.
 // TAIL: the instance whose frame-tail workgroup also runs the next frame's motion reduction ("tail" mode; 82 instead of 59 VGPRs: the default instance carries none of it)
@@ -147,8 +147,13 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         }
         return;
     }
-    const int a = iperm[j];
-    double* out = S + (size_t)j * ld;
+    // One workgroup per PERMUTED position a = blockIdx (row a of the factor, state row j = perm[a]): the row's loads depend on nothing but the
+    // block index, and j and the columns' state indices perm[b] — needed for the store addresses only — arrive with them: one memory round trip
+    // in front of the stores.  (Indexed by the state row, the chain was iperm[j] -> iperm[c] -> src[iperm[c]]: three of them, ~2 us each in a freshly
+    // launched grid.)
+    const int a = j;                                           // (the dispatch index above)
+    const int jj = perm[a];                                    // state row
+    double* out = S + (size_t)jj * ld;
     if (table && threadIdx.x < 2) {
         double srow[4] = { 0, 0, 0, 0 };
         const double zero3[3] = { 0, 0, 0 };
@@ -156,27 +161,39 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
 #pragma unroll
             for (int e = 0; e < 4; e++) srow[e] = (r - 4 + e >= a) ? Sp[(size_t)a * ld + (r - 4 + e)] : 0.0;    // the robot columns: permuted positions r-4 .. r-1
         }
-        table_rows(j, threadIdx.x, srow, zero3, a >= r);
+        table_rows(jj, threadIdx.x, srow, zero3, a >= r);
     }
     if (a >= r) {                                              // dropped direction: what the reference's clamp leaves
         // the same row every frame: written by the first frame of a staged run only (fs->const_rows_ok: set for the frames after it
         // by the next launch, cleared by k_set_run / k_set_frame; whoever else rewrites S goes through one of those first)
         if (sigR && fs->const_rows_ok) return;
-        for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == j) ? sqrt(eps) : 0.0;
+        for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == jj) ? sqrt(eps) : 0.0;
         return;
     }
     const double* src = Sp + (size_t)a * ld;
+    double* sh = A ? A + (size_t)a * ld : nullptr;
     double mx = 0.0;
     // columns left of the diagonal hold zeros in S (every writer keeps the strictly lower triangle zero) and in the permuted copy:
-    // only the row's upper part is written ("table" mode; the other callers rewrite the whole row as before)
-    for (int c = (sigR ? (j & ~3) : 0) + threadIdx.x; c < ld; c += 256) {
-        double v = 0.0;
-        if (c >= j && c < n) { v = src[iperm[c]]; if (c > j) mx = fmax(mx, fabs(v)); }
-        out[c] = v;
-    }
-    if (A) {
-        double* sh = A + (size_t)a * ld;
-        for (int b = (sigR ? (a & ~3) : 0) + threadIdx.x; b < ld; b += 256) sh[b] = (b >= a && b < n) ? src[b] : 0.0;
+    // only the row's upper part is written ("table" mode; the other callers rewrite the whole row as before).  A state column c = perm[b]
+    // left of the diagonal (c < jj) can only be a dropped one (b >= r): the residual of a column that is a copy of an earlier one, zero.
+    // (four trips' loads are requested before the first store: a row is one or two memory round trips, not one per 256 columns)
+    for (int b0 = (sigR ? (a & ~3) : 0) + threadIdx.x; b0 < ld; b0 += 4 * 256) {
+        double sv[4]; int cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = b0 + 256 * u;
+            sv[u] = (b >= a && b < n) ? src[b] : 0.0;
+            cc[u] = (b < n) ? perm[b] : b;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = b0 + 256 * u;
+            if (b >= ld) break;
+            const bool upper = b >= a && b < n && cc[u] >= jj;
+            if (sh) sh[b] = sv[u];
+            if (upper && cc[u] > jj) mx = fmax(mx, fabs(sv[u]));
+            if (upper || !sigR) out[cc[u]] = upper ? sv[u] : 0.0;
+        }
     }
     // theta clamp of the reference evaluated afterwards, as k_gmw_check does (SLAM.cpp:2204-2211, 2264-2285)
     mx = wave_max(mx);
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         const double beta2 = fmax(fmax(gamma, xi / nu), 1e-15);
         const double dj = D[a];
         const double th = mx * sqrt(dj);
-        if (th * th / beta2 > dj) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, j); }
+        if (th * th / beta2 > dj) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, jj); }
     }
 }
 
