@@ -31,16 +31,16 @@ struct HeadArgs {
 #define SRUKF_RANK_COLS 16
 __device__ __forceinline__ double srukf_rank_colsq(const double* __restrict__ M, int ld, int rows, int a, int kl)
 {
+    // 20 loads in flight per lane, clamped onto the last row (in bounds, masked out of the sum): a column of 640 rows is two memory round trips
+    // (with eight in flight and a scalar tail, 607 rows were five + six of them, and the null check was the longest chain of k_rank_expand)
     double v = 0.0;
-    int k = kl;
-    for (; k + 7 * 16 < rows; k += 8 * 16) {
-        double t[8];
+    for (int k = kl; k < rows; k += 20 * 16) {
+        double t[20];
 #pragma unroll
-        for (int u = 0; u < 8; u++) t[u] = M[(size_t)(k + 16 * u) * ld + a];
+        for (int u = 0; u < 20; u++) t[u] = M[(size_t)min(k + 16 * u, rows - 1) * ld + a];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v += t[u] * t[u];
+        for (int u = 0; u < 20; u++) v += (k + 16 * u < rows) ? t[u] * t[u] : 0.0;
     }
-    for (; k < rows; k += 16) { const double t = M[(size_t)k * ld + a]; v += t * t; }
     return v;
 }
 __device__ __forceinline__ void srukf_rank_gdiag_job(int n, int ld, int mu, const RankArgs ra, unsigned long long* gmax_bits, int blk)
