@@ -569,7 +569,10 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     }
     int frozen_now = fs->frozen;
     unsigned long long epoch_now = sy->epoch;                  // written by the previous launch's last workgroup
-    asm volatile("" : "+v"(mytile.x), "+v"(mytile.y), "+v"(t01), "+v"(t23), "+v"(frozen_now), "+v"(epoch_now));
+    // (Measured, both ways, per instance.  Register-resident tiles: pinned as VECTOR registers 148-150 us per launch at N = 200, as scalar ones 152-153.5.
+    //  Memory tiles (N = 500): as vector registers 46 VGPR spills and 627 us per launch, as scalar ones 27 spills and 575 us.)
+    if constexpr (MEM) asm volatile("" : "+s"(frozen_now), "+s"(epoch_now));
+    else asm volatile("" : "+v"(mytile.x), "+v"(mytile.y), "+v"(t01), "+v"(t23), "+v"(frozen_now), "+v"(epoch_now));
     if (frozen_now) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
     const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
     // (Letting the critical head tiles go first — every other role sleeping 1 .. 5 us before its first operand loads — was measured: 195.5 us per
@@ -580,6 +583,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     const int tail_on = (TAIL && tail) ? tap->on : 0;
     const bool tail_pivot = TAIL && tail && !(tail_on & 4), tail_work = TAIL && tail && !(tail_on & 8);
     if (role < 0) {
+        if constexpr (!MEM) {                                  // (the memory-tile instance has no helpers: none of their code, none of their registers)
         // Helpers take their jobs from one queue (sy->job_next), in this order: the head tiles (critical ones first), X += dX, the dropped
         // diagonal; then — tail fold — the next frame's projection jobs (srukf_tail.h).  However many of them are resident, every job is
         // taken by somebody; nobody waits for a helper that has not started.
@@ -631,6 +635,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         if (!good && wvu == 0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)blockIdx.x == nmain) GMW_TS(sy, 131, 1);
         if ((int)blockIdx.x == (int)gridDim.x - 1) GMW_TS(sy, 131, 2);
+        }
     } else if (role == 0) {
         bool head_ok = true;
         GMW_TS(sy, 128, 0);
