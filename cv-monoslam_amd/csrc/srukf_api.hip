@@ -23,7 +23,7 @@ void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const 
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, FrameScalars*, double*, double*, const double*, RankArgs, const double*, double*,
-                       const double*, int, const double*, double);
+                       const double*, int, const double*, double, const double*, int);
 void srukf_launch_project_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs);
 int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
@@ -44,7 +44,7 @@ void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, dou
 void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*, const TailArgs*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, double*);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, double*, srukf_params, double*, double*);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
@@ -338,6 +338,7 @@ struct srukf_ctx {
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
                                            // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
+    int dbg_tail_fuse = 1;                 // srukf_debug_set "tail_fuse": k_rank_expand also projects the next frame ("fused tail" mode); 0: k_project_table in front of every frame
     int dbg_tail_fold = 0;                 // srukf_debug_set "tail_fold" 1: the helpers of the persistent launch also project the NEXT frame's sigma points (srukf_tail.h: built,
                                            // bit-identical, NOT faster — the jobs cost the pivot chain what the projection launch cost); 0 (default): k_project_table
     TailArgs* d_tail = nullptr;            // ... their arguments (device copy, rebuilt with the null set)
@@ -543,12 +544,14 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
 // (as the full-rank form does: quantize_state before the tail).
 // table: "table" mode of the replay — the tail also prepares the next frame's table of robot poses (k_rank_expand)
 // tail: "tail" mode — the persistent launch has prepared that table (and projected the next frame): the tail runs the next frame's motion reduction instead
-static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool tail = false)
+// fuse: "fused tail" mode — this launch also projects the next frame's sigma points (k_rank_expand<2>)
+static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool tail = false, bool fuse = false)
 {
     const int n = c->d.n, np = c->d.np;
     const bool f32 = c->storage == SRUKF_STORAGE_F32;
+    const bool tt = table && frame_tail && !f32;
     srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
-                             (table && frame_tail && !f32) ? c->sigR : nullptr, c->w.gamma, (tail && table && frame_tail && !f32) ? 1 : 0, c->d, c->w, c->Cmat);
+                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 2 : (tt && tail) ? 1 : 0, c->d, c->w, c->Cmat, c->p, c->Z, c->DZ);
     if (f32) {
         quantize_state(c);
         srukf_launch_rank_round(c->stream, np, c->red_r, c->shadowA);
@@ -578,7 +581,13 @@ static bool replay_tail_mode(const srukf_ctx* c)
     return replay_motion_mode(c) == 2 && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->dbg_head_fold && c->gmw_shared == 0 && c->dbg_tail_fold && !(c->dbg_tail_fold & 16) && c->d_tail && c->tail_ok &&
            c->red_Tp <= GMW_TAIL_PANELS && tail_helpers(c) >= 32;
 }
-static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false, bool tail = false)
+// "fused tail" mode (default where "table" mode runs with k_pxy2 and NullSkip): k_rank_expand also projects the next frame (k_rank_expand<2>), the frame's motion reduction
+// rides on k_pxy2 (MeasArgs::fmode), k_gain re-centres the robot rows: a frame is k_pxy2, k_gain, k_gmw_persist, k_rank_expand, and only a run's first frame has a projection launch
+static bool replay_fuse_mode(const srukf_ctx* c)
+{
+    return replay_motion_mode(c) == 2 && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && c->dbg_tail_fuse && !replay_tail_mode(c);
+}
+static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false, bool tail = false, bool fuse = false)
 {
     const KDims& d = c->d;
     const int np = d.np, n = d.n;
@@ -629,7 +638,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
                                           (head_fold && (tail || (c->dbg_tail_fold & 16))) ? c->d_tail : nullptr);
         }
         ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
-        rank_expand(c, frame_tail, table, head_fold && tail);
+        rank_expand(c, frame_tail, table, head_fold && tail, fuse);
         return;
     }
     // ... or, where the owners cannot fold (memory tiles: more than two tiles per worker; one launch per panel), still in permuted
@@ -791,22 +800,24 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
 }
 // fused_motion: the frame's motion step ran inside k_project_motion: the statistics take the robot mean from fs->Xr1, k_gain commits Cmat
 // table: "table" mode of the replay — the product on the permuted operands (k_pxy2), k_gain takes it from there
-static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false)
+static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false)
 {
     const KDims& d = c->d;
     {
         const double nn = d.n;
         ProfScope ps(c, table ? KC_PXY2 : KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
         MeasArgs ms = {};
-        const double* xrob = fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
-        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{}, preamble ? 1 : 0 };
+        // ("fused tail" mode: the statistics are centred on the centre point's robot part, row 0 of the table: the mean does not exist yet)
+        const double* xrob = fmode ? c->sigR : fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
+        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{}, preamble ? 1 : 0,
+                                        fmode ? 1 : 0, c->Cmat };
         if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
         else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
     }
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
         srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
-                          fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ, sqrt(c->p.epsilon));
+                          fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ, sqrt(c->p.epsilon), c->sigR, fmode ? 1 : 0);
         c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
 }
@@ -977,7 +988,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     const size_t np = d.np, mp = d.mp;
     ALLOC(c->X, np); ALLOC(c->S, np * np); ALLOC(c->G, np * np); ALLOC(c->Gbak, np * np); ALLOC(c->Wf, np * np);
     ALLOC(c->sigR, (size_t)d.L * 8 + 8); ALLOC(c->mpart, srukf_meas_part_doubles(d.mp)); ALLOC(c->dxp, srukf_gain_part_doubles(d.np)); ALLOC(c->Cmat, (np + 64) * 4); ALLOC(c->Z, (size_t)d.L * mp); ALLOC(c->DZ, np * mp);
-    ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)(N > 0 ? N : 1)); ALLOC(c->PxyR, 4 * mp);
+    ALLOC(c->Ut, mp * np); ALLOC(c->h, mp); ALLOC(c->Si, 4 * (size_t)(N > 0 ? N : 1)); ALLOC(c->PxyR, 5 * mp);                       // rows 0..3: robot rows of the cross covariances; row 4: scratch of the "fused tail" statistics
     ALLOC(c->D, np); ALLOC(c->zcur, mp); ALLOC(c->odocur, 8); ALLOC(c->small, 64);
     ALLOC(c->vis, N > 0 ? N : 1); ALLOC(c->mcur, N > 0 ? N : 1); ALLOC(c->theta, np); ALLOC(c->fs, 1);
     { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
@@ -1704,8 +1715,12 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
 static void replay_one_frame(srukf_ctx* c)
 {
     const int mode = replay_motion_mode(c);
-    const bool tail = replay_tail_mode(c);
-    if (tail) {
+    const bool tail = replay_tail_mode(c), fuse = replay_fuse_mode(c);
+    if (fuse) {
+        // the previous frame's tail (or, for a run's first frame, run_frames_async) projected this frame; its motion reduction rides on k_pxy2
+        c->xr1_pending = true;
+        seq_gain(c, nullptr, nullptr, true, true, true, true, true);
+    } else if (tail) {
         // the previous frame's launches (or, for a run's first frame, run_frames_async) projected this frame and ran its motion reduction
         c->xr1_pending = true;
         seq_gain(c, nullptr, nullptr, true, true, true, true);
@@ -1717,7 +1732,7 @@ static void replay_one_frame(srukf_ctx* c)
         seq_predict_measurement(c, true);
         seq_gain(c, nullptr, nullptr, true);
     }
-    seq_refactor(c, 0, c->d.mp, false, false, false, true, mode == 2, tail);
+    seq_refactor(c, 0, c->d.mp, false, false, false, true, mode == 2, tail, fuse);
 }
 static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec_t* ge)
 {
@@ -1759,7 +1774,7 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     if (replay_motion_mode(c) == 2) srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs, c->red_iperm, c->red_r);
     // "tail" mode: ... and the first frame's projection + motion reduction (k_project_table); every later frame is projected inside its
     // predecessor's factorisation launch
-    if (replay_tail_mode(c)) seq_predict_fused(c, 2);
+    if (replay_tail_mode(c) || replay_fuse_mode(c)) seq_predict_fused(c, 2);
     if (c->use_graph && !c->profiling) {
         // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
         // captured frame replays for all frames: the 45 launches cost one hipGraphLaunch on the host
@@ -1985,6 +2000,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "nullskip")) c->dbg_nullskip = value ? 1 : 0;
     else if (!strcmp(key, "head_fold")) c->dbg_head_fold = value ? 1 : 0;
     else if (!strcmp(key, "tail_cap")) c->dbg_tail_cap = value < 0 ? 0 : value;
+    else if (!strcmp(key, "tail_fuse")) c->dbg_tail_fuse = value ? 1 : 0;
     else if (!strcmp(key, "tail_fold")) {
         c->dbg_tail_fold = value < 0 ? 0 : value > 31 ? 31 : value;    // > 1: timing only (2: no projection jobs; + 4 / + 8: pivot / worker rows with plain stores): the NEXT frame is garbage
         if (c->d_tail) { const int on = c->dbg_tail_fold ? c->dbg_tail_fold : 1; HIPCHK(c, hipMemcpy((char*)c->d_tail + offsetof(TailArgs, on), &on, sizeof on, hipMemcpyHostToDevice)); }

@@ -268,6 +268,10 @@ struct MeasArgs {
     FrameScalars* fs; int gx;                                  // gx = (N + 31) / 32 landmark groups
     NullSkip ns;                                               // ns.rows != null: the statistics walk that row list (+ every landmark's own null rows)
     int preamble;                                              // "tail" mode: k_pxy2 is the frame's first launch -> its first thread runs srukf_frame_preamble
+    int fmode;                                                 // "fused tail" mode: workgroup 0 of k_pxy2 is the frame's motion reduction (the table is complete, nothing else of the frame
+                                                               // has run); the statistics are centred on the CENTRE point's robot part (xrob = sigR row 0) and their final pass leaves the raw
+                                                               // sums (PxyR rows 0..3) and wi * sum(Z_c - Z_0) (row 4): k_gain, which runs after the reduction, re-centres them on the mean
+    double* Cm;                                                // fmode: where the motion reduction leaves R12 / R22 (k_gain commits them)
 };
 
 // ---- agent-scope (device-coherent) accesses: data handed from one workgroup to another INSIDE a launch ----

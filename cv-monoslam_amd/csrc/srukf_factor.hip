@@ -29,7 +29,7 @@ __device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w,
     }
     __syncthreads();
     if (!last) return;
-    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm);
+    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,14 +102,21 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
     static_assert(2 * 2 * 16 * PXY2_LS >= MEAS_SM_DOUBLES && 2 * 2 * 16 * PXY2_LS >= 4 * 64 * 17, "scratch");
     const int nstat = ms.Z ? MEAS_SLICES * ms.gx : 0;         // statistics jobs first: they start with the launch, the tiles fill in behind
     if (ms.preamble && blockIdx.x == 0 && threadIdx.x == 0) srukf_frame_preamble(ms.fs);   // "tail" mode: nothing of this frame runs before this launch
-    if ((int)blockIdx.x < nstat) {
+    const int nmot = ms.fmode ? 1 : 0;                         // "fused tail" mode: workgroup 0 is the frame's motion step (sums over the table the previous frame's tail completed)
+    if (nmot && blockIdx.x == 0) {
+        if (threadIdx.x >= 256) return;
+        const RankArgs ra0 = {};
+        motion_reduce_body<256, false>(d, w, const_cast<double*>(ms.X), nullptr, const_cast<double*>(ms.sigR), ms.Cm, ms.fs, ra0, shm);
+        return;
+    }
+    if ((int)blockIdx.x < nmot + nstat) {
         if ((skip & 1) || threadIdx.x >= 256) return;          // (skip: measurement runs of one half of the launch alone, srukf_debug_set "pxy2_skip")
-        const int job = blockIdx.x;                            // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
+        const int job = (int)blockIdx.x - nmot;                // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
         meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm, ms.ns);
         meas_job_done(d, w, ms, job % ms.gx, shm);
         return;
     }
-    const int4 tl = tiles[blockIdx.x - nstat];
+    const int4 tl = tiles[blockIdx.x - nstat - nmot];
     if (tl.x < 0 || (skip & 2)) return;                        // empty slot of the XCD-aware list
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int m0 = 64 * tl.x, b0 = 64 * tl.y;
@@ -636,7 +643,7 @@ int g_pxy2_skip = 0;
 void srukf_launch_pxy2(hipStream_t st, KDims d, const double* DZp, const double* A, double* P0, double* P1, const void* tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
 {
     const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
-    hipLaunchKernelGGL(k_pxy2, dim3(ntiles + extra), dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms, g_pxy2_skip);
+    hipLaunchKernelGGL(k_pxy2, dim3(ntiles + extra + (ms.fmode ? 1 : 0)), dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms, g_pxy2_skip);
 }
 // host-side tile list of k_pxy2 (4 ints per workgroup: mt, bt, half, halves; mt < 0: empty slot).  K ranges of at least PXY2_SPLIT
 // groups are cut in two.  XCD-aware: workgroup w runs on XCD w % 8 (round-robin dispatch; the statistics jobs in front of the

@@ -116,7 +116,7 @@ __device__ __forceinline__ double meas_slice_pair(const double* __restrict__ par
 __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                 const double* __restrict__ Z, const double (&t)[MEAS_NS],
                                                 double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                double* __restrict__ PxyR, int k);
+                                                double* __restrict__ PxyR, int k, int defer = 0);
 // landmark k: reduce the slices, finish h, Si, visible, PxyR
 template <bool COHERENT>
 __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w, const double* __restrict__ X, const double* __restrict__ sigR,
@@ -140,7 +140,7 @@ __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w
 __device__ __forceinline__ void meas_final_group(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                  const double* __restrict__ Z, const double* __restrict__ part,
                                                  double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                 double* __restrict__ PxyR, int bx, double* smem)
+                                                 double* __restrict__ PxyR, int bx, double* smem, int defer = 0)
 {
     double (*sm)[32][MEAS_NS] = (double (*)[32][MEAS_NS])smem;
     const int lx = threadIdx.x & 31, pr = threadIdx.x >> 5;
@@ -160,30 +160,43 @@ __device__ __forceinline__ void meas_final_group(const KDims& d, const KWeights&
             for (int u = 0; u < 8; u++) acc += sm[u][lx][q];
             t[q] = acc;
         }
-        meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k);
+        meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k, defer);
     }
 }
 __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                 const double* __restrict__ Z, const double (&t)[MEAS_NS],
                                                 double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                double* __restrict__ PxyR, int k)
+                                                double* __restrict__ PxyR, int k, int defer)
 {
+#pragma clang fp contract(off)
+    // (every fused multiply-add written out, contraction off: this function is compiled into three kernels — k_meas_final, k_pxy, k_pxy2 — and which of two
+    //  products the compiler fuses depends on the code around an inlined call; the step-wise API and the replay must give the same bits)
     const int mp = d.mp;
     const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * k);
     // h = wm0*Z0 + wi*sum_{c>=1} Z_c = Z0*(wm0 + 2Na*wi) + wi*sum (Z_c - Z0)      (SLAM.cpp:1678-1681)
     const double wsum = w.wm0 + 2.0 * d.Na * w.wi;
-    const double hx = wsum * z0.x + w.wi * t[0], hy = wsum * z0.y + w.wi * t[1];
+    const double hx = fma(wsum, z0.x, w.wi * t[0]), hy = fma(wsum, z0.y, w.wi * t[1]);
     // robot rows of Pxy: sum_c w_c (r_c - xr)(Z_c - h) = sum_c w_c (r_c - xr)(Z_c - Z0) - (h - Z0) * sum_c w_c (r_c - xr)
-    double rs[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) rs[e] = sigR[(size_t)d.L * 8 + e];      // sum_c w_c (r_c - xr), from k_motion
     const bool v = (hx != 0.0) && (hy != 0.0);
     h[2 * k] = hx; h[2 * k + 1] = hy;
     vis[k] = v ? 1 : 0;
+    if (defer) {
+        // "fused tail" mode: the motion reduction of this frame runs in the same launch, so neither the mean xr nor rs exist yet.  The sums were
+        // taken around the centre point's robot part r_0 instead of xr; with sum_c w_c (Z_c - Z_0) = wi t[0..1] (the centre's own term is zero)
+        //     sum_c w_c (r_c - xr)(Z_c - Z_0) = sum_c w_c (r_c - r_0)(Z_c - Z_0) - (xr - r_0) wi t[0..1]
+        // and k_gain applies that and the (h - Z_0) rs term: raw sums here, wi t[0..1] in row 4
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        PxyR[(size_t)e * mp + 2 * k]     = t[5 + e] - (hx - z0.x) * rs[e];
-        PxyR[(size_t)e * mp + 2 * k + 1] = t[9 + e] - (hy - z0.y) * rs[e];
+        for (int e = 0; e < 4; e++) { PxyR[(size_t)e * mp + 2 * k] = t[5 + e]; PxyR[(size_t)e * mp + 2 * k + 1] = t[9 + e]; }
+        PxyR[(size_t)4 * mp + 2 * k] = w.wi * t[0]; PxyR[(size_t)4 * mp + 2 * k + 1] = w.wi * t[1];
+    } else {
+        double rs[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) rs[e] = sigR[(size_t)d.L * 8 + e];      // sum_c w_c (r_c - xr), from k_motion
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            PxyR[(size_t)e * mp + 2 * k]     = fma(-(hx - z0.x), rs[e], t[5 + e]);
+            PxyR[(size_t)e * mp + 2 * k + 1] = fma(-(hy - z0.y), rs[e], t[9 + e]);
+        }
     }
     // Householder R of the 2Na x 2 matrix [a b] (GSL: beta = -sign(alpha) hypot(alpha, xnorm); tau = 0 if xnorm == 0)
     const double2 z1 = *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * k);
@@ -191,21 +204,21 @@ __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& 
     const double a0 = w.wi_sr * (z1.x - z0.x), b0 = w.wi_sr * (z1.y - z0.y);
     const double a1 = w.wi_sr * (z2.x - z0.x), b1 = w.wi_sr * (z2.y - z0.y);
     const double saa = t[2], sab = t[3], sbb = t[4];
-    const double xn2 = fmax(saa - a0 * a0, 0.0);
+    const double xn2 = fmax(fma(-a0, a0, saa), 0.0);
     double R00 = a0, R01 = b0, tau = 0.0, wv = 0.0, inv_s = 0.0;
     if (xn2 > 0.0) {
         const double beta = -(a0 >= 0.0 ? 1.0 : -1.0) * sqrt(saa);
         tau = (beta - a0) / beta;
         inv_s = 1.0 / (a0 - beta);
-        wv = b0 + (sab - a0 * b0) * inv_s;              // w = B_0 + sum_{r>=1} B_r v_r
+        wv = fma(fma(-a0, b0, sab), inv_s, b0);         // w = B_0 + sum_{r>=1} B_r v_r
         R00 = beta;
-        R01 = b0 - tau * wv;
+        R01 = fma(-tau, wv, b0);
     }
     // second column: b' = H1 b; |b'[1:]|^2 = |b|^2 - R01^2 (H1 orthogonal); R11 = -sign(b'_1) |b'[1:]|,
     // or b'_1 itself when the rest of the sub-column is zero
-    const double bp1 = b1 - tau * (a1 * inv_s) * wv;
-    const double nrm2 = fmax(sbb - R01 * R01, 0.0);
-    const double rest2 = nrm2 - bp1 * bp1;
+    const double bp1 = fma(-(tau * (a1 * inv_s)), wv, b1);
+    const double nrm2 = fmax(fma(-R01, R01, sbb), 0.0);
+    const double rest2 = fma(-bp1, bp1, nrm2);
     double R11 = bp1;
     if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(nrm2);
     Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;

@@ -13,6 +13,9 @@ __device__ __forceinline__ void motion_finish(double (&acc)[14], const double (&
                                               double* __restrict__ X, double* __restrict__ S, double* __restrict__ sigR, double* __restrict__ Cm,
                                               FrameScalars* __restrict__ fs, const RankArgs& ra, double* smem)
 {
+#pragma clang fp contract(off)
+    // (every fused multiply-add of this function and of motion_reduce_body is written out: they are compiled into several kernels — k_motion, k_project_motion,
+    //  k_project_table, k_pxy2, k_rank_expand — and must give the same bits in each)
     double (*part)[32] = (double (*)[32])smem;                 // [14][32]
     double* red = smem + 14 * 32;                              // [16]
     const int tid = threadIdx.x;
@@ -40,7 +43,7 @@ __device__ __forceinline__ void motion_finish(double (&acc)[14], const double (&
         // rs[e] = sum_c wc_c (sigma_c[e] - X[e]) with the covariance weights (wc0 for the centre): the constant
         // k_meas_final needs to re-centre the robot rows of Pxy on the mean h.
         //   sum_c wc_c sigma_c = mean + (wc0 - wm0) sigma_0,  sum_c wc_c = wc0 + 2 Na wi
-        sigR[(size_t)L * 8 + tid] = acc[tid] * (1.0 - (w.wc0 + 2.0 * Na * w.wi)) + (w.wc0 - w.wm0) * s0[tid];
+        sigR[(size_t)L * 8 + tid] = fma(acc[tid], 1.0 - (w.wc0 + 2.0 * Na * w.wi), (w.wc0 - w.wm0) * s0[tid]);
     }
     STAMP(4);
     double* g = acc + 4;
@@ -52,12 +55,12 @@ __device__ __forceinline__ void motion_finish(double (&acc)[14], const double (&
         for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) R[a][b] = 0.0;
         for (int a = 0; a < 4; a++) {
             double dsum = G4[a][a];
-            for (int k = 0; k < a; k++) dsum -= R[k][a] * R[k][a];
+            for (int k = 0; k < a; k++) dsum = fma(-R[k][a], R[k][a], dsum);
             const double raa = sqrt(fmax(dsum, 0.0));
             R[a][a] = raa;
             for (int b = a + 1; b < 4; b++) {
                 double v = G4[a][b];
-                for (int k = 0; k < a; k++) v -= R[k][a] * R[k][b];
+                for (int k = 0; k < a; k++) v = fma(-R[k][a], R[k][b], v);
                 R[a][b] = (raa > 0.0) ? v / raa : 0.0;
             }
         }
@@ -91,6 +94,7 @@ template <int NT, bool PREAMBLE = true>
 __device__ __forceinline__ void motion_reduce_body(const KDims& d, const KWeights& w, double* __restrict__ X, double* __restrict__ S,
                                                    double* __restrict__ sigR, double* __restrict__ Cm, FrameScalars* __restrict__ fs, const RankArgs& ra, double* smem)
 {
+#pragma clang fp contract(off)
     const int tid = threadIdx.x;
     const int n = d.n, Na = d.Na;
     if (fs->frozen) return;
@@ -123,7 +127,7 @@ __device__ __forceinline__ void motion_reduce_body(const KDims& d, const KWeight
         if (i + NT < Na) { rp = *reinterpret_cast<const double4*>(sigR + (size_t)(1 + i + NT) * 8); rm = *reinterpret_cast<const double4*>(sigR + (size_t)(1 + Na + i + NT) * 8); }
         double dm[4], dp[4];                                   // dev+ - dev-, dev+ + dev-
 #pragma unroll
-        for (int e = 0; e < 4; e++) { acc[e] += w.wi * r0[e]; acc[e] += w.wi * r1[e]; }
+        for (int e = 0; e < 4; e++) { acc[e] = fma(w.wi, r0[e], acc[e]); acc[e] = fma(w.wi, r1[e], acc[e]); }
         if (i < n - 4) {
 #pragma unroll
             for (int e = 0; e < 4; e++) { const double d0 = r0[e] - s0[e], d1 = r1[e] - s0[e]; dm[e] = k2 * (d0 - d1); dp[e] = k2 * (d0 + d1); }
@@ -132,7 +136,7 @@ __device__ __forceinline__ void motion_reduce_body(const KDims& d, const KWeight
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = a; b < 4; b++) acc[q++] += dp[a] * dp[b];
+                for (int b = a; b < 4; b++) { acc[q] = fma(dp[a], dp[b], acc[q]); q++; }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++) { dm[e] = w.wi_sr * (r0[e] - s0[e]); dp[e] = w.wi_sr * (r1[e] - s0[e]); }
@@ -140,7 +144,7 @@ __device__ __forceinline__ void motion_reduce_body(const KDims& d, const KWeight
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = a; b < 4; b++) acc[q++] += dm[a] * dm[b] + dp[a] * dp[b];
+                for (int b = a; b < 4; b++) { acc[q] += fma(dm[a], dm[b], dp[a] * dp[b]); q++; }
         }
     }
     __syncthreads();                                           // every wave has passed the frozen test at the top

@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
                                               FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra,
                                               const double* __restrict__ Cm, double* __restrict__ S,
-                                              const double* __restrict__ P1, int split_b0, const double* __restrict__ DZp, double sqeps)
+                                              const double* __restrict__ P1, int split_b0, const double* __restrict__ DZp, double sqeps,
+                                              const double* __restrict__ sigR, const double* __restrict__ Z0, int fmode)
 {
     __shared__ double red[4][64];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
@@ -502,8 +503,16 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                     p0 = sc * Ut[(size_t)(2 * k) * ld + r];
                     p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
                 } else {
-                    p0 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k];
-                    p1 = PxyR[(size_t)(r - (n - 4)) * mp + 2 * k + 1];
+                    const int e = r - (n - 4);
+                    p0 = PxyR[(size_t)e * mp + 2 * k];
+                    p1 = PxyR[(size_t)e * mp + 2 * k + 1];
+                    if (fmode) {
+                        // "fused tail" mode: the statistics left the sums around the centre point's robot part r_0 (srukf_meas.h, meas_final_tail); the frame's
+                        // motion reduction has run since: re-centre on the mean xr and on h
+                        const double dxs = fs->Xr1[e] - sigR[e], rse = sigR[(size_t)d.L * 8 + e];
+                        p0 = p0 - dxs * PxyR[(size_t)4 * mp + 2 * k] - (h[2 * k] - Z0[2 * k]) * rse;
+                        p1 = p1 - dxs * PxyR[(size_t)4 * mp + 2 * k + 1] - (h[2 * k + 1] - Z0[2 * k + 1]) * rse;
+                    }
                 }
                 u0 = p0 * lk[q][0] + p1 * lk[q][2];
                 u1 = p0 * lk[q][1] + p1 * lk[q][3];
@@ -703,10 +712,10 @@ int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
                        FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra, const double* Cm, double* S,
-                       const double* P1, int split_b0, const double* DZp, double sqeps)
+                       const double* P1, int split_b0, const double* DZp, double sqeps, const double* sigR, int fmode)
 {
     hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra, Cm, S,
-                       P1, split_b0, DZp, sqeps);
+                       P1, split_b0, DZp, sqeps, sigR, Z, fmode);
     if (w.wc0 != w.wm0)
         hipLaunchKernelGGL(k_gain_center, dim3(d.np / 256 + 1), dim3(256), 0, st, d, w, Ut, Z, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
 }

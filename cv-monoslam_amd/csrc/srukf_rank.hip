@@ -62,16 +62,25 @@ __global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* 
 // Sp: factor rows in permuted order (row a < r valid for columns b >= a), D: pivots in permuted order, perm[a] = state index at
 // permuted position a, iperm = inverse.  A (may be null): the shadow copy of the kept rows in permuted order.
 // TAIL: the instance whose frame-tail workgroup also runs the next frame's motion reduction ("tail" mode; 82 instead of 59 VGPRs: the default instance carries none of it)
-template <bool TAIL>
+// MODE 2 ("fused tail", the default of the exclusive rank-aware replay): every workgroup ALSO projects the next frame's sigma points of its direction
+// (passSigmaThroughMesaurementFunction, SLAM.cpp:1615-1690) — the row is in flight anyway, its robot part has just gone through the motion model, the
+// new mean is final — so that the next frame needs no projection launch: the row through LDS, one thread per landmark and +- pair (project_dir's
+// arithmetic, srukf_project_sigma).  Null rows: their own landmark; the frame tail: the centre point; five more workgroups: the noise rows.
+// The frame's motion reduction then rides on k_pxy2 (MeasArgs::fmode).  Dynamic LDS: ld doubles.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
                                                      const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
                                                      FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
                                                      double* __restrict__ A, double* __restrict__ sigR, double gamma,
-                                                     int tailmode, KDims d, KWeights w, double* __restrict__ Cm)
+                                                     int tailmode, KDims d, KWeights w, double* __restrict__ Cm,
+                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ)
 {
+    constexpr bool TAIL = MODE == 1, PROJ = MODE == 2;
+    extern __shared__ double lrow[];                           // PROJ: the workgroup's row of the factor (permuted order)
+    __shared__ double prow[2][8];                              // PROJ: robot part of the direction's two sigma points (what goes into the table)
     __shared__ double red[16 * 3];
     // the frame-tail workgroup comes first in dispatch order ("tail" mode: it carries the next frame's motion reduction, a one-workgroup chain)
-    const int j = !TAIL ? (int)blockIdx.x : (blockIdx.x == 0) ? n : ((int)blockIdx.x <= n ? (int)blockIdx.x - 1 : (int)blockIdx.x);
+    const int j = !TAIL ? (int)blockIdx.x : (blockIdx.x == 0) ? n : ((int)blockIdx.x <= n ? (int)blockIdx.x - 1 : (int)blockIdx.x);      // < n: row (permuted position), n: frame tail, > n: null checks (+ PROJ: noise rows)
     // "Table" mode of the replay (sigR != null): the workgroup that writes row j of S also pushes the NEXT frame's two sigma points
     // of direction j through the motion model — robot part only: pose before the step X[n-4..], the row's entries in the robot
     // columns, the control k_gain prepared in fs->ctl — and leaves them in the table the next k_project_table launch reads.
@@ -87,9 +96,42 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         else srukf_motion_point(mc, xr, srow, mnoise, sg ? -gamma : gamma, rr, c2, s2);
         double4* o = reinterpret_cast<double4*>(sigR + (size_t)(1 + sg * Na + i) * 8);
         o[0] = make_double4(rr[0], rr[1], rr[2], rr[3]); o[1] = make_double4(c2, s2, 0.0, 0.0);
+        if constexpr (PROJ) { double* q = prow[sg]; q[0] = rr[0]; q[1] = rr[1]; q[2] = rr[2]; q[3] = rr[3]; q[4] = c2; q[5] = s2; }
     };
+    // PROJ: landmark k under direction i (dev = the direction's six entries for that landmark, e0 / e1 = pixel-noise rows): both points, Z rows, DZ row
+    const double f1 = PROJ ? p.cam_f / p.cam_dx : 0.0, f2 = PROJ ? p.cam_f / p.cam_dy : 0.0;
+    auto project_pair = [&](const int i, const int k, const double (&dev)[6], const double e0, const double e1, const double* r0, const double* r1, const int dzrow) {
+        double base[6];
+#pragma unroll
+        for (int e = 0; e < 6; e++) base[e] = X[6 * k + e];
+        double zp[2], zm[2];
+        srukf_project_sigma(p, f1, f2, base, dev, e0, e1, gamma, r0, zp[0], zp[1]);
+        srukf_project_sigma(p, f1, f2, base, dev, e0, e1, -gamma, r1, zm[0], zm[1]);
+        *reinterpret_cast<double2*>(Z + (size_t)(1 + i) * d.mp + 2 * k) = make_double2(zp[0], zp[1]);
+        *reinterpret_cast<double2*>(Z + (size_t)(1 + Na + i) * d.mp + 2 * k) = make_double2(zm[0], zm[1]);
+        if (dzrow >= 0) *reinterpret_cast<double2*>(DZ + (size_t)dzrow * d.mp + 2 * k) = make_double2(zp[0] - zm[0], zp[1] - zm[1]);
+    };
+    if constexpr (PROJ) {
+        // five extra workgroups behind the null checks: the noise rows (directions n .. n+4) for every landmark
+        const int nchk = (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
+        if (j > n + nchk) {
+            if (!table) return;
+            const int q = j - n - nchk - 1;
+            if (threadIdx.x < 2) {
+                const double zero4[4] = { 0, 0, 0, 0 };
+                double mnoise[3] = { 0, 0, 0 };
+                if (q < 3) mnoise[q] = fs->ctl[5 + q];
+                table_rows(n + q, threadIdx.x, zero4, mnoise, false);
+            }
+            __syncthreads();
+            const double zero6[6] = { 0, 0, 0, 0, 0, 0 };
+            const double e0 = (q == 3) ? p.sigma_measure : 0.0, e1 = (q == 4) ? p.sigma_measure : 0.0;
+            for (int k = threadIdx.x; k < d.N; k += 256) project_pair(n + q, k, zero6, e0, e1, prow[0], prow[1], -1);
+            return;
+        }
+    }
     if (j == n) {
-        if (table && threadIdx.x < 11) {
+        if (table && threadIdx.x < (PROJ ? 1 : 11)) {
             const double zero4[4] = { 0, 0, 0, 0 };
             if (threadIdx.x == 0) {
                 const MotionCtl mc = { fs->ctl[0], fs->ctl[1], fs->ctl[2], fs->ctl[3], fs->ctl[4] };
@@ -98,11 +140,27 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                 srukf_motion_centre(mc, xr, s0, c0s, s0s);
                 double4* o = reinterpret_cast<double4*>(sigR);
                 o[0] = make_double4(s0[0], s0[1], s0[2], s0[3]); o[1] = make_double4(c0s, s0s, 0.0, 0.0);
+                if constexpr (PROJ) { double* q = prow[0]; q[0] = s0[0]; q[1] = s0[1]; q[2] = s0[2]; q[3] = s0[3]; q[4] = c0s; q[5] = s0s; }
             } else {
                 const int q = (threadIdx.x - 1) >> 1, sg = (threadIdx.x - 1) & 1;       // noise row n + q (control noise: q < 3)
                 double mnoise[3] = { 0, 0, 0 };
                 if (q < 3) mnoise[q] = fs->ctl[5 + q];
                 table_rows(n + q, sg, zero4, mnoise, false);
+            }
+        }
+        if constexpr (PROJ) {
+            // the centre point of the next frame for every landmark (row 0 of Z)
+            __syncthreads();
+            if (table) {
+                const double f1c = p.cam_f / p.cam_dx, f2c = p.cam_f / p.cam_dy;
+                for (int k = threadIdx.x; k < d.N; k += 256) {
+                    double base[6];
+#pragma unroll
+                    for (int e = 0; e < 6; e++) base[e] = X[6 * k + e];
+                    double ox, oy;
+                    srukf_project(p, f1c, f2c, base, prow[0][0], prow[0][1], prow[0][2], prow[0][4], prow[0][5], 0.0, 0.0, ox, oy);
+                    *reinterpret_cast<double2*>(Z + 2 * k) = make_double2(ox, oy);
+                }
             }
         }
         // frame tail: RobotPath.txt row (SLAM.cpp:3549-3556) with P = S^T S restricted to the robot x / y block (2404): the
@@ -164,6 +222,19 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         table_rows(jj, threadIdx.x, srow, zero3, a >= r);
     }
     if (a >= r) {                                              // dropped direction: what the reference's clamp leaves
+        if constexpr (PROJ) {
+            // its two sigma points move ONE landmark (NullSkip, srukf_device.h): jj / 6, by sqrt(EPSILON) gamma in one anchor coordinate
+            if (table) {
+                __syncthreads();                               // prow: the centre point's robot part (table_rows above, isnull)
+                if (threadIdx.x == 0) {
+                    const int k = jj / 6;
+                    double dev[6];
+#pragma unroll
+                    for (int e = 0; e < 6; e++) dev[e] = (6 * k + e == jj) ? sqrt(eps) : 0.0;
+                    project_pair(jj, k, dev, 0.0, 0.0, prow[0], prow[1], a);
+                }
+            }
+        }
         // the same row every frame: written by the first frame of a staged run only (fs->const_rows_ok: set for the frames after it
         // by the next launch, cleared by k_set_run / k_set_frame; whoever else rewrites S goes through one of those first)
         if (sigR && fs->const_rows_ok) return;
@@ -191,6 +262,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
             if (b >= ld) break;
             const bool upper = b >= a && b < n && cc[u] >= jj;
             if (sh) sh[b] = sv[u];
+            if constexpr (PROJ) lrow[b] = sv[u];
             if (upper && cc[u] > jj) mx = fmax(mx, fabs(sv[u]));
             if (upper || !sigR) out[cc[u]] = upper ? sv[u] : 0.0;
         }
@@ -208,6 +280,17 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         const double dj = D[a];
         const double th = mx * sqrt(dj);
         if (th * th / beta2 > dj) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, jj); }
+    }
+    if constexpr (PROJ) {
+        // the next frame's sigma points of direction jj for every landmark (the barrier above: lrow and prow are complete)
+        if (table) {
+            for (int k = threadIdx.x; k < d.N; k += 256) {
+                double dev[6];
+#pragma unroll
+                for (int e = 0; e < 6; e++) { const int col = 6 * k + e; dev[e] = (col >= jj) ? lrow[iperm[col]] : 0.0; }
+                project_pair(jj, k, dev, 0.0, 0.0, prow[0], prow[1], a);
+            }
+        }
     }
 }
 
@@ -233,11 +316,14 @@ void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, cons
 }
 void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
                               const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A, double* sigR, double gamma,
-                              int tailmode, KDims d, KWeights w, double* Cm)
+                              int tailmode, KDims d, KWeights w, double* Cm, srukf_params p, double* Z, double* DZ)
 {
-    const dim3 grid(n + 1 + (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS);
-    if (tailmode) hipLaunchKernelGGL(k_rank_expand<true>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm);
-    else hipLaunchKernelGGL(k_rank_expand<false>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm);
+    // tailmode 1: "tail" mode (motion reduction in the frame tail); 2: "fused tail" mode (projection of the next frame, five more workgroups, the row in LDS)
+    const int nchk = (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
+    const dim3 grid(n + 1 + nchk + (tailmode == 2 ? 5 : 0));
+    if (tailmode == 2) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, 0, d, w, Cm, p, Z, DZ);
+    else if (tailmode) hipLaunchKernelGGL(k_rank_expand<1>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ);
+    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ);
 }
 void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
 {
