@@ -226,12 +226,16 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
             // its two sigma points move ONE landmark (NullSkip, srukf_device.h): jj / 6, by sqrt(EPSILON) gamma in one anchor coordinate
             if (table) {
                 __syncthreads();                               // prow: the centre point's robot part (table_rows above, isnull)
-                if (threadIdx.x == 0) {
-                    const int k = jj / 6;
-                    double dev[6];
+                if (threadIdx.x < 2) {                         // one lane per sign (the pair in one lane is twice the latency, and 597 workgroups do nothing else)
+                    const int k = jj / 6, sg = threadIdx.x;
+                    double dev[6], base[6];
 #pragma unroll
-                    for (int e = 0; e < 6; e++) dev[e] = (6 * k + e == jj) ? sqrt(eps) : 0.0;
-                    project_pair(jj, k, dev, 0.0, 0.0, prow[0], prow[1], a);
+                    for (int e = 0; e < 6; e++) { dev[e] = (6 * k + e == jj) ? sqrt(eps) : 0.0; base[e] = X[6 * k + e]; }
+                    double ox, oy;
+                    srukf_project_sigma(p, f1, f2, base, dev, 0.0, 0.0, sg ? -gamma : gamma, prow[sg], ox, oy);
+                    *reinterpret_cast<double2*>(Z + (size_t)(1 + sg * Na + jj) * d.mp + 2 * k) = make_double2(ox, oy);
+                    const double pox = __shfl_xor(ox, 1), poy = __shfl_xor(oy, 1);
+                    if (sg == 0) *reinterpret_cast<double2*>(DZ + (size_t)a * d.mp + 2 * k) = make_double2(ox - pox, oy - poy);
                 }
             }
         }
