@@ -323,11 +323,14 @@ def test_rank_aware_follows_map_changes(srukf, oracle, synth):
     np.testing.assert_allclose(S4.T @ S4, So4.T @ So4, atol=1e-9)
 
 
-def test_three_filters_share_the_gpu(srukf, synth):
+@pytest.mark.parametrize("N", [100, 200])
+def test_three_filters_share_the_gpu(srukf, synth, N):
     """Three filters replaying concurrently in GPU_SHARED mode (persistent launches of half the CUs, at most two admitted at a
-    time by k_gmw_gate): every one reproduces, bit for bit, what it computes alone with the GPU to itself, and nothing is flagged."""
+    time by k_gmw_gate): every one reproduces, bit for bit, what it computes alone with the GPU to itself, and nothing is flagged.
+    N = 200 is the size bench.py's multi_sequence leg runs (there the exclusive filter uses the head fold and the XCD-aware tile
+    order, the shared ones k_syrk's head tiles and seven workers with two tiles: the same arithmetic)."""
     p = synth.scene_params()
-    N, F, B = 100, 24, 3
+    F, B = 24, 3
     scs = [synth.make_scene(N, F, seed=0, p=p, obs_seed=7000 + b) for b in range(B)]
     alone = []
     for sc in scs:
