@@ -44,7 +44,7 @@ void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, dou
 void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*, const TailArgs*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, double*, srukf_params, double*, double*);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, double*, srukf_params, double*, double*, int);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
@@ -338,6 +338,8 @@ struct srukf_ctx {
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
     int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
                                            // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
+    int dbg_f32_fuse = 1;                  // srukf_debug_set "f32_fuse": fp32 storage also runs in "fused tail" mode (rounding inside k_rank_expand<2> and the state update)
+    int dbg_table_perm = 1;                // srukf_debug_set "table_perm": "table" / "fused tail" mode also where the owners do not fold (k_syrk over the kept rows: N >= 300); 0: k_project_motion + k_pxy there
     int dbg_tail_fuse = 1;                 // srukf_debug_set "tail_fuse": k_rank_expand also projects the next frame ("fused tail" mode); 0: k_project_table in front of every frame
     int dbg_tail_fold = 0;                 // srukf_debug_set "tail_fold" 1: the helpers of the persistent launch also project the NEXT frame's sigma points (srukf_tail.h: built,
                                            // bit-identical, NOT faster — the jobs cost the pivot chain what the projection launch cost); 0 (default): k_project_table
@@ -470,10 +472,10 @@ static void quantize_state(srukf_ctx* c)
         hipLaunchKernelGGL(k_quantize, dim3(c->d.n + 1), dim3(256), 0, c->stream, c->d.n, c->d.np, c->S, c->X, c->S32, c->X32);
 }
 // rank-aware replay form: what k_motion / k_gain / k_syrk carry along (all null when the shadow copy does not exist)
-static RankArgs rank_args(const srukf_ctx* c, bool prep_next = false, bool dzperm = false)
+static RankArgs rank_args(const srukf_ctx* c, bool prep_next = false, bool dzperm = false, bool f32round = false)
 {
     RankArgs ra = {};
-    ra.prep_next = prep_next ? 1 : 0; ra.dzperm = dzperm ? 1 : 0;
+    ra.prep_next = prep_next ? 1 : 0; ra.dzperm = dzperm ? 1 : 0; ra.f32round = f32round ? 1 : 0;
     if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.perm = c->red_perm; ra.r = c->red_r; }
     return ra;
 }
@@ -548,10 +550,12 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
 static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool tail = false, bool fuse = false)
 {
     const int n = c->d.n, np = c->d.np;
-    const bool f32 = c->storage == SRUKF_STORAGE_F32;
+    const bool f32s = c->storage == SRUKF_STORAGE_F32;
+    const bool f32fuse = f32s && fuse && table && frame_tail;      // fp32 storage in "fused tail" mode: the launch rounds what it writes (no k_quantize / k_rank_round / k_traj behind it)
+    const bool f32 = f32s && !f32fuse;
     const bool tt = table && frame_tail && !f32;
     srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
-                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 2 : (tt && tail) ? 1 : 0, c->d, c->w, c->Cmat, c->p, c->Z, c->DZ);
+                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 2 : (tt && tail) ? 1 : 0, c->d, c->w, c->Cmat, c->p, c->Z, c->DZ, f32fuse ? 1 : 0);
     if (f32) {
         quantize_state(c);
         srukf_launch_rank_round(c->stream, np, c->red_r, c->shadowA);
@@ -567,9 +571,17 @@ static bool replay_red_fused(const srukf_ctx* c)
 }
 // 0: k_motion + k_project; 1: k_project_motion (motion workgroup + projection with the robot part inline); 2: "table" (k_project_table: the
 // previous frame's tail prepared the robot part of every sigma point) — only where the tail is k_rank_expand on fp64 storage
+// ... or forms them with k_syrk over the kept rows, still in permuted order (memory tiles, two tiles per worker, one launch per panel: seq_refactor's second branch)
+static bool replay_red_perm(const srukf_ctx* c)
+{
+    return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && rank_fused_mode() && c->dbg_table_perm;
+}
 static int replay_motion_mode(const srukf_ctx* c)
 {
-    if (c->dbg_fused_motion == 2 && !(replay_red_fused(c) && c->storage == SRUKF_STORAGE_F64)) return 1;
+    // fp32 storage: only as "fused tail" mode (k_rank_expand<2> and the state update round what they write; "table" mode alone has no such form)
+    const bool st_ok = c->storage == SRUKF_STORAGE_F64 ||
+                       (c->storage == SRUKF_STORAGE_F32 && c->dbg_f32_fuse && c->dbg_tail_fuse && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && !c->dbg_tail_fold);
+    if (c->dbg_fused_motion == 2 && !((replay_red_fused(c) || replay_red_perm(c)) && st_ok)) return 1;
     return c->dbg_fused_motion;
 }
 // "tail" mode on top of "table" mode: the helper workgroups of the persistent launch (head fold) stay and project the NEXT frame's sigma points
@@ -615,7 +627,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         if (!head_fold) {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
             ProfScope ps(c, KC_SYRK, head_flop, head_byte);
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table), take_xr1(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -626,7 +638,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             if (head_fold) {
                 ha.tiles = (const int2*)c->syrk_head_tiles; ha.ntiles = c->n_syrk_head_tiles; ha.ncrit = c->n_syrk_head_crit;
                 ha.dxp = c->dx_pending ? c->dxp : nullptr; ha.X = c->X; ha.xr1 = take_xr1(c); ha.ndx = c->dx_pending ? (n + 255) / 256 : 0;
-                ha.ra = rank_args(c, table); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
+                ha.ra = rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
                 // helper workgroups: one per CU the pivot and the workers leave free (they share a job queue), never more than there are jobs
                 // (tail fold: they share a job queue; otherwise one workgroup per job)
                 const int nhead = ha.ntiles + ha.ndx + ha.ngd;
@@ -648,7 +660,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         const double rr = c->red_r, rp = 64.0 * c->red_Tp;
         {
             ProfScope ps(c, KC_SYRK, rr * rr * rr / 3.0 + rr * rr * (n - rr) + 2.0 * d.mp * (rr * n - rr * rr / 2.0) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * (rr * n + (double)d.mp * n + rp * n));
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c), take_xr1(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -656,7 +668,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
         ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
-        rank_expand(c, frame_tail);
+        rank_expand(c, frame_tail, table, false, fuse);
         return;
     }
     const bool fused = !reduced && !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
@@ -817,7 +829,9 @@ static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool f
     {
         ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
         srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
-                          fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ, sqrt(c->p.epsilon), c->sigR, fmode ? 1 : 0);
+                          fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ,
+                          (fmode && c->storage == SRUKF_STORAGE_F32) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon),   // (the null rows of S as they are stored)
+                          c->sigR, fmode ? 1 : 0);
         c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
     }
 }
@@ -1793,6 +1807,8 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     } else {
         for (int f = 0; f < count; f++) replay_one_frame(c);
     }
+    // fp32 storage in "fused tail" mode: S and X are rounded as they are written; the float copies (srukf_get_state_f32) once per run
+    if (c->storage == SRUKF_STORAGE_F32 && replay_fuse_mode(c)) quantize_state(c);
     c->async_pending = true;
     c->phase = 0;
     HIPCHK(c, hipGetLastError());
@@ -2001,6 +2017,8 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "head_fold")) c->dbg_head_fold = value ? 1 : 0;
     else if (!strcmp(key, "tail_cap")) c->dbg_tail_cap = value < 0 ? 0 : value;
     else if (!strcmp(key, "tail_fuse")) c->dbg_tail_fuse = value ? 1 : 0;
+    else if (!strcmp(key, "table_perm")) c->dbg_table_perm = value ? 1 : 0;
+    else if (!strcmp(key, "f32_fuse")) c->dbg_f32_fuse = value ? 1 : 0;
     else if (!strcmp(key, "tail_fold")) {
         c->dbg_tail_fold = value < 0 ? 0 : value > 31 ? 31 : value;    // > 1: timing only (2: no projection jobs; + 4 / + 8: pivot / worker rows with plain stores): the NEXT frame is garbage
         if (c->d_tail) { const int on = c->dbg_tail_fold ? c->dbg_tail_fold : 1; HIPCHK(c, hipMemcpy((char*)c->d_tail + offsetof(TailArgs, on), &on, sizeof on, hipMemcpyHostToDevice)); }

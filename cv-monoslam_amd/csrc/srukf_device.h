@@ -241,8 +241,9 @@ __device__ __forceinline__ void srukf_project_sigma(const srukf_params& p, doubl
 // xr1 (replay path, may be null): the robot mean after the motion step, which k_project_motion left beside X because the
 // projection threads of its launch were still reading the mean before it
 // DEV: the new state is read by other workgroups of the SAME launch (tail jobs of the persistent factorisation): agent-scope store
+// f32: fp32 storage, "fused tail" mode: the new state is rounded to float here (what k_quantize does after the refactorisation in the other modes)
 template <bool DEV = false>
-__device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job, const double* xr1 = nullptr)
+__device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job, const double* xr1 = nullptr, int f32 = 0)
 {
     const int r = job * 256 + threadIdx.x;
     if (r >= n) return;
@@ -250,7 +251,9 @@ __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* _
 #pragma unroll
     for (int u = 0; u < GAIN_SLICES; u++) acc += dxp[(size_t)u * np + r];
     const double x = (xr1 && r >= n - 4) ? xr1[r - (n - 4)] : X[r];
-    if constexpr (DEV) __hip_atomic_store(&X[r], x + acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else X[r] = x + acc;
+    double v = x + acc;
+    if (f32) v = (double)(float)v;
+    if constexpr (DEV) __hip_atomic_store(&X[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else X[r] = v;
 }
 
 // measurement-statistics work attached to a k_pxy launch (replay path): Z == null -> none

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
     if ((int)blockIdx.x >= ntiles + ndx) { srukf_rank_gdiag_job(d.n, d.np, ue, ra, &fs->gmax_bits, blockIdx.x - ntiles - ndx); return; }
     if ((int)blockIdx.x >= ntiles) {
         if (ra.prep_next && (int)blockIdx.x == ntiles && threadIdx.x == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
-        srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles, xr1);
+        srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles, xr1, ra.f32round);
         return;
     }
     __shared__ double red[3][64][17];

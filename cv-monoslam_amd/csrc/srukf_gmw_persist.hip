@@ -621,11 +621,11 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
                 const int dj = job - ha.ntiles;
                 if (ha.ra.prep_next && dj == 0 && tid == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
                 if (TAIL && tail) {
-                    srukf_gain_dx_job<true>(n, ld, ha.dxp, ha.X, dj, ha.xr1);
+                    srukf_gain_dx_job<true>(n, ld, ha.dxp, ha.X, dj, ha.xr1, ha.ra.f32round);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(&sy->dx_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                } else srukf_gain_dx_job(n, ld, ha.dxp, ha.X, dj, ha.xr1);
+                } else srukf_gain_dx_job(n, ld, ha.dxp, ha.X, dj, ha.xr1, ha.ra.f32round);
             } else if (job < nhead) srukf_rank_gdiag_job(n, ld, u1, ha.ra, &fs->gmax_bits, job - ha.ntiles - ha.ndx);
             else if constexpr (TAIL) {
                 good = tail_job(tla, job - nhead, Sout, ld, T, sy, fs, (unsigned)ha.ndx, xreg, &Wc[0][0], &Lr[0][0], &ok, ts, tid);

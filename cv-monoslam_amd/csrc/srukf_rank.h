@@ -11,6 +11,8 @@ struct RankArgs {
     const int* perm;       // permuted position -> state index
     int r;                 // kept pivots (robot last: positions r-4 .. r-1)
     int dzperm;            // "table" mode: k_project_table writes the rows of DZ in permuted order (k_pxy2 contracts over them)
+    int f32round;          // fp32 storage in "fused tail" mode: the state update rounds X to float as it writes it (k_rank_expand<2> rounds the rows of S it writes:
+                           // the rounding points of k_quantize, without its launch)
     int prep_next;         // "table" mode of the replay: the k_syrk launch also prepares the NEXT frame's control in fs->ctl (this frame's motion
                            // step has consumed it; the tail that needs it must not read the frame counter it advances itself)
 };

@@ -73,9 +73,12 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                                                      FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
                                                      double* __restrict__ A, double* __restrict__ sigR, double gamma,
                                                      int tailmode, KDims d, KWeights w, double* __restrict__ Cm,
-                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ)
+                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32)
 {
     constexpr bool TAIL = MODE == 1, PROJ = MODE == 2;
+    // f32 (fp32 storage, "fused tail" mode): every value this launch writes into S / the permuted copy — and reads back for the table, the projection and
+    // the trajectory row — is rounded to float first: the rounding points of k_quantize / k_rank_round, without their launches
+    auto rnd = [&](double v) { return f32 ? (double)(float)v : v; };
     extern __shared__ double lrow[];                           // PROJ: the workgroup's row of the factor (permuted order)
     __shared__ double prow[2][8];                              // PROJ: robot part of the direction's two sigma points (what goes into the table)
     __shared__ double red[16 * 3];
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         const int bx = iperm[n - 4], by = iperm[n - 3];
         double v[3] = { 0, 0, 0 };
         for (int a = threadIdx.x; a < r; a += 256) {
-            const double p = (bx >= a) ? Sp[(size_t)a * ld + bx] : 0.0, q = (by >= a) ? Sp[(size_t)a * ld + by] : 0.0;
+            const double p = (bx >= a) ? rnd(Sp[(size_t)a * ld + bx]) : 0.0, q = (by >= a) ? rnd(Sp[(size_t)a * ld + by]) : 0.0;
             v[0] += p * p; v[1] += p * q; v[2] += q * q;
         }
         block_sum<3>(v, red);
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         const double zero3[3] = { 0, 0, 0 };
         if (a < r) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) srow[e] = (r - 4 + e >= a) ? Sp[(size_t)a * ld + (r - 4 + e)] : 0.0;    // the robot columns: permuted positions r-4 .. r-1
+            for (int e = 0; e < 4; e++) srow[e] = (r - 4 + e >= a) ? rnd(Sp[(size_t)a * ld + (r - 4 + e)]) : 0.0;    // the robot columns: permuted positions r-4 .. r-1
         }
         table_rows(jj, threadIdx.x, srow, zero3, a >= r);
     }
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                     const int k = jj / 6, sg = threadIdx.x;
                     double dev[6], base[6];
 #pragma unroll
-                    for (int e = 0; e < 6; e++) { dev[e] = (6 * k + e == jj) ? sqrt(eps) : 0.0; base[e] = X[6 * k + e]; }
+                    for (int e = 0; e < 6; e++) { dev[e] = (6 * k + e == jj) ? rnd(sqrt(eps)) : 0.0; base[e] = X[6 * k + e]; }
                     double ox, oy;
                     srukf_project_sigma(p, f1, f2, base, dev, 0.0, 0.0, sg ? -gamma : gamma, prow[sg], ox, oy);
                     *reinterpret_cast<double2*>(Z + (size_t)(1 + sg * Na + jj) * d.mp + 2 * k) = make_double2(ox, oy);
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
         // the same row every frame: written by the first frame of a staged run only (fs->const_rows_ok: set for the frames after it
         // by the next launch, cleared by k_set_run / k_set_frame; whoever else rewrites S goes through one of those first)
         if (sigR && fs->const_rows_ok) return;
-        for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == jj) ? sqrt(eps) : 0.0;
+        for (int c = threadIdx.x; c < ld; c += 256) out[c] = (c == jj) ? rnd(sqrt(eps)) : 0.0;
         return;
     }
     const double* src = Sp + (size_t)a * ld;
@@ -265,10 +268,11 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
             const int b = b0 + 256 * u;
             if (b >= ld) break;
             const bool upper = b >= a && b < n && cc[u] >= jj;
-            if (sh) sh[b] = sv[u];
-            if constexpr (PROJ) lrow[b] = sv[u];
-            if (upper && cc[u] > jj) mx = fmax(mx, fabs(sv[u]));
-            if (upper || !sigR) out[cc[u]] = upper ? sv[u] : 0.0;
+            if (upper && cc[u] > jj) mx = fmax(mx, fabs(sv[u]));          // (the theta check looks at the factor itself)
+            const double rv = rnd(sv[u]);
+            if (sh) sh[b] = rv;
+            if constexpr (PROJ) lrow[b] = rv;
+            if (upper || !sigR) out[cc[u]] = upper ? rv : 0.0;
         }
     }
     // theta clamp of the reference evaluated afterwards, as k_gmw_check does (SLAM.cpp:2204-2211, 2264-2285)
@@ -320,14 +324,14 @@ void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, cons
 }
 void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
                               const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A, double* sigR, double gamma,
-                              int tailmode, KDims d, KWeights w, double* Cm, srukf_params p, double* Z, double* DZ)
+                              int tailmode, KDims d, KWeights w, double* Cm, srukf_params p, double* Z, double* DZ, int f32)
 {
     // tailmode 1: "tail" mode (motion reduction in the frame tail); 2: "fused tail" mode (projection of the next frame, five more workgroups, the row in LDS)
     const int nchk = (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
     const dim3 grid(n + 1 + nchk + (tailmode == 2 ? 5 : 0));
-    if (tailmode == 2) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, 0, d, w, Cm, p, Z, DZ);
-    else if (tailmode) hipLaunchKernelGGL(k_rank_expand<1>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ);
-    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ);
+    if (tailmode == 2) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, 0, d, w, Cm, p, Z, DZ, f32);
+    else if (tailmode) hipLaunchKernelGGL(k_rank_expand<1>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ, 0);
+    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ, 0);
 }
 void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
 {

@@ -167,3 +167,32 @@ def test_fused_tail_agrees_with_table_mode(srukf, synth):
     t = srukf.Filter(N, p); t.debug_set("tail_fuse", 0); t.set_state(Xg, Sg); t.stage_sequence(sc["odo"], sc["z"], sc["matched"]); t.run_frames(1, 1)
     Zt, DZt = t.debug_copy("Z", L * mp), t.debug_copy("DZ", npad * mp)
     assert np.array_equal(Zf, Zt) and np.array_equal(DZf, DZt)
+
+
+@pytest.mark.parametrize("N,storage", [(100, "f64"), (300, "f64"), (200, "f32"), (500, "f32")])
+def test_fused_tail_on_the_other_paths(srukf, synth, N, storage):
+    """ "Fused tail" mode away from the headline configuration: where the owners do not fold (k_syrk over the kept rows: N = 100, 300, 500 — srukf_debug_set
+    "table_perm") and with fp32 storage of the state (configs[4]: N = 500; the tail and the state update round what they write — "f32_fuse" — instead of
+    k_quantize / k_rank_round / k_traj launches behind the tail).  Against the launch sequence of round 2 for those cases (k_project_motion, k_pxy, ...):
+    the same rounding points, agreement at fp64 rounding level, and with fp32 storage the stored state is float-representable."""
+    p = synth.scene_params()
+    F = 8
+    sc = synth.make_scene(N, F, seed=12, p=p)
+    res = []
+    for on in (1, 0):
+        f = srukf.Filter(N, p)
+        if storage == "f32": f.set_storage(srukf.STORAGE_F32); f.debug_set("f32_fuse", on)
+        else: f.debug_set("table_perm", on)
+        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        traj = np.vstack([f.run_frames(0, 3), f.run_frames(3, F - 3)])
+        X, S = f.get_state()
+        assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0
+        if storage == "f32":
+            X32, S32 = f.get_state_f32()
+            assert np.array_equal(X, X32.astype(np.float64)) and np.array_equal(np.triu(S), np.triu(S32).astype(np.float64)) and np.all(np.tril(S, -1) == 0.0)
+        res.append((traj, X, S.T @ S))
+    np.testing.assert_allclose(res[0][0][:, :4], res[1][0][:, :4], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(res[0][0][:, 4:], res[1][0][:, 4:], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=2e-10)
+    # (fp32 storage: an fp64 value that sits on a float rounding boundary may round the other way — one float ulp of one entry of S, seen in two of 1.4 million entries of P)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=2e-11 if storage == "f64" else 2e-9)
