@@ -109,14 +109,19 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
         motion_reduce_body<256, false>(d, w, const_cast<double*>(ms.X), nullptr, const_cast<double*>(ms.sigR), ms.Cm, ms.fs, ra0, shm);
         return;
     }
-    if ((int)blockIdx.x < nmot + nstat) {
+    // order of the grid: motion job, statistics jobs, tiles (PXY2_STATS_LAST = 1: the statistics behind the tiles)
+#ifndef PXY2_STATS_LAST
+#define PXY2_STATS_LAST 0                              // measured both ways: 5 207 / 5 207 frames/s at N = 200, 1 024 (last) / 1 033 (first) at N = 500
+#endif
+    const int stat0 = PXY2_STATS_LAST ? nmot + ntiles : nmot, tile0 = PXY2_STATS_LAST ? nmot : nmot + nstat;
+    if ((int)blockIdx.x >= stat0 && (int)blockIdx.x < stat0 + nstat) {
         if ((skip & 1) || threadIdx.x >= 256) return;          // (skip: measurement runs of one half of the launch alone, srukf_debug_set "pxy2_skip")
-        const int job = (int)blockIdx.x - nmot;                // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
+        const int job = (int)blockIdx.x - stat0;               // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
         meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm, ms.ns);
         meas_job_done(d, w, ms, job % ms.gx, shm);
         return;
     }
-    const int4 tl = tiles[blockIdx.x - nstat - nmot];
+    const int4 tl = tiles[blockIdx.x - tile0];
     if (tl.x < 0 || (skip & 2)) return;                        // empty slot of the XCD-aware list
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int m0 = 64 * tl.x, b0 = 64 * tl.y;
@@ -651,7 +656,9 @@ void srukf_launch_pxy2(hipStream_t st, KDims d, const double* DZp, const double*
 // pair: 0.16-0.33 MB) go to ONE XCD, pairs are dealt to the XCDs longest first onto the least loaded one, and each XCD walks its
 // pairs longest first.  (In plain bt-major order every slab of A was fetched by seven XCDs: 72 MB from the Infinity Cache per launch.)
 // Returns the number of slots; out may be null.
+#ifndef PXY2_SPLIT
 #define PXY2_SPLIT 16
+#endif
 int srukf_pxy2_build_tiles(int mp, int np, int kr, int* out)
 {
     const int ngmax = ((kr + 63) / 64) * 4, nmt = mp / 64;

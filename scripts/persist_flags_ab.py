@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "cv-monoslam_amd", "csrc")
 out = os.path.join(ROOT, "gpurun_out", "flagobj"); os.makedirs(out, exist_ok=True)
 base = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -w".split()
+SRC = os.environ.get("AB_SRC", "srukf_gmw_persist")
 variants = {
     "default": [],
     "max-ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
@@ -13,7 +14,10 @@ variants = {
     "bias100": ["-mllvm", "-amdgpu-schedule-metric-bias=100"],
     "bias0": ["-mllvm", "-amdgpu-schedule-metric-bias=0"],
 }
-others = [f"{csrc}/{s}.o" for s in ("srukf_api", "srukf_predict", "srukf_factor", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank")]
+others = [f"{csrc}/{s}.o" for s in ("srukf_api", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank") if s != SRC]
+if os.environ.get("AB_DEFS"):
+    variants = {"default": []}
+    for dv in os.environ["AB_DEFS"].split(";"): variants[dv] = ["-D" + x for x in dv.split(",")]
 child = r'''
 import sys, time
 sys.path.insert(0, ".")
@@ -37,7 +41,7 @@ for N, st in ((200, 0), (500, 1)):
 '''
 for name, fl in variants.items():
     obj = f"{out}/persist_{name}.o"; lib = f"{out}/libsrukf_{name}.so"
-    r = subprocess.run(["/opt/rocm/bin/hipcc"] + base + fl + ["-c", f"{csrc}/srukf_gmw_persist.hip", "-o", obj], capture_output=True, text=True)
+    r = subprocess.run(["/opt/rocm/bin/hipcc"] + base + fl + ["-c", f"{csrc}/{SRC}.hip", "-o", obj], capture_output=True, text=True)
     if r.returncode: print(name, "does not compile:", r.stderr.strip().splitlines()[-1] if r.stderr else ""); continue
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + others)
     print(name, flush=True)
