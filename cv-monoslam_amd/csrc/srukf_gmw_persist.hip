@@ -577,7 +577,8 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
     // (Letting the critical head tiles go first — every other role sleeping 1 .. 5 us before its first operand loads — was measured: 195.5 us per
     //  frame without, 196.8 / 197.2 / 198.6 / 199.0 / 203.8 with 0.9 / 1.7 / 2.6 / 3.4 / 5.1 us: every chain of the launch is critical.  Only the
-    //  non-critical HELPERS sleeping: 195.5 / 195.4 / 197.3 / 200.5 us with 0.9 / 1.7 / 2.6 / 4.3 us — nothing to gain either.)
+    //  non-critical HELPERS sleeping: 195.5 / 195.4 / 197.3 / 200.5 us with 0.9 / 1.7 / 2.6 / 4.3 us — nothing to gain either.  Nor from dispatching the critical
+    //  helpers right behind the pivot, in front of the workers: 5 201 frames/s without, 5 195 / 5 197 / 5 177 with the first 8 / 16 / 32 helper jobs there.)
     const bool tail = TAIL && tap != nullptr && fs->odo_seq && fs->frame + 1 < fs->seqF;   // (there is a next staged frame)                       // tail fold: the args live in device memory (a by-value copy costs every role ~200 SGPR spills)
     // (measurement only, srukf_debug_set "tail_fold" with bits 4 / 8: the pivot's / the workers' rows with plain stores and no counting)
     const int tail_on = (TAIL && tail) ? tap->on : 0;
