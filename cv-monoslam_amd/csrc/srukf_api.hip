@@ -580,7 +580,8 @@ static int replay_motion_mode(const srukf_ctx* c)
 {
     // fp32 storage: only as "fused tail" mode (k_rank_expand<2> and the state update round what they write; "table" mode alone has no such form)
     const bool st_ok = c->storage == SRUKF_STORAGE_F64 ||
-                       (c->storage == SRUKF_STORAGE_F32 && c->dbg_f32_fuse && c->dbg_tail_fuse && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && !c->dbg_tail_fold);
+                       (c->storage == SRUKF_STORAGE_F32 && c->dbg_f32_fuse && c->dbg_tail_fuse && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && !c->dbg_tail_fold &&
+                        (size_t)c->d.np * sizeof(double) <= 48 * 1024);
     if (c->dbg_fused_motion == 2 && !((replay_red_fused(c) || replay_red_perm(c)) && st_ok)) return 1;
     return c->dbg_fused_motion;
 }
@@ -597,7 +598,8 @@ static bool replay_tail_mode(const srukf_ctx* c)
 // rides on k_pxy2 (MeasArgs::fmode), k_gain re-centres the robot rows: a frame is k_pxy2, k_gain, k_gmw_persist, k_rank_expand, and only a run's first frame has a projection launch
 static bool replay_fuse_mode(const srukf_ctx* c)
 {
-    return replay_motion_mode(c) == 2 && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && c->dbg_tail_fuse && !replay_tail_mode(c);
+    return replay_motion_mode(c) == 2 && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && c->dbg_tail_fuse && !replay_tail_mode(c) &&
+           (size_t)c->d.np * sizeof(double) <= 48 * 1024;      // (k_rank_expand<2> keeps a row of the factor in dynamic LDS)
 }
 static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false, bool tail = false, bool fuse = false)
 {
