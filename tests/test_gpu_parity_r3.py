@@ -196,3 +196,29 @@ def test_fused_tail_on_the_other_paths(srukf, synth, N, storage):
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=2e-10)
     # (fp32 storage: an fp64 value that sits on a float rounding boundary may round the other way — one float ulp of one entry of S, seen in two of 1.4 million entries of P)
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=2e-11 if storage == "f64" else 2e-9)
+
+
+def test_fused_tail_with_partial_and_empty_matches(srukf, synth):
+    """The default replay at N = 200 ("fused tail": four launches per frame) on a sequence where a third of the landmarks is unmatched in every
+    frame, one frame has no match at all and one has a single match, against the replay with the motion step and the projection as launches of
+    their own (srukf_debug_set "fused_motion" 0: the step-wise API's kernels): same filter to rounding."""
+    p = synth.scene_params()
+    N, F = 200, 10
+    sc = synth.make_scene(N, F, seed=13, p=p)
+    rng = np.random.default_rng(5)
+    m = np.array(sc["matched"], copy=True)
+    m[rng.random(m.shape) < 0.33] = 0
+    m[4, :] = 0
+    m[7, :] = 0; m[7, 17] = 1
+    res = []
+    for mode in (2, 0):
+        f = srukf.Filter(N, p); f.debug_set("fused_motion", mode)
+        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], m)
+        traj = np.vstack([f.run_frames(0, 4), f.run_frames(4, F - 4)])
+        X, S = f.get_state()
+        assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0
+        res.append((traj, X, S.T @ S))
+    np.testing.assert_allclose(res[0][0][:, :4], res[1][0][:, :4], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(res[0][0][:, 4:], res[1][0][:, 4:], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=2e-10)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=1e-12)
