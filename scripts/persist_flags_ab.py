@@ -8,11 +8,9 @@ base = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preloa
 SRC = os.environ.get("AB_SRC", "srukf_gmw_persist")
 variants = {
     "default": [],
+    "Os": ["-Os"],
+    "Os+max-ilp": ["-Os", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
     "max-ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-    "max-memory-clause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
-    "iterative-ilp": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
-    "bias100": ["-mllvm", "-amdgpu-schedule-metric-bias=100"],
-    "bias0": ["-mllvm", "-amdgpu-schedule-metric-bias=0"],
 }
 others = [f"{csrc}/{s}.o" for s in ("srukf_api", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank") if s != SRC]
 if os.environ.get("AB_DEFS"):
