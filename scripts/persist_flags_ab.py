@@ -4,7 +4,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "cv-monoslam_amd", "csrc")
 out = os.path.join(ROOT, "gpurun_out", "flagobj"); os.makedirs(out, exist_ok=True)
-base = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -w".split()
+base = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -w".split() + os.environ.get("AB_BASE", "").split()
 SRC = os.environ.get("AB_SRC", "srukf_gmw_persist")
 variants = {
     "default": [],
