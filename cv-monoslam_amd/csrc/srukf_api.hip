@@ -12,9 +12,9 @@
 #include <algorithm>
 #include <utility>
 #include <atomic>
+#include <mutex>
 #include "srukf_device.h"
 #include "srukf_rank.h"
-#include "srukf_tail.h"
 
 extern "C" {
 void srukf_launch_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, FrameScalars*, const double*, const double*, RankArgs);
@@ -33,7 +33,6 @@ void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*,
 void srukf_launch_pxy2(hipStream_t, KDims, const double*, const double*, double*, double*, const void*, int, int, KWeights, MeasArgs);
 int srukf_pxy2_build_tiles(int mp, int np, int kr, int* out);
 int srukf_pxy2_split_groups(void);
-extern int g_pxy2_skip;
 void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*, RankArgs, const double*);
 void srukf_launch_gmw_step64(hipStream_t, int, int, int, double, double*, const void*, void*, double*, double*, const FrameScalars*);
 int srukf_gmw_panel_bytes(void);
@@ -41,10 +40,11 @@ int srukf_gmw_sync_bytes(int T);
 int srukf_gmw_build_tiles(int T, int Tp, short* out);
 int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
-void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*, const TailArgs*);
+void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
+void srukf_launch_rank_const_rows(hipStream_t, int, int, int, const int*, double*, double);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, double*, srukf_params, double*, double*, int);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
@@ -81,15 +81,18 @@ int srukf_app_tmpl_stride(void);
 // null stream it is ordered on; every free below happens after the streams that used the block have been synchronised.
 static void srukf_pool_init()
 {
-    static std::atomic<unsigned long long> done_mask{0};       // one bit per device: every device's pool is set up once, by whichever thread gets there first
+    static std::mutex mu;                                      // a second thread must not get its first allocation before the first has raised the threshold
+    static unsigned long long done_mask = 0;                   // one bit per device
     int dev = 0; hipMemPool_t pool = nullptr;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
     const unsigned long long bit = 1ull << dev;
-    if (done_mask.fetch_or(bit) & bit) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done_mask & bit) return;
     if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
         unsigned long long keep = ~0ull;
         hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
+    done_mask |= bit;
 }
 static hipError_t srukf_dmalloc_raw(void** p, size_t bytes)
 {
@@ -123,7 +126,7 @@ __global__ void k_set_frame(FrameScalars* fs, int frame, int clear_clamp)
     srukf_prepare_control(fs);
     fs->stat_count = 0;
     fs->const_rows_ok = 0; fs->const_rows_pending = 0;         // whatever happened to S since the last staged frame: its first tail writes every row again
-    for (int q = 0; q < 64; q++) fs->stat_cnt[q] = 0;
+    for (int q = 0; q < SRUKF_STAT_GROUPS; q++) fs->stat_cnt[q] = 0;
     fs->traj_base = nullptr;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
 }
@@ -135,7 +138,7 @@ __global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* 
     srukf_prepare_control(fs);                                 // the first frame's control (k_project_motion); later ones by the frame tails
     fs->stat_count = 0;
     fs->const_rows_ok = 0; fs->const_rows_pending = 0;         // whatever happened to S since the last staged frame: its first tail writes every row again
-    for (int q = 0; q < 64; q++) fs->stat_cnt[q] = 0;
+    for (int q = 0; q < SRUKF_STAT_GROUPS; q++) fs->stat_cnt[q] = 0;
     fs->traj_base = traj_base;
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
 }
@@ -202,7 +205,7 @@ static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_st
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
-static int g_dbg_shared_slack = 0;      // SRUKF_GPU_SHARED: CUs each tenant leaves free (srukf_debug_set "shared_slack")
+static std::atomic<int> g_dbg_shared_slack{0};      // SRUKF_GPU_SHARED: CUs each tenant leaves free (srukf_debug_set "shared_slack")
 struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1, tenants = 1, cus = 0; };
 static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 {
@@ -218,7 +221,7 @@ static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 // list order every XCD touches every column block (8 copies of the 9.8 MB operand set through 4 MB L2s — the 17 bandwidth-bound us at the head
 // of the launch).  Here the tiles whose owners compute them are cut into 8 compact 2D regions (two bands of block rows x four ranges of block
 // columns), one per XCD; the others (head rows, pass-on row) fill the XCDs up to equal counts.  Which worker owns which tile changes nothing else.
-static int g_dbg_tile_xcd = 1;
+static std::atomic<int> g_dbg_tile_xcd{1};
 static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles, int workers, int T, int Tp)
 {
     if (!g_dbg_tile_xcd || ntiles > workers || ntiles < 16) return;
@@ -263,7 +266,7 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 2;
     g.cus = cus;
-    const int cap = cus / (tenants > 1 ? tenants : 1) - 1 - (tenants > 1 ? g_dbg_shared_slack : 0);    // one workgroup per CU (registers), all of them resident
+    const int cap = cus / (tenants > 1 ? tenants : 1) - 1 - (tenants > 1 ? g_dbg_shared_slack.load() : 0);    // one workgroup per CU (registers), all of them resident
     g.workers = cap >= 1 ? srukf_gmw_persist_workers(g.T, g.Tp, cap) : -1;
     g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
@@ -288,7 +291,8 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
 //   rank_fold    0 = the owners never form their tiles themselves in the rank-aware replay (k_syrk over all kept rows instead)
 //   rank_aware   0 = no context looks for structurally null directions (per filter: srukf_set_rank_aware)
 //   graphs       0 = contexts created from now on launch eagerly (profilers with --pmc; per filter: key "use_graph")
-static int g_dbg_gmw_persist = 1, g_dbg_gmw_fused = 1, g_dbg_rank_fused = 1, g_dbg_rank_fold = 1, g_dbg_rank_aware = 1, g_dbg_graphs = 1;
+// (atomics: another thread's context may be launching while a switch is set; a switch applies to whatever is built or captured afterwards)
+static std::atomic<int> g_dbg_gmw_persist{1}, g_dbg_gmw_fused{1}, g_dbg_rank_fused{1}, g_dbg_rank_fold{1}, g_dbg_rank_aware{1}, g_dbg_graphs{1};
 static int gmw_persist_mode() { return g_dbg_gmw_persist; }
 
 struct srukf_ctx {
@@ -336,19 +340,19 @@ struct srukf_ctx {
     int gmw_shared = 0;                    // 0: the filter has the GPU to itself; 1: shared with other filters — persistent launches of at most half the CUs behind
                                            // the admission gate (k_gmw_gate); 2: one launch per panel (forced, or after an abandoned persistent launch)
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
-    int dbg_fused_motion = 2;              // srukf_debug_set "fused_motion": the replay's motion step — 0: its own launch, 1: inside the projection launch
+    // Measurement / test switches of srukf_debug_set (all default to the product path); one struct, so that a rebuilt context (map change) inherits them in one assignment
+    struct DbgSwitches {
+        int fused_motion = 2;              // "fused_motion": the replay's motion step — 0: its own launch (k_motion + k_project), 1: inside the projection launch
                                            // (k_project_motion), 2: "table" mode where the rank-aware tail allows it (replay_motion_mode)
-    int dbg_f32_fuse = 1;                  // srukf_debug_set "f32_fuse": fp32 storage also runs in "fused tail" mode (rounding inside k_rank_expand<2> and the state update)
-    int dbg_table_perm = 1;                // srukf_debug_set "table_perm": "table" / "fused tail" mode also where the owners do not fold (k_syrk over the kept rows: N >= 300); 0: k_project_motion + k_pxy there
-    int dbg_tail_fuse = 1;                 // srukf_debug_set "tail_fuse": k_rank_expand also projects the next frame ("fused tail" mode); 0: k_project_table in front of every frame
-    int dbg_tail_fold = 0;                 // srukf_debug_set "tail_fold" 1: the helpers of the persistent launch also project the NEXT frame's sigma points (srukf_tail.h: built,
-                                           // bit-identical, NOT faster — the jobs cost the pivot chain what the projection launch cost); 0 (default): k_project_table
-    TailArgs* d_tail = nullptr;            // ... their arguments (device copy, rebuilt with the null set)
-    int tail_jobs = 0; bool tail_ok = false;
-    int dbg_tail_cap = 0;                  // srukf_debug_set "tail_cap": at most this many helper workgroups (0: every CU the pivot and the workers leave free)
-    int dbg_head_fold = 1;                 // srukf_debug_set "head_fold": exclusive rank-aware replay without the k_syrk launch (helper workgroups of the persistent launch)
-    int dbg_nullskip = 1;                  // srukf_debug_set "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
-    int dbg_pxy2 = 1;                      // srukf_debug_set "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
+        int f32_fuse = 1;                  // "f32_fuse": fp32 storage also runs in "fused tail" mode (rounding inside k_rank_expand<2> and the state update)
+        int table_perm = 1;                // "table_perm": "table" / "fused tail" mode also where the owners do not fold (k_syrk over the kept rows: N >= 300); 0: k_project_motion + k_pxy there
+        int tail_fuse = 1;                 // "tail_fuse": k_rank_expand also projects the next frame ("fused tail" mode); 0: k_project_table in front of every frame
+        int head_fold = 1;                 // "head_fold": exclusive rank-aware replay without the k_syrk launch (helper workgroups of the persistent launch)
+        int nullskip = 1;                  // "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
+        int pxy2 = 1;                      // "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
+    } dbg;
+    bool tail_ok = false;                  // "fused tail" mode is possible: directions 0 and 1 are kept rows (the Si factor names their Z rows: they are projected for every landmark, which
+                                           // the frame tail only does for kept rows — a state where they are structurally null stays with k_project_table)
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
     int clamp_frame_host = -1, clamp_row_host = -1;   // what the last SRUKF_ERR_CLAMP_PENDING was about (srukf_clamp_info)
     double *ckS = nullptr, *ckX = nullptr; // srukf_run_frames: state before the block of frames in flight (recovery from a theta-clamp frame)
@@ -483,7 +487,7 @@ static RankArgs rank_args(const srukf_ctx* c, bool prep_next = false, bool dzper
 static NullSkip null_skip(const srukf_ctx* c)
 {
     NullSkip ns = {};
-    if (c->dbg_nullskip && c->dbg_pxy2 && c->nskip && c->red_r > 0) {
+    if (c->dbg.nullskip && c->dbg.pxy2 && c->nskip && c->red_r > 0) {
         ns.dirs = c->nskip; ns.nulls = c->nskip + c->ns_full; ns.rows = c->nskip + c->ns_full + c->ns_null;
         ns.nfull = c->ns_full; ns.nnull = c->ns_null; ns.nrows = c->ns_rows; ns.iperm = c->red_iperm; ns.r = c->red_r;
     }
@@ -502,7 +506,7 @@ static void seq_predict_fused(srukf_ctx* c, int mode)
 {
     const KDims& d = c->d;
     ProfScope ps(c, mode == 2 ? KC_PROJECT_TABLE : KC_PROJECT_MOTION, 2.0 * 60.0 * d.Na * d.N + 60.0 * d.L, 8.0 * ((double)d.n * d.n / 2 + 2.0 * d.L * 2 * d.N + (double)d.n * 2 * d.N + 8.0 * d.L + 8.0 * d.n));
-    if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c, false, c->dbg_pxy2 != 0), null_skip(c));
+    if (mode == 2) srukf_launch_project_table(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c, false, c->dbg.pxy2 != 0), null_skip(c));
     else srukf_launch_project_motion(c->stream, d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c));
     c->xr1_pending = true;
 }
@@ -537,17 +541,16 @@ static void shadow_rebuild(srukf_ctx* c)
 }
 static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c->gmw_shared != 2 && c->gplan.workers >= 0; }
 // SRUKF_GPU_SHARED: how many persistent launches share the GPU (each keeps to 1 / tenants of the CUs; the gate admits that many)
-static int g_dbg_shared_tenants = 2;
-static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants : 1; }
-static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants : 0; }
+static std::atomic<int> g_dbg_shared_tenants{2};
+static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants.load() : 1; }
+static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants.load() : 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
 // fp32 storage: S, X and the permuted copy are rounded to the stored values first, and the trajectory row is taken from those
 // (as the full-rank form does: quantize_state before the tail).
 // table: "table" mode of the replay — the tail also prepares the next frame's table of robot poses (k_rank_expand)
-// tail: "tail" mode — the persistent launch has prepared that table (and projected the next frame): the tail runs the next frame's motion reduction instead
 // fuse: "fused tail" mode — this launch also projects the next frame's sigma points (k_rank_expand<2>)
-static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool tail = false, bool fuse = false)
+static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool fuse = false)
 {
     const int n = c->d.n, np = c->d.np;
     const bool f32s = c->storage == SRUKF_STORAGE_F32;
@@ -555,7 +558,7 @@ static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool 
     const bool f32 = f32s && !f32fuse;
     const bool tt = table && frame_tail && !f32;
     srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
-                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 2 : (tt && tail) ? 1 : 0, c->d, c->w, c->Cmat, c->p, c->Z, c->DZ, f32fuse ? 1 : 0);
+                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 1 : 0, c->d, c->w, c->p, c->Z, c->DZ, f32fuse ? 1 : 0);
     if (f32) {
         quantize_state(c);
         srukf_launch_rank_round(c->stream, np, c->red_r, c->shadowA);
@@ -574,34 +577,30 @@ static bool replay_red_fused(const srukf_ctx* c)
 // ... or forms them with k_syrk over the kept rows, still in permuted order (memory tiles, two tiles per worker, one launch per panel: seq_refactor's second branch)
 static bool replay_red_perm(const srukf_ctx* c)
 {
-    return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && rank_fused_mode() && c->dbg_table_perm;
+    return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && rank_fused_mode() && c->dbg.table_perm;
 }
 static int replay_motion_mode(const srukf_ctx* c)
 {
     // fp32 storage: only as "fused tail" mode (k_rank_expand<2> and the state update round what they write; "table" mode alone has no such form)
     const bool st_ok = c->storage == SRUKF_STORAGE_F64 ||
-                       (c->storage == SRUKF_STORAGE_F32 && c->dbg_f32_fuse && c->dbg_tail_fuse && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && !c->dbg_tail_fold &&
+                       (c->storage == SRUKF_STORAGE_F32 && c->dbg.f32_fuse && c->dbg.tail_fuse && c->dbg.pxy2 && c->dbg.nullskip && c->nskip && c->tail_ok &&
                         (size_t)c->d.np * sizeof(double) <= 48 * 1024);
-    if (c->dbg_fused_motion == 2 && !((replay_red_fused(c) || replay_red_perm(c)) && st_ok)) return 1;
-    return c->dbg_fused_motion;
-}
-// "tail" mode on top of "table" mode: the helper workgroups of the persistent launch (head fold) stay and project the NEXT frame's sigma points
-// while the factorisation runs (srukf_tail.h); a frame is then k_pxy2, k_gain, k_gmw_persist, k_rank_expand, and only a run's first frame has a
-// projection launch.  Needs the head fold (a filter that has the GPU to itself) and a useful number of CUs beside the pivot and the workers.
-static int tail_helpers(const srukf_ctx* c) { const int fr = c->gplan_red.cus - 1 - c->gplan_red.workers; return c->dbg_tail_cap > 0 ? std::min(fr, c->dbg_tail_cap) : fr; }
-static bool replay_tail_mode(const srukf_ctx* c)
-{
-    return replay_motion_mode(c) == 2 && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->dbg_head_fold && c->gmw_shared == 0 && c->dbg_tail_fold && !(c->dbg_tail_fold & 16) && c->d_tail && c->tail_ok &&
-           c->red_Tp <= GMW_TAIL_PANELS && tail_helpers(c) >= 32;
+    if (c->dbg.fused_motion == 2 && !((replay_red_fused(c) || replay_red_perm(c)) && st_ok)) return 1;
+    return c->dbg.fused_motion;
 }
 // "fused tail" mode (default where "table" mode runs with k_pxy2 and NullSkip): k_rank_expand also projects the next frame (k_rank_expand<2>), the frame's motion reduction
 // rides on k_pxy2 (MeasArgs::fmode), k_gain re-centres the robot rows: a frame is k_pxy2, k_gain, k_gmw_persist, k_rank_expand, and only a run's first frame has a projection launch
 static bool replay_fuse_mode(const srukf_ctx* c)
 {
-    return replay_motion_mode(c) == 2 && c->dbg_pxy2 && c->dbg_nullskip && c->nskip && c->tail_ok && c->dbg_tail_fuse && !replay_tail_mode(c) &&
+    return replay_motion_mode(c) == 2 && c->dbg.pxy2 && c->dbg.nullskip && c->nskip && c->tail_ok && c->dbg.tail_fuse &&
            (size_t)c->d.np * sizeof(double) <= 48 * 1024;      // (k_rank_expand<2> keeps a row of the factor in dynamic LDS)
 }
-static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false, bool tail = false, bool fuse = false)
+#define SRUKF_HEAD_FOLD_MIN_FREE_CUS 16
+static bool head_fold_ok(const srukf_ctx* c)
+{
+    return c->dbg.head_fold && c->gmw_shared == 0 && c->gplan_red.cus - 1 - c->gplan_red.workers >= SRUKF_HEAD_FOLD_MIN_FREE_CUS;
+}
+static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false, bool fuse = false)
 {
     const KDims& d = c->d;
     const int np = d.np, n = d.n;
@@ -625,7 +624,10 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         const double head_flop = 2.0 * hr * n * (hr / 2.0 + d.mp) + 2.0 * (n - rr) * (rr + d.mp), head_byte = 8.0 * ((hr + d.mp) * n + (n - rr) * (rr + d.mp));
         // head fold (a filter that has the GPU to itself): the head tiles, the pending X += dX and the dropped diagonal are helper
         // workgroups of the persistent launch instead of a k_syrk launch in front of it (srukf_debug_set "head_fold", 0: two launches)
-        const bool head_fold = c->dbg_head_fold && c->gmw_shared == 0;
+        // Only with CUs to spare: the helpers are dispatched behind the pivot and the workers, which spin on their tiles — and the launch's static LDS allows one
+        // workgroup per CU.  A plan whose pivot + workers (nearly) fill the GPU (255-270 tiles) would leave the helpers waiting for a main workgroup to exit:
+        // the pivot's bounded wait would expire.  Such plans keep the k_syrk launch in front (head_fold_ok).
+        const bool head_fold = head_fold_ok(c);
         if (!head_fold) {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
             ProfScope ps(c, KC_SYRK, head_flop, head_byte);
@@ -641,18 +643,14 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
                 ha.tiles = (const int2*)c->syrk_head_tiles; ha.ntiles = c->n_syrk_head_tiles; ha.ncrit = c->n_syrk_head_crit;
                 ha.dxp = c->dx_pending ? c->dxp : nullptr; ha.X = c->X; ha.xr1 = take_xr1(c); ha.ndx = c->dx_pending ? (n + 255) / 256 : 0;
                 ha.ra = rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
-                // helper workgroups: one per CU the pivot and the workers leave free (they share a job queue), never more than there are jobs
-                // (tail fold: they share a job queue; otherwise one workgroup per job)
-                const int nhead = ha.ntiles + ha.ndx + ha.ngd;
-                ha.nhelp = (tail || (c->dbg_tail_fold & 16)) ? std::max(1, std::min(tail_helpers(c), nhead + c->tail_jobs)) : nhead;
+                ha.nhelp = ha.ntiles + ha.ndx + ha.ngd;             // one helper workgroup per job, behind the pivot and the workers in dispatch order
                 c->dx_pending = false;
             }
             srukf_launch_gmw_persist_head(c->stream, n, np, c->p.epsilon, c->Wf, c->gplan_red.pans, c->D, c->G, c->gplan_red.sync, c->gplan_red.tiles, c->gplan_red.ntiles,
-                                          c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c), head_fold ? &ha : nullptr,
-                                          (head_fold && (tail || (c->dbg_tail_fold & 16))) ? c->d_tail : nullptr);
+                                          c->gplan_red.workers, c->fs, c->shadowA, c->Utp, 0, d.mp, c->red_Tp, (c->red_r + 15) & ~15, gate_limit(c), head_fold ? &ha : nullptr);
         }
         ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
-        rank_expand(c, frame_tail, table, head_fold && tail, fuse);
+        rank_expand(c, frame_tail, table, fuse);
         return;
     }
     // ... or, where the owners cannot fold (memory tiles: more than two tiles per worker; one launch per panel), still in permuted
@@ -670,7 +668,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
         ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
-        rank_expand(c, frame_tail, table, false, fuse);
+        rank_expand(c, frame_tail, table, fuse);
         return;
     }
     const bool fused = !reduced && !slow && !keep_backup && gmw_use_persist(c) && ub == 0 && ue == d.mp && c->storage == SRUKF_STORAGE_F64 &&
@@ -921,21 +919,16 @@ static int update_null_set(srukf_ctx* c)
                     HIPCHK(c, srukf_dmalloc(&c->nskip, sizeof(int) * all.size()));
                     HIPCHK(c, hipMemcpy(c->nskip, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice));
                     c->ns_full = (int)dirs.size(); c->ns_null = (int)nulls.size(); c->ns_rows = (int)rows.size();
-                    // tail fold (srukf_tail.h): what the helpers of the persistent launch need to project the next frame
-                    TailArgs ta = {};
-                    ta.on = c->dbg_tail_fold > 1 ? c->dbg_tail_fold : 1; ta.N = c->d.N; ta.n = n; ta.Na = Na; ta.mp = c->d.mp; ta.r = r; ta.nnull = c->ns_null; ta.nchunk = (c->d.N + TAIL_LM - 1) / TAIL_LM;
-                    ta.p = c->p; ta.w = c->w; ta.X = c->X; ta.sigR = c->sigR; ta.Z = c->Z; ta.DZ = c->DZ;
-                    ta.perm = c->red_perm; ta.iperm = c->red_iperm; ta.nulls = c->nskip + c->ns_full;
-                    if (!c->d_tail) HIPCHK(c, srukf_dmalloc((void**)&c->d_tail, sizeof(TailArgs)));
-                    HIPCHK(c, hipMemcpy(c->d_tail, &ta, sizeof ta, hipMemcpyHostToDevice));
-                    c->tail_jobs = tail_jobs_total(ta);
                     // (directions 0 and 1 are projected for every landmark even when they are structurally null — the Si factor names their Z rows —
-                    //  and the tail jobs only do that for kept rows: such a state stays with k_project_table)
+                    //  and the frame tail (k_rank_expand<2>) only does that for kept rows: such a state stays with k_project_table)
                     c->tail_ok = iperm[0] < r && iperm[1] < r;
                 }
                 c->pxy2_split_b0 = np;                            // first permuted column whose K range is cut in two
                 for (int bt = 0; bt < np / 64; bt++) if (std::min(4 * (bt + 1), ((kr + 63) / 64) * 4) >= srukf_pxy2_split_groups()) { c->pxy2_split_b0 = 64 * bt; break; }
             }
+            // the dropped rows in the form the null set's consumers assume (k_rank_const_rows), as the stored precision holds it
+            srukf_launch_rank_const_rows(c->stream, n, np, r, c->red_perm, c->S, c->storage != SRUKF_STORAGE_F64 ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon));
+            quantize_state(c);
             shadow_rebuild(c);
         }
     }
@@ -974,6 +967,8 @@ static int alloc_zero(srukf_ctx* c, void** p, size_t bytes)
 int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void* stream)
 {
     if (!out || !p || N < 0) { g_create_error = "bad argument"; return SRUKF_ERR_BAD_ARG; }      // N = 0: the robot block only (SLAM.cpp:226-231), until landmarks are added
+    // the per-group counters of the measurement statistics (FrameScalars::stat_cnt) serve (N + 31) / 32 <= 64 landmark groups
+    if (N > 32 * SRUKF_STAT_GROUPS) { g_create_error = "more than 2048 landmarks: the per-group statistics counters (FrameScalars::stat_cnt) serve 64 groups of 32"; return SRUKF_ERR_UNSUPPORTED; }
     if (p->noise_type != 0) { g_create_error = "noise_type != 0 draws random numbers (SLAM.cpp:1505-1516) and is not built"; return SRUKF_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -1069,7 +1064,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->d_tail, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -1638,7 +1633,7 @@ static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     c->own_stream = own; c2->own_stream = false;
     c->profiling = c2->profiling; c->use_graph = c2->use_graph;
     // per-context switches the caller set on the handle survive the rebuild (before srukf_set_storage / update_null_set run on it)
-    c->rank_aware = c2->rank_aware; c->debug_allow_mixed = c2->debug_allow_mixed; c->debug_starve = c2->debug_starve;
+    c->rank_aware = c2->rank_aware; c->debug_allow_mixed = c2->debug_allow_mixed; c->debug_starve = c2->debug_starve; c->dbg = c2->dbg;
     const int shared = c2->gmw_shared;
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
@@ -1731,24 +1726,20 @@ int srukf_stage_sequence(srukf_ctx* c, int F, const double* odo, const double* z
 static void replay_one_frame(srukf_ctx* c)
 {
     const int mode = replay_motion_mode(c);
-    const bool tail = replay_tail_mode(c), fuse = replay_fuse_mode(c);
+    const bool fuse = replay_fuse_mode(c);
     if (fuse) {
         // the previous frame's tail (or, for a run's first frame, run_frames_async) projected this frame; its motion reduction rides on k_pxy2
         c->xr1_pending = true;
         seq_gain(c, nullptr, nullptr, true, true, true, true, true);
-    } else if (tail) {
-        // the previous frame's launches (or, for a run's first frame, run_frames_async) projected this frame and ran its motion reduction
-        c->xr1_pending = true;
-        seq_gain(c, nullptr, nullptr, true, true, true, true);
     } else if (mode) {
         seq_predict_fused(c, mode);
-        seq_gain(c, nullptr, nullptr, true, true, mode == 2 && c->dbg_pxy2);
+        seq_gain(c, nullptr, nullptr, true, true, mode == 2 && c->dbg.pxy2);
     } else {
         seq_predict_motion(c, nullptr);
         seq_predict_measurement(c, true);
         seq_gain(c, nullptr, nullptr, true);
     }
-    seq_refactor(c, 0, c->d.mp, false, false, false, true, mode == 2, tail, fuse);
+    seq_refactor(c, 0, c->d.mp, false, false, false, true, mode == 2, fuse);
 }
 static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec_t* ge)
 {
@@ -1788,9 +1779,8 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1, traj);
     // "table" mode: the first frame's table of robot poses (the frames after it get theirs from their predecessor's tail)
     if (replay_motion_mode(c) == 2) srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs, c->red_iperm, c->red_r);
-    // "tail" mode: ... and the first frame's projection + motion reduction (k_project_table); every later frame is projected inside its
-    // predecessor's factorisation launch
-    if (replay_tail_mode(c) || replay_fuse_mode(c)) seq_predict_fused(c, 2);
+    // "fused tail" mode: ... and the first frame's projection (k_project_table); every later frame is projected by its predecessor's tail
+    if (replay_fuse_mode(c)) seq_predict_fused(c, 2);
     if (c->use_graph && !c->profiling) {
         // every per-frame argument lives in HBM (frame counter, staged inputs, trajectory base), so ONE
         // captured frame replays for all frames: the 45 launches cost one hipGraphLaunch on the host
@@ -1994,10 +1984,9 @@ int srukf_debug_poke_state(srukf_ctx* c, int row, int col, double value)
 int srukf_debug_set(srukf_ctx* c, const char* key, int value)
 {
     if (!key) return SRUKF_ERR_BAD_ARG;
-    struct { const char* k; int* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
+    struct { const char* k; std::atomic<int>* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs },
                                                     { "tile_xcd", &g_dbg_tile_xcd } };      // tile_xcd: applies to plans built afterwards (set it before the state)
-    if (!strcmp(key, "pxy2_skip")) { g_pxy2_skip = value & 3; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }   // timing only: results are garbage
     if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
         if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;
@@ -2006,7 +1995,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     }
     for (auto& g : globals)
         if (!strcmp(key, g.k)) {
-            *g.v = value ? 1 : 0;
+            g.v->store(value ? 1 : 0);
             if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); drop_graphs(c); if (!strcmp(key, "rank_aware")) return update_null_set(c); }
             return SRUKF_OK;
         }
@@ -2014,18 +2003,13 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!strcmp(key, "use_graph")) c->use_graph = value != 0;
-    else if (!strcmp(key, "pxy2")) c->dbg_pxy2 = value ? 1 : 0;
-    else if (!strcmp(key, "nullskip")) c->dbg_nullskip = value ? 1 : 0;
-    else if (!strcmp(key, "head_fold")) c->dbg_head_fold = value ? 1 : 0;
-    else if (!strcmp(key, "tail_cap")) c->dbg_tail_cap = value < 0 ? 0 : value;
-    else if (!strcmp(key, "tail_fuse")) c->dbg_tail_fuse = value ? 1 : 0;
-    else if (!strcmp(key, "table_perm")) c->dbg_table_perm = value ? 1 : 0;
-    else if (!strcmp(key, "f32_fuse")) c->dbg_f32_fuse = value ? 1 : 0;
-    else if (!strcmp(key, "tail_fold")) {
-        c->dbg_tail_fold = value < 0 ? 0 : value > 31 ? 31 : value;    // > 1: timing only (2: no projection jobs; + 4 / + 8: pivot / worker rows with plain stores): the NEXT frame is garbage
-        if (c->d_tail) { const int on = c->dbg_tail_fold ? c->dbg_tail_fold : 1; HIPCHK(c, hipMemcpy((char*)c->d_tail + offsetof(TailArgs, on), &on, sizeof on, hipMemcpyHostToDevice)); }
-    }
-    else if (!strcmp(key, "fused_motion")) c->dbg_fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (!strcmp(key, "pxy2")) c->dbg.pxy2 = value ? 1 : 0;
+    else if (!strcmp(key, "nullskip")) c->dbg.nullskip = value ? 1 : 0;
+    else if (!strcmp(key, "head_fold")) c->dbg.head_fold = value ? 1 : 0;
+    else if (!strcmp(key, "tail_fuse")) c->dbg.tail_fuse = value ? 1 : 0;
+    else if (!strcmp(key, "table_perm")) c->dbg.table_perm = value ? 1 : 0;
+    else if (!strcmp(key, "f32_fuse")) c->dbg.f32_fuse = value ? 1 : 0;
+    else if (!strcmp(key, "fused_motion")) c->dbg.fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);
     return SRUKF_OK;

@@ -30,6 +30,7 @@ struct KDims {
 
 struct KWeights { double wm0, wc0, wi, wi_sr, gamma; };
 
+#define SRUKF_STAT_GROUPS 64   // landmark groups of 32 the riding statistics jobs count: N <= 2048 (srukf_create refuses more)
 // device-resident per-frame scalars
 struct FrameScalars {
     double Ut[3];              // rot1, trans, rot2                    SLAM.cpp:1452-1454
@@ -41,7 +42,7 @@ struct FrameScalars {
     int clamp_first;           // first such row
     int frame;                 // frame counter for staged sequences
     int stat_count;            // (unused since round 3: per-group counters below)
-    int stat_cnt[64];          // measurement-statistics jobs finished per landmark group of 32 in the current contraction launch: the last one
+    int stat_cnt[SRUKF_STAT_GROUPS];          // measurement-statistics jobs finished per landmark group of 32 in the current contraction launch: the last one
                                // of a group runs its final pass
     double* traj_base;         // device trajectory buffer of the current replay (row = absolute frame), or null
     int gmw_aborts;            // persistent GMW launches abandoned on an expired wait (their frames are flagged like clamp rows)
@@ -153,8 +154,8 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red)
 // feat = (xi yi zi theta phi rho), robot = (x y z), cs/sn = cos/sin of robot theta,
 // err = pixel-noise sigma rows.  Returns uvd = (x, y) = Z[2k], Z[2k+1].
 // Every fused multiply-add of this function is written out and the compiler's own contraction is off: which products it fuses
-// depends on the code around an inlined call, and the same sigma point projected by two kernels (k_project_table; the tail jobs of
-// the persistent launch, srukf_tail.h) must give the same bits.
+// depends on the code around an inlined call, and the same sigma point projected by two kernels (k_project_table; the frame tail
+// k_rank_expand<2>) must give the same bits.
 __device__ __forceinline__ void srukf_project(const srukf_params& p, double f1, double f2,
                                               const double feat[6], double px, double py, double pz,
                                               double cs, double sn, double e0, double e1,
@@ -240,9 +241,7 @@ __device__ __forceinline__ void srukf_project_sigma(const srukf_params& p, doubl
 #define GAIN_SLICES 32
 // xr1 (replay path, may be null): the robot mean after the motion step, which k_project_motion left beside X because the
 // projection threads of its launch were still reading the mean before it
-// DEV: the new state is read by other workgroups of the SAME launch (tail jobs of the persistent factorisation): agent-scope store
 // f32: fp32 storage, "fused tail" mode: the new state is rounded to float here (what k_quantize does after the refactorisation in the other modes)
-template <bool DEV = false>
 __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job, const double* xr1 = nullptr, int f32 = 0)
 {
     const int r = job * 256 + threadIdx.x;
@@ -253,7 +252,7 @@ __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* _
     const double x = (xr1 && r >= n - 4) ? xr1[r - (n - 4)] : X[r];
     double v = x + acc;
     if (f32) v = (double)(float)v;
-    if constexpr (DEV) __hip_atomic_store(&X[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else X[r] = v;
+    X[r] = v;
 }
 
 // measurement-statistics work attached to a k_pxy launch (replay path): Z == null -> none
@@ -284,13 +283,6 @@ struct MeasArgs {
 __device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <bool DEV> __device__ __forceinline__ double ld_g(const double* p) { if constexpr (DEV) return ld_dev(p); else return *p; }
-// 32 bytes, write-through, as two 128-bit stores (the atomic builtins stop at 64 bits): factor rows that tail jobs of the same launch read
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_d4_wt(double* p, d4 v)
-{
-    union { d4 d; u4v u[2]; } c; c.d = v;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(p), "v"(c.u[0]), "v"(c.u[1]) : "memory");
-}
 template <bool DEV> __device__ __forceinline__ void st_d4(double* p, d4 v)
 {
     if constexpr (DEV) { st_dev(p, v[0]); st_dev(p + 1, v[1]); st_dev(p + 2, v[2]); st_dev(p + 3, v[3]); }
@@ -303,7 +295,6 @@ template <bool DEV> __device__ __forceinline__ void st_d4(double* p, d4 v)
 #define GMW_EPOCH_SHIFT 12
 #define GMW_FLAG_COPIES 16          // the two panel flags are polled by every worker at once: one copy per 16 workgroups,
 #define GMW_FLAG_STRIDE 512         // 4 KB apart (unsigned long longs), so that the polls do not all queue on one memory channel
-#define GMW_TAIL_PANELS 32         // the tail fold serves factorisations of at most this many pivoted panels
 struct GmwSync {
     unsigned long long epoch;        // run counter (starts at 1)
     unsigned int exited;             // workgroups that have left the current launch
@@ -311,11 +302,7 @@ struct GmwSync {
     unsigned long long* dbg;         // diagnostic builds: host-visible progress markers (null in the product)
     unsigned int head_done;          // head fold: 32 x 32 tiles of the head rows of S^T S - U U^T finished by the helper workgroups of this launch
     unsigned int head_crit;          // ... and the first ha.ncrit of them: what the pivot needs before its first panel
-    // tail fold (srukf_tail.h): the helper workgroups stay, take their jobs from a queue and project the NEXT frame's sigma points row panel by row panel
-    unsigned int job_next;           // next job of the helpers' queue
-    unsigned int dx_done;            // state-update jobs finished (X is final)
-    unsigned int rows_done[GMW_TAIL_PANELS];   // per pivoted panel: writers of its factor rows (Sout) that have finished: complete at T - p
-    unsigned long long pad[59 - GMW_TAIL_PANELS / 2];
+    unsigned long long pad[60];
     unsigned long long panel_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];  // copy c at [c * STRIDE]: (epoch << SHIFT) + panels published
     unsigned long long half_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];   // same for the first half of a panel buffer (Tt1, E, pivots of sub-panel 1)
     // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)

@@ -13,6 +13,8 @@
 #include "srukf_gmw_cols.h"
 #include "srukf_meas.h"
 #include "srukf_motion_reduce.h"
+#include <vector>
+#include <algorithm>
 
 // A statistics job that rides on a contraction launch has stored its partial sums: the LAST of the MEAS_SLICES jobs of a landmark
 // group (device-scope counter per group) runs that group's final pass with its whole workgroup.  (One last workgroup for all
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // scripts/mb/mb_mfma_f64.hip; the four-wave form of this kernel took 20.6 us for its 8.5 us of MFMA).  Waves w and w + 4 share a
 // 32 x 32 sub-tile and take k-steps 0-1 / 2-3 of every group; the upper four hand their accumulators over through LDS at the end.
 __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
-                                              const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms, int skip)
+                                              const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
 {
     __shared__ double shm[2 * 2 * 16 * PXY2_LS];               // [buf][A|B][k][PXY2_LS]; >= MEAS_SM_DOUBLES (statistics scratch), >= 4 x 64 x 17 (hand-over)
     static_assert(2 * 2 * 16 * PXY2_LS >= MEAS_SM_DOUBLES && 2 * 2 * 16 * PXY2_LS >= 4 * 64 * 17, "scratch");
@@ -115,14 +117,14 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
 #endif
     const int stat0 = PXY2_STATS_LAST ? nmot + ntiles : nmot, tile0 = PXY2_STATS_LAST ? nmot : nmot + nstat;
     if ((int)blockIdx.x >= stat0 && (int)blockIdx.x < stat0 + nstat) {
-        if ((skip & 1) || threadIdx.x >= 256) return;          // (skip: measurement runs of one half of the launch alone, srukf_debug_set "pxy2_skip")
+        if (threadIdx.x >= 256) return;
         const int job = (int)blockIdx.x - stat0;               // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
         meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm, ms.ns);
         meas_job_done(d, w, ms, job % ms.gx, shm);
         return;
     }
     const int4 tl = tiles[blockIdx.x - tile0];
-    if (tl.x < 0 || (skip & 2)) return;                        // empty slot of the XCD-aware list
+    if (tl.x < 0) return;                                      // empty slot of the XCD-aware list
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int m0 = 64 * tl.x, b0 = 64 * tl.y;
     // A[a][b] = 0 for a > b and for a >= r.  Every range is a whole number of FOUR-group rounds (kr is rounded up to 64 rows — the
@@ -644,11 +646,10 @@ void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S
     const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
     hipLaunchKernelGGL(k_pxy, dim3(ntiles + extra), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles, ntiles, w, ms);
 }
-int g_pxy2_skip = 0;
 void srukf_launch_pxy2(hipStream_t st, KDims d, const double* DZp, const double* A, double* P0, double* P1, const void* tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
 {
     const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
-    hipLaunchKernelGGL(k_pxy2, dim3(ntiles + extra + (ms.fmode ? 1 : 0)), dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms, g_pxy2_skip);
+    hipLaunchKernelGGL(k_pxy2, dim3(ntiles + extra + (ms.fmode ? 1 : 0)), dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms);
 }
 // host-side tile list of k_pxy2 (4 ints per workgroup: mt, bt, half, halves; mt < 0: empty slot).  K ranges of at least PXY2_SPLIT
 // groups are cut in two.  XCD-aware: workgroup w runs on XCD w % 8 (round-robin dispatch; the statistics jobs in front of the
@@ -663,25 +664,28 @@ int srukf_pxy2_build_tiles(int mp, int np, int kr, int* out)
 {
     const int ngmax = ((kr + 63) / 64) * 4, nmt = mp / 64;
     struct Pair { int bt, h, halves, groups; };
-    Pair pairs[2 * 64]; int npairs = 0;
-    for (int bt = np / 64 - 1; bt >= 0 && npairs + 2 <= 2 * 64; bt--) {
+    std::vector<Pair> pairs;                                   // sized by the matrix: every (bt, half) pair appears exactly once, whatever N
+    pairs.reserve(2 * (size_t)(np / 64));
+    for (int bt = np / 64 - 1; bt >= 0; bt--) {
         const int ng = (4 * (bt + 1) < ngmax) ? 4 * (bt + 1) : ngmax;
         const int halves = ng >= PXY2_SPLIT ? 2 : 1, gh = (ng / 2) & ~3;
-        for (int h = 0; h < halves; h++) pairs[npairs++] = { bt, h, halves, halves == 1 ? ng : (h == 0 ? gh : ng - gh) };
+        for (int h = 0; h < halves; h++) pairs.push_back({ bt, h, halves, halves == 1 ? ng : (h == 0 ? gh : ng - gh) });
     }
-    for (int a = 1; a < npairs; a++) { const Pair t = pairs[a]; int b = a; while (b > 0 && pairs[b - 1].groups < t.groups) { pairs[b] = pairs[b - 1]; b--; } pairs[b] = t; }   // longest first
-    int load[8] = { 0 }, cnt[8] = { 0 }, lst[8][2 * 64];
+    const int npairs = (int)pairs.size();
+    std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.groups > b.groups; });   // longest first
+    int load[8] = { 0 };
+    std::vector<int> lst[8];
     for (int a = 0; a < npairs; a++) {
         int x = 0;
         for (int q = 1; q < 8; q++) if (load[q] < load[x]) x = q;
-        lst[x][cnt[x]++] = a; load[x] += pairs[a].groups;
+        lst[x].push_back(a); load[x] += pairs[a].groups;
     }
     int maxlen = 0;
-    for (int x = 0; x < 8; x++) maxlen = cnt[x] * nmt > maxlen ? cnt[x] * nmt : maxlen;
+    for (int x = 0; x < 8; x++) maxlen = (int)lst[x].size() * nmt > maxlen ? (int)lst[x].size() * nmt : maxlen;
     if (out) {
         for (int q = 0; q < maxlen * 8; q++) { out[4 * q] = -1; out[4 * q + 1] = 0; out[4 * q + 2] = 0; out[4 * q + 3] = 1; }
         for (int x = 0; x < 8; x++)
-            for (int a = 0; a < cnt[x]; a++)
+            for (int a = 0; a < (int)lst[x].size(); a++)
                 for (int mt = 0; mt < nmt; mt++) {
                     const Pair& pr = pairs[lst[x][a]];
                     int* o = out + 4 * ((a * nmt + mt) * 8 + x);

@@ -264,10 +264,9 @@ __device__ __forceinline__ void gmw_copy_t(const double* Tl, double* __restrict_
 
 // Follower wave 2: outputs of rows J0..J1-1 — S rows j0+J (diagonal-block part), pivots, per-row scales of the
 // panel buffer.  Lane l handles row J0 + (l >> 3) (when the group has 8 rows) and four columns.
-// swt: the S rows are read by other workgroups of the same launch (tail fold): write-through stores
 template <int J0, int J1, bool DEV> __device__ __forceinline__ void gmw_out_group(const GmwColsLds& w, unsigned dv, int lane, int n, int ld, int j0,
                                                                         double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
-                                                                        double* __restrict__ Dall, double* __restrict__ Sout, double* lsq, double* lrc, bool swt)
+                                                                        double* __restrict__ Dall, double* __restrict__ Sout, double* lsq, double* lrc)
 {
     gmw_wait_row(dv, J1 - 1);
     const int j = J0 + (lane >> 3), c0 = (lane & 7) * 4;
@@ -291,7 +290,7 @@ template <int J0, int J1, bool DEV> __device__ __forceinline__ void gmw_out_grou
         const int c = c0 + q;
         v[q] = (c > j && j0 + c < n && j0 + j < n) ? -(l[q] * sq) : ((c == j && j0 + j < n) ? sq : 0.0);
     }
-    if (swt) st_d4_wt(&Sout[(size_t)(j0 + j) * ld + j0 + c0], v); else *(d4*)&Sout[(size_t)(j0 + j) * ld + j0 + c0] = v;
+    *(d4*)&Sout[(size_t)(j0 + j) * ld + j0 + c0] = v;
 }
 // Two output waves (which = 0 / 1) take alternate groups, so the last group starts the moment its rows exist.
 // before_last(): called once, before the wave's last group — the persistent kernel requests the flag of the tile it stages next
@@ -301,17 +300,17 @@ template <bool DEV = false, class Hook = GmwNoHook>
 __device__ __forceinline__ void gmw_cols_out_wave(const GmwColsLds& w, int which, int lane, int n, int ld, int j0,
                                                   double* __restrict__ pD, double* __restrict__ psq, double* __restrict__ prD,
                                                   double* __restrict__ Dall, double* __restrict__ Sout, double* lsq = nullptr, double* lrc = nullptr,
-                                                  Hook&& before_last = Hook(), bool swt = false)
+                                                  Hook&& before_last = Hook())
 {
     const unsigned dv = lds_off(w.Dv);
     if (which == 0) {
-        gmw_out_group<0, 8, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc, swt);
-        gmw_out_group<16, 24, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc, swt);
+        gmw_out_group<0, 8, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
+        gmw_out_group<16, 24, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
         before_last();
-        gmw_out_group<28, 32, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc, swt);
+        gmw_out_group<28, 32, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     } else {
-        gmw_out_group<8, 16, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc, swt);
+        gmw_out_group<8, 16, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
         before_last();
-        gmw_out_group<24, 28, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc, swt);
+        gmw_out_group<24, 28, DEV>(w, dv, lane, n, ld, j0, pD, psq, prD, Dall, Sout, lsq, lrc);
     }
 }

@@ -91,8 +91,6 @@ __device__ __forceinline__ void stage32_tri_globalB(d4 (&acc)[2][2], const doubl
 // are requested together with the first half's — one memory round trip per step instead of two.
 // rows32: the panel has only its first 32 pivots (the rank-aware form's last pivoted panel when the kept pivots end there) and the
 // tile's own values are not needed: the call ends after the first half with the S rows j0 .. j0+31.
-// rows_cnt (first block row of the persistent launch's tail fold): the S rows go out with agent-scope stores and, once the whole workgroup's
-// have landed, *rows_cnt is incremented — tail jobs of the same launch read the finished row panel (srukf_tail.h).
 // acc: this wave's 32x32 quadrant.  load_tile / store_tile: read it from / write it back to G (the persistent kernel
 // keeps a tile in registers from its first update to its last).
 // DEV: G tiles are exchanged with other workgroups of the SAME launch (agent-scope accesses).  The panel buffer is read
@@ -104,7 +102,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                                                 const GmwPanel64* cur, double* __restrict__ Sout,
                                                 double (*Lr)[G64_LS], double (*Wc)[G64_LS], int tid, d4 (&acc)[2][2],
                                                 bool load_tile, bool store_tile, WaitHalf&& wait_half, WaitFull&& wait_full, Stored&& stored,
-                                                bool early2 = false, bool rows32 = false, unsigned int* rows_cnt = nullptr)
+                                                bool early2 = false, bool rows32 = false)
 {
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -222,12 +220,10 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const int jj = 16 * a + lk + 4 * t;
-                        if (j0 + jj < n) { double* sp = &Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr]; if (rows_cnt) st_dev(sp, W1[a][b][t] * sqr[a][t]); else *sp = W1[a][b][t] * sqr[a][t]; }
+                        if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr] = W1[a][b][t] * sqr[a][t];
                     }
         }
-        if (rows_cnt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // the LDS slabs may be rewritten by the caller's next step
-        if (rows_cnt && __builtin_amdgcn_readfirstlane(wv) == 0) { if (lane == 0) __hip_atomic_fetch_add(rows_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         return true;
     }
     __syncthreads();
@@ -320,19 +316,9 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                     const int jj = 16 * a + lk + 4 * t;
                     double* s1 = &Sout[(size_t)(j0 + jj) * ld + n0 + 16 * b + lr];
                     double* s2 = &Sout[(size_t)(j0 + 32 + jj) * ld + n0 + 16 * b + lr];
-                    if (rows_cnt) {
-                        if (j0 + jj < n) st_dev(s1, W1[a][b][t] * sqr[a][t]);
-                        if (j0 + 32 + jj < n) st_dev(s2, W2[a][b][t] * sqr[2 + a][t]);
-                    } else {
-                        if (j0 + jj < n) *s1 = W1[a][b][t] * sqr[a][t];
-                        if (j0 + 32 + jj < n) *s2 = W2[a][b][t] * sqr[2 + a][t];
-                    }
+                    if (j0 + jj < n) *s1 = W1[a][b][t] * sqr[a][t];
+                    if (j0 + 32 + jj < n) *s2 = W2[a][b][t] * sqr[2 + a][t];
                 }
-    }
-    if (rows_cnt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(wv) == 0) { if (lane == 0) __hip_atomic_fetch_add(rows_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
     return true;
 }

@@ -7,7 +7,6 @@
 #include "srukf_gmw_cols.h"
 #include "srukf_gmw_panel.h"
 #include "srukf_rank.h"
-#include "srukf_tail.h"
 
 // ------------------------------------------------------------------------------------------------
 // Persistent form: the whole factorisation in ONE launch (k_gmw_persist).
@@ -97,7 +96,7 @@ __device__ __forceinline__ void gmw_stage_tile(double (*dst)[G64_LS], const doub
 __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, double eps, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                   double* __restrict__ Dall, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
                                                   double (*Lr)[G64_LS], double (*Wc)[G64_LS], double* facreg, double* xreg, double* keepreg,
-                                                  int* okp, int* halfcnt, int* stageok, int tid, int klim, bool tail)
+                                                  int* okp, int* halfcnt, int* stageok, int tid, int klim)
 {
     const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int qa = wv >> 1, qb = wv & 1;
@@ -225,7 +224,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
                     const double sq = kp.sq[row];
                     d4 w = *(const d4*)&Wc[row][c4];
                     w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
-                    if (tail) st_d4_wt(&Sout[(size_t)(j0 + row) * ld + base + c4], w); else *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
+                    *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
                 }
             }
         }
@@ -313,12 +312,12 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
                     const double sq = (base + row < n) ? sqrt(Dr) * gmw_pivot_rcp(Dr) : 0.0;
                     d4 w = *(const d4*)&Wc[row][c4];
                     w[0] *= sq; w[1] *= sq; w[2] *= sq; w[3] *= sq;
-                    if (tail) st_d4_wt(&Sout[(size_t)(base + row) * ld + base + 32 + c4], w); else *(d4*)&Sout[(size_t)(base + row) * ld + base + 32 + c4] = w;
+                    *(d4*)&Sout[(size_t)(base + row) * ld + base + 32 + c4] = w;
                 }
             }
-            gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD, GmwNoHook(), tail);
+            gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD);
             if (!half_only) gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32,
-                                                    [&] { if (p >= 1 && p + 1 < Tp) early = __hip_atomic_load(&ver[(size_t)(wv1 ? p : p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, tail);
+                                                    [&] { if (p >= 1 && p + 1 < Tp) early = __hip_atomic_load(&ver[(size_t)(wv1 ? p : p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
             if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
         }
         if (p + 1 < Tp) {
@@ -340,17 +339,8 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
             }
         }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last pivoted panel: nothing to stage, but its stores must have landed before panel_ready
-        if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // closes the iteration: staged tiles visible, LDS arrays reusable
         if (wv3 && p + 1 < T) { gmw_set_panel_flag(sy->panel_ready, ebase + p + 1, lane); GMW_TS(sy, p + 64, 3); }
-        // tail fold: this workgroup's share of the factor rows of panel p (both diagonal blocks, the (0,1) part) and of panel p - 1
-        // (its columns of block p, written during this iteration's factor 1) has landed (every wave waited for its stores above)
-        if (tail && wv3) {
-            if (lane == 0) {
-                __hip_atomic_fetch_add(&sy->rows_done[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (p >= 1) __hip_atomic_fetch_add(&sy->rows_done[p - 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         if (wv0) GMW_TS(sy, p, 7);
         if (!*okp) { if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     }
@@ -367,8 +357,7 @@ struct KDimsLite { int n, ld; };
 // every lane sees its own earlier stores.
 __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, const GmwOwned& tl, d4 (&acc)[2][2], double* __restrict__ G,
                                                GmwPanel64* pans, double* __restrict__ Sout, GmwSync* sy, unsigned long long ebase,
-                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid, bool memtile = false, bool rows32 = false,
-                                               bool tail = false)
+                                               double (*Lr)[G64_LS], double (*Wc)[G64_LS], int* okp, bool wv0, int tid, bool memtile = false, bool rows32 = false)
 {
     unsigned long long* ver = gmw_sync_ver(sy);
     // the two row-panel tiles (k, I), (k, J) are finished (k updates each) — both flags, and the panel flag, in one round
@@ -408,7 +397,7 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
             return *okp != 0;
         },
         [&] { if (last && !tl.passon) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); },
-        behind, rows32 && tl.passon, (tail && tl.I - k - 1 == 0) ? &sy->rows_done[k] : nullptr);
+        behind, rows32 && tl.passon);
 }
 
 // k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any), both kept in accumulator
@@ -535,14 +524,13 @@ __device__ __forceinline__ bool gmw_wait_head(const unsigned int* cnt, unsigned 
     return false;
 }
 
-// TAIL: the instance with the tail fold (srukf_tail.h) compiled in; the other one carries none of it (same code as before the fold existed)
-template <bool MEM, bool TAIL>
+template <bool MEM>
 __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int Tp, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                      double* __restrict__ Sout, double* __restrict__ Dall, double eps,
                                                      GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, int ntiles,
                                                      FrameScalars* __restrict__ fs,
                                                      const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows, int gated,
-                                                     const HeadArgs ha, const TailArgs* __restrict__ tap)
+                                                     const HeadArgs ha)
 {
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
@@ -560,7 +548,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     int2 mytile = make_int2(-1, -1);
     unsigned long long t01 = 0, t23 = 0;                       // GmwTile entries (4 shorts each) of a worker's two tiles
     if (!MEM) {
-        if (role < 0) { const int hb = (int)blockIdx.x - nmain; if (!(TAIL && tap != nullptr) && hb < ha.ntiles) mytile = ha.tiles[hb]; }
+        if (role < 0) { const int hb = (int)blockIdx.x - nmain; if (hb < ha.ntiles) mytile = ha.tiles[hb]; }
         else if (role > 0) {
             const unsigned long long* tq = (const unsigned long long*)tiles;
             if (role - 1 < ntiles) t01 = tq[role - 1];
@@ -579,61 +567,28 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     //  frame without, 196.8 / 197.2 / 198.6 / 199.0 / 203.8 with 0.9 / 1.7 / 2.6 / 3.4 / 5.1 us: every chain of the launch is critical.  Only the
     //  non-critical HELPERS sleeping: 195.5 / 195.4 / 197.3 / 200.5 us with 0.9 / 1.7 / 2.6 / 4.3 us — nothing to gain either.  Nor from dispatching the critical
     //  helpers right behind the pivot, in front of the workers: 5 201 frames/s without, 5 195 / 5 197 / 5 177 with the first 8 / 16 / 32 helper jobs there.)
-    const bool tail = TAIL && tap != nullptr && fs->odo_seq && fs->frame + 1 < fs->seqF;   // (there is a next staged frame)                       // tail fold: the args live in device memory (a by-value copy costs every role ~200 SGPR spills)
-    // (measurement only, srukf_debug_set "tail_fold" with bits 4 / 8: the pivot's / the workers' rows with plain stores and no counting)
-    const int tail_on = (TAIL && tail) ? tap->on : 0;
-    const bool tail_pivot = TAIL && tail && !(tail_on & 4), tail_work = TAIL && tail && !(tail_on & 8);
     if (role < 0) {
         if constexpr (!MEM) {                                  // (the memory-tile instance has no helpers: none of their code, none of their registers)
-        // Helpers take their jobs from one queue (sy->job_next), in this order: the head tiles (critical ones first), X += dX, the dropped
-        // diagonal; then — tail fold — the next frame's projection jobs (srukf_tail.h).  However many of them are resident, every job is
-        // taken by somebody; nobody waits for a helper that has not started.
+        // One helper workgroup per job, in this order: the head tiles (critical ones first), X += dX, the dropped diagonal.  They sit behind the
+        // pivot and the workers in dispatch order; nobody waits for a helper that has not started (every wait is bounded).
         const int nhead = ha.ntiles + ha.ndx + ha.ngd;
-        TailArgs tla = {};
-        if constexpr (TAIL) { if (tail) tla = *tap; }
-        const int njobs = nhead + (TAIL ? tail_jobs_total(tla) : 0);
         const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        TailState ts = { -1, false };
-        bool good = true;
+        const int job = (int)blockIdx.x - nmain;
         if ((int)blockIdx.x == nmain) GMW_TS(sy, 131, 0);
-        for (int pass = 0;; pass++) {
-            int job = (int)blockIdx.x - nmain;                 // without the tail fold: one workgroup per job, as many helpers as jobs (no queue on the way to the critical tiles)
-            if (TAIL && tap != nullptr) {                      // (queue whenever the launcher sized the helpers for it, also when there is no next frame to project)
-                if (wvu == 0) {
-                    unsigned int v = 0;
-                    if (lane == 0) v = __hip_atomic_fetch_add(&sy->job_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    halfcnt = __builtin_amdgcn_readfirstlane((int)v);
-                }
-                __syncthreads();
-                job = halfcnt;
-                __syncthreads();
-            } else if (pass) break;
-            if (job >= njobs) break;
-            if (job < ha.ntiles) {
-                if (job == 0) GMW_TS(sy, 132, 0);
-                gmw_head_tile_job(n, ld, krows, S0, Ut0, u0, u1, (TAIL && tap != nullptr) ? ha.tiles[job] : mytile, G, fs, &Lr[0][0], tid, sy, job == 0);
-                if (job == 0) GMW_TS(sy, 132, 4);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tile stores have landed ...
-                __syncthreads();
-                if (job == 0) GMW_TS(sy, 132, 5);
-                // the list starts with the ha.ncrit tiles the pivot needs before its first panel ((0,0), (0,1), (1,1) in 64 x 64 terms)
-                if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(job < ha.ncrit ? &sy->head_crit : &sy->head_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            } else if (job < ha.ntiles + ha.ndx) {
-                const int dj = job - ha.ntiles;
-                if (ha.ra.prep_next && dj == 0 && tid == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
-                if (TAIL && tail) {
-                    srukf_gain_dx_job<true>(n, ld, ha.dxp, ha.X, dj, ha.xr1, ha.ra.f32round);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(&sy->dx_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                } else srukf_gain_dx_job(n, ld, ha.dxp, ha.X, dj, ha.xr1, ha.ra.f32round);
-            } else if (job < nhead) srukf_rank_gdiag_job(n, ld, u1, ha.ra, &fs->gmax_bits, job - ha.ntiles - ha.ndx);
-            else if constexpr (TAIL) {
-                good = tail_job(tla, job - nhead, Sout, ld, T, sy, fs, (unsigned)ha.ndx, xreg, &Wc[0][0], &Lr[0][0], &ok, ts, tid);
-                if (!good) break;
-            }
-        }
-        if (!good && wvu == 0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (job < ha.ntiles) {
+            if (job == 0) GMW_TS(sy, 132, 0);
+            gmw_head_tile_job(n, ld, krows, S0, Ut0, u0, u1, mytile, G, fs, &Lr[0][0], tid, sy, job == 0);
+            if (job == 0) GMW_TS(sy, 132, 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tile stores have landed ...
+            __syncthreads();
+            if (job == 0) GMW_TS(sy, 132, 5);
+            // the list starts with the ha.ncrit tiles the pivot needs before its first panel ((0,0), (0,1), (1,1) in 64 x 64 terms)
+            if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(job < ha.ncrit ? &sy->head_crit : &sy->head_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        } else if (job < ha.ntiles + ha.ndx) {
+            const int dj = job - ha.ntiles;
+            if (ha.ra.prep_next && dj == 0 && tid == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
+            srukf_gain_dx_job(n, ld, ha.dxp, ha.X, dj, ha.xr1, ha.ra.f32round);
+        } else if (job < nhead) srukf_rank_gdiag_job(n, ld, u1, ha.ra, &fs->gmax_bits, job - ha.ntiles - ha.ndx);
         if ((int)blockIdx.x == nmain) GMW_TS(sy, 131, 1);
         if ((int)blockIdx.x == (int)gridDim.x - 1) GMW_TS(sy, 131, 2);
         }
@@ -647,7 +602,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             __syncthreads();
         }
         GMW_TS(sy, 128, 1);
-        if (head_ok) gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid, krows, tail_pivot);
+        if (head_ok) gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid, krows);
         else if (tid == 0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         GMW_TS(sy, 128, 2);
     } else {
@@ -697,8 +652,8 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         if (role == nmain - 1) GMW_TS(sy, 130, 2);
         const int kmax = max(ta.nsteps, tb.nsteps);
         for (int k = 0; k < kmax && good; k++) {
-            if (k < ta.nsteps && k >= ta.kfirst) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1, tail_work);
-            if (good && k < tb.nsteps && k >= tb.kfirst) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1, tail_work);
+            if (k < ta.nsteps && k >= ta.kfirst) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1);
+            if (good && k < tb.nsteps && k >= tb.kfirst) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1);
         }
         }
         if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -716,9 +671,6 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->head_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->head_crit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->job_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->dx_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int q = 0; q < GMW_TAIL_PANELS; q++) __hip_atomic_store(&sy->rows_done[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gated) atomicSub(&g_gmw_admitted, 1);
         }
@@ -758,7 +710,7 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers)
 // S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G); gate_limit > 0: behind k_gmw_gate
 void srukf_launch_gmw_persist_head(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
                                    void* sync, const void* tiles, int ntiles, int workers, void* fs,
-                                   const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit, const HeadArgs* hap, const TailArgs* tap)
+                                   const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit, const HeadArgs* hap)
 {
     if (gate_limit > 0) hipLaunchKernelGGL(k_gmw_gate, dim3(1), dim3(64), 0, st, (FrameScalars*)fs, gate_limit);
     const int T = ld / 64;
@@ -766,22 +718,18 @@ void srukf_launch_gmw_persist_head(hipStream_t st, int n, int ld, double eps, do
     if (krows <= 0 || krows > ld) krows = ld;
     HeadArgs ha = {};
     if (hap) ha = *hap;
-    if (!hap || Tp > GMW_TAIL_PANELS) tap = nullptr;           // tap: DEVICE pointer to the tail-fold arguments (or null)
     if (workers > 0 && ntiles > GMW_OWNED_MAX * workers)
-        hipLaunchKernelGGL((k_gmw_persist<true, false>), dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, HeadArgs{}, (const TailArgs*)nullptr);
-    else if (tap)
-        hipLaunchKernelGGL((k_gmw_persist<false, true>), dim3(ha.nhelp + 1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, ha, tap);
+        hipLaunchKernelGGL((k_gmw_persist<true>), dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, HeadArgs{});
     else
-        hipLaunchKernelGGL((k_gmw_persist<false, false>), dim3(ha.nhelp + 1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
-                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, ha, (const TailArgs*)nullptr);
+        hipLaunchKernelGGL((k_gmw_persist<false>), dim3(ha.nhelp + 1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
+                           (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, ha);
 }
 void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
                               void* sync, const void* tiles, int ntiles, int workers, void* fs,
                               const double* S0, const double* Ut0, int u0, int u1, int Tp, int krows, int gate_limit)
 {
-    srukf_launch_gmw_persist_head(st, n, ld, eps, G, pans, D, Sout, sync, tiles, ntiles, workers, fs, S0, Ut0, u0, u1, Tp, krows, gate_limit, nullptr, nullptr);
+    srukf_launch_gmw_persist_head(st, n, ld, eps, G, pans, D, Sout, sync, tiles, ntiles, workers, fs, S0, Ut0, u0, u1, Tp, krows, gate_limit, nullptr);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }

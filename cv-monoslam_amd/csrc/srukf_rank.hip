@@ -40,6 +40,17 @@ __global__ __launch_bounds__(256) void k_rank_shadow(int n, int ld, int r, const
     for (int b = threadIdx.x; b < ld; b += 256) out[b] = (b >= a && b < n) ? src[perm[b]] : 0.0;
 }
 
+// The structurally null rows in the form every consumer of the null set assumes (NullSkip: both sigma points of such a direction ARE the centre point for every
+// other landmark; k_gain: their share of a cross covariance is sqrt(EPSILON) DZ[i]): S[k] = sqrt(EPSILON) e_k, k = perm[r + blockIdx] — what the reference's clamp
+// leaves there and what every frame tail rewrites.  The null-set decision only knows that the row's energy is below 1e-12 (a state from srukf_set_state may hold
+// zeros or another small diagonal there): the rows are brought into that form when the set is taken, which changes no entry of P by more than 1e-12.
+__global__ __launch_bounds__(256) void k_rank_const_rows(int n, int ld, int r, const int* __restrict__ perm, double* __restrict__ S, double sqeps)
+{
+    const int k = perm[r + blockIdx.x];
+    double* row = S + (size_t)k * ld;
+    for (int c = threadIdx.x; c < ld; c += 256) row[c] = (c == k) ? sqeps : 0.0;
+}
+
 // e[k] = sum_i S[k][i]^2, one workgroup per row
 __global__ __launch_bounds__(256) void k_row_energy(int n, int ld, const double* __restrict__ S, double* __restrict__ e)
 {
@@ -61,7 +72,6 @@ __global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* 
 // One workgroup per row (permuted position a; state row perm[a]), one for the frame tail, and one per 16 dropped indices for the null-direction check.
 // Sp: factor rows in permuted order (row a < r valid for columns b >= a), D: pivots in permuted order, perm[a] = state index at
 // permuted position a, iperm = inverse.  A (may be null): the shadow copy of the kept rows in permuted order.
-// TAIL: the instance whose frame-tail workgroup also runs the next frame's motion reduction ("tail" mode; 82 instead of 59 VGPRs: the default instance carries none of it)
 // MODE 2 ("fused tail", the default of the exclusive rank-aware replay): every workgroup ALSO projects the next frame's sigma points of its direction
 // (passSigmaThroughMesaurementFunction, SLAM.cpp:1615-1690) — the row is in flight anyway, its robot part has just gone through the motion model, the
 // new mean is final — so that the next frame needs no projection launch: the row through LDS, one thread per landmark and +- pair (project_dir's
@@ -72,25 +82,23 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                                                      const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
                                                      FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
                                                      double* __restrict__ A, double* __restrict__ sigR, double gamma,
-                                                     int tailmode, KDims d, KWeights w, double* __restrict__ Cm,
+                                                     KDims d, KWeights w,
                                                      srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32)
 {
-    constexpr bool TAIL = MODE == 1, PROJ = MODE == 2;
+    constexpr bool PROJ = MODE == 2;
     // f32 (fp32 storage, "fused tail" mode): every value this launch writes into S / the permuted copy — and reads back for the table, the projection and
     // the trajectory row — is rounded to float first: the rounding points of k_quantize / k_rank_round, without their launches
     auto rnd = [&](double v) { return f32 ? (double)(float)v : v; };
     extern __shared__ double lrow[];                           // PROJ: the workgroup's row of the factor (permuted order)
     __shared__ double prow[2][8];                              // PROJ: robot part of the direction's two sigma points (what goes into the table)
     __shared__ double red[16 * 3];
-    // the frame-tail workgroup comes first in dispatch order ("tail" mode: it carries the next frame's motion reduction, a one-workgroup chain)
-    const int j = !TAIL ? (int)blockIdx.x : (blockIdx.x == 0) ? n : ((int)blockIdx.x <= n ? (int)blockIdx.x - 1 : (int)blockIdx.x);      // < n: row (permuted position), n: frame tail, > n: null checks (+ PROJ: noise rows)
+    const int j = (int)blockIdx.x;                             // < n: row (permuted position), n: frame tail, > n: null checks (+ PROJ: noise rows)
     // "Table" mode of the replay (sigR != null): the workgroup that writes row j of S also pushes the NEXT frame's two sigma points
     // of direction j through the motion model — robot part only: pose before the step X[n-4..], the row's entries in the robot
     // columns, the control k_gain prepared in fs->ctl — and leaves them in the table the next k_project_table launch reads.
     // Two lanes per workgroup, hidden behind the row copy; the frame tail does the centre point and the five noise rows.
     const int Na = n + 5;
-    // tailmode: the persistent launch in front of this one has written the whole table already (tail fold, srukf_tail.h)
-    const bool table = sigR && !(TAIL && tailmode) && fs->ctl_next_valid && !fs->frozen;
+    const bool table = sigR && fs->ctl_next_valid && !fs->frozen;
     auto table_rows = [&](const int i, const int sg, const double (&srow)[4], const double (&mnoise)[3], const bool isnull) {
         const MotionCtl mc = { fs->ctl[0], fs->ctl[1], fs->ctl[2], fs->ctl[3], fs->ctl[4] };
         const double xr[4] = { X[n - 4], X[n - 3], X[n - 2], X[n - 1] };
@@ -185,13 +193,6 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
             fs->frame += 1;
             fs->const_rows_pending = 1;                         // this launch wrote (or found) every structurally null row of S as sqrt(EPSILON) e_k
             if (!sigR) srukf_prepare_control(fs);              // control of the next staged frame (k_project_motion); "table" mode: k_gain did it
-        }
-        if constexpr (TAIL) if (sigR && tailmode) {
-            // "tail" mode: the next frame's sigma points are projected and its table of robot poses is complete -> its motion step
-            // (sums over the table, srukf_motion_reduce.h) runs here, and the frame starts with k_pxy2.  Results wait in fs->Xr1 / Cm.
-            __shared__ double msm[MOTION_SM_DOUBLES];
-            __syncthreads();
-            if (fs->ctl_next_valid) { RankArgs ra = {}; motion_reduce_body<256, false>(d, w, const_cast<double*>(X), S, sigR, Cm, fs, ra, msm); }
         }
         return;
     }
@@ -314,6 +315,10 @@ void srukf_launch_rank_round(hipStream_t st, int ld, int r, double* A)
 {
     hipLaunchKernelGGL(k_rank_round, dim3(r), dim3(256), 0, st, ld, A);
 }
+void srukf_launch_rank_const_rows(hipStream_t st, int n, int ld, int r, const int* perm, double* S, double sqeps)
+{
+    if (n > r) hipLaunchKernelGGL(k_rank_const_rows, dim3(n - r), dim3(256), 0, st, n, ld, r, perm, S, sqeps);
+}
 void srukf_launch_row_energy(hipStream_t st, int n, int ld, const double* S, double* e)
 {
     hipLaunchKernelGGL(k_row_energy, dim3(n), dim3(256), 0, st, n, ld, S, e);
@@ -324,14 +329,13 @@ void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, cons
 }
 void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
                               const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A, double* sigR, double gamma,
-                              int tailmode, KDims d, KWeights w, double* Cm, srukf_params p, double* Z, double* DZ, int f32)
+                              int fuse, KDims d, KWeights w, srukf_params p, double* Z, double* DZ, int f32)
 {
-    // tailmode 1: "tail" mode (motion reduction in the frame tail); 2: "fused tail" mode (projection of the next frame, five more workgroups, the row in LDS)
+    // fuse: "fused tail" mode (projection of the next frame: five more workgroups, the row in LDS)
     const int nchk = (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
-    const dim3 grid(n + 1 + nchk + (tailmode == 2 ? 5 : 0));
-    if (tailmode == 2) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, 0, d, w, Cm, p, Z, DZ, f32);
-    else if (tailmode) hipLaunchKernelGGL(k_rank_expand<1>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ, 0);
-    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, tailmode, d, w, Cm, p, Z, DZ, 0);
+    const dim3 grid(n + 1 + nchk + (fuse ? 5 : 0));
+    if (fuse) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32);
+    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, 0);
 }
 void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
 {

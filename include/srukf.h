@@ -258,17 +258,24 @@ int  srukf_profile_get(srukf_ctx* ctx, int i, const char** name, double* total_m
                        double* alg_flops, double* alg_bytes);
 int  srukf_profile_reset(srukf_ctx* ctx);
 
-/* Test hook, not for hosts: persistent factorisation launches of this context start without their worker workgroups, as
- * if another process held the GPU (exercises the bounded waits and the fallback to per-panel launches). */
-int  srukf_debug_poke_state(srukf_ctx* ctx, int row, int col, double value);   /* test hook: one entry of S, untracked */
+/* Test hooks, not for hosts.  poke_state: one entry of S behind the back of everything that tracks S.  starve_workers: persistent
+ * factorisation launches of this context start without their worker workgroups, as if another process held the GPU (exercises the
+ * bounded waits and the fallback to per-panel launches). */
+int  srukf_debug_poke_state(srukf_ctx* ctx, int row, int col, double value);
 int  srukf_debug_starve_workers(srukf_ctx* ctx, int on);
 /* Study hook, not for hosts: lets srukf_set_storage accept SRUKF_STORAGE_F32_MIXED below its epsilon floor (where the filter
  * diverges; scripts/mixed_eps_study.py documents exactly that). */
 int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
 
-/* Measurement / test switches, not for hosts (every one defaults to the product path).  Process-wide keys (ctx may be NULL):
- * "gmw_persist", "gmw_fused", "rank_fused", "rank_fold", "rank_aware", "graphs" (0: contexts created afterwards launch eagerly,
- * which rocprofv3 --pmc needs); per-context keys: "use_graph", "fused_motion".  See srukf_api.hip. */
+/* Measurement / test switches, not for hosts (every one defaults to the product path; captured graphs are dropped).
+ * Process-wide keys (ctx may be NULL; they apply to what is built or captured afterwards):
+ *   "gmw_persist" (0: one launch per 64-row panel), "gmw_fused", "rank_fused", "rank_fold" (0: the owners of the persistent launch never form
+ *   their tiles of S^T S - U U^T themselves), "rank_aware", "graphs" (0: contexts created afterwards launch eagerly, which rocprofv3 --pmc needs),
+ *   "tile_xcd" (0: tile list of the persistent launch in plain order), "shared_slack" (0..64), "shared_tenants" (2..8: persistent launches that
+ *   share the GPU in SRUKF_GPU_SHARED).
+ * Per-context keys: "use_graph" (0: eager launches), "fused_motion" (0: k_motion + k_project as two launches, 1: k_project_motion, 2: "table"
+ *   mode), "pxy2" (0: k_pxy instead of k_pxy2), "nullskip", "head_fold" (0: k_syrk launch in front of the persistent launch), "tail_fuse"
+ *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse".  See srukf_api.hip (srukf_ctx::DbgSwitches). */
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
 /* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared"). */
 int  srukf_debug_get(srukf_ctx* ctx, const char* key, long long* value);

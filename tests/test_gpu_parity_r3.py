@@ -109,27 +109,6 @@ def test_head_fold_is_the_same_arithmetic(srukf, synth):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
-def test_tail_fold_is_the_same_arithmetic(srukf, synth):
-    """Exclusive rank-aware replay at N = 200: the NEXT frame's sigma points projected by the helper workgroups of the persistent
-    factorisation launch, row panel by row panel as the factor rows become final ("tail" mode, srukf_debug_set "tail_fold": a frame is k_pxy2, k_gain,
-    k_gmw_persist, k_rank_expand), against "table" mode (k_project_table in front of every frame; "tail_fuse" off in both).  Same device functions on the same
-    values: trajectories and states are bit-identical — over a run split into three calls (each call starts with a projection launch),
-    with graphs and with eager launches."""
-    p = synth.scene_params()
-    N, F = 200, 14
-    sc = synth.make_scene(N, F, seed=8, p=p)
-    res = []
-    for fold, graph in ((1, 1), (0, 1), (1, 0)):
-        f = srukf.Filter(N, p); f.debug_set("tail_fuse", 0); f.debug_set("tail_fold", fold); f.debug_set("use_graph", graph)
-        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
-        traj = np.vstack([f.run_frames(0, 1), f.run_frames(1, 9), f.run_frames(10, F - 10)])
-        X, S = f.get_state()
-        assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0
-        res.append((traj, X, S))
-    for r in res[1:]:
-        assert np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2])
-
-
 def test_fused_tail_agrees_with_table_mode(srukf, synth):
     """ "Fused tail" mode (default at N = 200: k_rank_expand also projects the next frame's sigma points, the frame's motion reduction rides on
     k_pxy2, k_gain re-centres the robot rows of the cross covariances; a frame is four launches) against "table" mode (k_project_table in front of
