@@ -45,13 +45,23 @@ def w_alg(N, M=None):
     return 2.0 * n * n * M + n ** 3 / 3.0 + 2.0 * M * n * n + n ** 3 / 3.0 + 60.0 * L * N
 
 
-def pmc_traffic(kernel):
+def profile_files(pattern, tag):
+    """profiles/<pattern> of one workload, oldest first: tag None = the headline workload (N = 200; files of the other legs carry "n500" / "batch" in their
+    names), otherwise the files whose name contains the tag."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if tag is None:
+        return [f for f in names if "n500" not in os.path.basename(f) and "batch" not in os.path.basename(f)]
+    return [f for f in names if tag in os.path.basename(f)]
+
+
+def pmc_traffic(kernel, tag=None):
     """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
     rocprofv3 --pmc passes, gfx950 correction applied) recorded in the newest
     profiles/*_pmc_traffic.json.  Counters cannot be read from inside this process, so the value
     comes from the committed profile of this same workload; None if there is no profile."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = profile_files("*_pmc_traffic.json", tag)
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -59,11 +69,11 @@ def pmc_traffic(kernel):
     return (k["traffic_bytes"] if k else None), os.path.relpath(files[-1], ROOT)
 
 
-def pmc_mfma(kernel):
+def pmc_mfma(kernel, tag=None):
     """Busy % of the matrix pipes over the kernel's duration (SQ_VALU_MFMA_BUSY_CYCLES, own rocprofv3 --pmc pass) and the
     MFMA flops the hardware counted, from the newest profiles/*_mfma.json of this workload; (None, None, None) without one."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma.json")))
+    files = profile_files("*_mfma.json", tag)
     if not files:
         return None, None, None
     k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
@@ -138,10 +148,12 @@ def launch_selftest(rank, world, force=False):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     n = 16
     sc = {"X0": np.full(n, 1.0 + rank), "S0": np.triu(np.full((n, n), 2.0 + rank))}
-    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, torch.device("cpu"), force=use_dist)
+    binfo = {}
+    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, torch.device("cpu"), force=use_dist, info=binfo)
     same = bool((X0 == 1.0).all() and (S0 == torch.triu(torch.full((n, n), 2.0, dtype=torch.float64))).all())
     traj = torch.full((3, 8), float(rank), dtype=torch.float64)
     tt = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    walls = per_rank_walls(torch, dist, tt, world, use_dist)     # before the max all-reduce overwrites tt
     if use_dist:
         dist.barrier()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -153,11 +165,22 @@ def launch_selftest(rank, world, force=False):
     ok = same and [float(t[0, 0]) for t in allt] == [float(r) for r in range(world)]
     if rank == 0:
         print(json.dumps({"metric": "srukf_updates_per_sec", "value": None, "unit": "frames/s", "n_gpus": seen,
-                          "selftest": True, "collectives_ok": ok, "collectives": (dist.get_backend() if use_dist else None), "wall_max": float(tt.item()), "scaling": "weak"}))
+                          "selftest": True, "collectives_ok": ok, "collectives": (dist.get_backend() if use_dist else None), "wall_max": float(tt.item()), "scaling": "weak",
+                          "rccl_world_size": seen, "per_rank_wall_s": walls, "per_rank_frames_per_s": [3 / w for w in walls],
+                          "slowest_rank": int(np.argmax(walls)), "map_broadcast": binfo or None}))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def per_rank_walls(torch, dist, tt, world, use_dist):
+    """Every rank's own wall time of the timed region (all-gather of one double per rank): which rank set the max the headline uses."""
+    if not use_dist:
+        return [float(tt.item())]
+    parts = [torch.empty_like(tt) for _ in range(world)]
+    dist.all_gather(parts, tt)
+    return [float(p.item()) for p in parts]
 
 
 def build_inputs(synth, N, F, rank, map_seed=0):
@@ -165,25 +188,67 @@ def build_inputs(synth, N, F, rank, map_seed=0):
     return synth.make_scene(N, F, seed=map_seed, p=synth.scene_params(), obs_seed=1000 + rank)
 
 
-def broadcast_map(torch, dist, sc, n, rank, world, device, force=False):
-    """RCCL broadcast of the shared initial map (X0: n doubles, S0: n*n doubles) from rank 0."""
+def broadcast_map(torch, dist, sc, n, rank, world, device, force=False, info=None):
+    """RCCL broadcast of the shared initial map (X0: n doubles, S0: n*n doubles) from rank 0.  info (dict): bytes and wall milliseconds of the
+    two broadcasts as this rank saw them (the first one carries the communicator's lazy setup)."""
     X = torch.empty(n, dtype=torch.float64, device=device)
     S = torch.empty(n, n, dtype=torch.float64, device=device)
     if rank == 0:
         X.copy_(torch.from_numpy(sc["X0"]))
         S.copy_(torch.from_numpy(np.ascontiguousarray(sc["S0"])))
     if world > 1 or force:
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
         dist.broadcast(X, src=0)
         dist.broadcast(S, src=0)
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        if info is not None:
+            info.update({"bytes": 8 * (n + n * n), "ms": (time.perf_counter() - t0) * 1e3})
     return X, S
+
+
+CPU_CHILD = (
+    "import sys, time, json\n"
+    "import numpy as np\n"
+    "sys.path.insert(0, {root!r})\n"
+    "import __graft_entry__ as ge\n"
+    "synth = ge.load_package().synth\n"
+    "from oracle import oracle as O\n"
+    "N, th, F, ra, skip, obs, out, Fr = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7], int(sys.argv[8])\n"
+    "p = synth.scene_params(); sc = synth.make_scene(N, F, seed=0, p=p, obs_seed=(None if obs < 0 else obs)); F = Fr\n"
+    "m = O.Matched(N, p, threads=th); m.set_state(sc['X0'], sc['S0'])\n"
+    "nd = m.set_rank_aware(True) if ra else 0\n"
+    "t_a = m.run_frames(sc['odo'][:skip + 1], sc['z'][:skip], sc['matched'][:skip]) if skip else np.zeros((0, 8))\n"
+    "t0 = time.perf_counter(); t_b = m.run_frames(sc['odo'][skip:F + 1], sc['z'][skip:F], sc['matched'][skip:F]); dt = time.perf_counter() - t0\n"
+    "if out != '-': np.save(out, np.vstack([t_a, t_b]))\n"
+    "print(json.dumps({{'fps': (F - skip) / dt, 'isa': m.isa, 'fallbacks': m.clamp_fallbacks(), 'rank_fallbacks': m.rank_fallbacks(), 'null_directions': nd,\n"
+    "                  'phase_ms': {{k: round(v / F * 1e3, 3) for k, v in m.phase_times().items()}}}}))\n")
+
+
+def run_matched_child(N, threads, F, rank_aware, skip=2, obs_seed=1000, traj_path=None, timeout=1800, run_only=None):
+    """oracle/srukf_matched.c on `threads` cores in a FRESH process (no torch / HIP runtime threads beside the OpenMP team; libgomp reads its binding
+    policy at load time): the bench scene (seed 0, obs_seed), F frames from the initial state, the first `skip` untimed.  rank_aware: the GPU path's
+    own rank-aware form (mt_set_rank_aware).  traj_path: the whole trajectory (F x 8) as .npy.  Returns the child's JSON dict or None."""
+    import subprocess
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", CPU_CHILD.format(root=ROOT), str(N), str(threads), str(F), str(1 if rank_aware else 0), str(skip),
+                        str(-1 if obs_seed is None else obs_seed), traj_path or "-", str(run_only or F)], env=env, capture_output=True, text=True, timeout=timeout)
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
 
 
 def cpu_baseline(synth, sc, N, frames, matched_frames=24):
     """CPU figures of the same workload on this box's host cores (the reference binary cannot be built: a port).
-      value          — oracle/srukf_matched.c: the GPU path's own formulation (structured motion update, one batched
-                       refactor, blocked modified Cholesky) with OpenMP and AVX-512/AVX2 register tiles, best over a
-                       few thread counts up to all host cores; `cores` = the threads of the best run.  This is the
-                       algorithm-matched, multi-core baseline the >= 30x target has to be read against.
+      value          — oracle/srukf_matched.c in the GPU default path's OWN formulation: structured motion update, one batched refactor, blocked modified
+                       Cholesky, and the rank-aware form (structurally null pivots skipped, K <= r, NullSkip) — OpenMP and AVX-512/AVX2 register tiles,
+                       best over a few thread counts up to all host cores; `cores` = the threads of the best run.  The like-for-like baseline.
+      full_rank_value — the same port factoring every pivot (round 3's `value`; what the GPU's full_rank_path is matched to).
       port_value     — oracle/srukf_oracle.c, single thread, batched-refactor mode: `frames` whole frames.
       faithful_value — the reference's own structure (2M refactors per frame, single thread): a few measurement columns
                        timed and extrapolated."""
@@ -214,69 +279,79 @@ def cpu_baseline(synth, sc, N, frames, matched_frames=24):
     except Exception:
         pass
     usable = int(min(ncpu, quota)) if quota else ncpu
-    # every thread count in a FRESH process (no torch / HIP runtime threads beside the OpenMP team, libgomp reads its binding
-    # policy at load time): the same scene, `matched_frames` frames after 2 warm-up frames
-    import subprocess
-    child = (
-        "import sys, time, json\n"
-        f"sys.path.insert(0, {ROOT!r})\n"
-        "import __graft_entry__ as ge\n"
-        "synth = ge.load_package().synth\n"
-        "from oracle import oracle as O\n"
-        "N, th, F = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])\n"
-        "p = synth.scene_params(); sc = synth.make_scene(N, F + 2, seed=0, p=p, obs_seed=1000)\n"
-        "m = O.Matched(N, p, threads=th); m.set_state(sc['X0'], sc['S0'])\n"
-        "m.run_frames(sc['odo'][:3], sc['z'][:2], sc['matched'][:2])\n"
-        "t0 = time.perf_counter(); m.run_frames(sc['odo'][2:], sc['z'][2:], sc['matched'][2:]); dt = time.perf_counter() - t0\n"
-        "print(json.dumps({'fps': F / dt, 'isa': m.isa, 'fallbacks': m.clamp_fallbacks(), 'phase_ms': {k: round(v / (F + 2) * 1e3, 3) for k, v in m.phase_times().items()}}))\n")
-    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMP_NUM_THREADS"):
-        env.pop(k, None)
-    tried, best = {}, None
+    tried = {"rank_aware": {}, "full_rank": {}}
+    best = {"rank_aware": None, "full_rank": None}
     for th in sorted({max(1, usable // 4), max(1, usable // 2), usable, min(ncpu, 2 * usable)}, reverse=True):
-        r = subprocess.run([sys.executable, "-c", child, str(N), str(th), str(matched_frames)], env=env, capture_output=True, text=True, timeout=900)
-        try:
-            res = json.loads(r.stdout.strip().splitlines()[-1])
-        except Exception:
-            tried[str(th)] = None
-            continue
-        tried[str(th)] = round(res["fps"], 2)
-        if best is None or res["fps"] > best[0]:
-            best = (res["fps"], th, res["isa"], res["phase_ms"], res["fallbacks"])
-    if best is None:
+        for form in ("rank_aware", "full_rank"):
+            res = run_matched_child(N, th, matched_frames + 2, form == "rank_aware", skip=2, timeout=900)
+            tried[form][str(th)] = round(res["fps"], 2) if res else None
+            if res and (best[form] is None or res["fps"] > best[form][0]):
+                best[form] = (res["fps"], th, res)
+    if best["rank_aware"] is None or best["full_rank"] is None:
         raise RuntimeError("the matched CPU baseline did not run")
+    bra, bfr = best["rank_aware"], best["full_rank"]
     return {
-        "value": best[0], "unit": "frames/s", "cores": best[1], "kind": "port",
-        "sample": f"{matched_frames} whole frames at N={N} of oracle/srukf_matched.c (algorithm-matched to the GPU's full-rank path: batched refactor, "
-                  f"structured motion update, every pivot factored; OpenMP, {best[2]} tiles) per thread count {sorted(int(k) for k in tried)}, best kept; "
+        "value": bra[0], "unit": "frames/s", "cores": bra[1], "kind": "port",
+        "sample": f"{matched_frames} whole frames at N={N} of oracle/srukf_matched.c in the GPU default path's own formulation (batched refactor, structured motion "
+                  f"update, rank-aware form: {bra[2]['null_directions']} structurally null pivots skipped, K <= r, NullSkip; OpenMP, {bra[2]['isa']} tiles) per thread count "
+                  f"{sorted(int(k) for k in tried['rank_aware'])}, best kept; the same port factoring every pivot (full_rank_value) likewise; "
                   f"single-thread oracle/srukf_oracle.c: {frames} frames in batched-refactor mode ({dt:.1f} s) and {cols} of {2 * N} "
                   f"columns of the reference-structured refactor ({dcol:.3f} s/column) extrapolated",
-        "matched_by_threads": tried, "matched_ms_per_phase": best[3], "matched_clamp_fallbacks": best[4],
+        "matched_by_threads": tried["rank_aware"], "matched_ms_per_phase": bra[2]["phase_ms"], "matched_clamp_fallbacks": bra[2]["fallbacks"],
+        "matched_rank_fallbacks": bra[2]["rank_fallbacks"],
+        "full_rank_value": bfr[0], "full_rank_cores": bfr[1], "full_rank_by_threads": tried["full_rank"], "full_rank_ms_per_phase": bfr[2]["phase_ms"],
+        "full_rank_clamp_fallbacks": bfr[2]["fallbacks"],
         "port_value": frames / dt, "port_cores": 1,
         "faithful_value": 1.0 / faithful_frame, "faithful_cores": 1,
         "cpu_model": model, "host_cores_available": ncpu, "host_cpu_quota": quota,
-        "note": "host_cpu_quota = CPUs' worth of time the container's cgroup grants (cpu.max); thread counts above it lose",
+        "note": "host_cpu_quota = CPUs' worth of time the container's cgroup grants (cpu.max); thread counts above it lose; a whole socket cannot be measured under it",
     }, traj
+
+
+def whole_run_vs_cpu_port_prefix(N, F_scene, F_cmp, gpu_traj, threads, obs_seed, tag):
+    """Same, on the first F_cmp frames of a scene generated for F_scene frames (the scene's odometry depends on its length: the child builds the same one)."""
+    return whole_run_vs_cpu_port(N, F_scene, gpu_traj, threads, obs_seed, tag, F_cmp)
+
+
+def whole_run_vs_cpu_port(N, F, gpu_traj, threads, obs_seed, tag, F_cmp=None):
+    """The north star's "pose RMSE within 1e-6 of reference" over the RUN: the CPU port (oracle/srukf_matched.c, full-rank formulation = the reference's own
+    refactorisation semantics, every pivot factored) replays all F frames of the leg's scene from the same initial state in a fresh process; its trajectory
+    against the device's, frame by frame."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"srukf_cpu_traj_{tag}_{os.getpid()}.npy")
+    res = run_matched_child(N, threads, F, False, skip=0, obs_seed=obs_seed, traj_path=path, run_only=F_cmp)
+    if res is None or not os.path.exists(path):
+        return {"frames_compared": 0, "error": "the CPU port did not run"}
+    ct = np.load(path)
+    os.remove(path)
+    F = F_cmp or F
+    g = np.asarray(gpu_traj)[:F]
+    return {"frames_compared": int(F), "pose_rmse_vs_cpu_port_m": float(np.sqrt(np.mean((g[:, :2] - ct[:, :2]) ** 2))),
+            "max_abs_dpose_vs_cpu_port": float(np.abs(g[:, :4] - ct[:, :4]).max()),
+            "max_abs_dP_robot_vs_cpu_port": float(np.abs(g[:, 4:] - ct[:, 4:]).max()),
+            "cpu_port": f"oracle/srukf_matched.c, full-rank form, {threads} threads, {res['fps']:.1f} frames/s, clamp fallbacks {res['fallbacks']}"}
 
 
 def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
     """BASELINE configs[4] observed by the driver: N = 500 landmarks (n = 3004), fp32 STORAGE of the filter state (X and S live as float
     between frames, every frame computes in fp64 from exactly what fp32 holds: srukf_set_storage), same synthetic scene family, K frames
     of graph replay after W warm-up frames; its own roofline object for the dominant kernel (eager leg of PF frames with HIP events)."""
-    sc = synth.make_scene(N, 4 + PF + W + K, seed=0, p=synth.scene_params())
+    Ftot = 4 + PF + W + K
+    sc = synth.make_scene(N, Ftot, seed=0, p=synth.scene_params())
     f = srukf.Filter(N, sc["params"], device=local)
     f.set_state(sc["X0"], sc["S0"])
     f.set_storage(srukf.STORAGE_F32)
     f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    traj = torch.zeros(Ftot, 8, dtype=torch.float64, device=torch.device("cuda", local))
     f.set_profiling(1)
-    f.run_frames_async(0, 4); f.synchronize(); f.profile_reset()
-    f.run_frames_async(4, PF); f.synchronize()
+    f.run_frames_async(0, 4, srukf.UPDATE_BATCHED, traj.data_ptr()); f.synchronize(); f.profile_reset()
+    f.run_frames_async(4, PF, srukf.UPDATE_BATCHED, traj[4:].data_ptr()); f.synchronize()
     prof = f.profile(); f.set_profiling(0)
     f.prepare_frames(K)
-    f.run_frames_async(4 + PF, W); f.synchronize()
+    f.run_frames_async(4 + PF, W, srukf.UPDATE_BATCHED, traj[4 + PF:].data_ptr()); f.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    f.run_frames_async(4 + PF + W, K); f.synchronize()
+    f.run_frames_async(4 + PF + W, K, srukf.UPDATE_BATCHED, traj[4 + PF + W:].data_ptr()); f.synchronize()
     dt = time.perf_counter() - t0
     pose, _ = f.get_robot()
     err = float(np.abs(np.asarray(pose)[:2] - sc["odo"][4 + PF + W + K, :2]).max())
@@ -289,13 +364,17 @@ def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
     else:
         roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof.update({"traffic": None, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches_per_frame": d["launches"] / PF})
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(dom, "n500")
+    roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma(dom, "n500")
+    roof.update({"kernel": dom, "avg_launch_us": avg_s * 1e6, "launches_per_frame": d["launches"] / PF})
     out = {"workload": f"BASELINE configs[4]: {N} landmarks (n={6 * N + 4}), fp32 storage of X / S between frames, fp64 arithmetic, one GPU",
            "value": K / dt, "unit": "frames/s", "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "dtype": "f64 (state stored as f32)",
            "roofline": roof, "null_directions_skipped": f.null_directions(), "pose_err_vs_truth_m": err,
            "kernels_us_per_frame": {k: round(v["ms"] / PF * 1e3, 1) for k, v in prof.items() if v["launches"]},
            "note": "the mixed-precision sqrt(S) downdate of configs[4] (SRUKF_STORAGE_F32_MIXED) is refused below epsilon = 1e-9: DESIGN.md, row g"}
     f.close()
+    out["_traj"] = traj.cpu().numpy()                              # (popped by the caller: the whole-run comparison with the CPU port)
+    out["_frames"] = Ftot
     return out
 
 
@@ -347,6 +426,7 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames-n500", type=int, default=24, help="frames of the configs4 leg the CPU port replays for the whole-run comparison (>= 20)")
     ap.add_argument("--sequences-per-gpu", type=int, default=3,
                     help="extra measurement: B concurrent independent sequences on one GPU (0 = skip)")
     ap.add_argument("--launch-selftest", action="store_true",
@@ -395,7 +475,8 @@ def main():
     n = 6 * N + 4
     F = W + K + PF + 4
     sc = build_inputs(synth, N, F, rank)
-    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, device, force=use_dist)
+    binfo = {}
+    X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, device, force=use_dist, info=binfo)
 
     # a dedicated HIP stream shared by torch (events, barriers) and the filter (kernel launches):
     # torch.cuda.Event only sees work on the stream it is recorded on
@@ -441,6 +522,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     tt = torch.tensor([wall], dtype=torch.float64, device=device)
+    walls = per_rank_walls(torch, dist, tt, world, use_dist)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     wall_max = float(tt.item())
@@ -485,6 +567,9 @@ def main():
             "frame_full_rank_gflop": w_alg(N) / 1e9,
             "frame_mfma_frac": sum(v["alg_flops"] for v in prof.values()) / PF * (K / wall_max) / (FP64_MFMA_PEAK_TFLOPS * 1e12),
             "collectives": (dist.get_backend() if use_dist else None),     # "nccl" = RCCL: broadcast of the map, barrier, max all-reduce, all-gather all ran
+            # what a scaling run can be checked against: the world size the process group saw, every rank's own rate (value = world * K / max wall), who was slowest
+            "rccl_world_size": (dist.get_world_size() if use_dist else 1), "per_rank_frames_per_s": [K / w for w in walls], "slowest_rank": int(np.argmax(walls)),
+            "map_broadcast": (binfo or None),
             "null_directions_skipped": f.null_directions(),
             "device_ms_per_step": dev_ms / K,
             "pose_rmse_vs_truth_m": pose_rmse_truth,
@@ -501,10 +586,20 @@ def main():
                 "note": "B independent Monte-Carlo sequences replayed concurrently on one GPU (one context/stream each, SRUKF_GPU_SHARED: "
                         "persistent launches of half the CUs, at most two admitted at a time); median over the repetitions of the same block length "
                         "(a repetition far below the median met the ~70 ms multi-stream stall described in DESIGN.md); not the headline value"}
+        c4_traj = c4_frames = None
         if world == 1 and not args.no_configs4:
             out["configs4"] = configs4_leg(torch, synth, srukf, local)
+            c4_traj, c4_frames = out["configs4"].pop("_traj"), out["configs4"].pop("_frames")
         if world == 1 and not args.no_cpu_baseline:
             cb, otraj = cpu_baseline(synth, sc, N, args.cpu_frames)
+            # the whole run (every frame the device computed: measurement leg, warm-up, timed block) against the CPU port's trajectory of the same scene
+            out["whole_run_vs_cpu_port"] = whole_run_vs_cpu_port(N, F, trajs[0], cb["full_rank_cores"], 1000 + rank, "headline")
+            for k in ("pose_rmse_vs_cpu_port_m", "max_abs_dP_robot_vs_cpu_port", "frames_compared"):
+                out[k] = out["whole_run_vs_cpu_port"].get(k)
+            if c4_traj is not None:
+                nf = min(c4_frames, args.cpu_frames_n500)
+                out["configs4"]["whole_run_vs_cpu_port"] = whole_run_vs_cpu_port(500, c4_frames, c4_traj, cb["full_rank_cores"], None, "configs4") if nf >= c4_frames else \
+                    whole_run_vs_cpu_port_prefix(500, c4_frames, nf, c4_traj, cb["full_rank_cores"], None, "configs4")
             g = srukf.Filter(N, sc["params"], device=local)
             g.set_state(sc["X0"], sc["S0"])
             g.stage_sequence(sc["odo"][:args.cpu_frames + 1], sc["z"][:args.cpu_frames], sc["matched"][:args.cpu_frames])
@@ -524,9 +619,15 @@ def main():
             g.close()
             out["full_rank_path"] = {"frames_per_s": full_rank_fps, "note": "same workload with srukf_set_rank_aware(0): every pivot factored, as in round 1 and in the matched CPU baseline"}
             out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = {"matched_all_cores": out["value"] / cb["value"], "matched_all_cores_full_rank_gpu_path": full_rank_fps / cb["value"],
-                                   "port_1_thread": out["value"] / cb["port_value"],
-                                   "reference_structure_1_thread": out["value"] / cb["faithful_value"]}
+            out["gpu_over_cpu"] = {
+                # like for like: the GPU's default path against the CPU port running the SAME algorithm (rank-aware form) on the cores the cgroup grants
+                "matched_same_algorithm": out["value"] / cb["value"],
+                # the two ratios of round 3: default GPU path / full-rank GPU path against the CPU port that factors every pivot
+                "matched_all_cores": out["value"] / cb["full_rank_value"], "matched_all_cores_full_rank_gpu_path": full_rank_fps / cb["full_rank_value"],
+                "port_1_thread": out["value"] / cb["port_value"],
+                "reference_structure_1_thread": out["value"] / cb["faithful_value"],
+                "note": "the north star's >= 30x is stated against a single SOCKET; this container's cgroup grants host_cpu_quota CPUs, so no socket figure exists here: "
+                        "matched_same_algorithm is against those CPUs only"}
             out["pose_rmse_vs_oracle_m"] = float(np.sqrt(np.mean((gt[:, :2] - otraj[:, :2]) ** 2)))
             out["max_abs_dP_robot_vs_oracle"] = float(np.abs(gt[:, 4:] - otraj[:, 4:]).max())
         if world == 1 and not use_dist and not args.no_collectives_check:

@@ -206,7 +206,8 @@ struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
 static std::atomic<int> g_dbg_shared_slack{0};      // SRUKF_GPU_SHARED: CUs each tenant leaves free (srukf_debug_set "shared_slack")
-struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, T = 0, Tp = 0, workers = -1, tenants = 1, cus = 0; };
+// nreal: the tiles that hold values (ntiles minus the T - Tp pass-on tiles of the rank-aware form, which ride as a register-free third slot of the first workers)
+struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, nreal = 0, T = 0, Tp = 0, workers = -1, tenants = 1, cus = 0; };
 static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 {
     if (g.pans) srukf_dfree_on(g.pans, st);
@@ -222,8 +223,9 @@ static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 // of the launch).  Here the tiles whose owners compute them are cut into 8 compact 2D regions (two bands of block rows x four ranges of block
 // columns), one per XCD; the others (head rows, pass-on row) fill the XCDs up to equal counts.  Which worker owns which tile changes nothing else.
 static std::atomic<int> g_dbg_tile_xcd{1};
-static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles, int workers, int T, int Tp)
+static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles_all, int workers, int T, int Tp)
 {
+    const int ntiles = ntiles_all - ((Tp > 0 && Tp < T) ? T - Tp : 0);         // the pass-on tiles stay at the end of the list (third slot of the first workers)
     if (!g_dbg_tile_xcd || ntiles > workers || ntiles < 16) return;
     struct Tl { short v[4]; };
     std::vector<Tl> comp, rest;
@@ -269,6 +271,7 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     const int cap = cus / (tenants > 1 ? tenants : 1) - 1 - (tenants > 1 ? g_dbg_shared_slack.load() : 0);    // one workgroup per CU (registers), all of them resident
     g.workers = cap >= 1 ? srukf_gmw_persist_workers(g.T, g.Tp, cap) : -1;
     g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
+    g.nreal = g.ntiles - (g.Tp < g.T ? g.T - g.Tp : 0);
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
     srukf_gmw_build_tiles(g.T, g.Tp, tk.data());
     gmw_tiles_xcd_order(tk, g.ntiles, g.workers, g.T, g.Tp);
@@ -566,10 +569,15 @@ static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool 
     }
 }
 // the rank-aware replay whose owners form their tiles of S^T S - U U^T themselves (seq_refactor below): what a whole staged frame takes
+// How many tiles per worker (in percent) the owners' fold accepts: 106 = about one tile per worker (measured in round 2: with two tiles per worker, both to be formed
+// before the first step, the exclusive replay loses — N = 300: 1 544 against 1 663 frames/s); srukf_debug_set "fold_tiles_pct" 200 lets filters that share the GPU
+// (many tenants of few CUs each: two register tiles per worker) fold as well
+static std::atomic<int> g_dbg_fold_tiles_pct{106};
+static int fold_tiles_pct() { return g_dbg_fold_tiles_pct.load(); }
 static bool replay_red_fused(const srukf_ctx* c)
 {
     return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && gmw_use_persist(c) &&
-           c->gplan_red.workers >= 0 && c->gplan_red.ntiles <= c->gplan_red.workers + c->gplan_red.workers / 16 && c->gplan_red.T >= 16 &&
+           c->gplan_red.workers >= 0 && c->gplan_red.nreal <= c->gplan_red.workers * fold_tiles_pct() / 100 && c->gplan_red.T >= 16 &&
            !c->debug_starve && gmw_fused_mode() && rank_fused_mode() && rank_fold_mode();
 }
 // 0: k_motion + k_project; 1: k_project_motion (motion workgroup + projection with the robot part inline); 2: "table" (k_project_table: the
@@ -1987,6 +1995,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     struct { const char* k; std::atomic<int>* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs },
                                                     { "tile_xcd", &g_dbg_tile_xcd } };      // tile_xcd: applies to plans built afterwards (set it before the state)
+    if (!strcmp(key, "fold_tiles_pct")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
     if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
         if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;

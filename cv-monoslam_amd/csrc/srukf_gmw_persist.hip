@@ -546,13 +546,18 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     // launched grid is ~2 us (cold TLB and L2, 256 workgroups asking at once), and flag -> list entry -> operands was a chain of three of them in front
     // of the critical head tiles (time stamps: 7.5 us before the first MFMA).  The asm pins all four loads in front of the first use.
     int2 mytile = make_int2(-1, -1);
-    unsigned long long t01 = 0, t23 = 0;                       // GmwTile entries (4 shorts each) of a worker's two tiles
+    unsigned long long t01 = 0, t23 = 0, t45 = 0;              // GmwTile entries (4 shorts each) of a worker's two tiles and of its pass-on tile
+    // The pass-on tiles of the rank-aware form (row block Tp: they turn the last pivoted panel into S rows for their columns, hold no values) stand at the end
+    // of the list and are a THIRD slot of the first npass workers: they join at step Tp - 1, when every register tile has retired (nsteps <= Tp - 1), and use
+    // its accumulator set — T - Tp workgroups (CUs) fewer per launch than one worker per pass-on tile.
+    const int npass = (!MEM && Tp < T) ? T - Tp : 0, nreal = ntiles - npass;
     if (!MEM) {
         if (role < 0) { const int hb = (int)blockIdx.x - nmain; if (hb < ha.ntiles) mytile = ha.tiles[hb]; }
         else if (role > 0) {
             const unsigned long long* tq = (const unsigned long long*)tiles;
-            if (role - 1 < ntiles) t01 = tq[role - 1];
-            if (role - 1 + nmain - 1 < ntiles) t23 = tq[role - 1 + nmain - 1];
+            if (role - 1 < nreal) t01 = tq[role - 1];
+            if (role - 1 + nmain - 1 < nreal) t23 = tq[role - 1 + nmain - 1];
+            if (role - 1 < npass) t45 = tq[nreal + role - 1];
         }
     }
     int frozen_now = fs->frozen;
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
     // (Measured, both ways, per instance.  Register-resident tiles: pinned as VECTOR registers 148-150 us per launch at N = 200, as scalar ones 152-153.5.
     //  Memory tiles (N = 500): as vector registers 46 VGPR spills and 627 us per launch, as scalar ones 27 spills and 575 us.)
     if constexpr (MEM) asm volatile("" : "+s"(frozen_now), "+s"(epoch_now));
-    else asm volatile("" : "+v"(mytile.x), "+v"(mytile.y), "+v"(t01), "+v"(t23), "+v"(frozen_now), "+v"(epoch_now));
+    else asm volatile("" : "+v"(mytile.x), "+v"(mytile.y), "+v"(t01), "+v"(t23), "+v"(t45), "+v"(frozen_now), "+v"(epoch_now));
     if (frozen_now) return;                                    // staged replay behind a flagged frame: every workgroup leaves before it touches the sync block
     const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
     // (Letting the critical head tiles go first — every other role sleeping 1 .. 5 us before its first operand loads — was measured: 195.5 us per
@@ -626,10 +631,11 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
                     good = gmw_owner_step(n, ld, T, k, tm, accm, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, true, half_last && k == Tp - 1);
                 }
         } else {
-        GmwOwned ta = { 0, 0, 0, false, 0, false }, tb = { 0, 0, 0, false, 0, false };
+        GmwOwned ta = { 0, 0, 0, false, 0, false }, tb = { 0, 0, 0, false, 0, false }, tc = { 0, 0, 0, false, 0, false };
         auto entry = [](unsigned long long q) { GmwTile t; t.I = (short)(q & 0xffff); t.J = (short)((q >> 16) & 0xffff); t.nsteps = (short)((q >> 32) & 0xffff); t.pad = (short)((q >> 48) & 0xffff); return t; };
-        if (w < ntiles) { const GmwTile t = entry(t01); ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; ta.kfirst = t.pad; ta.passon = Tp < T && t.I == Tp; }
-        if (w + workers < ntiles) { const GmwTile t = entry(t23); tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; tb.kfirst = t.pad; tb.passon = Tp < T && t.I == Tp; }
+        if (w < nreal) { const GmwTile t = entry(t01); ta.I = t.I; ta.J = t.J; ta.nsteps = t.nsteps; ta.kfirst = t.pad; ta.passon = Tp < T && t.I == Tp; }
+        if (w + workers < nreal) { const GmwTile t = entry(t23); tb.I = t.I; tb.J = t.J; tb.nsteps = t.nsteps; tb.kfirst = t.pad; tb.passon = Tp < T && t.I == Tp; }
+        if (w < npass) { const GmwTile t = entry(t45); tc.I = t.I; tc.J = t.J; tc.nsteps = t.nsteps; tc.kfirst = t.pad; tc.passon = true; tc.computed = true; }
         d4 acca[2][2], accb[2][2];
         zero_acc(acca); zero_acc(accb);
         if (role == 1) GMW_TS(sy, 129, 0);
@@ -655,6 +661,8 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             if (k < ta.nsteps && k >= ta.kfirst) good = gmw_owner_step(n, ld, T, k, ta, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1);
             if (good && k < tb.nsteps && k >= tb.kfirst) good = gmw_owner_step(n, ld, T, k, tb, accb, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last && k == Tp - 1);
         }
+        // the pass-on slot: step Tp - 1 only, behind every step of the register tiles (which end at Tp - 2 at the latest); its accumulator values are never used
+        if (good && tc.nsteps > 0) good = gmw_owner_step(n, ld, T, tc.kfirst, tc, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last);
         }
         if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (role == 1) GMW_TS(sy, 129, 3);
@@ -702,10 +710,20 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers)
 {
     const int nt = srukf_gmw_build_tiles(T, Tp, nullptr);
     if (nt == 0) return 0;
-    if (nt <= max_workers) return nt;
-    if (nt <= GMW_OWNED_MAX * max_workers) return max_workers;
-    if (nt <= GMW_OWNED_MEM * max_workers) return max_workers;   // > GMW_OWNED_MAX tiles per worker: the memory-tile form
+    // register form: the pass-on tiles (row block Tp of the rank-aware form, the last T - Tp entries of the list) ride as a third, register-free slot
+    const int npass = (Tp > 0 && Tp < T) ? T - Tp : 0, nreal = nt - npass;
+    if (nreal >= 1 && nreal <= GMW_OWNED_MAX * max_workers) {
+        const int w = nreal <= max_workers ? nreal : max_workers;
+        if (npass <= w) return w;
+    }
+    if (nt <= GMW_OWNED_MEM * max_workers) return max_workers;   // > GMW_OWNED_MAX tiles per worker: the memory-tile form (no third slot: every tile is a list entry)
     return -1;
+}
+// register form (true) or memory-tile form (false) for `workers` workers: what srukf_launch_gmw_persist_head decides by
+static bool gmw_register_form(int T, int Tp, int ntiles, int workers)
+{
+    const int npass = (Tp > 0 && Tp < T) ? T - Tp : 0, nreal = ntiles - npass;
+    return workers > 0 && nreal <= GMW_OWNED_MAX * workers && npass <= workers;
 }
 // S0 / Ut0 / [u0, u1): see k_gmw_persist (null: every tile is read from G); gate_limit > 0: behind k_gmw_gate
 void srukf_launch_gmw_persist_head(hipStream_t st, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout,
@@ -718,7 +736,7 @@ void srukf_launch_gmw_persist_head(hipStream_t st, int n, int ld, double eps, do
     if (krows <= 0 || krows > ld) krows = ld;
     HeadArgs ha = {};
     if (hap) ha = *hap;
-    if (workers > 0 && ntiles > GMW_OWNED_MAX * workers)
+    if (workers > 0 && !gmw_register_form(T, Tp, ntiles, workers))
         hipLaunchKernelGGL((k_gmw_persist<true>), dim3(1 + workers), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps,
                            (GmwSync*)sync, (const GmwTile*)tiles, ntiles, (FrameScalars*)fs, S0, Ut0, u0, u1, krows, gate_limit > 0 ? 1 : 0, HeadArgs{});
     else

@@ -280,6 +280,10 @@ def matched_lib():
         L.mt_clamp_fallbacks.argtypes = [C.c_void_p]
         L.mt_phase_times.argtypes = [C.c_void_p, _dp]
         L.mt_isa_name.restype = C.c_char_p
+        L.mt_set_rank_aware.argtypes = [C.c_void_p, C.c_int]
+        L.mt_null_directions.argtypes = [C.c_void_p]
+        L.mt_rank_fallbacks.restype = C.c_longlong
+        L.mt_rank_fallbacks.argtypes = [C.c_void_p]
         _mlib = L
     return _mlib
 
@@ -326,6 +330,18 @@ class Matched:
 
     def clamp_fallbacks(self):
         return int(matched_lib().mt_clamp_fallbacks(self._h))
+
+    def set_rank_aware(self, on=True):
+        """The GPU path's rank-aware refactorisation (structurally null pivots skipped, K <= r in the contractions, NullSkip in the projection) for the
+        CPU port as well: takes the null set from the CURRENT state (call after set_state).  Returns the number of skipped directions."""
+        return int(matched_lib().mt_set_rank_aware(self._h, 1 if on else 0))
+
+    def null_directions(self):
+        return int(matched_lib().mt_null_directions(self._h))
+
+    def rank_fallbacks(self):
+        """Frames of the rank-aware form that were repeated on the full-rank path (a skipped direction not null, or the theta clamp)."""
+        return int(matched_lib().mt_rank_fallbacks(self._h))
 
     def phase_times(self):
         """Seconds spent so far in (motion, measurement, gains, S^T S - U U^T, factorisation, exact fallback)."""

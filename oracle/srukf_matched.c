@@ -34,6 +34,11 @@ typedef struct mt_state {
     double *D;                         /* np pivots                                                                   */
     double *h, *Si; int *vis;
     long long clamp_fallbacks;
+    /* rank-aware form (mt_set_rank_aware; the GPU path's default, DESIGN.md "Rank-aware refactorisation"): the r kept directions first, same relative order */
+    int rank_aware, r;                 /* r = 0: the full-rank form runs                                              */
+    int *perm, *iperm;                 /* permuted position -> state index and back (np entries)                      */
+    double *A;                         /* np x np: kept rows of S in permuted column order (rows >= r unused)         */
+    long long rank_fallbacks;          /* frames whose skipped directions were found not to be null (full path taken) */
     double t_phase[6];                 /* seconds spent in motion, measurement, gains, S^T S - U U^T, factorisation, fallback */
 } mt_state;
 
@@ -54,6 +59,8 @@ ORC_API mt_state *mt_create(int N, const srukf_params *p, int threads)
     m->D = (double *)calloc(np, sizeof(double));
     m->h = (double *)calloc(mp, sizeof(double)); m->Si = (double *)calloc(4 * (size_t)(N > 0 ? N : 1), sizeof(double));
     m->vis = (int *)calloc(N > 0 ? N : 1, sizeof(int));
+    m->perm = (int *)calloc(np, sizeof(int)); m->iperm = (int *)calloc(np, sizeof(int));
+    m->A = (double *)calloc(np * np, sizeof(double));
     if (threads > 0) omp_set_num_threads(threads);
     return m;
 }
@@ -62,7 +69,7 @@ ORC_API void mt_destroy(mt_state *m)
     if (!m) return;
     orc_destroy(m->o);
     free(m->S); free(m->G); free(m->Gbak); free(m->sigR); free(m->Z); free(m->DZ); free(m->Ut); free(m->Lw); free(m->D);
-    free(m->h); free(m->Si); free(m->vis); free(m);
+    free(m->h); free(m->Si); free(m->vis); free(m->perm); free(m->iperm); free(m->A); free(m);
 }
 ORC_API int mt_threads(void) { int t = 1;
 #pragma omp parallel
@@ -256,10 +263,29 @@ static void mt_measure(mt_state *m)
     orc_state *o = m->o; const srukf_params *p = &o->p;
     const int n = m->n, Na = m->Na, L = m->L, N = m->N; const size_t np = m->np, mp = m->mp;
     const double g = o->gamma;
+    const int ra = m->r > 0;
+    if (ra) {                                                                     /* the centre point first: structurally null directions copy its row */
+        double err0[2] = { 0, 0 }, Rwc[9], Rcw[9];
+        const double *rob = m->sigR;
+        transfer_matrix(Rwc, rob[3]); inv3(Rwc, Rcw);
+        for (int k = 0; k < N; k++) mt_project(o, p, o->X + 6 * k, rob, Rcw, err0, m->Z + 2 * k);
+    }
 #pragma omp parallel for schedule(dynamic, 8)
-    for (int c = 0; c < L; c++) {
+    for (int c = ra ? 1 : 0; c < L; c++) {
         const int i = c > 0 ? (c - 1) % Na : -1; const double sg = (c - 1) < Na ? g : -g;
         double err[2] = { 0, 0 };
+        if (ra && i < n && m->iperm[i] >= m->r) {
+            /* NullSkip (srukf_device.h): row i of S is sqrt(EPSILON) e_i and moves ONE landmark; every other landmark's sigma point is the centre
+             * point's, bit for bit (same function, same inputs: the robot part of this sigma point equals the centre's) */
+            const int k = i / 6;
+            const double *rob = m->sigR + (size_t)c * 4;
+            double *zr = m->Z + (size_t)c * mp, Rwc[9], Rcw[9], feat[6];
+            memcpy(zr, m->Z, sizeof(double) * 2 * N);
+            transfer_matrix(Rwc, rob[3]); inv3(Rwc, Rcw);
+            for (int e = 0; e < 6; e++) { const int col = 6 * k + e; feat[e] = o->X[col] * 1 + ((col >= i) ? m->S[(size_t)i * np + col] : 0.0) * sg + 0; }
+            mt_project(o, p, feat, rob, Rcw, err, zr + 2 * k);
+            continue;
+        }
         if (i == n + 3) err[0] = 0.0 * 1 + o->Qt[0] * sg + 0; else if (i == n + 4) err[1] = 0.0 * 1 + o->Qt[1] * sg + 0;
         const double *rob = m->sigR + (size_t)c * 4;
         double *zr = m->Z + (size_t)c * mp;
@@ -276,9 +302,10 @@ static void mt_measure(mt_state *m)
         }
     }
 #pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; i++) {
+    for (int a = 0; a < n; a++) {                                                 /* rank-aware form: the rows of DZ in permuted order */
+        const int i = ra ? m->perm[a] : a;
         const double *zp = m->Z + (size_t)(1 + i) * mp, *zm = m->Z + (size_t)(1 + Na + i) * mp;
-        double *d = m->DZ + (size_t)i * mp;
+        double *d = m->DZ + (size_t)a * mp;
         for (int q = 0; q < 2 * N; q++) d[q] = zp[q] - zm[q];
     }
     const double wsum = o->wm0 + 2.0 * Na * o->wi;
@@ -314,14 +341,25 @@ static void mt_gain(mt_state *m, const double *z, const int *matched)
     const double sc = o->wi * o->gamma;
     /* landmark rows of all cross covariances: Ut_raw[q][r] = sum_{i <= r} S[i][r] DZ[i][q]  (S upper: K truncated) */
     const int MR = ((int)np + 95) / 96, MQ = (int)mp / 48;
+    const int ra = m->r > 0, kr = m->r;
+    const double *Sop = ra ? m->A : m->S;                                         /* rank-aware form: kept rows, permuted columns, K <= r */
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
     for (int mr = MR - 1; mr >= 0; mr--)
         for (int mq = 0; mq < MQ; mq++) {
             const int r0 = mr * 96, q0 = mq * 48;
             const int nct = ((int)np - r0 < 96 ? (int)np - r0 : 96) / 24;
             int K = r0 + 24 * nct; if (K > n) K = n;
-            mt_macro_tn(K, m->DZ + q0, mp, m->S + r0, np, m->Ut + (size_t)q0 * np + r0, np, 6, nct, 1.0, 0, 2, r0, 0, 0, 0);
+            if (ra && K > kr) K = kr;
+            mt_macro_tn(K, m->DZ + q0, mp, Sop + r0, np, m->Ut + (size_t)q0 * np + r0, np, 6, nct, 1.0, 0, (ra && r0 + 24 * nct > kr) ? 0 : 2, r0, 0, 0, 0);
         }
+    if (ra) {                                                                     /* the null rows' share: sqrt(EPSILON) DZ[i] into column i only */
+        const double sqeps = sqrt(o->p.epsilon);
+#pragma omp parallel for schedule(static)
+        for (int b = kr; b < n; b++) {
+            const int k = m->perm[b] / 6;
+            for (int e = 0; e < 2; e++) m->Ut[(size_t)(2 * k + e) * np + b] += sqeps * m->DZ[(size_t)b * mp + 2 * k + e];
+        }
+    }
     /* robot rows of Pxy: sum_c w_c (r_c - X_r)(Z_c - h) */
     double *pr = (double *)calloc((size_t)4 * mp, sizeof(double));
 #pragma omp parallel for schedule(static)
@@ -346,10 +384,11 @@ static void mt_gain(mt_state *m, const double *z, const int *matched)
     }
     const double cw = o->wc0 - o->wm0;
 #pragma omp parallel for schedule(static)
-    for (int r = 0; r < n; r++) {
+    for (int rq = 0; rq < n; rq++) {
+        const int r = ra ? m->perm[rq] : rq;                                      /* state row; rq = its column of U^T */
         double dxr = 0.0;
         for (int k = 0; k < N; k++) {
-            double *u0p = m->Ut + (size_t)(2 * k) * np + r, *u1p = m->Ut + (size_t)(2 * k + 1) * np + r;
+            double *u0p = m->Ut + (size_t)(2 * k) * np + rq, *u1p = m->Ut + (size_t)(2 * k + 1) * np + rq;
             if (!(matched[k] && m->vis[k])) { *u0p = 0.0; *u1p = 0.0; continue; }
             const double *l = lk + 8 * k;
             double p0, p1;
@@ -461,16 +500,198 @@ static int mt_gmw(mt_state *m)
     return clamp;
 }
 
+
+/* ==== rank-aware form (the GPU path's default; cv-monoslam_amd/csrc/srukf_rank.hip): the structurally null pivots are not factored ====
+ * Rows of S with energy below 1e-12 (never the robot's) are structurally null directions (anchors of jointly initialised landmarks are
+ * copies of one robot position, SLAM.cpp:1223, 1247): the reference's modified Cholesky clamps their pivots to EPSILON (2279-2285).  The
+ * refactorisation runs on the permuted matrix (kept indices first, same relative order), pivots only the r kept rows, carries all n columns
+ * along, and writes sqrt(EPSILON) e_k for the rest; the contractions end at K = r.  Same rule, same check, same fallback as the device. */
+#define MT_NULL_ENERGY 1e-12
+static void mt_rebuild_A(mt_state *m)
+{
+    const int n = m->n, r = m->r; const size_t np = m->np;
+#pragma omp parallel for schedule(static)
+    for (int a = 0; a < r; a++) {
+        const double *src = m->S + (size_t)m->perm[a] * np; double *dst = m->A + (size_t)a * np;
+        for (int b = 0; b < (int)np; b++) dst[b] = (b >= a && b < n) ? src[m->perm[b]] : 0.0;
+    }
+}
+ORC_API int mt_set_rank_aware(mt_state *m, int on)
+{
+    const int n = m->n; const size_t np = m->np;
+    m->rank_aware = on ? 1 : 0; m->r = 0;
+    if (!on || n < 128) return 0;
+    int r = 0, nd = 0;
+    int *drop = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        double e = 0.0; for (int i = k; i < n; i++) e += m->S[(size_t)k * np + i] * m->S[(size_t)k * np + i];
+        if (k < n - 4 && e < MT_NULL_ENERGY) drop[nd++] = k; else m->perm[r++] = k;
+    }
+    if (nd == 0) { free(drop); return 0; }
+    for (int q = 0; q < nd; q++) m->perm[r + q] = drop[q];
+    for (int k = n; k < (int)np; k++) m->perm[k] = k;
+    for (int a = 0; a < (int)np; a++) m->iperm[m->perm[a]] = a;
+    const double sqeps = sqrt(m->o->p.epsilon);
+    for (int q = 0; q < nd; q++) { double *row = m->S + (size_t)drop[q] * np; memset(row, 0, sizeof(double) * np); row[drop[q]] = sqeps; }   /* k_rank_const_rows */
+    free(drop);
+    m->r = r;
+    mt_rebuild_A(m);
+    return nd;
+}
+ORC_API int mt_null_directions(const mt_state *m) { return m->r > 0 ? m->n - m->r : 0; }
+ORC_API long long mt_rank_fallbacks(const mt_state *m) { return m->rank_fallbacks; }
+
+/* Gp = A^T A - Up Up^T on the kept rows (a < r) x all permuted columns b >= a, K <= r; gdiag[b] for the dropped positions into D[b] (scratch) */
+static void mt_syrk_ra(mt_state *m, double *gdiag)
+{
+    const int n = m->n, r = m->r; const size_t np = m->np, mp = m->mp;
+    const int MI = (r + 47) / 48, MJ = ((int)np + 95) / 96;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int mi = MI - 1; mi >= 0; mi--)
+        for (int mj = 0; mj < MJ; mj++) {
+            const int i0 = mi * 48, j0 = mj * 96;
+            if (j0 + 96 <= i0) continue;
+            const int nct = ((int)np - j0 < 96 ? (int)np - j0 : 96) / 24;
+            int K = i0 + 48; if (K > r) K = r;
+            double *C = m->G + (size_t)i0 * np + j0;
+            mt_macro_tn(K, m->A + i0, np, m->A + j0, np, C, np, 6, nct, 1.0, 0, (i0 + 48 > r) ? 0 : 1, i0, 1, i0, j0);
+            mt_macro_tn((int)mp, m->Ut + i0, np, m->Ut + j0, np, C, np, 6, nct, -1.0, 1, 0, 0, 1, i0, j0);
+        }
+#pragma omp parallel for schedule(static)
+    for (int b = r; b < n; b++) {
+        double t = 0.0;
+        for (int k = 0; k < r; k++) { const double v = m->A[(size_t)k * np + b]; t += v * v; }
+        for (int q = 0; q < (int)mp; q++) { const double v = m->Ut[(size_t)q * np + b]; t -= v * v; }
+        gdiag[b] = t;
+    }
+}
+/* the blocked modified Cholesky of mt_gmw on the leading r pivots of Gp; then back to state order.  Returns clamp rows + failed null checks. */
+static int mt_gmw_ra(mt_state *m, const double *gdiag)
+{
+    const int n = m->n, r = m->r; const size_t np = m->np;
+    double *G = m->G, *D = m->D; const double eps = m->o->p.epsilon;
+    double gmax = -INFINITY, xi = -INFINITY;
+#pragma omp parallel for reduction(max : gmax, xi) schedule(static)
+    for (int a = 0; a < n; a++) {
+        if (a >= r) { if (gdiag[a] > gmax) gmax = gdiag[a]; continue; }
+        if (G[(size_t)a * np + a] > gmax) gmax = G[(size_t)a * np + a];
+        for (int c = a + 1; c < n; c++) if (G[(size_t)a * np + c] > xi) xi = G[(size_t)a * np + c];   /* kept rows x all columns: holds every value of the dropped block (copies) */
+    }
+    xi = fmax(xi, 0.0);
+    const double nu = fmax(1.0, sqrt((double)n * n - 1.0)), beta2 = fmax(fmax(gmax, xi / nu), 1e-15);
+    for (int j0 = 0; j0 < r; j0 += MT_NB) {
+        const int nb = (r - j0 < MT_NB) ? r - j0 : MT_NB, t0 = j0 + nb;
+        for (int j = j0; j < j0 + nb; j++) {
+            double *wj = G + (size_t)j * np;
+            const double dj = fmax(eps, fabs(wj[j]));
+            D[j] = dj;
+            for (int k = j + 1; k < j0 + nb; k++) {
+                const double f = wj[k] / dj;
+                double *wk = G + (size_t)k * np;
+                for (int i = k; i < j0 + nb; i++) wk[i] -= f * wj[i];
+            }
+        }
+        /* the panel's rows right of the diagonal block: all n columns are carried along */
+        const int ncol = (int)np - t0, slab = 96, nsl = (ncol + slab - 1) / slab;
+#pragma omp parallel for schedule(static)
+        for (int s = 0; s < nsl; s++) {
+            const int ib = t0 + s * slab, ie = (ib + slab < (int)np) ? ib + slab : (int)np;
+            mt_panel_rows(nb, j0, ib, ie, G, np, D);
+            for (int j = j0; j < j0 + nb; j++) {
+                const double id = 1.0 / D[j];
+                const double *wj = G + (size_t)j * np; double *lj = m->Lw + (size_t)(j - j0) * np;
+                for (int i = ib; i < ie; i++) lj[i] = wj[i] * id;
+            }
+        }
+        if (t0 >= r) break;                                   /* (a full panel: t0 = j0 + 48 keeps the 8 x 24 tile grid) */
+        /* trailing update of the KEPT rows only: k in [t0, r), i >= k */
+        const int T8 = (r - t0 + 7) / 8, T24 = ((int)np - t0) / 24;
+#pragma omp parallel for schedule(dynamic, 8) collapse(2)
+        for (int tk = 0; tk < T8; tk++)
+            for (int ti = 0; ti < T24; ti++) {
+                const int k0 = t0 + tk * 8, i0 = t0 + ti * 24;
+                if (i0 + 24 <= k0) continue;
+                mt_tile_tn(nb, m->Lw + k0, np, G + (size_t)j0 * np + i0, np, G + (size_t)k0 * np + i0, np, -1.0, 1);
+            }
+    }
+    /* checks BEFORE anything is written (the state before the refactorisation stays intact for the fallback): theta clamp of the reference on the kept
+     * rows (as k_gmw_check / k_rank_expand do), and every skipped direction null in THIS frame's G: G_bb - sum_{a<r} Sp[a][b]^2 <= 1e-12 */
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int a = 0; a < r; a++) {
+        const int j = m->perm[a];
+        const double sd = sqrt(D[a]), is = 1.0 / sd;
+        const double *wa = G + (size_t)a * np;
+        double mx = 0.0;
+        for (int b = a + 1; b < n; b++) if (m->perm[b] > j) { const double v = fabs(wa[b] * is); if (v > mx) mx = v; }
+        const double th = mx * sd;
+        if (th * th / beta2 > D[a]) bad++;
+    }
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int b = r; b < n; b++) {
+        double t = 0.0;
+        for (int a = 0; a < r; a++) { const double v = G[(size_t)a * np + b]; t += v * v / D[a]; }
+        if (gdiag[b] - t > MT_NULL_ENERGY) bad++;
+    }
+    return bad;
+}
+/* back to state order (k_rank_expand): kept rows are upper triangular there (what stands left of the diagonal belongs to a column that is a copy of an
+ * earlier one: residual zero), dropped rows sqrt(EPSILON) e_k; the permuted copy A alongside */
+static void mt_expand_ra(mt_state *m)
+{
+    const int n = m->n, r = m->r; const size_t np = m->np;
+    const double *G = m->G, *D = m->D; const double eps = m->o->p.epsilon;
+#pragma omp parallel for schedule(static)
+    for (int a = 0; a < n; a++) {
+        const int j = m->perm[a];
+        double *sj = m->S + (size_t)j * np;
+        memset(sj, 0, sizeof(double) * np);
+        if (a >= r) { sj[j] = sqrt(eps); continue; }
+        const double sd = sqrt(D[a]), is = 1.0 / sd;
+        const double *wa = G + (size_t)a * np; double *aa = m->A + (size_t)a * np;
+        for (int b = 0; b < a; b++) aa[b] = 0.0;
+        aa[a] = sd; sj[j] = sd;
+        for (int b = a + 1; b < n; b++) {
+            const double v = wa[b] * is; const int c = m->perm[b];
+            aa[b] = v;
+            if (c > j) sj[c] = v;
+        }
+        for (int b = n; b < (int)np; b++) aa[b] = 0.0;
+    }
+}
+
 ORC_API int mt_frame(mt_state *m, const double odo_prev[3], const double odo_cur[3], const double *z, const int *matched)
 {
     const int n = m->n, N = m->N; const size_t np = m->np;
     double t0 = omp_get_wtime(), t1;
 #define MT_LAP(i) do { t1 = omp_get_wtime(); m->t_phase[i] += t1 - t0; t0 = t1; } while (0)
-    mt_motion(m, odo_prev, odo_cur); MT_LAP(0);
+    mt_motion(m, odo_prev, odo_cur);
+    if (m->r > 0) {                                            /* the permuted copy follows the motion step: robot columns = permuted positions r-4 .. r-1 */
+        for (int a = 0; a < m->r; a++) for (int e = 0; e < 4; e++) m->A[(size_t)a * np + (m->r - 4 + e)] = (m->perm[a] <= n - 4 + e) ? m->S[(size_t)m->perm[a] * np + (n - 4 + e)] : 0.0;
+    }
+    MT_LAP(0);
     mt_measure(m); MT_LAP(1);
     int nm = 0; for (int k = 0; k < N; k++) nm += matched[k] ? 1 : 0;
     if (nm == 0) return SRUKF_OK;
     mt_gain(m, z, matched); MT_LAP(2);
+    if (m->r > 0) {
+        double *gdiag = (double *)malloc(sizeof(double) * np);
+        mt_syrk_ra(m, gdiag); MT_LAP(3);
+        const int bad = mt_gmw_ra(m, gdiag);
+        free(gdiag);
+        if (bad == 0) { mt_expand_ra(m); MT_LAP(4); return SRUKF_OK; }
+        /* a skipped direction was not null in this frame's S^T S - U U^T, or the theta clamp would have been active: the refactorisation is repeated on
+         * the full-rank path (S is untouched; U^T back to state order), and the null set is taken again from its result */
+        m->rank_fallbacks++;
+#pragma omp parallel for schedule(static)
+        for (int q = 0; q < (int)m->mp; q++) {
+            double *tmp = m->Gbak + (size_t)q * np, *u = m->Ut + (size_t)q * np;
+            memcpy(tmp, u, sizeof(double) * np);
+            for (int b = 0; b < n; b++) u[m->perm[b]] = tmp[b];
+        }
+        m->r = 0;
+    }
+    const int redo_rank = m->rank_aware && m->r == 0;
     mt_syrk(m); MT_LAP(3);
 #pragma omp parallel for schedule(static)
     for (int r = 0; r < n; r++) memcpy(m->Gbak + (size_t)r * np + r, m->G + (size_t)r * np + r, sizeof(double) * (n - r));
@@ -485,6 +706,7 @@ ORC_API int mt_frame(mt_state *m, const double odo_prev[3], const double odo_cur
         m->clamp_fallbacks++;
         MT_LAP(5);
     }
+    if (redo_rank) mt_set_rank_aware(m, 1);
 #undef MT_LAP
     return SRUKF_OK;
 }

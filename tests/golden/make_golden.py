@@ -116,7 +116,42 @@ def g7_sequential(N, F, seed):
                 P_absmax=np.abs(P).max(), clamps=np.array(list(o.clamp_stats().values())))
 
 
+def g8_match_pattern(N, F, seed):
+    """Association outcome of the g8 sequence: every frame a third of the landmarks unmatched (which third rotates), frame 7 with NO match at all
+    (KalmanUpdate returns at once, SLAM.cpp:2050-2051), frame 19 with a single match."""
+    rng = np.random.default_rng(seed)
+    m = np.ones((F, N), dtype=np.int32)
+    for t in range(F):
+        m[t, rng.permutation(N)[:N // 3]] = 0
+    m[7] = 0
+    m[19] = 0; m[19, 5] = 1
+    return m
+
+
+def g8_batched(N=200, F=40, seed=81):
+    """A multi-frame pin of the path the benchmark times: 40 consecutive frames at N = 200 through the oracle in BATCHED mode (one refactor per frame — held to the
+    reference's SEQUENTIAL structure by g7 / test_g7_batched_equals_sequential_at_benchmark_sizes), partial / empty / single-match frames included.
+    ~2 s of single-thread CPU per frame.  Stored: the association pattern, the trajectory, and of the final state X, diag P, the robot columns of P, every
+    landmark's 6 x 6 block and P V for 16 seeded +-1 probe vectors."""
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=seed, p=p)
+    matched = g8_match_pattern(N, F, seed)
+    o = O.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    traj = o.run_frames(sc["odo"], sc["z"], matched, O.Oracle.BATCHED)
+    X, S = o.get_state()
+    P = S.T @ S
+    n = 6 * N + 4
+    V = np.random.default_rng(800 + N).choice([-1.0, 1.0], size=(n, 16))
+    blocks = np.stack([P[6 * k:6 * k + 6, 6 * k:6 * k + 6] for k in range(N)])
+    return dict(N=N, F=F, seed=seed, matched=matched.astype(np.int8), traj=traj, X=X, P_diag=np.diag(P).copy(), P_robot_cols=P[:, n - 4:].copy(), P_blocks=blocks,
+                V=V, PV=P @ V, P_absmax=np.abs(P).max(), clamps=np.array(list(o.clamp_stats().values())))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        # separate (slow) target:  python tests/golden/make_golden.py g8
+        np.savez_compressed(os.path.join(OUT, "g8_batched_n200.npz"), **g8_batched())
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g7":
         # separate (slow) target:  python tests/golden/make_golden.py g7 [n50|n200]
         which = sys.argv[2:] or ["n50", "n200"]

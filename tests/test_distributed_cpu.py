@@ -48,6 +48,9 @@ def test_bench_gpus_flag_spawns_ranks():
     assert len(lines) == 1                                      # exactly one JSON line, relayed from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["collectives_ok"] and out["wall_max"] == 0.2
+    # what a scaling run is checked against: the world size the process group saw, one rate per rank, the rank that set the max, the map broadcast
+    assert out["rccl_world_size"] == 2 and out["per_rank_wall_s"] == [0.1, 0.2] and len(out["per_rank_frames_per_s"]) == 2 and out["slowest_rank"] == 1
+    assert out["map_broadcast"]["bytes"] == 8 * (16 + 16 * 16) and out["map_broadcast"]["ms"] > 0
 
 
 def test_bench_gpus_flag_fails_in_the_children_without_gpus():
@@ -71,3 +74,4 @@ def test_bench_force_dist_one_rank_goes_through_the_collectives():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["collectives_ok"] and d["collectives"] == "gloo"
+    assert d["rccl_world_size"] == 1 and len(d["per_rank_frames_per_s"]) == 1 and d["map_broadcast"]["bytes"] > 0

@@ -69,6 +69,9 @@ def test_bench_force_dist_runs_the_rccl_collectives_with_one_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["collectives"] == "nccl" and d["steps"] == 6
     assert d["value"] > 100 and d["pose_rmse_vs_truth_m"] < 1e-3
+    # the keys a scaling run is checked against (round 4): world size the process group saw, one rate per rank, the map broadcast's size and time
+    assert d["rccl_world_size"] == 1 and len(d["per_rank_frames_per_s"]) == 1 and d["slowest_rank"] == 0
+    assert d["map_broadcast"]["bytes"] == 8 * (1204 + 1204 * 1204) and d["map_broadcast"]["ms"] > 0
 
 
 @pytest.mark.parametrize("N", [20, 200])

@@ -1,0 +1,63 @@
+"""GPU parity tests added in round 4 (-m gpu).
+
+g8 (tests/golden/g8_batched_n200.npz, make_golden.py g8): 40 consecutive frames at N = 200 through the ORACLE (BATCHED mode, itself held to the reference's
+SEQUENTIAL structure by g7), a third of the landmarks unmatched in every frame, one frame without any match, one with a single match.  The path bench.py times —
+the default staged replay: fused tail, head fold, graphs — and the launch sequences around it are held to it, not to each other."""
+import numpy as np
+import pytest
+
+from g7_check import g7_check
+
+pytestmark = pytest.mark.gpu
+
+
+def _g8_scene(golden, synth):
+    g = golden["g8_batched_n200"]
+    N, F = int(g["N"]), int(g["F"])
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=int(g["seed"]), p=p)
+    return g, N, F, p, sc, g["matched"].astype(np.int32)
+
+
+def _hold_to_g8(g, traj, X, S):
+    np.testing.assert_allclose(traj[:, :4], g["traj"][:, :4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(traj[:, 4:], g["traj"][:, 4:], rtol=0, atol=1e-12)
+    g7_check(g, X, S.T @ S, 1e-9, 1e-11)
+
+
+@pytest.mark.parametrize("variant", ["default", "eager", "shared", "table", "split_calls"])
+def test_g8_default_replay_against_the_oracle_over_40_frames(srukf, golden, synth, variant):
+    """default: one call, captured graphs (what bench.py times); eager: the same launches without graphs; shared: SRUKF_GPU_SHARED (persistent launches of half the
+    CUs behind the gate, k_syrk head launch instead of the head fold); table: k_project_table in front of every frame instead of the fused tail; split_calls: the
+    run cut into blocks of 1 + 6 + 13 + 20 frames (every call starts with the projection launch its predecessor's tail would have made unnecessary)."""
+    g, N, F, p, sc, matched = _g8_scene(golden, synth)
+    f = srukf.Filter(N, p)
+    if variant == "eager":
+        f.debug_set("use_graph", 0)
+    if variant == "shared":
+        f.set_exclusive(srukf.GPU_SHARED)
+    if variant == "table":
+        f.debug_set("tail_fuse", 0)
+    f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], matched)
+    assert f.null_directions() == 3 * (N - 1)
+    if variant == "split_calls":
+        traj = np.vstack([f.run_frames(0, 1), f.run_frames(1, 6), f.run_frames(7, 13), f.run_frames(20, F - 20)])
+    else:
+        traj = f.run_frames(0, F)
+    assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0
+    X, S = f.get_state()
+    _hold_to_g8(g, traj, X, S)
+
+
+def test_g8_step_api_against_the_oracle_over_40_frames(srukf, golden, synth):
+    """The same 40 frames through the step-wise API (predictMotion -> predictMeasurement -> host -> KalmanUpdate), rank-aware form on."""
+    g, N, F, p, sc, matched = _g8_scene(golden, synth)
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    traj = np.zeros((F, 8))
+    for t in range(F):
+        f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); f.predict_measurement()
+        f.update(sc["z"][t], matched[t], mode=srukf.UPDATE_BATCHED)
+        pose, P4 = f.get_robot()
+        traj[t, :4] = pose; traj[t, 4:] = np.asarray(P4).reshape(4, 4)[:2, :2].ravel()
+    X, S = f.get_state()
+    _hold_to_g8(g, traj, X, S)

@@ -106,3 +106,32 @@ def test_device_sincos_header_is_correctly_rounded(tmp_path):
     for x in [0.0, -0.0, np.pi / 4, -np.pi / 2, np.pi, 1e-300, 2.0 ** 20]:
         L.crt_sincos_host(x, C.byref(s), C.byref(c))
         assert abs(s.value - np.sin(x)) <= 2 * np.spacing(abs(np.sin(x))) and abs(c.value - np.cos(x)) <= 2 * np.spacing(abs(np.cos(x)))
+
+
+def test_pxy2_tile_list_covers_every_tile_once(pkg):
+    """Host-side tile list of k_pxy2 (srukf_pxy2_build_tiles): every (measurement tile, state block, K half) exactly once, for matrices up to
+    200 block columns (N = 2 130; round 3 kept the (block, half) pairs in a fixed array of 128 and silently dropped the lowest blocks from N = 693)."""
+    lib = pkg.srukf.load_library()
+    fn = lib.srukf_pxy2_build_tiles
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    split = lib.srukf_pxy2_split_groups()
+    for T in (1, 2, 5, 19, 47, 64, 65, 66, 67, 100, 128, 200):
+        np_, mp = 64 * T, 64 * max(1, T // 3)
+        for kr in sorted({16, np_ // 2 // 16 * 16 or 16, np_}):
+            cnt = fn(mp, np_, kr, None)
+            out = np.zeros(4 * cnt, dtype=np.int32)
+            assert fn(mp, np_, kr, out.ctypes.data) == cnt and cnt % 8 == 0
+            tl = out.reshape(-1, 4)
+            live = tl[tl[:, 0] >= 0]
+            seen = {}
+            for mt, bt, h, halves in live:
+                ng = min(4 * (bt + 1), (kr + 63) // 64 * 4)
+                assert halves == (2 if ng >= split else 1) and 0 <= h < halves and 0 <= mt < mp // 64 and 0 <= bt < T
+                seen[(mt, bt, h)] = seen.get((mt, bt, h), 0) + 1
+            want = sum((2 if min(4 * (bt + 1), (kr + 63) // 64 * 4) >= split else 1) for bt in range(T)) * (mp // 64)
+            assert len(seen) == want == len(live) and set(seen.values()) == {1}, (T, kr)
+            # all tiles that contract the same slab of A (one (bt, half) pair) sit on ONE XCD (slot index % 8)
+            xcd = {}
+            for slot, (mt, bt, h, halves) in enumerate(tl):
+                if mt >= 0:
+                    assert xcd.setdefault((bt, h), slot % 8) == slot % 8

@@ -317,6 +317,50 @@ def test_matched_cpu_baseline_equals_oracle(oracle, synth, N, F, kw):
     assert np.all(np.tril(Sm, -1) == 0.0) and m.clamp_fallbacks() == 0
 
 
+@pytest.mark.parametrize("N,F", [(24, 4), (50, 3)])
+def test_matched_rank_aware_equals_oracle(oracle, synth, N, F):
+    """The CPU port in the GPU path's rank-aware form (mt_set_rank_aware: the 3 (N - 1) structurally null pivots skipped, K <= r in S^T S - U U^T and in the
+    cross covariance, NullSkip in the projection) against the reference-structured oracle: a third of the landmarks unmatched in every frame."""
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=70 + N, p=p)
+    matched = sc["matched"].copy()
+    for t in range(F):
+        matched[t, (np.arange(N) + t) % 3 == 0] = 0
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    to = o.run_frames(sc["odo"], sc["z"], matched, mode=oracle.Oracle.BATCHED)
+    Xo, So = o.get_state()
+    for threads in (1, 3):
+        m = oracle.Matched(N, p, threads=threads); m.set_state(sc["X0"], sc["S0"])
+        assert m.set_rank_aware(True) == 3 * (N - 1) == m.null_directions()
+        tm = m.run_frames(sc["odo"], sc["z"], matched)
+        Xm, Sm = m.get_state()
+        assert m.rank_fallbacks() == 0 and m.clamp_fallbacks() == 0
+        np.testing.assert_allclose(tm, to, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(Xm, Xo, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(Sm.T @ Sm, So.T @ So, rtol=0, atol=1e-11)
+        assert np.all(np.tril(Sm, -1) == 0.0)
+        # the skipped rows are exactly what the reference's clamp leaves: sqrt(EPSILON) e_k
+        null = [k for k in range(6 * N) if np.count_nonzero(Sm[k]) == 1 and Sm[k, k] == np.sqrt(p["epsilon"])]
+        assert len(null) == 3 * (N - 1)
+
+
+def test_matched_rank_aware_falls_back_on_theta_clamp(oracle, synth):
+    """Shipped a1..a4 = 8 at N = 24: the theta clamp fires; the rank-aware form notices BEFORE it writes anything, repeats the refactorisation on the full-rank
+    path (which in turn takes the exact orc_gmw) and re-derives the null set."""
+    p = synth.default_params()
+    N, F = 24, 3
+    sc = synth.make_scene(N, F, seed=1, p=p)
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    to = o.run_frames(sc["odo"], sc["z"], sc["matched"], mode=oracle.Oracle.BATCHED)
+    m = oracle.Matched(N, p, threads=2); m.set_state(sc["X0"], sc["S0"]); m.set_rank_aware(True)
+    tm = m.run_frames(sc["odo"], sc["z"], sc["matched"])
+    assert o.clamp_stats()["theta"] > 0 and m.rank_fallbacks() >= 1 and m.clamp_fallbacks() >= 1
+    # (with these constants S^T S - U U^T is indefinite and the filter diverges — test_default_gain_structure_... — so the 1e-13 by which the canonical
+    #  null rows differ from the zero rows of S0 grows by two orders per frame: 2e-11, 2e-9, 1e-6 relative; the full-rank port: 1e-12, 6e-11, 1e-10)
+    rel = (np.abs(tm - to) / np.maximum(1.0, np.abs(to))).max(axis=1)
+    assert rel[0] <= 1e-9 and rel[1] <= 1e-7 and rel[2] <= 1e-4, rel
+
+
 def test_matched_cpu_baseline_theta_clamp_fallback(oracle, synth):
     """With the shipped a1..a4 = 8 the theta clamp fires in frame 3: the blocked factorisation notices afterwards and
     repeats that refactor with the exact orc_gmw, like the device path."""
@@ -346,3 +390,25 @@ def test_g7_batched_equals_sequential_at_benchmark_sizes(oracle, golden, synth, 
     np.testing.assert_allclose(traj[:, 4:], g["traj"][:, 4:], rtol=0, atol=1e-14)
     _g7_check(g, X, S.T @ S, 1e-11, 1e-13)
     assert g["clamps"][1] == 0                                  # the theta clamp never fired in the sequential run either
+
+
+@pytest.mark.parametrize("rank_aware", [False, True])
+def test_g8_matched_port_over_40_frames(oracle, golden, synth, rank_aware):
+    """The CPU port bench.py times (both forms) against the g8 fixture: 40 frames at N = 200 of the oracle in BATCHED mode, partial / empty / single-match
+    frames included (tests/golden/make_golden.py g8) — the fixture the device's default replay is held to in tests/test_gpu_parity_r4.py."""
+    from g7_check import g7_check
+    g = golden["g8_batched_n200"]
+    N, F = int(g["N"]), int(g["F"])
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=int(g["seed"]), p=p)
+    matched = g["matched"].astype(np.int32)
+    assert matched[7].sum() == 0 and matched[19].sum() == 1 and all(matched[t].sum() == N - N // 3 for t in range(F) if t not in (7, 19))
+    m = oracle.Matched(N, p, threads=4); m.set_state(sc["X0"], sc["S0"])
+    if rank_aware:
+        assert m.set_rank_aware(True) == 3 * (N - 1)
+    traj = m.run_frames(sc["odo"], sc["z"], matched)
+    assert m.clamp_fallbacks() == 0 and m.rank_fallbacks() == 0
+    np.testing.assert_allclose(traj[:, :4], g["traj"][:, :4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(traj[:, 4:], g["traj"][:, 4:], rtol=0, atol=1e-12)
+    X, S = m.get_state()
+    g7_check(g, X, S.T @ S, 1e-9, 1e-11)
