@@ -434,6 +434,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="go through torch.distributed.run -> init_process_group('nccl') -> broadcast / all-reduce / all-gather even with ONE rank "
                          "(the only way the RCCL calls of the N-rank path execute on a 1-GPU box)")
+    ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
+                    help="precision the filter state is STORED in between frames (f32 with --landmarks 500 = the configs4 workload as the profiled one: scripts/profile_round.sh)")
     ap.add_argument("--no-configs4", action="store_true", help="skip the N = 500 / fp32-storage leg (BASELINE configs[4]) of the 1-GPU line")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 --pmc passes need it)")
     ap.add_argument("--no-collectives-check", action="store_true",
@@ -484,6 +486,8 @@ def main():
     torch.cuda.set_stream(tstream)
     f = srukf.Filter(N, sc["params"], device=local, stream=tstream.cuda_stream)
     f.set_state_device(X0.data_ptr(), S0.data_ptr(), n)
+    if args.storage == "f32":
+        f.set_storage(srukf.STORAGE_F32)
     f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
     traj = torch.zeros(F, 8, dtype=torch.float64, device=device)
 
@@ -556,7 +560,7 @@ def main():
         out = {
             "metric": "srukf_updates_per_sec", "value": world * K / wall_max, "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.storage == "f64" else "f64 (state stored as f32)", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: {N} inverse-depth landmarks (n={n}, Na={n + 5}, L={2 * (n + 5) + 1}), "
                                    "M=N matched, fp64, one batched refactor per frame, synthetic 640x480 figure-8 sequence",
                        "landmarks": N, "state_dim": n, "sequences_per_gpu": 1, "update_mode": "batched"},

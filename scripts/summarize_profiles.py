@@ -21,6 +21,7 @@ def kname(raw):
 
 
 tag, stats, fetch, write = sys.argv[1:5]
+workload = sys.argv[6] if len(sys.argv) > 6 else "bench.py N=200"
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
 
@@ -34,7 +35,7 @@ def agg(path):
 
 
 f, w = agg(fetch), agg(write)
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches: bench.py --eager), bench.py N=200",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches: bench.py --eager), " + workload,
        "unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     if not k.startswith("k_"):
@@ -61,7 +62,7 @@ if len(sys.argv) > 5:
     for r in csv.DictReader(open(stats)):
         dur[kname(r["Name"])] = float(r["AverageNs"])
     res = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE "
-                     "(own pass, eager launches), bench.py N=200; per launch averages",
+                     "(own pass, eager launches), " + workload + "; per launch averages",
            "formulas": {"mfma_util_pct": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024) * 100", "mfma_gflop": "SQ_INSTS_VALU_MFMA_MOPS_F64 * 512 / 1e9",
                         "mfma_tflops": "mfma_gflop / kernel-trace average duration", "peak_fp64_mfma_tflops": 78.6,
                         "mfma_busy_pct_of_kernel_time": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel-trace duration * 2.4 GHz * 1024 SIMDs) * 100"}, "kernels": {}}
