@@ -42,13 +42,14 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
 void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
-void srukf_launch_rank_const_rows(hipStream_t, int, int, int, const int*, double*, double);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
 void srukf_launch_rank_round(hipStream_t, int, int, double*);
+void srukf_launch_syrk_own(hipStream_t, int, int, const double*, const double*, int, int, int, double*, void*, const void*, int, int);
+int srukf_gmw_register_form(int, int, int, int);
 int srukf_gmw_head_rows(void);
 int srukf_gmw_head_extra_diag(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
@@ -260,6 +261,25 @@ static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles_all, int work
         for (int e = 0; e < 4; e++) tk[4 * w + e] = t.v[e];
     }
 }
+// srukf_debug_set "batch_tenants": cap of the tenants srukf_run_frames_batch picks (0: SRUKF_MAX_TENANTS); "pair_adjacent" 1: a worker with two register tiles owns two
+// tiles that retire one after the other (list positions 2w, 2w + 1) instead of an early and a late one (w, w + workers): early workers leave their CU sooner
+static std::atomic<int> g_dbg_batch_tenants{0}, g_dbg_pair_adjacent{0};
+static void gmw_tiles_pair_adjacent(std::vector<short>& tk, int nreal, int workers)
+{
+    if (!g_dbg_pair_adjacent || nreal <= workers || nreal > 2 * workers) return;
+    struct Tl { short v[4]; };
+    std::vector<Tl> src(nreal), dst(nreal);
+    for (int q = 0; q < nreal; q++) for (int e = 0; e < 4; e++) src[q].v[e] = tk[4 * q + e];
+    // worker w reads list positions w and w + workers: give it sorted tiles 2w and 2w + 1 while both exist; the workers past the pairs get single tiles
+    const int npair = nreal - workers;                          // workers with two tiles
+    int pos = 0;
+    for (int w = 0; w < workers; w++) {
+        // the LAST npair workers get the pairs (late rows: two tiles per step fit the panel period), the first workers - npair the early single tiles
+        if (w < workers - npair) dst[w] = src[pos++];
+        else { dst[w] = src[pos++]; dst[w + workers] = src[pos++]; }
+    }
+    for (int q = 0; q < nreal; q++) for (int e = 0; e < 4; e++) tk[4 * q + e] = dst[q].v[e];
+}
 static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int tenants = 1)
 {
     g.T = np / 64;
@@ -275,6 +295,7 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
     srukf_gmw_build_tiles(g.T, g.Tp, tk.data());
     gmw_tiles_xcd_order(tk, g.ntiles, g.workers, g.T, g.Tp);
+    gmw_tiles_pair_adjacent(tk, g.nreal, g.workers);
     const size_t sync_bytes = (size_t)srukf_gmw_sync_bytes(g.T);
     if (srukf_dmalloc_on(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
         srukf_dmalloc_on(&g.sync, sync_bytes, st) != hipSuccess ||
@@ -340,6 +361,7 @@ struct srukf_ctx {
     int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
     double red_fac_flop = 0, red_own_flop = 0;         // algorithmic flop of the rank-aware persistent launch: factorisation / owners' tiles of S^T S - U U^T
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
+    int shared_tenants = 2;                // SRUKF_GPU_SHARED: how many persistent launches share the GPU (each keeps to cus / tenants CUs; the gate admits that many)
     int gmw_shared = 0;                    // 0: the filter has the GPU to itself; 1: shared with other filters — persistent launches of at most half the CUs behind
                                            // the admission gate (k_gmw_gate); 2: one launch per panel (forced, or after an abandoned persistent launch)
     int debug_allow_mixed = 0;             // srukf_debug_allow_mixed: the tolerance study runs the mixed mode below its epsilon floor on purpose
@@ -354,6 +376,7 @@ struct srukf_ctx {
         int nullskip = 1;                  // "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
         int pxy2 = 1;                      // "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
     } dbg;
+    bool null_canonical = false;           // every structurally null row of S is exactly sqrt(EPSILON) e_k (update_null_set checks; true behind every rank-aware frame tail)
     bool tail_ok = false;                  // "fused tail" mode is possible: directions 0 and 1 are kept rows (the Si factor names their Z rows: they are projected for every landmark, which
                                            // the frame tail only does for kept rows — a state where they are structurally null stays with k_project_table)
     int debug_starve = 0;                  // srukf_debug_starve_workers: persistent launches start without their workers (tests of the fallback)
@@ -544,9 +567,12 @@ static void shadow_rebuild(srukf_ctx* c)
 }
 static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c->gmw_shared != 2 && c->gplan.workers >= 0; }
 // SRUKF_GPU_SHARED: how many persistent launches share the GPU (each keeps to 1 / tenants of the CUs; the gate admits that many)
+// (per context: srukf_run_frames_batch picks it from the number of filters it runs — one tenant per filter up to SRUKF_MAX_TENANTS; srukf_set_exclusive alone uses the
+//  process-wide default of srukf_debug_set "shared_tenants")
 static std::atomic<int> g_dbg_shared_tenants{2};
-static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants.load() : 1; }
-static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_shared_tenants.load() : 0; }
+#define SRUKF_MAX_TENANTS 4                                    // 4 x (1 pivot + 63 workers with two register tiles each) fill 256 CUs at N = 200
+static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? c->shared_tenants : 1; }
+static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? c->shared_tenants : 0; }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
 // fp32 storage: S, X and the permuted copy are rounded to the stored values first, and the trajectory row is taken from those
@@ -593,7 +619,8 @@ static int replay_motion_mode(const srukf_ctx* c)
     const bool st_ok = c->storage == SRUKF_STORAGE_F64 ||
                        (c->storage == SRUKF_STORAGE_F32 && c->dbg.f32_fuse && c->dbg.tail_fuse && c->dbg.pxy2 && c->dbg.nullskip && c->nskip && c->tail_ok &&
                         (size_t)c->d.np * sizeof(double) <= 48 * 1024);
-    if (c->dbg.fused_motion == 2 && !((replay_red_fused(c) || replay_red_perm(c)) && st_ok)) return 1;
+    // (null_canonical: "table" mode and everything on top of it read the structurally null rows of S as sqrt(EPSILON) e_k without looking)
+    if (c->dbg.fused_motion == 2 && !((replay_red_fused(c) || replay_red_perm(c)) && st_ok && c->null_canonical)) return 1;
     return c->dbg.fused_motion;
 }
 // "fused tail" mode (default where "table" mode runs with k_pxy2 and NullSkip): k_rank_expand also projects the next frame (k_rank_expand<2>), the frame's motion reduction
@@ -666,8 +693,17 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
     const bool red_perm = reduced && !red_fused && !keep_backup && ub == 0 && ue == d.mp && c->shadowA && c->w.wc0 == c->w.wm0 && rank_fused_mode();
     if (red_perm) {
         const double rr = c->red_r, rp = 64.0 * c->red_Tp;
+        // A filter that shares the GPU and whose workers own two register tiles (three or four tenants): the head rows by k_syrk, every other tile by k_syrk_own in
+        // the summation order of the owners' fold — bit for bit what the same filter computes when it runs alone (its owners fold) — then the persistent launch reads
+        // its tiles from Gp.  (The memory-tile form and the launches per panel keep the split-K k_syrk over the kept rows: nothing to be identical to.)
+        const bool own_order = c->gmw_shared == 1 && gmw_use_persist(c) && c->gplan_red.workers > 0 && c->gplan_red.T >= 16 && !c->debug_starve && gmw_fused_mode() && rank_fold_mode() &&
+                               srukf_gmw_register_form(c->gplan_red.T, c->gplan_red.Tp, c->gplan_red.ntiles, c->gplan_red.workers);
         {
             ProfScope ps(c, KC_SYRK, rr * rr * rr / 3.0 + rr * rr * (n - rr) + 2.0 * d.mp * (rr * n - rr * rr / 2.0) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * (rr * n + (double)d.mp * n + rp * n));
+            if (own_order) {
+                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
+                srukf_launch_syrk_own(c->stream, n, np, c->shadowA, c->Utp, 0, d.mp, (c->red_r + 15) & ~15, c->Wf, c->fs, c->gplan_red.tiles, c->gplan_red.ntiles, c->red_Tp);
+            } else
             srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
             c->dx_pending = false;
         }
@@ -857,9 +893,19 @@ static int update_null_set(srukf_ctx* c)
     if (enabled && c->rank_aware && n >= 128) {
         srukf_launch_row_energy(c->stream, n, np, c->S, c->D);
         HIPCHK(c, hipMemcpyAsync(c->hstage, c->D, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(c->hstage + np, sizeof(double), c->S, sizeof(double) * (np + 1), sizeof(double), n, hipMemcpyDeviceToHost, c->stream));   // diag S
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<int> perm, drop;
         for (int k = 0; k < n; k++) ((k < n - 4 && c->hstage[k] < SRUKF_NULL_ENERGY) ? drop : perm).push_back(k);
+        // NullSkip and the sqrt(EPSILON) DZ term of k_gain assume that every structurally null row IS sqrt(EPSILON) e_k (what the reference's clamp leaves there and
+        // every frame tail rewrites).  A state from outside only promises energy < 1e-12 (zero rows after joint initialisation, another small diagonal): then the
+        // first staged frame runs the launch sequence that reads the rows as they are, and its tail makes them canonical (null_canonical, run_frames_async).
+        {
+            const double sq = c->storage != SRUKF_STORAGE_F64 ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon);
+            bool canon = true;
+            for (int k : drop) canon = canon && c->hstage[np + k] == sq && c->hstage[k] == sq * sq;
+            c->null_canonical = canon;
+        }
         const int r = (int)perm.size(), Tp = (r + 63) / 64;
         if (!drop.empty() && Tp < T) {                            // worth it only if at least one whole panel leaves the pivot chain
             perm.insert(perm.end(), drop.begin(), drop.end());
@@ -934,9 +980,6 @@ static int update_null_set(srukf_ctx* c)
                 c->pxy2_split_b0 = np;                            // first permuted column whose K range is cut in two
                 for (int bt = 0; bt < np / 64; bt++) if (std::min(4 * (bt + 1), ((kr + 63) / 64) * 4) >= srukf_pxy2_split_groups()) { c->pxy2_split_b0 = 64 * bt; break; }
             }
-            // the dropped rows in the form the null set's consumers assume (k_rank_const_rows), as the stored precision holds it
-            srukf_launch_rank_const_rows(c->stream, n, np, r, c->red_perm, c->S, c->storage != SRUKF_STORAGE_F64 ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon));
-            quantize_state(c);
             shadow_rebuild(c);
         }
     }
@@ -1281,6 +1324,7 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
 }
 
 static void drop_graphs(srukf_ctx* c);
+static void set_null_canonical(srukf_ctx* c);
 static int read_fs(srukf_ctx* c)
 {
     HIPCHK(c, hipMemcpyAsync(c->hfs, c->fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
@@ -1366,7 +1410,10 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     // other null rows (a frame that went to the exact path because a skipped direction was found not to be null must not meet the
     // same null set again)
     if (reorder == SRUKF_NEED_REORDER || exact_ran) { const int rc = update_null_set(c); if (rc) return rc; }
-    else shadow_rebuild(c);
+    else {
+        shadow_rebuild(c);
+        if (c->storage != SRUKF_STORAGE_F32_MIXED) set_null_canonical(c);     // the rank-aware tail (k_rank_expand) has written sqrt(EPSILON) e_k into every skipped row
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     return SRUKF_OK;
@@ -1382,15 +1429,23 @@ static void drop_graphs(srukf_ctx* c)
     if (c->graphN) { hipGraphDestroy(c->graphN); c->graphN = nullptr; }
     c->graphN_frames = 0;
 }
+static int set_shared(srukf_ctx* c, int shared, int tenants);
 int srukf_set_exclusive(srukf_ctx* c, int exclusive)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));                         // the plans below size themselves on the CURRENT device's CU count
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int shared = exclusive == SRUKF_GPU_SHARED ? 1 : exclusive == SRUKF_GPU_SHARED_PER_PANEL ? 2 : 0;
-    if (shared == c->gmw_shared) return SRUKF_OK;
+    return set_shared(c, shared, g_dbg_shared_tenants.load());
+}
+// shared: 0 exclusive, 1 shared (tenants persistent launches at a time), 2 one launch per panel
+static int set_shared(srukf_ctx* c, int shared, int tenants)
+{
+    if (tenants < 2) tenants = 2;
+    if (shared == c->gmw_shared && (shared != 1 || tenants == c->shared_tenants)) return SRUKF_OK;
     const int was = plan_tenants(c);
     c->gmw_shared = shared;
+    if (shared == 1) c->shared_tenants = tenants;
     drop_graphs(c);
     if (plan_tenants(c) != was) {                              // the persistent launches keep to half the CUs / may use all of them again
         gmw_plan_destroy(c->gplan, c->stream);
@@ -1642,13 +1697,13 @@ static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     c->profiling = c2->profiling; c->use_graph = c2->use_graph;
     // per-context switches the caller set on the handle survive the rebuild (before srukf_set_storage / update_null_set run on it)
     c->rank_aware = c2->rank_aware; c->debug_allow_mixed = c2->debug_allow_mixed; c->debug_starve = c2->debug_starve; c->dbg = c2->dbg;
-    const int shared = c2->gmw_shared;
+    const int shared = c2->gmw_shared, tenants = c2->shared_tenants;
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
     c2->profiling = false; c2->pev.clear();
     srukf_destroy(c2);
     c->phase = 0;
-    if (shared != c->gmw_shared) srukf_set_exclusive(c, shared == 1 ? SRUKF_GPU_SHARED : shared == 2 ? SRUKF_GPU_SHARED_PER_PANEL : SRUKF_GPU_EXCLUSIVE);
+    if (shared != c->gmw_shared) set_shared(c, shared, tenants);
 }
 
 // deleteOneFeature, numeric part (SLAM.cpp:2637-2668): landmark id (0-based, state order) leaves the state.  The
@@ -1775,6 +1830,11 @@ int srukf_prepare_frames(srukf_ctx* c, int count)
     c->graphN_frames = count;
     return SRUKF_OK;
 }
+// the null rows are canonical from here on (a rank-aware frame tail has been issued): captured frames of the other launch sequence are stale
+static void set_null_canonical(srukf_ctx* c)
+{
+    if (c->red_r > 0 && !c->null_canonical) { c->null_canonical = true; drop_graphs(c); }
+}
 int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double* d_traj)
 {
     if (!c || first < 0 || count < 1) return SRUKF_ERR_BAD_ARG;
@@ -1784,7 +1844,20 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     const KDims& d = c->d;
     // traj rows are indexed by the absolute frame counter; offset so that frame `first` lands in row 0
     double* traj = d_traj ? d_traj - (size_t)8 * first : nullptr;
-    hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, c->async_pending ? 0 : 1, traj);
+    int clear = c->async_pending ? 0 : 1;
+    if (c->red_r > 0 && !c->null_canonical) {
+        // A state that arrived from outside with structurally null rows that are not (yet) sqrt(EPSILON) e_k — zero rows after the joint initialisation, say: the
+        // run's first frame takes the launch sequence that reads those rows as they are (k_project_motion, k_pxy; replay_motion_mode), eagerly; its tail writes the
+        // canonical rows, and the frames behind it run the default sequence.
+        hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, clear, traj);
+        replay_one_frame(c);
+        set_null_canonical(c);
+        c->async_pending = true; c->phase = 0; clear = 0;
+        first += 1; count -= 1;
+        HIPCHK(c, hipGetLastError());
+        if (count == 0) return SRUKF_OK;
+    }
+    hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, c->stream, c->fs, first, clear, traj);
     // "table" mode: the first frame's table of robot poses (the frames after it get theirs from their predecessor's tail)
     if (replay_motion_mode(c) == 2) srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs, c->red_iperm, c->red_r);
     // "fused tail" mode: ... and the first frame's projection (k_project_table); every later frame is projected by its predecessor's tail
@@ -1838,7 +1911,7 @@ static int run_staged_frame_exact(srukf_ctx* c, int frame, double* traj_row)
         for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
         quantize_state(c);
         rc = update_null_set(c); if (rc) return rc;      // the null set is re-derived from the exact factor (see srukf_update)
-    }
+    } else if (c->storage != SRUKF_STORAGE_F32_MIXED) set_null_canonical(c);
     srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -1861,10 +1934,12 @@ int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_
     }
     double* dt = nullptr;
     HIPCHK(c, srukf_dmalloc((void**)&dt, sizeof(double) * 8 * (size_t)count));
+    bool ck_canon = c->null_canonical;
     auto checkpoint = [&](bool save) {
         hipMemcpyAsync(save ? c->ckS : c->S, save ? c->S : c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync(save ? c->ckX : c->X, save ? c->X : c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
-        if (!save) { quantize_state(c); shadow_rebuild(c); }
+        if (save) ck_canon = c->null_canonical;
+        else { if (c->null_canonical != ck_canon) { c->null_canonical = ck_canon; drop_graphs(c); } quantize_state(c); shadow_rebuild(c); }
     };
     int rc = SRUKF_OK, done = 0;
     while (done < count) {
@@ -1901,12 +1976,14 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
     if (!ctxs || B < 1 || count < 1) return SRUKF_ERR_BAD_ARG;
     for (int b = 0; b < B; b++) if (!ctxs[b]) return SRUKF_ERR_BAD_ARG;
     std::vector<double*> dt(B, nullptr);
-    std::vector<int> rcs(B, SRUKF_OK);
+    std::vector<int> rcs(B, SRUKF_OK), canon0(B, 0);
     int rc = SRUKF_OK;
     for (int b = 0; b < B && rc == SRUKF_OK; b++) {
         srukf_ctx* c = ctxs[b];
         if (hipSetDevice(c->device) != hipSuccess) rc = SRUKF_ERR_HIP;
-        if (rc == SRUKF_OK && B > 1 && c->gmw_shared == 0) rc = srukf_set_exclusive(c, SRUKF_GPU_SHARED);
+        // one tenant per filter up to SRUKF_MAX_TENANTS (every filter's persistent launch admitted at once, each on cus / tenants CUs); a filter that is in
+        // per-panel mode (forced, or after an abandoned persistent launch) stays there
+        if (rc == SRUKF_OK && B > 1 && c->gmw_shared != 2) rc = set_shared(c, 1, std::min(std::max(B, 2), g_dbg_batch_tenants.load() > 0 ? g_dbg_batch_tenants.load() : SRUKF_MAX_TENANTS));
         if (rc == SRUKF_OK && srukf_dmalloc((void**)&dt[b], sizeof(double) * 8 * (size_t)count) != hipSuccess) { c->err = "run_frames_batch: out of device memory"; rc = SRUKF_ERR_NOMEM; }
         if (rc == SRUKF_OK && !c->ckS) {                        // the state before the block, for the recovery of a flagged filter
             const size_t np = c->d.np;
@@ -1916,6 +1993,7 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
             const size_t np = c->d.np;
             hipMemcpyAsync(c->ckS, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
             hipMemcpyAsync(c->ckX, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
+            canon0[b] = c->null_canonical ? 1 : 0;
         }
     }
     const int chunk = 2 * SRUKF_GRAPH_FRAMES;
@@ -1933,6 +2011,7 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
             const size_t np = c->d.np;
             hipMemcpyAsync(c->S, c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream);
             hipMemcpyAsync(c->X, c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream);
+            if (c->null_canonical != (canon0[b] != 0)) { c->null_canonical = canon0[b] != 0; drop_graphs(c); }
             quantize_state(c); shadow_rebuild(c);
             std::vector<double> th((size_t)8 * count);
             rcs[b] = srukf_run_frames(c, first, count, mode, th.data());
@@ -1996,6 +2075,8 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs },
                                                     { "tile_xcd", &g_dbg_tile_xcd } };      // tile_xcd: applies to plans built afterwards (set it before the state)
     if (!strcmp(key, "fold_tiles_pct")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
+    if (!strcmp(key, "batch_tenants")) { if (value < 0 || value > 8) return SRUKF_ERR_BAD_ARG; g_dbg_batch_tenants = value; return SRUKF_OK; }
+    if (!strcmp(key, "pair_adjacent")) { g_dbg_pair_adjacent = value ? 1 : 0; return SRUKF_OK; }     // applies to plans built afterwards
     if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
         if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;

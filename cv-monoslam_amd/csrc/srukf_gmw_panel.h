@@ -89,6 +89,7 @@ __device__ __forceinline__ void stage32_tri_globalB(d4 (&acc)[2][2], const doubl
 // after the tile store — the persistent kernel raises the tile's flag there, before the S rows nobody waits for.
 // early2: the whole panel buffer is known to be complete already (a worker that is behind): the second half's operands
 // are requested together with the first half's — one memory round trip per step instead of two.
+// early2_light: of the second half only the T2 fragments are requested early, the per-row scales follow after wait_full (fewer live registers).
 // rows32: the panel has only its first 32 pivots (the rank-aware form's last pivoted panel when the kept pivots end there) and the
 // tile's own values are not needed: the call ends after the first half with the S rows j0 .. j0+31.
 // acc: this wave's 32x32 quadrant.  load_tile / store_tile: read it from / write it back to G (the persistent kernel
@@ -102,7 +103,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                                                 const GmwPanel64* cur, double* __restrict__ Sout,
                                                 double (*Lr)[G64_LS], double (*Wc)[G64_LS], int tid, d4 (&acc)[2][2],
                                                 bool load_tile, bool store_tile, WaitHalf&& wait_half, WaitFull&& wait_full, Stored&& stored,
-                                                bool early2 = false, bool rows32 = false)
+                                                bool early2 = false, bool rows32 = false, bool early2_light = false)
 {
     const int lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, lk = lane >> 4;
@@ -159,6 +160,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                 if (u < 4) tb0[u] = cur->Tt2[o];
                 tb1[u] = cur->Tt2[o + 16];
             }
+          if (!early2_light) {
 #pragma unroll
             for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -167,6 +169,7 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
             for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
+          }
         }
 #pragma unroll
         for (int q = 0; q < 2; q++)
@@ -248,6 +251,8 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
                 if (u < 4) tb0[u] = cur->Tt2[o];
                 tb1[u] = cur->Tt2[o + 16];
             }
+        }
+        if (!early2 || early2_light) {
 #pragma unroll
             for (int q = 0; q < 2; q++)
 #pragma unroll

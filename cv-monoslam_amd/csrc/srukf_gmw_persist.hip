@@ -347,6 +347,12 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
     // the last panel buffers are never read by a worker (steps T-2 and T-1 have no trailing tiles)
 }
 
+// A memory-tile worker that is behind the pivot: 2 = it requests ALL operands of a step at once (one memory round trip per step, as the register form does;
+// with the accumulator set, the three-stage slab and both halves' operands live the instance needs ~40 VGPR spills), 1 = only the second half's T fragments
+// early (27 spills), 0 = second half requested after the first (no spills, no scratch: one more round trip per step).  Measured at N = 500: DESIGN.md.
+#ifndef GMW_MEM_EARLY2
+#define GMW_MEM_EARLY2 0
+#endif
 // Worker side of one update step of an owned tile; returns false when a wait expired.
 // kfirst: first panel step the owner takes part in.  passon: a tile of row block Tp of the rank-aware form — its own values are never used, it only
 // turns the LAST pivoted panel into S rows for its columns, so it joins at that step (kfirst = Tp - 1), neither loads nor stores a tile and raises no flag.
@@ -397,7 +403,7 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
             return *okp != 0;
         },
         [&] { if (last && !tl.passon) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); },
-        behind, rows32 && tl.passon);
+        behind && (!memtile || GMW_MEM_EARLY2 > 0), rows32 && tl.passon, memtile && GMW_MEM_EARLY2 == 1);
 }
 
 // k_gmw_persist: grid = 1 + workers; worker w owns tiles[w - 1] and tiles[w - 1 + workers] (if any), both kept in accumulator
@@ -446,6 +452,30 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
         if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
         if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
     }
+}
+
+// k_syrk_own: the tiles of S^T S - U U^T that the owners of the persistent launch would form themselves (gmw_owner_syrk), as a launch of its own — same device
+// function, same summation order (K ascending per 32 x 32 quadrant, no split-K), so the factorisation that then READS its tiles from G gives, bit for bit, the
+// result of the launch whose owners fold.  Used where a worker owns two register tiles (filters that share the GPU with three or four tenants: forming both tiles
+// before the first step would hold up the pivot chain), so that a filter's results do not depend on how many filters run beside it.
+// One workgroup per tile of the persistent launch's list, longest K first; tiles the head launch covers leave at once.
+__global__ __launch_bounds__(256) void k_syrk_own(int n, int ld, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows,
+                                                  double* __restrict__ G, FrameScalars* __restrict__ fs, const GmwTile* __restrict__ tiles, int nreal)
+{
+    const GmwTile t = tiles[nreal - 1 - (int)blockIdx.x];
+    if (!gmw_owner_computes(t.I, t.J)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    d4 acc[2][2];
+    const KDimsLite dl = { n, ld };
+    gmw_owner_syrk(dl, S0, Ut0, u0, u1, t.I, t.J, acc, fs, tid, krows);
+    const int m0 = 64 * t.I + 32 * (wv >> 1), c0 = 64 * t.J + 32 * (wv & 1);
+    if (m0 >= ld || c0 >= ld || c0 + 32 <= m0) return;         // (what gmw_tile_update's `live` loads)
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) G[(size_t)(m0 + 16 * a + lk + 4 * tt) * ld + c0 + 16 * b + lr] = acc[a][b][tt];
 }
 
 // Admission of persistent launches when several filters share the GPU (srukf_set_exclusive(ctx, 0)): every such launch keeps to
@@ -749,6 +779,15 @@ void srukf_launch_gmw_persist(hipStream_t st, int n, int ld, double eps, double*
 {
     srukf_launch_gmw_persist_head(st, n, ld, eps, G, pans, D, Sout, sync, tiles, ntiles, workers, fs, S0, Ut0, u0, u1, Tp, krows, gate_limit, nullptr);
 }
+// the owners' tiles as a launch of its own (k_syrk_own): tiles / ntiles = the persistent launch's list, Tp / T its shape
+void srukf_launch_syrk_own(hipStream_t st, int n, int ld, const double* S0, const double* Ut0, int u0, int u1, int krows, double* G, void* fs, const void* tiles, int ntiles, int Tp)
+{
+    const int T = ld / 64;
+    const int nreal = ntiles - ((Tp > 0 && Tp < T) ? T - Tp : 0);
+    if (krows <= 0 || krows > ld) krows = ld;
+    if (nreal > 0) hipLaunchKernelGGL(k_syrk_own, dim3(nreal), dim3(256), 0, st, n, ld, S0, Ut0, u0, u1, krows, G, (FrameScalars*)fs, (const GmwTile*)tiles, nreal);
+}
+int srukf_gmw_register_form(int T, int Tp, int ntiles, int workers) { return gmw_register_form(T, Tp, ntiles, workers) ? 1 : 0; }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }
 }  // extern "C"

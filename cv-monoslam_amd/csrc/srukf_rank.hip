@@ -40,17 +40,6 @@ __global__ __launch_bounds__(256) void k_rank_shadow(int n, int ld, int r, const
     for (int b = threadIdx.x; b < ld; b += 256) out[b] = (b >= a && b < n) ? src[perm[b]] : 0.0;
 }
 
-// The structurally null rows in the form every consumer of the null set assumes (NullSkip: both sigma points of such a direction ARE the centre point for every
-// other landmark; k_gain: their share of a cross covariance is sqrt(EPSILON) DZ[i]): S[k] = sqrt(EPSILON) e_k, k = perm[r + blockIdx] — what the reference's clamp
-// leaves there and what every frame tail rewrites.  The null-set decision only knows that the row's energy is below 1e-12 (a state from srukf_set_state may hold
-// zeros or another small diagonal there): the rows are brought into that form when the set is taken, which changes no entry of P by more than 1e-12.
-__global__ __launch_bounds__(256) void k_rank_const_rows(int n, int ld, int r, const int* __restrict__ perm, double* __restrict__ S, double sqeps)
-{
-    const int k = perm[r + blockIdx.x];
-    double* row = S + (size_t)k * ld;
-    for (int c = threadIdx.x; c < ld; c += 256) row[c] = (c == k) ? sqeps : 0.0;
-}
-
 // e[k] = sum_i S[k][i]^2, one workgroup per row
 __global__ __launch_bounds__(256) void k_row_energy(int n, int ld, const double* __restrict__ S, double* __restrict__ e)
 {
@@ -314,10 +303,6 @@ extern "C" {
 void srukf_launch_rank_round(hipStream_t st, int ld, int r, double* A)
 {
     hipLaunchKernelGGL(k_rank_round, dim3(r), dim3(256), 0, st, ld, A);
-}
-void srukf_launch_rank_const_rows(hipStream_t st, int n, int ld, int r, const int* perm, double* S, double sqeps)
-{
-    if (n > r) hipLaunchKernelGGL(k_rank_const_rows, dim3(n - r), dim3(256), 0, st, n, ld, r, perm, S, sqeps);
 }
 void srukf_launch_row_energy(hipStream_t st, int n, int ld, const double* S, double* e)
 {

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrukf_hip.so")
+# SRUKF_LIB: an A/B build of the same library (scripts/build_variants.sh; measurement only)
+LIB_PATH = os.environ.get("SRUKF_LIB") or os.path.join(_HERE, "libsrukf_hip.so")
 
 _DBL_FIELDS = ["cam_dx", "cam_dy", "cam_cx", "cam_cy", "cam_k1", "cam_k2", "cam_f", "image_w", "image_h",
                "a1", "a2", "a3", "a4", "sigma_measure", "rho0", "sigma_rho", "sigma_x", "sigma_y", "sigma_z",

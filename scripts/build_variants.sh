@@ -1,0 +1,17 @@
+#!/bin/bash
+# A/B builds of libsrukf_hip.so that differ in ONE compile-time macro of one file (measurement only; the product is csrc/Makefile's build):
+#   bash scripts/build_variants.sh <file.hip> <MACRO> <value> [<value> ...]   ->  cv-monoslam_amd/libsrukf_hip_<MACRO>_<value>.so
+# select one at run time with SRUKF_LIB=<path> (cv-monoslam_amd/srukf.py).
+set -e
+cd "$(dirname "$0")/../cv-monoslam_amd/csrc"
+make -s -j8
+f=$1; m=$2; shift 2
+flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16"
+[ "$f" = srukf_gmw_persist.hip ] && flags="$flags -Os -mllvm -amdgpu-sched-strategy=max-ilp"
+[ "$f" = srukf_assoc.hip ] && flags="$flags -ffp-contract=off"
+for v in "$@"; do
+  /opt/rocm/bin/hipcc $flags -D$m=$v -c $f -o /tmp/variant_$m_$v.o
+  objs=$(ls *.o | grep -v "^${f%.hip}.o$")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrukf_hip_${m}_$v.so $objs /tmp/variant_$m_$v.o
+  echo built ../libsrukf_hip_${m}_$v.so
+done

@@ -61,3 +61,37 @@ def test_g8_step_api_against_the_oracle_over_40_frames(srukf, golden, synth):
         traj[t, :4] = pose; traj[t, 4:] = np.asarray(P4).reshape(4, 4)[:2, :2].ravel()
     X, S = f.get_state()
     _hold_to_g8(g, traj, X, S)
+
+
+@pytest.mark.parametrize("B", [2, 4])
+def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle, synth, B):
+    """srukf_run_frames_batch with B filters at N = 200 (Monte-Carlo runs: one map, own measurement noise; one tenant per filter: B persistent launches of
+    256 / B CUs admitted at a time, two register tiles per worker at B = 4, the tiles of S^T S - U U^T from k_syrk_own in the owners' summation order):
+    every filter's first two frames against the ORACLE (BATCHED), and the whole block against the same sequence replayed ALONE (exclusive mode, owners' fold,
+    head fold) — bit for bit, trajectory and state."""
+    N, F, Fo = 200, 12, 2
+    p = synth.scene_params()
+    scs = [synth.make_scene(N, F, seed=0, p=p, obs_seed=7000 + b) for b in range(B)]
+    fs = []
+    for sc in scs:
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"]); fs.append(f)
+    t2 = srukf.run_frames_batch(fs, 0, Fo)
+    mid = [f.get_state() for f in fs]
+    t10 = srukf.run_frames_batch(fs, Fo, F - Fo)
+    for b, sc in enumerate(scs):
+        assert fs[b].debug_get("gmw_aborts") == 0 and fs[b].debug_get("clamp_rows") == 0 and fs[b].debug_get("gate_timeouts") == 0
+        assert fs[b].debug_get("gmw_shared") == 1
+        o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+        to = o.run_frames(sc["odo"][:Fo + 1], sc["z"][:Fo], sc["matched"][:Fo], oracle.Oracle.BATCHED)
+        Xo, So = o.get_state()
+        np.testing.assert_allclose(t2[b][:, :4], to[:, :4], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(t2[b][:, 4:], to[:, 4:], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(mid[b][0], Xo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(mid[b][1].T @ mid[b][1], So.T @ So, rtol=0, atol=1e-11)
+        g = srukf.Filter(N, p); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        ts = np.vstack([g.run_frames(0, Fo), g.run_frames(Fo, F - Fo)])
+        Xs, Ss = g.get_state(); Xb, Sb = fs[b].get_state()
+        assert np.array_equal(np.vstack([t2[b], t10[b]]), ts) and np.array_equal(Xs, Xb) and np.array_equal(Ss, Sb)
+        g.close()
+    for f in fs:
+        f.close()
