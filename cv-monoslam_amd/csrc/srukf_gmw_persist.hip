@@ -348,8 +348,10 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
 }
 
 // A memory-tile worker that is behind the pivot: 2 = it requests ALL operands of a step at once (one memory round trip per step, as the register form does;
-// with the accumulator set, the three-stage slab and both halves' operands live the instance needs ~40 VGPR spills), 1 = only the second half's T fragments
-// early (27 spills), 0 = second half requested after the first (no spills, no scratch: one more round trip per step).  Measured at N = 500: DESIGN.md.
+// with the accumulator set, the three-stage slab and both halves' operands live the instance needs ~40 VGPR spills, 164 B of scratch), 1 = only the second
+// half's T fragments early (27 spills), 0 = the second half requested after the first: no spills, no scratch (256 VGPRs + 236 AGPRs), one more round trip per step.
+// Measured at N = 500 (round 4, k_gmw_persist<MEM> per launch / frames per second, fp64 and fp32 storage alike): 0: 506 us / 1 092;  1: 543 us / 1 048;
+// 2: 587 us / 999 — the scratch traffic in the step loop costs more than the round trip it saves.  (Round 3's 553 us / 1 048 was form 2 with 22 spills.)
 #ifndef GMW_MEM_EARLY2
 #define GMW_MEM_EARLY2 0
 #endif

@@ -143,10 +143,12 @@ def test_fused_tail_agrees_with_table_mode(srukf, synth):
     # graphs against eager launches of the same mode: the same launches, bit-identical
     assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
     # the projection itself: start both modes from the SAME state, run one frame; the fused tail has then projected frame 1, table mode does it when frame 1 runs
-    g = srukf.Filter(N, p); g.debug_set("tail_fuse", 1); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"]); g.run_frames(0, 1)
+    # (two frames: the structurally null rows of the joint-initialised S0 are zero rows, not sqrt(EPSILON) e_k, so a run's FIRST frame takes the launch sequence that
+    #  reads them as they are — k_project_motion, k_pxy — and the fused tail starts with the second; round 4, srukf_api.hip null_canonical)
+    g = srukf.Filter(N, p); g.debug_set("tail_fuse", 1); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"]); g.run_frames(0, 2)
     Xg, Sg = g.get_state()
     Zf, DZf = g.debug_copy("Z", L * mp), g.debug_copy("DZ", npad * mp)
-    t = srukf.Filter(N, p); t.debug_set("tail_fuse", 0); t.set_state(Xg, Sg); t.stage_sequence(sc["odo"], sc["z"], sc["matched"]); t.run_frames(1, 1)
+    t = srukf.Filter(N, p); t.debug_set("tail_fuse", 0); t.set_state(Xg, Sg); t.stage_sequence(sc["odo"], sc["z"], sc["matched"]); t.run_frames(2, 1)
     Zt, DZt = t.debug_copy("Z", L * mp), t.debug_copy("DZ", npad * mp)
     assert np.array_equal(Zf, Zt) and np.array_equal(DZf, DZt)
 
