@@ -261,25 +261,8 @@ static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles_all, int work
         for (int e = 0; e < 4; e++) tk[4 * w + e] = t.v[e];
     }
 }
-// srukf_debug_set "batch_tenants": cap of the tenants srukf_run_frames_batch picks (0: SRUKF_MAX_TENANTS); "pair_adjacent" 1: a worker with two register tiles owns two
-// tiles that retire one after the other (list positions 2w, 2w + 1) instead of an early and a late one (w, w + workers): early workers leave their CU sooner
-static std::atomic<int> g_dbg_batch_tenants{0}, g_dbg_pair_adjacent{0};
-static void gmw_tiles_pair_adjacent(std::vector<short>& tk, int nreal, int workers)
-{
-    if (!g_dbg_pair_adjacent || nreal <= workers || nreal > 2 * workers) return;
-    struct Tl { short v[4]; };
-    std::vector<Tl> src(nreal), dst(nreal);
-    for (int q = 0; q < nreal; q++) for (int e = 0; e < 4; e++) src[q].v[e] = tk[4 * q + e];
-    // worker w reads list positions w and w + workers: give it sorted tiles 2w and 2w + 1 while both exist; the workers past the pairs get single tiles
-    const int npair = nreal - workers;                          // workers with two tiles
-    int pos = 0;
-    for (int w = 0; w < workers; w++) {
-        // the LAST npair workers get the pairs (late rows: two tiles per step fit the panel period), the first workers - npair the early single tiles
-        if (w < workers - npair) dst[w] = src[pos++];
-        else { dst[w] = src[pos++]; dst[w + workers] = src[pos++]; }
-    }
-    for (int q = 0; q < nreal; q++) for (int e = 0; e < 4; e++) tk[4 * q + e] = dst[q].v[e];
-}
+// srukf_debug_set "batch_tenants": cap of the tenants srukf_run_frames_batch picks (0: SRUKF_MAX_TENANTS)
+static std::atomic<int> g_dbg_batch_tenants{0};
 static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int tenants = 1)
 {
     g.T = np / 64;
@@ -295,7 +278,6 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     std::vector<short> tk((size_t)4 * (g.ntiles > 0 ? g.ntiles : 1), 0);
     srukf_gmw_build_tiles(g.T, g.Tp, tk.data());
     gmw_tiles_xcd_order(tk, g.ntiles, g.workers, g.T, g.Tp);
-    gmw_tiles_pair_adjacent(tk, g.nreal, g.workers);
     const size_t sync_bytes = (size_t)srukf_gmw_sync_bytes(g.T);
     if (srukf_dmalloc_on(&g.pans, (size_t)srukf_gmw_panel_bytes() * g.T, st) != hipSuccess ||
         srukf_dmalloc_on(&g.sync, sync_bytes, st) != hipSuccess ||
@@ -595,15 +577,18 @@ static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool 
     }
 }
 // the rank-aware replay whose owners form their tiles of S^T S - U U^T themselves (seq_refactor below): what a whole staged frame takes
-// How many tiles per worker (in percent) the owners' fold accepts: 106 = about one tile per worker (measured in round 2: with two tiles per worker, both to be formed
-// before the first step, the exclusive replay loses — N = 300: 1 544 against 1 663 frames/s); srukf_debug_set "fold_tiles_pct" 200 lets filters that share the GPU
-// (many tenants of few CUs each: two register tiles per worker) fold as well
+// How many tiles per worker (in percent) the owners' fold accepts.  A filter that has the GPU to itself: 106 = about one tile per worker (measured in round 2: with two
+// tiles per worker, both to be formed before the first step, the exclusive replay loses — N = 300: 1 544 against 1 663 frames/s; srukf_debug_set "fold_tiles_pct").
+// A filter that shares the GPU (three or four tenants of 256 / tenants CUs: two register tiles per worker): 200 — measured in round 4 at N = 200, four filters and four
+// tenants, aggregate frames/s: owners fold both tiles 12 260; the same tiles from a launch of their own in the owners' summation order (k_syrk_own) 8 500 - 11 900;
+// split-K k_syrk over the kept rows 13 100 but then the results differ in rounding from the same filter running alone ("fold_tiles_pct_shared").
 static std::atomic<int> g_dbg_fold_tiles_pct{106};
-static int fold_tiles_pct() { return g_dbg_fold_tiles_pct.load(); }
+static std::atomic<int> g_dbg_fold_tiles_pct_shared{200};
+static int fold_tiles_pct(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_fold_tiles_pct_shared.load() : g_dbg_fold_tiles_pct.load(); }
 static bool replay_red_fused(const srukf_ctx* c)
 {
     return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && gmw_use_persist(c) &&
-           c->gplan_red.workers >= 0 && c->gplan_red.nreal <= c->gplan_red.workers * fold_tiles_pct() / 100 && c->gplan_red.T >= 16 &&
+           c->gplan_red.workers >= 0 && c->gplan_red.nreal <= c->gplan_red.workers * fold_tiles_pct(c) / 100 && c->gplan_red.T >= 16 &&
            !c->debug_starve && gmw_fused_mode() && rank_fused_mode() && rank_fold_mode();
 }
 // 0: k_motion + k_project; 1: k_project_motion (motion workgroup + projection with the robot part inline); 2: "table" (k_project_table: the
@@ -2074,9 +2059,9 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     struct { const char* k; std::atomic<int>* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs },
                                                     { "tile_xcd", &g_dbg_tile_xcd } };      // tile_xcd: applies to plans built afterwards (set it before the state)
+    if (!strcmp(key, "fold_tiles_pct_shared")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct_shared = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
     if (!strcmp(key, "fold_tiles_pct")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
     if (!strcmp(key, "batch_tenants")) { if (value < 0 || value > 8) return SRUKF_ERR_BAD_ARG; g_dbg_batch_tenants = value; return SRUKF_OK; }
-    if (!strcmp(key, "pair_adjacent")) { g_dbg_pair_adjacent = value ? 1 : 0; return SRUKF_OK; }     // applies to plans built afterwards
     if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
         if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;
