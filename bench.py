@@ -387,8 +387,7 @@ def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local, reps=5):
     fs = []
     for b in range(B):
         sc = synth.make_scene(N, W + reps * K, seed=0, p=synth.scene_params(), obs_seed=5000 + b)
-        f = srukf.Filter(N, sc["params"], device=local)          # own stream
-        f.set_exclusive(srukf.GPU_SHARED)                        # B filters share the GPU: persistent launches of half the CUs, two admitted at a time
+        f = srukf.Filter(N, sc["params"], device=local)
         f.set_state(sc["X0"], sc["S0"])
         f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
         fs.append(f)

@@ -50,6 +50,15 @@ void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const i
 void srukf_launch_rank_round(hipStream_t, int, int, double*);
 void srukf_launch_syrk_own(hipStream_t, int, int, const double*, const double*, int, int, int, double*, void*, const void*, int, int);
 int srukf_gmw_register_form(int, int, int, int);
+int srukf_pxy2_b_per(int, int);
+void srukf_launch_pxy2_b(hipStream_t, KDims, const void*, int, const void*, int, int, KWeights, int);
+void srukf_launch_gain_b(hipStream_t, KDims, KWeights, const void*, int, int, double);
+void srukf_launch_syrk_b(hipStream_t, KDims, const void*, int, const void*, int, int, int, int);
+void srukf_launch_syrk_own_b(hipStream_t, int, int, const void*, int, int, int, int, const void*, int, int);
+void srukf_launch_gmw_step64_b(hipStream_t, int, int, int, double, const void*, int, int, int);
+void srukf_launch_gmw_pivslab_b(hipStream_t, int, int, int, double, const void*, int, int);
+void srukf_launch_gmw_trail_b(hipStream_t, int, int, const void*, int, int);
+void srukf_launch_rank_expand_b(hipStream_t, int, int, int, double, const void*, int, double, KDims, KWeights, srukf_params);
 int srukf_gmw_head_rows(void);
 int srukf_gmw_head_extra_diag(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
@@ -263,6 +272,10 @@ static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles_all, int work
 }
 // srukf_debug_set "batch_tenants": cap of the tenants srukf_run_frames_batch picks (0: SRUKF_MAX_TENANTS)
 static std::atomic<int> g_dbg_batch_tenants{0};
+// srukf_debug_set "batch_wide" 0: srukf_run_frames_batch never takes the batched launches (one stream per filter, persistent launches behind the gate: round 3's form)
+static std::atomic<int> g_dbg_batch_wide{1};
+static std::atomic<int> g_dbg_batch_groups{0};
+static std::atomic<int> g_dbg_batch_split{1};                 // "batch_split" 0: one k_gmw_step64_b launch per panel (every tile recomputes its slabs) instead of slabs + plain updates                // "batch_groups": groups the batched filters are cut into (0: two from eight filters on)
 static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int tenants = 1)
 {
     g.T = np / 64;
@@ -338,6 +351,7 @@ struct srukf_ctx {
     int *red_perm = nullptr, *red_iperm = nullptr;     // permuted position <-> state index, kept indices first
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
     double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
+    double *slabW = nullptr, *slabL = nullptr;         // batched replay: the current panel's slabs W and L = W / D (64 x np each)
     double* P1 = nullptr; int* pxy2_tiles = nullptr; int n_pxy2_tiles = 0, pxy2_split_b0 = 0;   // "table" mode: k_pxy2's second K half, its tile list
     int* nskip = nullptr; int ns_full = 0, ns_null = 0, ns_rows = 0;   // NullSkip lists (srukf_device.h): [dirs | nulls | rows] in one buffer
     int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
@@ -1086,10 +1100,12 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     return SRUKF_OK;
 }
 
+static void batch_plan_forget(const srukf_ctx* c);
 int srukf_destroy(srukf_ctx* c)
 {
     if (!c) return SRUKF_OK;
     hipSetDevice(c->device);
+    batch_plan_forget(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_collect(c);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
@@ -1100,7 +1116,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -1950,6 +1966,181 @@ int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_
     return rc;
 }
 
+// ---- batched replay: B filters of ONE shape, ONE launch per stage, ONE stream, one graph (srukf_run_frames_batch) --------------------------------------------
+// The filters of a Monte-Carlo run (MonoSLAMView.cpp:526-572 once per sequence: same map, own measurements) have the same dimensions, the same null set and
+// the same launch grids; what differs are the buffers.  Every stage of the staged frame then runs as one launch over all of them — k_pxy2_b, k_gain_b, k_syrk_b
+// (head tiles, X += dX, dropped diagonal), k_syrk_own_b (the other tiles of S^T S - U U^T in the summation order of the owners' fold), one k_gmw_step64_b per
+// 64-row panel (B critical-path workgroups side by side, the trailing tiles of all filters around them: no workgroup waits for another inside a launch, so no
+// CU is held idle — the persistent launch's workers are, three quarters of the time —, no gate, no residency assumption), k_rank_expand_b — with the per-filter
+// pointers in small device tables.  Same device functions on the same values as the filter that runs alone (the per-panel and the persistent factorisation are
+// bit-identical given the same tiles; k_syrk_own is the owners' arithmetic): trajectories and states are bit-identical to solo runs.
+struct BatchPlan {
+    std::vector<srukf_ctx*> cs;
+    int B = 0;
+    void *t_pxy2 = nullptr, *t_gain = nullptr, *t_syrk = nullptr, *t_own = nullptr, *t_step = nullptr, *t_exp = nullptr;
+    hipGraph_t g1 = nullptr, g8 = nullptr; hipGraphExec_t e1 = nullptr, e8 = nullptr;
+    std::vector<unsigned long long> sig;                    // what the captured launches depend on besides the tables' CONTENTS
+};
+// (one plan per group of filters: srukf_run_frames_batch cuts B filters into groups that run side by side, each on the stream of its first filter)
+#define SRUKF_BATCH_GROUPS_MAX 4
+static thread_local BatchPlan* g_batches[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr };
+// The groups' streams: created together, once, so that they sit on different hardware queues whatever the filters' own streams map to (streams that share a
+// queue serialise: with the groups on their first filters' streams, 4 + 4 filters ran slower than 4 alone).
+static thread_local hipStream_t g_batch_streams[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr };
+static hipStream_t batch_stream(int grp)
+{
+    if (!g_batch_streams[0])
+        for (int q = 0; q < SRUKF_BATCH_GROUPS_MAX; q++) if (hipStreamCreateWithFlags(&g_batch_streams[q], hipStreamNonBlocking) != hipSuccess) g_batch_streams[q] = nullptr;
+    return g_batch_streams[grp];
+}
+static void batch_plan_drop_graphs(BatchPlan* bp)
+{
+    if (bp->e1) { hipGraphExecDestroy(bp->e1); bp->e1 = nullptr; }
+    if (bp->g1) { hipGraphDestroy(bp->g1); bp->g1 = nullptr; }
+    if (bp->e8) { hipGraphExecDestroy(bp->e8); bp->e8 = nullptr; }
+    if (bp->g8) { hipGraphDestroy(bp->g8); bp->g8 = nullptr; }
+}
+static void batch_plan_destroy(int grp)
+{
+    BatchPlan* bp = g_batches[grp];
+    if (!bp) return;
+    batch_plan_drop_graphs(bp);
+    for (void* t : { bp->t_pxy2, bp->t_gain, bp->t_syrk, bp->t_own, bp->t_step, bp->t_exp }) if (t) srukf_dfree(t);
+    delete bp;
+    g_batches[grp] = nullptr;
+}
+static void batch_plan_forget(const srukf_ctx* c)
+{
+    for (int grp = 0; grp < SRUKF_BATCH_GROUPS_MAX; grp++) {
+        if (!g_batches[grp]) continue;
+        for (const srukf_ctx* q : g_batches[grp]->cs) if (q == c) { hipStreamSynchronize(batch_stream(grp)); batch_plan_destroy(grp); break; }
+    }
+}
+// Can these filters run as one batch?  Same device and shape, the default launch sequence of a filter that has the GPU to itself ("fused tail" mode on the permuted
+// operands, fp64 storage), canonical null rows, nothing pending.
+static bool batch_eligible(srukf_ctx* const* cs, int B)
+{
+    if (B < 2 || B > 64 || !g_dbg_batch_wide.load()) return false;
+    const srukf_ctx* a = cs[0];
+    for (int b = 0; b < B; b++) {
+        const srukf_ctx* c = cs[b];
+        for (int q = 0; q < b; q++) if (cs[q] == c) return false;
+        if (c->device != a->device || c->d.N != a->d.N || c->d.N < 1 || c->storage != SRUKF_STORAGE_F64 || c->w.wc0 != c->w.wm0) return false;
+        if (c->red_r <= 0 || c->red_r != a->red_r || c->red_Tp != a->red_Tp || !c->shadowA || !c->null_canonical || !c->nskip || !c->tail_ok) return false;
+        if (c->ns_full != a->ns_full || c->ns_null != a->ns_null || c->ns_rows != a->ns_rows || c->n_pxy2_tiles != a->n_pxy2_tiles) return false;
+        if (!c->dbg.pxy2 || !c->dbg.nullskip || !c->dbg.tail_fuse || c->dbg.fused_motion != 2 || !c->dbg.table_perm || c->profiling || !c->use_graph || c->debug_starve) return false;
+        if (memcmp(&c->p, &a->p, sizeof c->p) != 0 || c->gplan_red.T < 16 || (size_t)c->d.np * sizeof(double) > 48 * 1024 || !rank_fused_mode()) return false;
+        if (!c->odo_seq || c->seqF != a->seqF) return false;
+    }
+    return true;
+}
+static void batch_frame(const BatchPlan* bp, hipStream_t st)
+{
+    const srukf_ctx* c = bp->cs[0];
+    const KDims& d = c->d;
+    const int n = d.n, np = d.np, r = c->red_r, Tp = c->red_Tp, B = bp->B, kr = (r + 15) & ~15;
+    srukf_launch_pxy2_b(st, d, bp->t_pxy2, B, c->pxy2_tiles, c->n_pxy2_tiles, kr, c->w, (d.N + 31) / 32);
+    srukf_launch_gain_b(st, d, c->w, bp->t_gain, B, c->pxy2_split_b0, sqrt(c->p.epsilon));
+    srukf_launch_syrk_b(st, d, bp->t_syrk, B, c->syrk_head_tiles, c->n_syrk_head_tiles, std::min(np, kr), (n + 255) / 256, (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS);
+    srukf_launch_syrk_own_b(st, n, np, bp->t_own, B, 0, d.mp, kr, c->gplan_red.tiles, c->gplan_red.ntiles, Tp);
+    int pb = 0;
+    for (int j0 = -64; j0 + 64 < np && j0 + 64 <= 64 * Tp; j0 += 64, pb ^= 1) {
+        if (!g_dbg_batch_split.load()) {
+            srukf_launch_gmw_step64_b(st, n, np, j0, c->p.epsilon, bp->t_step, B, std::max(1, Tp - j0 / 64 - 1), pb);    // rows of the kept pivots only; the last panel: the pass-on row
+            continue;
+        }
+        // split form: A = critical-path workgroups + the panel's slabs (and S rows) once per column block, B = the trailing tiles of the kept rows as plain K = 64
+        // updates.  The last pivoted panel has no tiles to update (the pass-on row's values are never used: its S rows come from the slab workgroups).
+        srukf_launch_gmw_pivslab_b(st, n, np, j0, c->p.epsilon, bp->t_step, B, pb);
+        if (j0 >= 0 && Tp - j0 / 64 - 1 >= 1) srukf_launch_gmw_trail_b(st, np, j0, bp->t_step, B, Tp - j0 / 64 - 1);
+    }
+    srukf_launch_rank_expand_b(st, n, np, r, c->p.epsilon, bp->t_exp, B, c->w.gamma, d, c->w, c->p);
+}
+static int batch_capture(BatchPlan* bp, hipStream_t st, int nframes, hipGraph_t* g, hipGraphExec_t* ge)
+{
+    srukf_ctx* c = bp->cs[0];
+    HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int q = 0; q < nframes; q++) batch_frame(bp, st);
+    const hipError_t launch_err = hipGetLastError();
+    HIPCHK(c, hipStreamEndCapture(st, g));
+    HIPCHK(c, launch_err);
+    HIPCHK(c, hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+    return SRUKF_OK;
+}
+// frames [first, first + count) of all filters on cs[0]'s stream; dt[b]: device trajectory buffers (count rows).  Asynchronous; the caller synchronises that stream.
+static int batch_run(srukf_ctx* const* cs, int B, int first, int count, double* const* dt, int grp)
+{
+    srukf_ctx* c0 = cs[0];
+    hipStream_t st = batch_stream(grp);
+    if (!st) { c0->err = "run_frames_batch: no stream for the group"; return SRUKF_ERR_HIP; }
+    BatchPlan* bp = g_batches[grp];
+    bool same = bp && bp->B == B;
+    for (int b = 0; same && b < B; b++) same = bp->cs[b] == cs[b];
+    if (!same) {
+        batch_plan_destroy(grp);
+        bp = g_batches[grp] = new BatchPlan();
+        bp->B = B; bp->cs.assign(cs, cs + B);
+        if (srukf_dmalloc(&bp->t_pxy2, sizeof(Pxy2Args) * B) != hipSuccess || srukf_dmalloc(&bp->t_gain, sizeof(GainArgs) * B) != hipSuccess ||
+            srukf_dmalloc(&bp->t_syrk, sizeof(SyrkArgs) * B) != hipSuccess || srukf_dmalloc(&bp->t_own, sizeof(SyrkOwnArgs) * B) != hipSuccess ||
+            srukf_dmalloc(&bp->t_step, sizeof(Step64Args) * B) != hipSuccess || srukf_dmalloc(&bp->t_exp, sizeof(ExpandArgs) * B) != hipSuccess) {
+            batch_plan_destroy(grp); c0->err = "run_frames_batch: out of device memory (argument tables)"; return SRUKF_ERR_NOMEM;
+        }
+    }
+    // the tables' contents (buffers may have been re-staged or rebuilt since the last call: rewritten every call, the captured launches only hold the tables' addresses)
+    std::vector<Pxy2Args> a1(B); std::vector<GainArgs> a2(B); std::vector<SyrkArgs> a3(B); std::vector<SyrkOwnArgs> a4(B); std::vector<Step64Args> a5(B); std::vector<ExpandArgs> a6(B);
+    std::vector<unsigned long long> sig;
+    for (int b = 0; b < B; b++) {
+        srukf_ctx* c = cs[b];
+        const KDims& d = c->d;
+        a1[b] = Pxy2Args{ c->DZ, c->shadowA, c->Utp, c->P1,
+                          MeasArgs{ c->X, c->sigR, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, null_skip(c), 1, 1, c->Cmat } };
+        a2[b] = GainArgs{ c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, c->m_seq, c->fs, c->dxp, rank_args(c), c->Cmat, c->S, c->P1, c->DZ, c->sigR, c->Z };
+        a3[b] = SyrkArgs{ c->shadowA, c->Utp, c->Wf, c->fs, c->dxp, c->X, rank_args(c, true), (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) };
+        a4[b] = SyrkOwnArgs{ c->shadowA, c->Utp, c->Wf, c->fs };
+        if (!c->slabW) {
+            HIPCHK(c, srukf_dmalloc(&c->slabW, sizeof(double) * 64 * (size_t)d.np)); HIPCHK(c, srukf_dmalloc(&c->slabL, sizeof(double) * 64 * (size_t)d.np));
+            HIPCHK(c, hipMemset(c->slabW, 0, sizeof(double) * 64 * (size_t)d.np)); HIPCHK(c, hipMemset(c->slabL, 0, sizeof(double) * 64 * (size_t)d.np));
+        }
+        a5[b] = Step64Args{ c->Wf, c->G, c->D, { c->pan[0], c->pan[1] }, c->slabW, c->slabL };
+        a6[b] = ExpandArgs{ c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, c->S, c->shadowA, c->sigR, c->Z, c->DZ };
+    }
+    {
+        const srukf_ctx* c = c0;
+        for (unsigned long long v : { (unsigned long long)(size_t)st, (unsigned long long)c->d.N, (unsigned long long)c->red_r, (unsigned long long)c->red_Tp, (unsigned long long)(size_t)c->pxy2_tiles,
+                                      (unsigned long long)c->n_pxy2_tiles, (unsigned long long)(size_t)c->syrk_head_tiles, (unsigned long long)c->n_syrk_head_tiles,
+                                      (unsigned long long)(size_t)c->gplan_red.tiles, (unsigned long long)c->gplan_red.ntiles, (unsigned long long)c->pxy2_split_b0 }) sig.push_back(v);
+    }
+    if (sig != bp->sig) { batch_plan_drop_graphs(bp); bp->sig = sig; }
+    HIPCHK(c0, hipSetDevice(c0->device));
+    HIPCHK(c0, hipMemcpyAsync(bp->t_pxy2, a1.data(), sizeof(Pxy2Args) * B, hipMemcpyHostToDevice, st));
+    HIPCHK(c0, hipMemcpyAsync(bp->t_gain, a2.data(), sizeof(GainArgs) * B, hipMemcpyHostToDevice, st));
+    HIPCHK(c0, hipMemcpyAsync(bp->t_syrk, a3.data(), sizeof(SyrkArgs) * B, hipMemcpyHostToDevice, st));
+    HIPCHK(c0, hipMemcpyAsync(bp->t_own, a4.data(), sizeof(SyrkOwnArgs) * B, hipMemcpyHostToDevice, st));
+    HIPCHK(c0, hipMemcpyAsync(bp->t_step, a5.data(), sizeof(Step64Args) * B, hipMemcpyHostToDevice, st));
+    HIPCHK(c0, hipMemcpyAsync(bp->t_exp, a6.data(), sizeof(ExpandArgs) * B, hipMemcpyHostToDevice, st));
+    HIPCHK(c0, hipStreamSynchronize(st));                      // (the host vectors are pageable and go out of scope)
+    if (!bp->e1) {
+        int rc = batch_capture(bp, st, 1, &bp->g1, &bp->e1); if (rc) return rc;
+        rc = batch_capture(bp, st, SRUKF_GRAPH_FRAMES, &bp->g8, &bp->e8); if (rc) return rc;
+    }
+    // start of the run, per filter: frame counter / flags / trajectory base, the first frame's table of robot poses and its projection (the frames behind it are
+    // projected by their predecessors' tails)
+    for (int b = 0; b < B; b++) {
+        srukf_ctx* c = cs[b];
+        double* traj = dt[b] ? dt[b] - (size_t)8 * first : nullptr;
+        hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, st, c->fs, first, c->async_pending ? 0 : 1, traj);
+        srukf_launch_sigr_rows(st, c->d, c->w, c->X, c->S, c->sigR, c->fs, c->red_iperm, c->red_r);
+        srukf_launch_project_table(st, c->d, c->w, c->p, c->X, c->S, c->sigR, c->Cmat, c->Z, c->DZ, c->fs, rank_args(c, false, true), null_skip(c));
+        c->xr1_pending = false; c->dx_pending = false;          // (the batched launches apply both themselves, every frame)
+        c->async_pending = true; c->phase = 0;
+    }
+    int f = 0;
+    for (; f + SRUKF_GRAPH_FRAMES <= count; f += SRUKF_GRAPH_FRAMES) HIPCHK(c0, hipGraphLaunch(bp->e8, st));
+    for (; f < count; f++) HIPCHK(c0, hipGraphLaunch(bp->e1, st));
+    HIPCHK(c0, hipGetLastError());
+    return SRUKF_OK;
+}
+
 // B filters (independent sequences: Monte-Carlo runs, several cameras) through the same block of staged frames, concurrently on one
 // GPU.  Every filter keeps its own context and stream; the frames are issued round-robin in chunks of two captured 8-frame graphs,
 // so that the filters' launches interleave on the device, then all are awaited.  Filters that were left in SRUKF_GPU_EXCLUSIVE are
@@ -1966,9 +2157,6 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
     for (int b = 0; b < B && rc == SRUKF_OK; b++) {
         srukf_ctx* c = ctxs[b];
         if (hipSetDevice(c->device) != hipSuccess) rc = SRUKF_ERR_HIP;
-        // one tenant per filter up to SRUKF_MAX_TENANTS (every filter's persistent launch admitted at once, each on cus / tenants CUs); a filter that is in
-        // per-panel mode (forced, or after an abandoned persistent launch) stays there
-        if (rc == SRUKF_OK && B > 1 && c->gmw_shared != 2) rc = set_shared(c, 1, std::min(std::max(B, 2), g_dbg_batch_tenants.load() > 0 ? g_dbg_batch_tenants.load() : SRUKF_MAX_TENANTS));
         if (rc == SRUKF_OK && srukf_dmalloc((void**)&dt[b], sizeof(double) * 8 * (size_t)count) != hipSuccess) { c->err = "run_frames_batch: out of device memory"; rc = SRUKF_ERR_NOMEM; }
         if (rc == SRUKF_OK && !c->ckS) {                        // the state before the block, for the recovery of a flagged filter
             const size_t np = c->d.np;
@@ -1981,12 +2169,56 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
             canon0[b] = c->null_canonical ? 1 : 0;
         }
     }
-    const int chunk = 2 * SRUKF_GRAPH_FRAMES;
-    for (int k0 = 0; k0 < count && rc == SRUKF_OK; k0 += chunk)
-        for (int b = 0; b < B && rc == SRUKF_OK; b++) {
-            rcs[b] = srukf_run_frames_async(ctxs[b], first + k0, std::min(chunk, count - k0), mode, dt[b] + (size_t)8 * k0);
-            if (rcs[b] != SRUKF_OK) rc = rcs[b];
+    // The batched launches (one launch per stage for all filters, one stream: batch_run) where the filters have one shape and run the default launch sequence.
+    // Filters whose structurally null rows are not canonical yet (a fresh state) run their first frame on their own, one after the other.
+    int done0 = 0;
+    bool wide = false;
+    if (rc == SRUKF_OK && B > 1 && mode == SRUKF_UPDATE_BATCHED && g_dbg_batch_wide.load()) {
+        for (int b = 0; b < B; b++) hipStreamSynchronize(ctxs[b]->stream);       // the checkpoint copies; whatever the filters did before
+        bool fresh = false, others_ok = true;
+        for (int b = 0; b < B; b++) { fresh = fresh || (ctxs[b]->red_r > 0 && !ctxs[b]->null_canonical); others_ok = others_ok && ctxs[b]->odo_seq && ctxs[b]->seqF >= first + count; }
+        if (fresh && others_ok && count >= 2) {
+            for (int b = 0; b < B; b++) {
+                rcs[b] = srukf_run_frames_async(ctxs[b], first, 1, mode, dt[b]);
+                if (rcs[b] == SRUKF_OK) rcs[b] = srukf_synchronize(ctxs[b]);
+            }
+            done0 = 1;
         }
+        bool all_ok = true;
+        for (int b = 0; b < B; b++) all_ok = all_ok && rcs[b] == SRUKF_OK;
+        if (all_ok && others_ok && batch_eligible(ctxs, B)) {
+            std::vector<double*> dtb(B);
+            for (int b = 0; b < B; b++) dtb[b] = dt[b] + (size_t)8 * done0;
+            // groups of filters side by side, each group one batch on the stream of its first filter: while one group sits in a launch that cannot fill the GPU
+            // (the pivot chains of a panel step), the other group's launches do
+            // (measured at N = 200, round 4, aggregate frames/s with 1 / 2 / 3 / 4 groups: 8 filters 10 270 / 11 450 / 11 280 / 11 700; 16: 12 710 / 14 260 / 14 300 / 14 790;
+            //  32: 14 600 / 15 560 / 15 790 / 16 430; 48: 14 840 / 15 710 / 16 460 / 16 650)
+            int G = g_dbg_batch_groups.load() > 0 ? g_dbg_batch_groups.load() : SRUKF_BATCH_GROUPS_MAX;
+            G = std::max(1, std::min(std::min(G, SRUKF_BATCH_GROUPS_MAX), B / 2));
+            for (int grp = 0; grp < G && rc == SRUKF_OK; grp++) {
+                const int b0 = (int)((long long)B * grp / G), b1 = (int)((long long)B * (grp + 1) / G);
+                rc = batch_run(ctxs + b0, b1 - b0, first + done0, count - done0, dtb.data() + b0, grp);
+            }
+            for (int grp = 0; grp < G; grp++) {
+                const int b0 = (int)((long long)B * grp / G);
+                if (hipStreamSynchronize(batch_stream(grp)) != hipSuccess && rc == SRUKF_OK) { ctxs[b0]->err = "run_frames_batch: the batched launches failed"; rc = SRUKF_ERR_HIP; }
+            }
+            wide = true;
+        }
+    }
+    if (!wide) {
+        // one stream per filter, persistent launches behind the admission gate: one tenant per filter up to SRUKF_MAX_TENANTS (every filter's persistent launch
+        // admitted at once, each on cus / tenants CUs); a filter in per-panel mode (forced, or after an abandoned persistent launch) stays there
+        for (int b = 0; b < B && rc == SRUKF_OK; b++)
+            if (B > 1 && ctxs[b]->gmw_shared != 2) rc = set_shared(ctxs[b], 1, std::min(std::max(B, 2), g_dbg_batch_tenants.load() > 0 ? g_dbg_batch_tenants.load() : SRUKF_MAX_TENANTS));
+        const int chunk = 2 * SRUKF_GRAPH_FRAMES;
+        for (int k0 = done0; k0 < count && rc == SRUKF_OK; k0 += chunk)
+            for (int b = 0; b < B && rc == SRUKF_OK; b++) {
+                if (rcs[b] != SRUKF_OK) continue;                          // (flagged in its first frame: rerun alone below)
+                rcs[b] = srukf_run_frames_async(ctxs[b], first + k0, std::min(chunk, count - k0), mode, dt[b] + (size_t)8 * k0);
+                if (rcs[b] != SRUKF_OK && rcs[b] != SRUKF_ERR_CLAMP_PENDING) rc = rcs[b];
+            }
+    }
     for (int b = 0; b < B; b++) {
         srukf_ctx* c = ctxs[b];
         int r = srukf_synchronize(c);
@@ -2061,6 +2293,9 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
                                                     { "tile_xcd", &g_dbg_tile_xcd } };      // tile_xcd: applies to plans built afterwards (set it before the state)
     if (!strcmp(key, "fold_tiles_pct_shared")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct_shared = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
     if (!strcmp(key, "fold_tiles_pct")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
+    if (!strcmp(key, "batch_split")) { g_dbg_batch_split = value ? 1 : 0; for (int grp = 0; grp < SRUKF_BATCH_GROUPS_MAX; grp++) if (g_batches[grp]) { hipStreamSynchronize(batch_stream(grp)); batch_plan_drop_graphs(g_batches[grp]); } return SRUKF_OK; }
+    if (!strcmp(key, "batch_groups")) { if (value < 0 || value > SRUKF_BATCH_GROUPS_MAX) return SRUKF_ERR_BAD_ARG; g_dbg_batch_groups = value; return SRUKF_OK; }
+    if (!strcmp(key, "batch_wide")) { g_dbg_batch_wide = value ? 1 : 0; return SRUKF_OK; }
     if (!strcmp(key, "batch_tenants")) { if (value < 0 || value > 8) return SRUKF_ERR_BAD_ARG; g_dbg_batch_tenants = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards

@@ -330,5 +330,9 @@ __device__ unsigned long long srukf_stamps[32];
 #define STAMPW(i)
 #endif
 
+// ---- batched launches (srukf_run_frames_batch): per-filter arguments of the B-wide kernels, one table entry per filter in device memory ----
+struct Step64Args { double* G; double* Sout; double* D; void* pan[2]; double* Wb; double* Lb; };   // Wb / Lb: the panel's slabs in global memory (64 x ld each)
+struct SyrkOwnArgs { const double* S0; const double* Ut0; double* G; FrameScalars* fs; };
+
 // ---- launch prototypes (host side, implemented in the .hip files) ---------------------------
 struct LaunchCtx;   // defined in srukf_api.hip

@@ -97,15 +97,16 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // 512 threads: EIGHT waves, two per SIMD — a single wave per SIMD issues FP64 MFMAs at 44 % of the rate (34 of 78 TFLOP/s,
 // scripts/mb/mb_mfma_f64.hip; the four-wave form of this kernel took 20.6 us for its 8.5 us of MFMA).  Waves w and w + 4 share a
 // 32 x 32 sub-tile and take k-steps 0-1 / 2-3 of every group; the upper four hand their accumulators over through LDS at the end.
-__global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
-                                              const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
+// (the body takes the workgroup's index explicitly: k_pxy2 passes blockIdx.x, the batched launch k_pxy2_b the index within its filter's share of the grid)
+__device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
+                                          const int4* __restrict__ tiles, int ntiles, int kr, const KWeights& w, const MeasArgs& ms, const int bid)
 {
     __shared__ double shm[2 * 2 * 16 * PXY2_LS];               // [buf][A|B][k][PXY2_LS]; >= MEAS_SM_DOUBLES (statistics scratch), >= 4 x 64 x 17 (hand-over)
     static_assert(2 * 2 * 16 * PXY2_LS >= MEAS_SM_DOUBLES && 2 * 2 * 16 * PXY2_LS >= 4 * 64 * 17, "scratch");
     const int nstat = ms.Z ? MEAS_SLICES * ms.gx : 0;         // statistics jobs first: they start with the launch, the tiles fill in behind
-    if (ms.preamble && blockIdx.x == 0 && threadIdx.x == 0) srukf_frame_preamble(ms.fs);   // "tail" mode: nothing of this frame runs before this launch
+    if (ms.preamble && bid == 0 && threadIdx.x == 0) srukf_frame_preamble(ms.fs);   // "tail" mode: nothing of this frame runs before this launch
     const int nmot = ms.fmode ? 1 : 0;                         // "fused tail" mode: workgroup 0 is the frame's motion step (sums over the table the previous frame's tail completed)
-    if (nmot && blockIdx.x == 0) {
+    if (nmot && bid == 0) {
         if (threadIdx.x >= 256) return;
         const RankArgs ra0 = {};
         motion_reduce_body<256, false>(d, w, const_cast<double*>(ms.X), nullptr, const_cast<double*>(ms.sigR), ms.Cm, ms.fs, ra0, shm);
@@ -116,14 +117,15 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
 #define PXY2_STATS_LAST 0                              // measured both ways: 5 207 / 5 207 frames/s at N = 200, 1 024 (last) / 1 033 (first) at N = 500
 #endif
     const int stat0 = PXY2_STATS_LAST ? nmot + ntiles : nmot, tile0 = PXY2_STATS_LAST ? nmot : nmot + nstat;
-    if ((int)blockIdx.x >= stat0 && (int)blockIdx.x < stat0 + nstat) {
+    if (bid >= stat0 && bid < stat0 + nstat) {
         if (threadIdx.x >= 256) return;
-        const int job = (int)blockIdx.x - stat0;               // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
+        const int job = bid - stat0;               // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
         meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm, ms.ns);
         meas_job_done(d, w, ms, job % ms.gx, shm);
         return;
     }
-    const int4 tl = tiles[blockIdx.x - tile0];
+    if (bid - tile0 >= ntiles) return;                         // (padding of the batched grid)
+    const int4 tl = tiles[bid - tile0];
     if (tl.x < 0) return;                                      // empty slot of the XCD-aware list
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int m0 = 64 * tl.x, b0 = 64 * tl.y;
@@ -195,6 +197,19 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
             for (int t = 0; t < 4; t++)
                 P[(size_t)(m0 + mo + 16 * a + lk + 4 * t) * d.np + b0 + bo + 16 * b + lr] = acc[a][b][t] + ho[wv][lane][(a * 2 + b) * 4 + t];
 }
+__global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
+                                              const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
+{
+    pxy2_body(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x);
+}
+// Batched form (srukf_run_frames_batch, B filters of one shape in ONE launch per stage): filter f owns workgroups [f per, (f + 1) per) — per is a multiple of 8, so
+// the XCD-aware tile list keeps its meaning — and takes its pointers from tab[f] (device memory: one scalar load round trip at the head of the launch).
+__global__ __launch_bounds__(512) void k_pxy2_b(KDims d, const Pxy2Args* __restrict__ tab, int per, const int4* __restrict__ tiles, int ntiles, int kr, KWeights w)
+{
+    const int f = (int)blockIdx.x / per, bid = (int)blockIdx.x - f * per;
+    const Pxy2Args a = tab[f];
+    pxy2_body(d, a.DZp, a.A, a.P0, a.P1, tiles, ntiles, kr, w, a.ms, bid);
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_syrk: G = S^T S - U U^T on the upper triangle (SLAM.cpp:2118-2120, 2149 batched over all
@@ -204,22 +219,23 @@ __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict_
 // grid = one workgroup per upper-triangle 32x32 tile (XCD-aware order from the tile table), 4-way
 // split-K over the concatenated K range [S rows 0..r0+32) ++ [Ut rows).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
-                                              int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
-                                              const int2* __restrict__ tiles, int ntiles, const double* __restrict__ dxp, double* __restrict__ X,
-                                              int krows, int ndx, const RankArgs ra, const double* __restrict__ xr1)
+__device__ __forceinline__ void syrk_body(const KDims& d, const double* __restrict__ S, const double* __restrict__ Ut,
+                                          int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
+                                          const int2* __restrict__ tiles, int ntiles, const double* __restrict__ dxp, double* __restrict__ X,
+                                          int krows, int ndx, const RankArgs& ra, const double* __restrict__ xr1, const int bid, const int nblocks)
 {
     // workgroups past the tile list: the state update X += sum_k K_k (z_k - h_k) left over by k_gain, then (rank-aware replay)
     // the diagonal of G at the dropped positions
-    if ((int)blockIdx.x >= ntiles + ndx) { srukf_rank_gdiag_job(d.n, d.np, ue, ra, &fs->gmax_bits, blockIdx.x - ntiles - ndx); return; }
-    if ((int)blockIdx.x >= ntiles) {
-        if (ra.prep_next && (int)blockIdx.x == ntiles && threadIdx.x == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
-        srukf_gain_dx_job(d.n, d.np, dxp, X, blockIdx.x - ntiles, xr1, ra.f32round);
+    if (bid >= nblocks) return;                                // (padding of the batched grid)
+    if (bid >= ntiles + ndx) { srukf_rank_gdiag_job(d.n, d.np, ue, ra, &fs->gmax_bits, bid - ntiles - ndx); return; }
+    if (bid >= ntiles) {
+        if (ra.prep_next && bid == ntiles && threadIdx.x == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
+        srukf_gain_dx_job(d.n, d.np, dxp, X, bid - ntiles, xr1, ra.f32round);
         return;
     }
     __shared__ double red[3][64][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int2 tl = tiles[blockIdx.x];  // upper-triangle tiles only, XCD-aware order
+    const int2 tl = tiles[bid];  // upper-triangle tiles only, XCD-aware order
     if (tl.x < 0) return;
     const int m0 = tl.x * 32;    // row r
     const int n0 = tl.y * 32;    // col c
@@ -268,6 +284,20 @@ __global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict_
         if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
         if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
     }
+}
+__global__ __launch_bounds__(256) void k_syrk(KDims d, const double* __restrict__ S, const double* __restrict__ Ut,
+                                              int ub, int ue, double* __restrict__ G, FrameScalars* __restrict__ fs,
+                                              const int2* __restrict__ tiles, int ntiles, const double* __restrict__ dxp, double* __restrict__ X,
+                                              int krows, int ndx, const RankArgs ra, const double* __restrict__ xr1)
+{
+    syrk_body(d, S, Ut, ub, ue, G, fs, tiles, ntiles, dxp, X, krows, ndx, ra, xr1, (int)blockIdx.x, (int)gridDim.x);
+}
+// batched form: filter f owns workgroups [f per, (f + 1) per), nblocks of them live; all downdate rows [0, ue) (the replay's launch)
+__global__ __launch_bounds__(256) void k_syrk_b(KDims d, const SyrkArgs* __restrict__ tab, int per, int nblocks, int ue, const int2* __restrict__ tiles, int ntiles, int krows, int ndx)
+{
+    const int f = (int)blockIdx.x / per, bid = (int)blockIdx.x - f * per;
+    const SyrkArgs a = tab[f];
+    syrk_body(d, a.S, a.Ut, 0, ue, a.G, a.fs, tiles, ntiles, a.dxp, a.X, krows, ndx, a.ra, a.xr1, bid, nblocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,24 +538,96 @@ __device__ __forceinline__ void gmw_step64_block00(int n, int ld, int j0, int fi
 //   3. first block row only: writes the final S rows j0..j0+63 for its column slab;
 //   4. block (0,0) takes its own route (gmw_step64_block00).
 // grid = (T, T), T = (ld - base)/64; blocks strictly below the diagonal exit.
-__global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int first, double* __restrict__ G,
-                                                    const GmwPanel64* __restrict__ cur, double* __restrict__ Sout, GmwPanel64* __restrict__ nxt,
-                                                    double* __restrict__ Dall, double eps, const FrameScalars* __restrict__ fs)
+__device__ __forceinline__ void gmw_step64_body(int n, int ld, int j0, int first, double* __restrict__ G,
+                                                const GmwPanel64* __restrict__ cur, double* __restrict__ Sout, GmwPanel64* __restrict__ nxt,
+                                                double* __restrict__ Dall, double eps, const int bx, const int by)
 {
-    if (blockIdx.x < blockIdx.y) return;
+    if (bx < by) return;
     STAMP(0);
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
     __shared__ double facreg[2 * GMW_FAC_DOUBLES];           // block (0,0): one column-factor workspace per sub-panel
     __shared__ double xreg[1024 + 1024 + 32 * 33];            // block (0,0): staged panel matrices, then X01 | X11 | T1'
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (bx == 0 && by == 0) {
         gmw_step64_block00(n, ld, j0, first, eps, G, cur, nxt, Dall, Sout, Lr, Wc, facreg, xreg, tid);
         return;
     }
     d4 acc[2][2];
     zero_acc(acc);
-    gmw_tile_update<false>(n, ld, j0, blockIdx.y, blockIdx.x, G, cur, Sout, Lr, Wc, tid, acc, true, true, [] { return true; }, [] { return true; }, [] {});
+    gmw_tile_update<false>(n, ld, j0, by, bx, G, cur, Sout, Lr, Wc, tid, acc, true, true, [] { return true; }, [] { return true; }, [] {});
+}
+__global__ __launch_bounds__(256) void k_gmw_step64(int n, int ld, int j0, int first, double* __restrict__ G,
+                                                    const GmwPanel64* __restrict__ cur, double* __restrict__ Sout, GmwPanel64* __restrict__ nxt,
+                                                    double* __restrict__ Dall, double eps, const FrameScalars* __restrict__ fs)
+{
+    gmw_step64_body(n, ld, j0, first, G, cur, Sout, nxt, Dall, eps, (int)blockIdx.x, (int)blockIdx.y);
+}
+// Batched form: one launch per 64-row panel for B filters.  Workgroup index = idx B + f, so that the B critical-path workgroups (idx 0: block (0,0) of every filter)
+// are dispatched first; idx -> (by, bx) over `rows` block rows x `cols` block columns of the trailing square (the rank-aware form only needs the rows of the kept
+// pivots: the caller passes rows < cols), tiles below the diagonal leave at once.  cur / nxt alternate between the two panel buffers of a filter (flip).
+__global__ __launch_bounds__(256) void k_gmw_step64_b(int n, int ld, int j0, int first, const Step64Args* __restrict__ tab, int B, int cols, int flip, double eps)
+{
+    const int f = (int)blockIdx.x % B, idx = (int)blockIdx.x / B;
+    const Step64Args a = tab[f];
+    gmw_step64_body(n, ld, j0, first, a.G, (const GmwPanel64*)a.pan[flip ^ 1], a.Sout, (GmwPanel64*)a.pan[flip], a.D, eps, idx % cols, idx / cols);
+}
+
+// Batched replay, split form of a panel step (srukf_gmw_panel.h, gmw_slab_to_global): launch A = the B critical-path workgroups (block (0,0): apply the panel to the
+// next diagonal region, factor it) beside one slab workgroup per column block of every filter; launch B = the trailing tiles as plain K = 64 updates from the slab
+// rows — no LDS, few registers, many waves per SIMD.  Same instruction sequences on the same values as k_gmw_step64: bit-identical.
+// A: workgroup index = idx B + f; idx 0: block (0,0); idx 1 + q: the slabs of column blocks 2q and 2q + 1 (four waves: their 32-column halves).
+__global__ __launch_bounds__(256) void k_gmw_pivslab_b(int n, int ld, int j0, int first, const Step64Args* __restrict__ tab, int B, int flip, double eps)
+{
+    __shared__ double Lr[64][G64_LS];
+    __shared__ double Wc[64][G64_LS];
+    __shared__ double facreg[2 * GMW_FAC_DOUBLES];
+    __shared__ double xreg[1024 + 1024 + 32 * 33];
+    const int f = (int)blockIdx.x % B, idx = (int)blockIdx.x / B;
+    const Step64Args a = tab[f];
+    const GmwPanel64* cur = (const GmwPanel64*)a.pan[flip ^ 1];
+    if (idx == 0) {
+        gmw_step64_block00(n, ld, j0, first, eps, a.G, cur, (GmwPanel64*)a.pan[flip], a.D, a.Sout, Lr, Wc, facreg, xreg, threadIdx.x);
+        return;
+    }
+    const int wv = threadIdx.x >> 6, bx = 2 * (idx - 1) + (wv >> 1);
+    gmw_slab_to_global(n, ld, j0, j0 + 64 + 64 * bx + 32 * (wv & 1), a.G, cur, a.Sout, a.Wb, a.Lb, bx >= 1, threadIdx.x & 63);
+}
+// B: workgroup index = idx B + f, idx -> (by, bx) over rows x cols; tiles below the diagonal and (0,0) leave at once
+__global__ __launch_bounds__(256) void k_gmw_trail_b(int ld, int j0, const Step64Args* __restrict__ tab, int B, int cols)
+{
+    const int f = (int)blockIdx.x % B, idx = (int)blockIdx.x / B;
+    const int by = idx / cols, bx = idx % cols;
+    if (bx < by || (bx == 0 && by == 0)) return;
+    const Step64Args a = tab[f];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const int base = j0 + 64;
+    const int m0 = base + 64 * by + 32 * (wv >> 1), c0 = base + 64 * bx + 32 * (wv & 1);
+    if (!((m0 < ld) && (c0 < ld) && (c0 + 32 > m0))) return;
+    double* __restrict__ G = a.G;
+    const double* __restrict__ Lb = a.Lb; const double* __restrict__ Wb = a.Wb;
+    d4 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[q][b][t] = G[(size_t)(m0 + 16 * q + lk + 4 * t) * ld + c0 + 16 * b + lr];
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+        const double a0 = -Lb[(size_t)(k + lk) * ld + m0 + lr], a1 = -Lb[(size_t)(k + lk) * ld + m0 + 16 + lr];
+        const double b0 = Wb[(size_t)(k + lk) * ld + c0 + lr], b1 = Wb[(size_t)(k + lk) * ld + c0 + 16 + lr];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) G[(size_t)(m0 + 16 * q + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[q][b][t];
 }
 
 // k_gmw_check: was the reference's third pivot candidate theta_j^2/beta^2 ever the largest?
@@ -715,6 +817,43 @@ void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, 
     hipLaunchKernelGGL(k_gmw_step64, dim3(T, T), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, G, (const GmwPanel64*)cur, Sout, (GmwPanel64*)nxt, D, eps, fs);
 }
 int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel64); }
+// split form of a batched panel step: A (critical-path workgroups + slabs of every column block of the trailing square), B (trailing tiles of `rows` block rows)
+void srukf_launch_gmw_pivslab_b(hipStream_t st, int n, int ld, int j0, double eps, const void* tab, int B, int flip)
+{
+    const int rem = ld - j0 - 64;
+    if (rem <= 0) return;
+    const int cols = (j0 < 0) ? 0 : rem / 64;                  // j0 = -64: no panel yet, block (0,0) only
+    hipLaunchKernelGGL(k_gmw_pivslab_b, dim3((1 + (cols + 1) / 2) * B), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, (const Step64Args*)tab, B, flip, eps);
+}
+void srukf_launch_gmw_trail_b(hipStream_t st, int ld, int j0, const void* tab, int B, int rows)
+{
+    const int cols = (ld - j0 - 64) / 64;
+    if (j0 < 0 || cols <= 0 || rows < 1) return;
+    if (rows > cols) rows = cols;
+    hipLaunchKernelGGL(k_gmw_trail_b, dim3(rows * cols * B), dim3(256), 0, st, ld, j0, (const Step64Args*)tab, B, cols);
+}
+// ---- batched launches (srukf_run_frames_batch): B filters of one shape, one launch per stage, arguments per filter in device tables ----
+int srukf_pxy2_b_per(int ntiles, int gx) { return (ntiles + MEAS_SLICES * gx + 1 + 7) & ~7; }
+void srukf_launch_pxy2_b(hipStream_t st, KDims d, const void* tab, int B, const void* tiles, int ntiles, int kr, KWeights w, int gx)
+{
+    const int per = srukf_pxy2_b_per(ntiles, gx);
+    hipLaunchKernelGGL(k_pxy2_b, dim3(per * B), dim3(512), 0, st, d, (const Pxy2Args*)tab, per, (const int4*)tiles, ntiles, kr, w);
+}
+void srukf_launch_syrk_b(hipStream_t st, KDims d, const void* tab, int B, const void* tiles, int ntiles, int krows, int ndx, int ngd)
+{
+    const int nblocks = ntiles + ndx + ngd, per = (nblocks + 7) & ~7;
+    hipLaunchKernelGGL(k_syrk_b, dim3(per * B), dim3(256), 0, st, d, (const SyrkArgs*)tab, per, nblocks, d.mp, (const int2*)tiles, ntiles, krows, ndx);
+}
+// j0 = -64: the first 64 x 64 region only; rows = block rows of the trailing square that are updated (>= 1), flip = which panel buffer receives the new panel
+void srukf_launch_gmw_step64_b(hipStream_t st, int n, int ld, int j0, double eps, const void* tab, int B, int rows, int flip)
+{
+    const int rem = ld - j0 - 64;
+    if (rem <= 0) return;
+    const int cols = (j0 < 0) ? 1 : rem / 64;
+    if (j0 < 0 || rows < 1) rows = 1;
+    if (rows > cols) rows = cols;
+    hipLaunchKernelGGL(k_gmw_step64_b, dim3(rows * cols * B), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, (const Step64Args*)tab, B, cols, flip, eps);
+}
 void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, const double* S, FrameScalars* fs, const double* X, int do_traj, double* Scopy)
 {
     hipLaunchKernelGGL(k_gmw_check, dim3(n + (do_traj ? 1 : 0)), dim3(256), 0, st, n, ld, D, S, fs, X, do_traj, Scopy);

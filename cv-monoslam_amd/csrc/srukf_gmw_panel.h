@@ -328,3 +328,90 @@ __device__ __forceinline__ bool gmw_tile_update(int n, int ld, int j0, int by, i
     return true;
 }
 
+
+// ---- batched replay (srukf_run_frames_batch): the panel's slabs ONCE per column block, in global memory ----
+// In the two forms above every trailing tile recomputes the slabs it needs (no workgroup waits for another: latency first).  With B filters per launch the
+// trailing tiles are throughput work, and the slab stages are 80 of the 144 MFMAs of a tile step: here one wave per 32-column half forms W (64 x 32) and
+// L = W / D with exactly the instruction sequence of gmw_tile_update's slab part and leaves them in the filter's slab rows Wb / Lb (row kk of the panel at
+// [kk * ld + column]); the tiles then are plain K = 64 updates from those rows (k_gmw_trail_b).  write_s: the panel's final S rows for these columns.
+__device__ __forceinline__ void gmw_slab_to_global(int n, int ld, int j0, int n0, const double* __restrict__ G, const GmwPanel64* __restrict__ cur,
+                                                   double* __restrict__ Sout, double* __restrict__ Wb, double* __restrict__ Lb, bool write_s, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    if (n0 >= ld) return;
+    d4 X2[2][2], W1[2][2], W2[2][2];
+    double fb0[8], fb1[8];
+    double ta0[4], ta1[8], ea0[8], ea1[8], tb0[4], tb1[8], dr[2][4], dr2[2][4], sqr[4][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) X2[a][b][t] = G[(size_t)(j0 + 32 + 16 * a + lk + 4 * t) * ld + n0 + 16 * b + lr];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        fb0[u] = G[(size_t)(j0 + 4 * u + lk) * ld + n0 + lr]; fb1[u] = G[(size_t)(j0 + 4 * u + lk) * ld + n0 + 16 + lr];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int o = (4 * u + lk) * 32 + lr;
+        if (u < 4) { ta0[u] = cur->Tt1[o]; tb0[u] = cur->Tt2[o]; }
+        ta1[u] = cur->Tt1[o + 16]; tb1[u] = cur->Tt2[o + 16];
+        ea0[u] = cur->E[o]; ea1[u] = cur->E[o + 16];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) { dr[q][t] = cur->rD[16 * q + lk + 4 * t]; dr2[q][t] = cur->rD[32 + 16 * q + lk + 4 * t]; }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) sqr[q][t] = write_s ? cur->sq[16 * q + lk + 4 * t] : 0.0;
+    zero_acc(W1);
+    // W1 = T1 G1
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (u < 4) {
+            W1[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0[u], fb0[u], W1[0][0], 0, 0, 0);
+            W1[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0[u], fb1[u], W1[0][1], 0, 0, 0);
+        }
+        W1[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1[u], fb0[u], W1[1][0], 0, 0, 0);
+        W1[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1[u], fb1[u], W1[1][1], 0, 0, 0);
+    }
+    // G2' = G2 - E^T W1
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int a2 = u >> 2, t = u & 3;
+        X2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea0[u], W1[a2][0][t], X2[0][0], 0, 0, 0);
+        X2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea0[u], W1[a2][1][t], X2[0][1], 0, 0, 0);
+        X2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea1[u], W1[a2][0][t], X2[1][0], 0, 0, 0);
+        X2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea1[u], W1[a2][1][t], X2[1][1], 0, 0, 0);
+    }
+    zero_acc(W2);
+    // W2 = T2 G2'
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int a2 = u >> 2, t = u & 3;
+        if (u < 4) {
+            W2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb0[u], X2[a2][0][t], W2[0][0], 0, 0, 0);
+            W2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb0[u], X2[a2][1][t], W2[0][1], 0, 0, 0);
+        }
+        W2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb1[u], X2[a2][0][t], W2[1][0], 0, 0, 0);
+        W2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb1[u], X2[a2][1][t], W2[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int jj = 16 * a + lk + 4 * t, col = n0 + 16 * b + lr;
+                const double w1 = W1[a][b][t], w2 = W2[a][b][t];
+                Wb[(size_t)jj * ld + col] = w1;        Lb[(size_t)jj * ld + col] = w1 * dr[a][t];
+                Wb[(size_t)(32 + jj) * ld + col] = w2; Lb[(size_t)(32 + jj) * ld + col] = w2 * dr2[a][t];
+                if (write_s) {
+                    if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + col] = w1 * sqr[a][t];
+                    if (j0 + 32 + jj < n) Sout[(size_t)(j0 + 32 + jj) * ld + col] = w2 * sqr[2 + a][t];
+                }
+            }
+}

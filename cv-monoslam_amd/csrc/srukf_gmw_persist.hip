@@ -461,10 +461,10 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
 // result of the launch whose owners fold.  Used where a worker owns two register tiles (filters that share the GPU with three or four tenants: forming both tiles
 // before the first step would hold up the pivot chain), so that a filter's results do not depend on how many filters run beside it.
 // One workgroup per tile of the persistent launch's list, longest K first; tiles the head launch covers leave at once.
-__global__ __launch_bounds__(256) void k_syrk_own(int n, int ld, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows,
-                                                  double* __restrict__ G, FrameScalars* __restrict__ fs, const GmwTile* __restrict__ tiles, int nreal)
+__device__ __forceinline__ void syrk_own_body(int n, int ld, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows,
+                                              double* __restrict__ G, FrameScalars* __restrict__ fs, const GmwTile* __restrict__ tiles, int nreal, const int bid)
 {
-    const GmwTile t = tiles[nreal - 1 - (int)blockIdx.x];
+    const GmwTile t = tiles[nreal - 1 - bid];
     if (!gmw_owner_computes(t.I, t.J)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     d4 acc[2][2];
@@ -478,6 +478,18 @@ __global__ __launch_bounds__(256) void k_syrk_own(int n, int ld, const double* _
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int tt = 0; tt < 4; tt++) G[(size_t)(m0 + 16 * a + lk + 4 * tt) * ld + c0 + 16 * b + lr] = acc[a][b][tt];
+}
+__global__ __launch_bounds__(256) void k_syrk_own(int n, int ld, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows,
+                                                  double* __restrict__ G, FrameScalars* __restrict__ fs, const GmwTile* __restrict__ tiles, int nreal)
+{
+    syrk_own_body(n, ld, S0, Ut0, u0, u1, krows, G, fs, tiles, nreal, (int)blockIdx.x);
+}
+// batched form: workgroup index = tile B + f (the B filters' longest tiles first)
+__global__ __launch_bounds__(256) void k_syrk_own_b(int n, int ld, const SyrkOwnArgs* __restrict__ tab, int B, int u0, int u1, int krows, const GmwTile* __restrict__ tiles, int nreal)
+{
+    const int f = (int)blockIdx.x % B, bid = (int)blockIdx.x / B;
+    const SyrkOwnArgs a = tab[f];
+    syrk_own_body(n, ld, a.S0, a.Ut0, u0, u1, krows, a.G, a.fs, tiles, nreal, bid);
 }
 
 // Admission of persistent launches when several filters share the GPU (srukf_set_exclusive(ctx, 0)): every such launch keeps to
@@ -788,6 +800,13 @@ void srukf_launch_syrk_own(hipStream_t st, int n, int ld, const double* S0, cons
     const int nreal = ntiles - ((Tp > 0 && Tp < T) ? T - Tp : 0);
     if (krows <= 0 || krows > ld) krows = ld;
     if (nreal > 0) hipLaunchKernelGGL(k_syrk_own, dim3(nreal), dim3(256), 0, st, n, ld, S0, Ut0, u0, u1, krows, G, (FrameScalars*)fs, (const GmwTile*)tiles, nreal);
+}
+void srukf_launch_syrk_own_b(hipStream_t st, int n, int ld, const void* tab, int B, int u0, int u1, int krows, const void* tiles, int ntiles, int Tp)
+{
+    const int T = ld / 64;
+    const int nreal = ntiles - ((Tp > 0 && Tp < T) ? T - Tp : 0);
+    if (krows <= 0 || krows > ld) krows = ld;
+    if (nreal > 0) hipLaunchKernelGGL(k_syrk_own_b, dim3(nreal * B), dim3(256), 0, st, n, ld, (const SyrkOwnArgs*)tab, B, u0, u1, krows, (const GmwTile*)tiles, nreal);
 }
 int srukf_gmw_register_form(int T, int Tp, int ntiles, int workers) { return gmw_register_form(T, Tp, ntiles, workers) ? 1 : 0; }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }

@@ -432,25 +432,25 @@ __global__ __launch_bounds__(256) void k_meas_final(KDims d, KWeights w, const d
 // workgroups (srukf_gain_dx_job).  Block (0,0) also clears the gamma / xi accumulators of that k_syrk.
 // ------------------------------------------------------------------------------------------------
 #define GAIN_LM_MAX 64
-__global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
-                                              double* __restrict__ Ut, const double* __restrict__ PxyR,
-                                              const double* __restrict__ Si, const int* __restrict__ vis,
-                                              const double* __restrict__ h, const double* __restrict__ z_seq,
-                                              const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
-                                              FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra,
-                                              const double* __restrict__ Cm, double* __restrict__ S,
-                                              const double* __restrict__ P1, int split_b0, const double* __restrict__ DZp, double sqeps,
-                                              const double* __restrict__ sigR, const double* __restrict__ Z0, int fmode)
+__device__ __forceinline__ void gain_body(const KDims& d, const KWeights& w,
+                                          double* __restrict__ Ut, const double* __restrict__ PxyR,
+                                          const double* __restrict__ Si, const int* __restrict__ vis,
+                                          const double* __restrict__ h, const double* __restrict__ z_seq,
+                                          const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
+                                          FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs& ra,
+                                          const double* __restrict__ Cm, double* __restrict__ S,
+                                          const double* __restrict__ P1, int split_b0, const double* __restrict__ DZp, double sqeps,
+                                          const double* __restrict__ sigR, const double* __restrict__ Z0, int fmode, const int bx, const int by)
 {
     __shared__ double red[4][64];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
+    if (bx == 0 && by == 0 && threadIdx.x == 0) { fs->gmax_bits = 0ull; fs->ximax_bits = 0ull; }
     const int rl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int r = blockIdx.x * 64 + rl;
+    const int r = bx * 64 + rl;
     const int n = d.n, ld = d.np, mp = d.mp, N = d.N;
     // replay path: the motion step of this frame (workgroup 0 of k_project_motion) left the new last four columns of S in Cm —
     // the projection threads of its launch were reading the old ones.  Committed here, one row per thread, before the
     // k_syrk launch reads them: R12 rows (r < n-4), R22 rows (the robot block); the permuted copy of the rank-aware form too.
-    if (Cm && blockIdx.y == 0 && sl == 0 && r < n) {
+    if (Cm && by == 0 && sl == 0 && r < n) {
         const double4 v = *reinterpret_cast<const double4*>(Cm + (size_t)r * 4);
         *reinterpret_cast<double2*>(S + (size_t)r * ld + (n - 4)) = make_double2(v.x, v.y);
         *reinterpret_cast<double2*>(S + (size_t)r * ld + (n - 2)) = make_double2(v.z, v.w);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     const int* mt = m_cur ? m_cur : (m_seq + (size_t)fs->frame * N);
     const double sc = w.wi * w.gamma;
     const int per = (N + GAIN_SLICES - 1) / GAIN_SLICES;
-    const int k_beg = blockIdx.y * per, k_end = min(N, k_beg + per);
+    const int k_beg = by * per, k_end = min(N, k_beg + per);
     const int rp = ra.Utp ? ra.iperm[r] : 0;                  // rank-aware replay: U^T also with permuted columns
     // per-landmark constants of this slice once per workgroup (they are a chain of small dependent loads: fetched per
     // thread and iteration they cost more than the streaming of Ut itself): Si^{-1}, Si^{-T}(z - h), "matched and visible"
@@ -527,7 +527,26 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
     }
     red[sl][rl] = dx;
     __syncthreads();
-    if (sl == 0) dxp[(size_t)blockIdx.y * ld + r] = (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
+    if (sl == 0) dxp[(size_t)by * ld + r] = (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
+}
+__global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
+                                              double* __restrict__ Ut, const double* __restrict__ PxyR,
+                                              const double* __restrict__ Si, const int* __restrict__ vis,
+                                              const double* __restrict__ h, const double* __restrict__ z_seq,
+                                              const double* z_cur, const int* __restrict__ m_seq, const int* m_cur,
+                                              FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra,
+                                              const double* __restrict__ Cm, double* __restrict__ S,
+                                              const double* __restrict__ P1, int split_b0, const double* __restrict__ DZp, double sqeps,
+                                              const double* __restrict__ sigR, const double* __restrict__ Z0, int fmode)
+{
+    gain_body(d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra, Cm, S, P1, split_b0, DZp, sqeps, sigR, Z0, fmode, (int)blockIdx.x, (int)blockIdx.y);
+}
+// batched form (srukf_run_frames_batch): grid (np / 64, GAIN_SLICES B), filter f = blockIdx.y / GAIN_SLICES; staged inputs only, "fused tail" mode
+__global__ __launch_bounds__(256) void k_gain_b(KDims d, KWeights w, const GainArgs* __restrict__ tab, int split_b0, double sqeps)
+{
+    const int f = (int)blockIdx.y / GAIN_SLICES, by = (int)blockIdx.y - f * GAIN_SLICES;
+    const GainArgs a = tab[f];
+    gain_body(d, w, a.Ut, a.PxyR, a.Si, a.vis, a.h, a.z_seq, nullptr, a.m_seq, nullptr, a.fs, a.dxp, a.ra, a.Cm, a.S, a.P1, split_b0, a.DZp, sqeps, a.sigR, a.Z0, 1, (int)blockIdx.x, by);
 }
 // k_gain_center: weight types with wc0 != wm0 (FLAG_4_WEIGHT2, SLAM.cpp:1077-1088: wc0 = wm0 + 1 - alpha^2 + beta).
 // calculateOneFeatureCrossCovariance centres on the RUNNING state (s1 = sigma_i - m_X_k, 2030) which KalmanUpdate has
@@ -709,6 +728,10 @@ void srukf_launch_meas_stats(hipStream_t st, KDims d, KWeights w, const double* 
     hipLaunchKernelGGL(k_meas_final, dim3((d.N + 255) / 256), dim3(256), 0, st, d, w, X, sigR, Z, part, h, Si, vis, PxyR);
 }
 int srukf_meas_part_doubles(int mp) { return MEAS_SLICES * MEAS_NS * (mp / 2); }
+void srukf_launch_gain_b(hipStream_t st, KDims d, KWeights w, const void* tab, int B, int split_b0, double sqeps)
+{
+    hipLaunchKernelGGL(k_gain_b, dim3(d.np / 64, GAIN_SLICES * B), dim3(256), 0, st, d, w, (const GainArgs*)tab, split_b0, sqeps);
+}
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
                        FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra, const double* Cm, double* S,

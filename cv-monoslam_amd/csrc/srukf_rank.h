@@ -1,6 +1,7 @@
 // srukf_rank.h — rank-aware refactorisation (srukf_rank.hip): pieces other kernels carry along.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "srukf_device.h"
 
 // What the replay path of the rank-aware form hands to k_motion / k_gain / k_syrk (all null / 0: the plain path).
 struct RankArgs {
@@ -15,6 +16,18 @@ struct RankArgs {
                            // the rounding points of k_quantize, without its launch)
     int prep_next;         // "table" mode of the replay: the k_syrk launch also prepares the NEXT frame's control in fs->ctl (this frame's motion
                            // step has consumed it; the tail that needs it must not read the frame counter it advances itself)
+};
+
+// per-filter arguments of the batched launches that carry RankArgs / MeasArgs (srukf_run_frames_batch; tables in device memory)
+struct Pxy2Args { const double* DZp; const double* A; double* P0; double* P1; MeasArgs ms; };
+struct SyrkArgs { const double* S; const double* Ut; double* G; FrameScalars* fs; const double* dxp; double* X; RankArgs ra; const double* xr1; };
+struct GainArgs {
+    double* Ut; const double* PxyR; const double* Si; const int* vis; const double* h; const double* z_seq; const int* m_seq; FrameScalars* fs; double* dxp;
+    RankArgs ra; const double* Cm; double* S; const double* P1; const double* DZp; const double* sigR; const double* Z0;
+};
+struct ExpandArgs {
+    const double* Sp; const double* D; const int* perm; const int* iperm; const double* gdiag; FrameScalars* fs; const double* X; double* S; double* A;
+    double* sigR; double* Z; double* DZ;
 };
 
 // Head fold of the persistent factorisation launch (srukf_gmw_persist.hip): what its helper workgroups take over from k_syrk.

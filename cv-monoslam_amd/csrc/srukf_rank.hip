@@ -67,12 +67,12 @@ __global__ __launch_bounds__(256) void k_rank_diag(int n, int ld, const double* 
 // arithmetic, srukf_project_sigma).  Null rows: their own landmark; the frame tail: the centre point; five more workgroups: the noise rows.
 // The frame's motion reduction then rides on k_pxy2 (MeasArgs::fmode).  Dynamic LDS: ld doubles.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
-                                                     const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
-                                                     FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
-                                                     double* __restrict__ A, double* __restrict__ sigR, double gamma,
-                                                     KDims d, KWeights w,
-                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32)
+__device__ __forceinline__ void rank_expand_body(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
+                                                 const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
+                                                 FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
+                                                 double* __restrict__ A, double* __restrict__ sigR, double gamma,
+                                                 const KDims& d, const KWeights& w,
+                                                 const srukf_params& p, double* __restrict__ Z, double* __restrict__ DZ, int f32, const int bid)
 {
     constexpr bool PROJ = MODE == 2;
     // f32 (fp32 storage, "fused tail" mode): every value this launch writes into S / the permuted copy — and reads back for the table, the projection and
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     extern __shared__ double lrow[];                           // PROJ: the workgroup's row of the factor (permuted order)
     __shared__ double prow[2][8];                              // PROJ: robot part of the direction's two sigma points (what goes into the table)
     __shared__ double red[16 * 3];
-    const int j = (int)blockIdx.x;                             // < n: row (permuted position), n: frame tail, > n: null checks (+ PROJ: noise rows)
+    const int j = bid;                                         // < n: row (permuted position), n: frame tail, > n: null checks (+ PROJ: noise rows)
     // "Table" mode of the replay (sigR != null): the workgroup that writes row j of S also pushes the NEXT frame's two sigma points
     // of direction j through the motion model — robot part only: pose before the step X[n-4..], the row's entries in the robot
     // columns, the control k_gain prepared in fs->ctl — and leaves them in the table the next k_project_table launch reads.
@@ -292,6 +292,24 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, double eps, const double* __restrict__ Sp, const double* __restrict__ D,
+                                                     const int* __restrict__ perm, const int* __restrict__ iperm, const double* __restrict__ gdiag,
+                                                     FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
+                                                     double* __restrict__ A, double* __restrict__ sigR, double gamma,
+                                                     KDims d, KWeights w,
+                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32)
+{
+    rank_expand_body<MODE>(n, ld, r, eps, Sp, D, perm, iperm, gdiag, fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, (int)blockIdx.x);
+}
+// batched form (srukf_run_frames_batch; "fused tail" mode, fp64 storage): filter f owns workgroups [f per, (f + 1) per)
+__global__ __launch_bounds__(256) void k_rank_expand_b(int n, int ld, int r, double eps, const ExpandArgs* __restrict__ tab, int per, double gamma, KDims d, KWeights w, srukf_params p)
+{
+    const int f = (int)blockIdx.x / per, bid = (int)blockIdx.x - f * per;
+    const ExpandArgs a = tab[f];
+    rank_expand_body<2>(n, ld, r, eps, a.Sp, a.D, a.perm, a.iperm, a.gdiag, a.fs, a.X, 1, a.S, a.A, a.sigR, gamma, d, w, p, a.Z, a.DZ, 0, bid);
+}
+
 // fp32 storage: the permuted copy holds what the stored (float) state holds, like S after k_quantize
 __global__ __launch_bounds__(256) void k_rank_round(int ld, double* __restrict__ A)
 {
@@ -321,6 +339,12 @@ void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, 
     const dim3 grid(n + 1 + nchk + (fuse ? 5 : 0));
     if (fuse) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32);
     else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, 0);
+}
+void srukf_launch_rank_expand_b(hipStream_t st, int n, int ld, int r, double eps, const void* tab, int B, double gamma, KDims d, KWeights w, srukf_params p)
+{
+    const int nchk = (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
+    const int per = n + 1 + nchk + 5;
+    hipLaunchKernelGGL(k_rank_expand_b, dim3(per * B), dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, (const ExpandArgs*)tab, per, gamma, d, w, p);
 }
 void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
 {

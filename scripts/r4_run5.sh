@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_parity_r4.py -m gpu -q -x -k "batched_filters" > gpurun_out/r4e_pytest.log 2>&1; tail -30 gpurun_out/r4e_pytest.log
+timeout 600 python scripts/batch_probe.py > gpurun_out/r4e_batch.log 2>&1
+cat gpurun_out/r4e_batch.log

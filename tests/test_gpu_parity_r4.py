@@ -63,13 +63,15 @@ def test_g8_step_api_against_the_oracle_over_40_frames(srukf, golden, synth):
     _hold_to_g8(g, traj, X, S)
 
 
-@pytest.mark.parametrize("B", [2, 4])
-def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle, synth, B):
-    """srukf_run_frames_batch with B filters at N = 200 (Monte-Carlo runs: one map, own measurement noise; one tenant per filter: B persistent launches of
-    256 / B CUs admitted at a time, two register tiles per worker at B = 4, the tiles of S^T S - U U^T from k_syrk_own in the owners' summation order):
-    every filter's first two frames against the ORACLE (BATCHED), and the whole block against the same sequence replayed ALONE (exclusive mode, owners' fold,
-    head fold) — bit for bit, trajectory and state."""
+@pytest.mark.parametrize("B,wide", [(2, 1), (4, 1), (8, 1), (4, 0)])
+def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle, synth, B, wide):
+    """srukf_run_frames_batch with B filters at N = 200 (Monte-Carlo runs: one map, own measurement noise).  wide = 1 (default): ONE launch per stage for all
+    filters on one stream — k_pxy2_b, k_gain_b, k_syrk_b, k_syrk_own_b, one k_gmw_step64_b per panel, k_rank_expand_b — behind each filter's first frame, which a
+    fresh state runs alone.  wide = 0: round 3's form, one stream per filter and one tenant per filter (B persistent launches of 256 / B CUs admitted at a time,
+    two register tiles per worker at B = 4).  Every filter's first two frames against the ORACLE (BATCHED), and the whole block against the same sequence
+    replayed ALONE (exclusive mode, owners' fold, head fold) — bit for bit, trajectory and state."""
     N, F, Fo = 200, 12, 2
+    srukf.debug_set_global("batch_wide", wide)
     p = synth.scene_params()
     scs = [synth.make_scene(N, F, seed=0, p=p, obs_seed=7000 + b) for b in range(B)]
     fs = []
@@ -80,7 +82,7 @@ def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle,
     t10 = srukf.run_frames_batch(fs, Fo, F - Fo)
     for b, sc in enumerate(scs):
         assert fs[b].debug_get("gmw_aborts") == 0 and fs[b].debug_get("clamp_rows") == 0 and fs[b].debug_get("gate_timeouts") == 0
-        assert fs[b].debug_get("gmw_shared") == 1
+        assert fs[b].debug_get("gmw_shared") == (0 if wide else 1)
         o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
         to = o.run_frames(sc["odo"][:Fo + 1], sc["z"][:Fo], sc["matched"][:Fo], oracle.Oracle.BATCHED)
         Xo, So = o.get_state()
@@ -95,3 +97,4 @@ def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle,
         g.close()
     for f in fs:
         f.close()
+    srukf.debug_set_global("batch_wide", 1)
