@@ -22,11 +22,8 @@ import time
 
 import numpy as np
 
-# The multi-sequence leg runs B filters beside the main one, each on its own HIP stream.  The runtime maps streams onto 4 hardware
-# queues by default; streams that share a queue serialise (measured: 6 100 instead of 10 400 frames/s aggregate at B = 3 with the
-# main filter's stream alive).  Read once when HIP initialises, so it is set before anything imports torch; no effect on the
-# single-filter figures.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (Round 3 exported GPU_MAX_HW_QUEUES=8 here for the multi-sequence leg — one stream per filter.  The batched launches of round 4 run a group of filters per
+#  stream, four streams at most: the runtime's default of four hardware queues is enough, nothing is exported.)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -378,42 +375,46 @@ def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
     return out
 
 
-def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local, reps=5):
-    """B independent sequences (Monte-Carlo runs: same map, own measurement noise) on ONE GPU, one
-    context + HIP stream each, frames replayed concurrently.  The block of K frames is run `reps` times; returns the
-    aggregate frames/s of every repetition.  (Round 3 found that about one multi-stream block in ten waits ~70 ms on the
-    host side of the runtime — no launch abandoned, no frame flagged, all filters finish together — whatever the block length;
-    a single number from one block was either clean or ten times too low.  The median and the count are reported.)"""
-    fs = []
-    for b in range(B):
-        sc = synth.make_scene(N, W + reps * K, seed=0, p=synth.scene_params(), obs_seed=5000 + b)
-        f = srukf.Filter(N, sc["params"], device=local)
-        f.set_state(sc["X0"], sc["S0"])
-        f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
-        fs.append(f)
-    shared_traj = srukf.run_frames_batch(fs, 0, W)               # C entry point for B filters: round-robin chunks of 16 frames, then all awaited
-    rates = []
-    for r in range(reps):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        srukf.run_frames_batch(fs, W + r * K, K)
-        rates.append(B * K / (time.perf_counter() - t0))
-    # correctness of the leg, in the run: every filter's trajectory of the whole leg and its final state against the same sequence replayed ALONE
-    # (a filter that has the GPU to itself: exclusive mode, its own launch sequence) — bit for bit
-    shared_full = []
-    for f in fs:
-        X, S = f.get_state(); shared_full.append((X, S)); f.close()
+def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local, reps=3, small=(8,)):
+    """B independent sequences (Monte-Carlo runs: same map, own measurement noise) on ONE GPU through srukf_run_frames_batch: the filters have one shape, so every
+    stage of the frame is ONE launch over a group of them (k_pxy2_b, k_gain_b, k_syrk_b, k_syrk_own_b, slabs + plain trailing updates per 64-row panel,
+    k_rank_expand_b; groups side by side on their own streams, one host thread).  The block of K frames is run `reps` times, each repetition its own frames;
+    returns the aggregate frames/s of every repetition, the same for the first `small` filters alone, and whether every filter's trajectory and final state
+    equal, bit for bit, those of the same sequence replayed ALONE (exclusive mode: persistent factorisation launch, owners' fold) in this same run."""
+    F = W + reps * K
+    base = synth.make_scene(N, F, seed=0, p=synth.scene_params(), obs_seed=5000)
+    scs = [base] + [synth.make_scene(N, F, seed=0, p=synth.scene_params(), obs_seed=5000 + b) for b in range(1, B)]
+    def fresh(b):
+        f = srukf.Filter(N, scs[b]["params"], device=local)
+        f.set_state(scs[b]["X0"], scs[b]["S0"]); f.stage_sequence(scs[b]["odo"], scs[b]["z"], scs[b]["matched"])
+        return f
+    out = {}
+    for nb in list(small) + [B]:
+        if nb > B:
+            continue
+        fs = [fresh(b) for b in range(nb)]
+        trajs = [srukf.run_frames_batch(fs, 0, W)]               # (a fresh state: every filter's first frame runs alone, the rest batched)
+        rates = []
+        for r in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            trajs.append(srukf.run_frames_batch(fs, W + r * K, K))
+            rates.append(nb * K / (time.perf_counter() - t0))
+        out[nb] = rates
+        if nb == B:
+            full = np.concatenate(trajs, axis=1)
+            states = [f.get_state() for f in fs]
+            flagged = int(sum(f.debug_get("gmw_aborts") + f.debug_get("clamp_rows") for f in fs))
+        for f in fs:
+            f.close()
+    # correctness of the leg, in the run: every filter's trajectory of the whole leg and its final state against the same sequence replayed ALONE — bit for bit
     identical = True
     for b in range(B):
-        sc = synth.make_scene(N, W + reps * K, seed=0, p=synth.scene_params(), obs_seed=5000 + b)
-        g = srukf.Filter(N, sc["params"], device=local)
-        g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
-        t_solo = g.run_frames(0, W)
-        for r in range(reps):
-            g.run_frames(W + r * K, K)
+        g = fresh(b)
+        t_solo = np.vstack([g.run_frames(0, W)] + [g.run_frames(W + r * K, K) for r in range(reps)])
         Xs, Ss = g.get_state(); g.close()
-        identical = identical and bool(np.array_equal(np.asarray(shared_traj[b]), t_solo) and np.array_equal(Xs, shared_full[b][0]) and np.array_equal(Ss, shared_full[b][1]))
-    return rates, identical
+        identical = identical and bool(np.array_equal(full[b], t_solo) and np.array_equal(Xs, states[b][0]) and np.array_equal(Ss, states[b][1]))
+    return out, identical, flagged
 
 
 def main():
@@ -426,7 +427,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--cpu-frames-n500", type=int, default=24, help="frames of the configs4 leg the CPU port replays for the whole-run comparison (>= 20)")
-    ap.add_argument("--sequences-per-gpu", type=int, default=3,
+    ap.add_argument("--sequences-per-gpu", type=int, default=32,
                     help="extra measurement: B concurrent independent sequences on one GPU (0 = skip)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="CPU/gloo check of the N-rank launcher and collectives only (no filter, no GPU)")
@@ -580,15 +581,18 @@ def main():
         }
         if world == 1 and args.sequences_per_gpu > 1:
             B = args.sequences_per_gpu
-            rates, same = multi_sequence_throughput(torch, synth, srukf, N, B, min(K, 100), 10, local)
-            med = float(np.median(rates))
-            out["multi_sequence"] = {"sequences_per_gpu": B, "frames_per_s_aggregate": med, "repetitions": [round(r, 1) for r in rates],
-                                     "repetitions_stalled": int(sum(r < 0.5 * med for r in rates)),
-                                     "bit_identical_to_solo_runs": same,      # trajectories of the warm-up block and final states of the whole leg, every filter, against the same sequences replayed alone
-
-                "note": "B independent Monte-Carlo sequences replayed concurrently on one GPU (one context/stream each, SRUKF_GPU_SHARED: "
-                        "persistent launches of half the CUs, at most two admitted at a time); median over the repetitions of the same block length "
-                        "(a repetition far below the median met the ~70 ms multi-stream stall described in DESIGN.md); not the headline value"}
+            small = tuple(b for b in (4, 8) if b < B)
+            rates, same, flagged = multi_sequence_throughput(torch, synth, srukf, N, B, 96, 10, local, small=small)
+            med = float(np.median(rates[B]))
+            out["multi_sequence"] = {
+                "sequences_per_gpu": B, "frames_per_s_aggregate": med, "repetitions": [round(r, 1) for r in rates[B]], "frames_per_repetition_and_filter": 96,
+                "repetitions_stalled": int(sum(r < 0.5 * med for r in rates[B])),
+                "bit_identical_to_solo_runs": same,      # trajectories of the whole leg and final states, every filter, against the same sequences replayed alone
+                "flagged_frames": flagged,
+                "fewer_filters": {str(b): round(float(np.median(rates[b])), 1) for b in small},
+                "launches": "batched: one launch per stage for a group of filters (srukf_run_frames_batch), 4 groups on their own streams, one host thread; "
+                            "no admission gate, no residency assumption, default hardware-queue count",
+                "note": "B independent Monte-Carlo sequences (one map, own measurement noise) replayed on one GPU; median over the repetitions; not the headline value"}
         c4_traj = c4_frames = None
         if world == 1 and not args.no_configs4:
             out["configs4"] = configs4_leg(torch, synth, srukf, local)

@@ -215,7 +215,6 @@ static const char* kclass_name[KC_COUNT] = { "k_motion", "k_project", "k_meas_st
 struct ProfEvent { hipEvent_t a, b; int kc; };
 
 // ---- persistent GMW launch (k_gmw_persist): per-matrix-size resources --------------------------------
-static std::atomic<int> g_dbg_shared_slack{0};      // SRUKF_GPU_SHARED: CUs each tenant leaves free (srukf_debug_set "shared_slack")
 // nreal: the tiles that hold values (ntiles minus the T - Tp pass-on tiles of the rank-aware form, which ride as a register-free third slot of the first workers)
 struct GmwPlan { void* pans = nullptr; void* sync = nullptr; void* tiles = nullptr; int ntiles = 0, nreal = 0, T = 0, Tp = 0, workers = -1, tenants = 1, cus = 0; };
 static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
@@ -227,16 +226,15 @@ static void gmw_plan_destroy(GmwPlan& g, hipStream_t st = nullptr)
 }
 // workers = -1 afterwards: the matrix has more tiles than resident workgroups can own (the per-panel launches are used)
 // tenants = 2: the plan of a filter that shares the GPU (gmw_shared = 1): at most half the CUs, so that two admitted launches are resident together
-// XCD-aware order of the tile list when every worker owns ONE tile (srukf_debug_set "tile_xcd", default on).  Workgroup b runs on XCD b % 8, and
+// XCD-aware order of the tile list when every worker owns ONE tile.  Workgroup b runs on XCD b % 8, and
 // in the fused replay the owner of tile (I, J) streams the operand columns of blocks I and J through its XCD's L2: with the tiles dealt out in
 // list order every XCD touches every column block (8 copies of the 9.8 MB operand set through 4 MB L2s — the 17 bandwidth-bound us at the head
 // of the launch).  Here the tiles whose owners compute them are cut into 8 compact 2D regions (two bands of block rows x four ranges of block
 // columns), one per XCD; the others (head rows, pass-on row) fill the XCDs up to equal counts.  Which worker owns which tile changes nothing else.
-static std::atomic<int> g_dbg_tile_xcd{1};
 static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles_all, int workers, int T, int Tp)
 {
     const int ntiles = ntiles_all - ((Tp > 0 && Tp < T) ? T - Tp : 0);         // the pass-on tiles stay at the end of the list (third slot of the first workers)
-    if (!g_dbg_tile_xcd || ntiles > workers || ntiles < 16) return;
+    if (ntiles > workers || ntiles < 16) return;
     struct Tl { short v[4]; };
     std::vector<Tl> comp, rest;
     const int h0 = srukf_gmw_head_rows() / 64, hx = h0 + srukf_gmw_head_extra_diag();
@@ -270,8 +268,6 @@ static void gmw_tiles_xcd_order(std::vector<short>& tk, int ntiles_all, int work
         for (int e = 0; e < 4; e++) tk[4 * w + e] = t.v[e];
     }
 }
-// srukf_debug_set "batch_tenants": cap of the tenants srukf_run_frames_batch picks (0: SRUKF_MAX_TENANTS)
-static std::atomic<int> g_dbg_batch_tenants{0};
 // srukf_debug_set "batch_wide" 0: srukf_run_frames_batch never takes the batched launches (one stream per filter, persistent launches behind the gate: round 3's form)
 static std::atomic<int> g_dbg_batch_wide{1};
 static std::atomic<int> g_dbg_batch_groups{0};
@@ -284,7 +280,7 @@ static int gmw_plan_create(GmwPlan& g, int np, hipStream_t st, int Tp = 0, int t
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 2;
     g.cus = cus;
-    const int cap = cus / (tenants > 1 ? tenants : 1) - 1 - (tenants > 1 ? g_dbg_shared_slack.load() : 0);    // one workgroup per CU (registers), all of them resident
+    const int cap = cus / (tenants > 1 ? tenants : 1) - 1;    // one workgroup per CU (registers), all of them resident
     g.workers = cap >= 1 ? srukf_gmw_persist_workers(g.T, g.Tp, cap) : -1;
     g.ntiles = srukf_gmw_build_tiles(g.T, g.Tp, nullptr);
     g.nreal = g.ntiles - (g.Tp < g.T ? g.T - g.Tp : 0);
@@ -595,10 +591,8 @@ static void rank_expand(srukf_ctx* c, bool frame_tail, bool table = false, bool 
 // tiles per worker, both to be formed before the first step, the exclusive replay loses — N = 300: 1 544 against 1 663 frames/s; srukf_debug_set "fold_tiles_pct").
 // A filter that shares the GPU (three or four tenants of 256 / tenants CUs: two register tiles per worker): 200 — measured in round 4 at N = 200, four filters and four
 // tenants, aggregate frames/s: owners fold both tiles 12 260; the same tiles from a launch of their own in the owners' summation order (k_syrk_own) 8 500 - 11 900;
-// split-K k_syrk over the kept rows 13 100 but then the results differ in rounding from the same filter running alone ("fold_tiles_pct_shared").
-static std::atomic<int> g_dbg_fold_tiles_pct{106};
-static std::atomic<int> g_dbg_fold_tiles_pct_shared{200};
-static int fold_tiles_pct(const srukf_ctx* c) { return c->gmw_shared == 1 ? g_dbg_fold_tiles_pct_shared.load() : g_dbg_fold_tiles_pct.load(); }
+// split-K k_syrk over the kept rows 13 100 but then the results differ in rounding from the same filter running alone.
+static int fold_tiles_pct(const srukf_ctx* c) { return c->gmw_shared == 1 ? 200 : 106; }
 static bool replay_red_fused(const srukf_ctx* c)
 {
     return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && gmw_use_persist(c) &&
@@ -2028,7 +2022,7 @@ static bool batch_eligible(srukf_ctx* const* cs, int B)
         if (c->device != a->device || c->d.N != a->d.N || c->d.N < 1 || c->storage != SRUKF_STORAGE_F64 || c->w.wc0 != c->w.wm0) return false;
         if (c->red_r <= 0 || c->red_r != a->red_r || c->red_Tp != a->red_Tp || !c->shadowA || !c->null_canonical || !c->nskip || !c->tail_ok) return false;
         if (c->ns_full != a->ns_full || c->ns_null != a->ns_null || c->ns_rows != a->ns_rows || c->n_pxy2_tiles != a->n_pxy2_tiles) return false;
-        if (!c->dbg.pxy2 || !c->dbg.nullskip || !c->dbg.tail_fuse || c->dbg.fused_motion != 2 || !c->dbg.table_perm || c->profiling || !c->use_graph || c->debug_starve) return false;
+        if (!c->dbg.pxy2 || !c->dbg.nullskip || !c->dbg.tail_fuse || c->dbg.fused_motion != 2 || !c->dbg.table_perm || c->profiling || c->use_graph != a->use_graph || c->debug_starve) return false;
         if (memcmp(&c->p, &a->p, sizeof c->p) != 0 || c->gplan_red.T < 16 || (size_t)c->d.np * sizeof(double) > 48 * 1024 || !rank_fused_mode()) return false;
         if (!c->odo_seq || c->seqF != a->seqF) return false;
     }
@@ -2119,7 +2113,8 @@ static int batch_run(srukf_ctx* const* cs, int B, int first, int count, double* 
     HIPCHK(c0, hipMemcpyAsync(bp->t_step, a5.data(), sizeof(Step64Args) * B, hipMemcpyHostToDevice, st));
     HIPCHK(c0, hipMemcpyAsync(bp->t_exp, a6.data(), sizeof(ExpandArgs) * B, hipMemcpyHostToDevice, st));
     HIPCHK(c0, hipStreamSynchronize(st));                      // (the host vectors are pageable and go out of scope)
-    if (!bp->e1) {
+    const bool graphs = c0->use_graph;                         // ("graphs" 0 / "use_graph" 0: eager launches, which rocprofv3 --pmc needs)
+    if (graphs && !bp->e1) {
         int rc = batch_capture(bp, st, 1, &bp->g1, &bp->e1); if (rc) return rc;
         rc = batch_capture(bp, st, SRUKF_GRAPH_FRAMES, &bp->g8, &bp->e8); if (rc) return rc;
     }
@@ -2135,8 +2130,10 @@ static int batch_run(srukf_ctx* const* cs, int B, int first, int count, double* 
         c->async_pending = true; c->phase = 0;
     }
     int f = 0;
-    for (; f + SRUKF_GRAPH_FRAMES <= count; f += SRUKF_GRAPH_FRAMES) HIPCHK(c0, hipGraphLaunch(bp->e8, st));
-    for (; f < count; f++) HIPCHK(c0, hipGraphLaunch(bp->e1, st));
+    if (graphs) {
+        for (; f + SRUKF_GRAPH_FRAMES <= count; f += SRUKF_GRAPH_FRAMES) HIPCHK(c0, hipGraphLaunch(bp->e8, st));
+        for (; f < count; f++) HIPCHK(c0, hipGraphLaunch(bp->e1, st));
+    } else for (; f < count; f++) batch_frame(bp, st);
     HIPCHK(c0, hipGetLastError());
     return SRUKF_OK;
 }
@@ -2210,7 +2207,7 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
         // one stream per filter, persistent launches behind the admission gate: one tenant per filter up to SRUKF_MAX_TENANTS (every filter's persistent launch
         // admitted at once, each on cus / tenants CUs); a filter in per-panel mode (forced, or after an abandoned persistent launch) stays there
         for (int b = 0; b < B && rc == SRUKF_OK; b++)
-            if (B > 1 && ctxs[b]->gmw_shared != 2) rc = set_shared(ctxs[b], 1, std::min(std::max(B, 2), g_dbg_batch_tenants.load() > 0 ? g_dbg_batch_tenants.load() : SRUKF_MAX_TENANTS));
+            if (B > 1 && ctxs[b]->gmw_shared != 2) rc = set_shared(ctxs[b], 1, std::min(std::max(B, 2), SRUKF_MAX_TENANTS));
         const int chunk = 2 * SRUKF_GRAPH_FRAMES;
         for (int k0 = done0; k0 < count && rc == SRUKF_OK; k0 += chunk)
             for (int b = 0; b < B && rc == SRUKF_OK; b++) {
@@ -2289,15 +2286,11 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
 {
     if (!key) return SRUKF_ERR_BAD_ARG;
     struct { const char* k; std::atomic<int>* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
-                                                    { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs },
-                                                    { "tile_xcd", &g_dbg_tile_xcd } };      // tile_xcd: applies to plans built afterwards (set it before the state)
-    if (!strcmp(key, "fold_tiles_pct_shared")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct_shared = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
-    if (!strcmp(key, "fold_tiles_pct")) { if (value < 100 || value > 200) return SRUKF_ERR_BAD_ARG; g_dbg_fold_tiles_pct = value; if (c) { hipStreamSynchronize(c->stream); drop_graphs(c); } return SRUKF_OK; }
+                                                    { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs }
+                                                  };
     if (!strcmp(key, "batch_split")) { g_dbg_batch_split = value ? 1 : 0; for (int grp = 0; grp < SRUKF_BATCH_GROUPS_MAX; grp++) if (g_batches[grp]) { hipStreamSynchronize(batch_stream(grp)); batch_plan_drop_graphs(g_batches[grp]); } return SRUKF_OK; }
     if (!strcmp(key, "batch_groups")) { if (value < 0 || value > SRUKF_BATCH_GROUPS_MAX) return SRUKF_ERR_BAD_ARG; g_dbg_batch_groups = value; return SRUKF_OK; }
     if (!strcmp(key, "batch_wide")) { g_dbg_batch_wide = value ? 1 : 0; return SRUKF_OK; }
-    if (!strcmp(key, "batch_tenants")) { if (value < 0 || value > 8) return SRUKF_ERR_BAD_ARG; g_dbg_batch_tenants = value; return SRUKF_OK; }
-    if (!strcmp(key, "shared_slack")) { if (value < 0 || value > 64) return SRUKF_ERR_BAD_ARG; g_dbg_shared_slack = value; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
         if (value < 2 || value > 8) return SRUKF_ERR_BAD_ARG;
         g_dbg_shared_tenants = value;

@@ -271,8 +271,9 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  * Process-wide keys (ctx may be NULL; they apply to what is built or captured afterwards):
  *   "gmw_persist" (0: one launch per 64-row panel), "gmw_fused", "rank_fused", "rank_fold" (0: the owners of the persistent launch never form
  *   their tiles of S^T S - U U^T themselves), "rank_aware", "graphs" (0: contexts created afterwards launch eagerly, which rocprofv3 --pmc needs),
- *   "tile_xcd" (0: tile list of the persistent launch in plain order), "shared_slack" (0..64), "shared_tenants" (2..8: persistent launches that
- *   share the GPU in SRUKF_GPU_SHARED), "fold_tiles_pct" (100..200: tiles per worker, in percent, up to which the owners form their tiles themselves).
+ *   "shared_tenants" (2..8: persistent launches that share the GPU after srukf_set_exclusive(SRUKF_GPU_SHARED); srukf_run_frames_batch picks its own),
+ *   "batch_wide" (0: srukf_run_frames_batch never takes the batched launches), "batch_groups" (1..4: groups the batched filters are cut into),
+ *   "batch_split" (0: one launch per panel in the batched replay instead of slabs + plain trailing updates).
  * Per-context keys: "use_graph" (0: eager launches), "fused_motion" (0: k_motion + k_project as two launches, 1: k_project_motion, 2: "table"
  *   mode), "pxy2" (0: k_pxy instead of k_pxy2), "nullskip", "head_fold" (0: k_syrk launch in front of the persistent launch), "tail_fuse"
  *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse".  See srukf_api.hip (srukf_ctx::DbgSwitches). */

@@ -1,6 +1,6 @@
 """Aggregate frames/s of B filters through srukf_run_frames_batch at N = 200: the batched launches (one launch per stage for all filters, one stream) against
 round 3's form (batch_wide 0: one stream per filter, one tenant per filter up to four).  Every repetition replays its own block of frames.
-  python scripts/batch_probe.py [B,B,...] [wide,wide,...] [N]"""
+  python scripts/batch_probe.py [B,B,...] [wide,wide,...] [N] [groups,...] [eager]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ".")
@@ -11,6 +11,8 @@ arg = lambda i, d: [int(x) for x in sys.argv[i].split(",")] if len(sys.argv) > i
 B_l, wide_l = arg(1, [2, 4, 8, 12, 16]), arg(2, [1, 0])
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 G_l = arg(4, [0])
+if len(sys.argv) > 5 and sys.argv[5] == "eager":                # eager launches instead of graphs (rocprofv3 --pmc)
+    srukf.debug_set_global("graphs", 0)
 K, W, R = 96, 16, 3
 scs = [synth.make_scene(N, W + R * K, seed=0, p=synth.scene_params(), obs_seed=5000 + b) for b in range(max(B_l))]
 for wide, G in [(w, g) for w in wide_l for g in (G_l if w else [0])]:

@@ -8,7 +8,7 @@ import torch
 import __graft_entry__ as ge
 pkg = ge.load_package(); synth, srukf = pkg.synth, pkg.srukf
 N, K, W, B = 200, int(sys.argv[2]) if len(sys.argv) > 2 else 100, 10, 3
-if len(sys.argv) > 3: srukf.debug_set_global("shared_slack", int(sys.argv[3]))
+
 sc0 = synth.make_scene(N, 40, seed=0, p=synth.scene_params())
 ts = torch.cuda.Stream()
 main = srukf.Filter(N, sc0["params"], device=0, stream=ts.cuda_stream); main.set_state(sc0["X0"], sc0["S0"]); main.stage_sequence(sc0["odo"], sc0["z"], sc0["matched"])
