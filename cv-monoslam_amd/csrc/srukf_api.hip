@@ -2012,7 +2012,7 @@ static void batch_plan_forget(const srukf_ctx* c)
 }
 // Can these filters run as one batch?  Same device and shape, the default launch sequence of a filter that has the GPU to itself ("fused tail" mode on the permuted
 // operands, fp64 storage), canonical null rows, nothing pending.
-static bool batch_eligible(srukf_ctx* const* cs, int B)
+static bool batch_eligible(srukf_ctx* const* cs, int B, bool ignore_canonical = false)
 {
     if (B < 2 || B > 64 || !g_dbg_batch_wide.load()) return false;
     const srukf_ctx* a = cs[0];
@@ -2020,7 +2020,7 @@ static bool batch_eligible(srukf_ctx* const* cs, int B)
         const srukf_ctx* c = cs[b];
         for (int q = 0; q < b; q++) if (cs[q] == c) return false;
         if (c->device != a->device || c->d.N != a->d.N || c->d.N < 1 || c->storage != SRUKF_STORAGE_F64 || c->w.wc0 != c->w.wm0) return false;
-        if (c->red_r <= 0 || c->red_r != a->red_r || c->red_Tp != a->red_Tp || !c->shadowA || !c->null_canonical || !c->nskip || !c->tail_ok) return false;
+        if (c->red_r <= 0 || c->red_r != a->red_r || c->red_Tp != a->red_Tp || !c->shadowA || (!c->null_canonical && !ignore_canonical) || !c->nskip || !c->tail_ok) return false;
         if (c->ns_full != a->ns_full || c->ns_null != a->ns_null || c->ns_rows != a->ns_rows || c->n_pxy2_tiles != a->n_pxy2_tiles) return false;
         if (!c->dbg.pxy2 || !c->dbg.nullskip || !c->dbg.tail_fuse || c->dbg.fused_motion != 2 || !c->dbg.table_perm || c->profiling || c->use_graph != a->use_graph || c->debug_starve) return false;
         if (memcmp(&c->p, &a->p, sizeof c->p) != 0 || c->gplan_red.T < 16 || (size_t)c->d.np * sizeof(double) > 48 * 1024 || !rank_fused_mode()) return false;
@@ -2170,11 +2170,13 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
     // Filters whose structurally null rows are not canonical yet (a fresh state) run their first frame on their own, one after the other.
     int done0 = 0;
     bool wide = false;
-    if (rc == SRUKF_OK && B > 1 && mode == SRUKF_UPDATE_BATCHED && g_dbg_batch_wide.load()) {
+    // (decided before anything runs: a filter that changes its launch sequence in the middle of a block — exclusive for its first frame, shared behind it — rebuilds its
+    //  permuted copy from S in between and is then no longer bit-identical to the same filter running alone)
+    bool fresh = false, others_ok = true;
+    for (int b = 0; b < B; b++) { fresh = fresh || (ctxs[b]->red_r > 0 && !ctxs[b]->null_canonical); others_ok = others_ok && ctxs[b]->odo_seq && ctxs[b]->seqF >= first + count; }
+    if (rc == SRUKF_OK && B > 1 && mode == SRUKF_UPDATE_BATCHED && g_dbg_batch_wide.load() && others_ok && batch_eligible(ctxs, B, true) && !(fresh && count < 2)) {
         for (int b = 0; b < B; b++) hipStreamSynchronize(ctxs[b]->stream);       // the checkpoint copies; whatever the filters did before
-        bool fresh = false, others_ok = true;
-        for (int b = 0; b < B; b++) { fresh = fresh || (ctxs[b]->red_r > 0 && !ctxs[b]->null_canonical); others_ok = others_ok && ctxs[b]->odo_seq && ctxs[b]->seqF >= first + count; }
-        if (fresh && others_ok && count >= 2) {
+        if (fresh) {
             for (int b = 0; b < B; b++) {
                 rcs[b] = srukf_run_frames_async(ctxs[b], first, 1, mode, dt[b]);
                 if (rcs[b] == SRUKF_OK) rcs[b] = srukf_synchronize(ctxs[b]);

@@ -17,6 +17,8 @@ def kname(raw):
     k = raw.split("(")[0].strip()
     if k.startswith("void "):
         k = k[5:]
+    if k.startswith("k_rank_expand<"):                         # <0> (first frame of a fresh state) and <2> (the frame tail that also projects) are different kernels
+        return k
     return re.sub(r"<.*>$", "", k)
 
 
