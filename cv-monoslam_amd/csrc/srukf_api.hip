@@ -2183,27 +2183,34 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
             }
             done0 = 1;
         }
-        bool all_ok = true;
-        for (int b = 0; b < B; b++) all_ok = all_ok && rcs[b] == SRUKF_OK;
-        if (all_ok && others_ok && batch_eligible(ctxs, B)) {
-            std::vector<double*> dtb(B);
-            for (int b = 0; b < B; b++) dtb[b] = dt[b] + (size_t)8 * done0;
-            // groups of filters side by side, each group one batch on the stream of its first filter: while one group sits in a launch that cannot fill the GPU
-            // (the pivot chains of a panel step), the other group's launches do
+        // the filters that are still clean (one flagged in its first frame is rerun alone below) go on as one batch — or, if what is left cannot be batched, one
+        // after the other: filters in exclusive mode cannot share the GPU, and switching them to the shared form in the middle of a block would cost the bit-identity
+        std::vector<srukf_ctx*> sub; std::vector<double*> dtb; std::vector<int> idx;
+        for (int b = 0; b < B; b++) if (rcs[b] == SRUKF_OK) { sub.push_back(ctxs[b]); dtb.push_back(dt[b] + (size_t)8 * done0); idx.push_back(b); }
+        const int nb = (int)sub.size();
+        if (nb >= 2 && batch_eligible(sub.data(), nb)) {
+            // groups of filters side by side, each group one batch on a stream of its own: while one group sits in a launch that cannot fill the GPU
+            // (the pivot chains of a panel step), the other groups' launches do
             // (measured at N = 200, round 4, aggregate frames/s with 1 / 2 / 3 / 4 groups: 8 filters 10 270 / 11 450 / 11 280 / 11 700; 16: 12 710 / 14 260 / 14 300 / 14 790;
             //  32: 14 600 / 15 560 / 15 790 / 16 430; 48: 14 840 / 15 710 / 16 460 / 16 650)
             int G = g_dbg_batch_groups.load() > 0 ? g_dbg_batch_groups.load() : SRUKF_BATCH_GROUPS_MAX;
-            G = std::max(1, std::min(std::min(G, SRUKF_BATCH_GROUPS_MAX), B / 2));
+            G = std::max(1, std::min(std::min(G, SRUKF_BATCH_GROUPS_MAX), nb / 2));
             for (int grp = 0; grp < G && rc == SRUKF_OK; grp++) {
-                const int b0 = (int)((long long)B * grp / G), b1 = (int)((long long)B * (grp + 1) / G);
-                rc = batch_run(ctxs + b0, b1 - b0, first + done0, count - done0, dtb.data() + b0, grp);
+                const int b0 = (int)((long long)nb * grp / G), b1 = (int)((long long)nb * (grp + 1) / G);
+                rc = batch_run(sub.data() + b0, b1 - b0, first + done0, count - done0, dtb.data() + b0, grp);
             }
             for (int grp = 0; grp < G; grp++) {
-                const int b0 = (int)((long long)B * grp / G);
-                if (hipStreamSynchronize(batch_stream(grp)) != hipSuccess && rc == SRUKF_OK) { ctxs[b0]->err = "run_frames_batch: the batched launches failed"; rc = SRUKF_ERR_HIP; }
+                const int b0 = (int)((long long)nb * grp / G);
+                if (hipStreamSynchronize(batch_stream(grp)) != hipSuccess && rc == SRUKF_OK) { sub[b0]->err = "run_frames_batch: the batched launches failed"; rc = SRUKF_ERR_HIP; }
             }
-            wide = true;
+        } else {
+            for (int q = 0; q < nb && rc == SRUKF_OK; q++) {
+                rcs[idx[q]] = srukf_run_frames_async(sub[q], first + done0, count - done0, mode, dtb[q]);
+                if (rcs[idx[q]] != SRUKF_OK && rcs[idx[q]] != SRUKF_ERR_CLAMP_PENDING) rc = rcs[idx[q]];
+                hipStreamSynchronize(sub[q]->stream);
+            }
         }
+        wide = true;
     }
     if (!wide) {
         // one stream per filter, persistent launches behind the admission gate: one tenant per filter up to SRUKF_MAX_TENANTS (every filter's persistent launch

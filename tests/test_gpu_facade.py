@@ -254,9 +254,10 @@ def test_cslam_facade_map_changes_mid_sequence(tmp_path, synth, oracle):
     R = sc["F_STARVE"] + 2                                                           # frames up to and including the NEED_REORDER update
     np.testing.assert_allclose(traj[:R, :4], otraj[:R, :4], rtol=0, atol=1e-9)
     np.testing.assert_allclose(traj[:R, 4:], otraj[:R, 4:], rtol=0, atol=1e-11)
-    # behind it the 3K null directions of the new anchors are pivoted with EPSILON by both sides from factors that differ by
-    # rounding noise there, which the reference algorithm divides by 1e-13 (test_need_reorder_matches_oracle): the
-    # north star's pose tolerance
-    np.testing.assert_allclose(traj[R:, :4], otraj[R:, :4], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(traj[R:, 4:], otraj[R:, 4:], rtol=0, atol=1e-8)
+    # behind it the 3K null directions of the new anchors are pivoted with EPSILON by both sides from factors that differ by rounding noise there, which the
+    # reference algorithm divides by 1e-13 (test_need_reorder_matches_oracle).  Round 3 held these frames to 1e-6 / 1e-8 without knowing how much of that
+    # was used; measured in round 4: max |dpose| 1.2e-11, max |dP| 2.0e-13 — the tolerance of every other frame holds here too.
+    print(f"map-change scenario, frames behind the NEED_REORDER update: max |dpose| {np.abs(traj[R:, :4] - otraj[R:, :4]).max():.3e}, max |dP| {np.abs(traj[R:, 4:] - otraj[R:, 4:]).max():.3e}")
+    np.testing.assert_allclose(traj[R:, :4], otraj[R:, :4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(traj[R:, 4:], otraj[R:, 4:], rtol=0, atol=1e-11)
     assert np.abs(traj[:, :2] - sc["odo"][1:, :2]).max() < 2e-3                      # and the filter keeps tracking through the changes

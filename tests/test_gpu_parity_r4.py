@@ -128,3 +128,30 @@ def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle,
     for f in fs:
         f.close()
     srukf.debug_set_global("batch_wide", 1)
+
+
+def test_batched_filters_recover_from_flagged_frames(srukf, oracle, synth):
+    """The batched replay with the shipped a1..a4 = 8 at N = 200: S^T S - U U^T turns indefinite within a few frames and the reference's theta clamp becomes active
+    (test_replay_recovers_from_theta_clamp_frame at N = 8).  The frame tail of the batched launches flags the frame per filter, the rest of that filter's block is
+    void; srukf_run_frames_batch rewinds the filter to the state before the block and reruns it alone through srukf_run_frames (good frames replayed, the flagged
+    frame on the exact column path).  Result: what the same filter computes alone, bit for bit, and the oracle's frames to the tolerance a diverging filter allows."""
+    p = synth.default_params()
+    N, F, B = 200, 4, 2
+    scs = [synth.make_scene(N, F, seed=1, p=p, obs_seed=300 + b) for b in range(B)]
+    fs = []
+    for sc in scs:
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"]); fs.append(f)
+    traj = srukf.run_frames_batch(fs, 0, F)
+    for b, sc in enumerate(scs):
+        g = srukf.Filter(N, p); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        ts = g.run_frames(0, F)
+        Xs, Ss = g.get_state(); Xb, Sb = fs[b].get_state()
+        assert np.array_equal(traj[b], ts) and np.array_equal(Xs, Xb) and np.array_equal(Ss, Sb)
+        g.close()
+    o = oracle.Oracle(N, p); o.set_state(scs[0]["X0"], scs[0]["S0"])
+    to = o.run_frames(scs[0]["odo"], scs[0]["z"], scs[0]["matched"], mode=oracle.Oracle.BATCHED)
+    assert o.clamp_stats()["theta"] > 0                                  # (the scenario does need the clamp)
+    rel = np.abs(traj[0] - to) / np.maximum(1.0, np.abs(to))
+    assert rel[:2].max() <= 1e-8 and rel.max() <= 1e-5, rel.max(axis=1)
+    for f in fs:
+        f.close()
