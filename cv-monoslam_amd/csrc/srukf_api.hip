@@ -2104,6 +2104,15 @@ static int batch_run(srukf_ctx* const* cs, int B, int first, int count, double* 
                                       (unsigned long long)c->n_pxy2_tiles, (unsigned long long)(size_t)c->syrk_head_tiles, (unsigned long long)c->n_syrk_head_tiles,
                                       (unsigned long long)(size_t)c->gplan_red.tiles, (unsigned long long)c->gplan_red.ntiles, (unsigned long long)c->pxy2_split_b0 }) sig.push_back(v);
     }
+    {
+        // (the captured launches also embed the parameters and the weights by value)
+        unsigned long long h = 1469598103934665603ull;
+        const unsigned char* pb = (const unsigned char*)&c0->p;
+        for (size_t q = 0; q < sizeof c0->p; q++) h = (h ^ pb[q]) * 1099511628211ull;
+        const unsigned char* wb = (const unsigned char*)&c0->w;
+        for (size_t q = 0; q < sizeof c0->w; q++) h = (h ^ wb[q]) * 1099511628211ull;
+        sig.push_back(h); sig.push_back((unsigned long long)g_dbg_batch_split.load());
+    }
     if (sig != bp->sig) { batch_plan_drop_graphs(bp); bp->sig = sig; }
     HIPCHK(c0, hipSetDevice(c0->device));
     HIPCHK(c0, hipMemcpyAsync(bp->t_pxy2, a1.data(), sizeof(Pxy2Args) * B, hipMemcpyHostToDevice, st));
