@@ -41,6 +41,7 @@ int srukf_gmw_build_tiles(int T, int Tp, short* out);
 int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
 void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
+void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int);
@@ -348,6 +349,10 @@ struct srukf_ctx {
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
     double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
     double *slabW = nullptr, *slabL = nullptr;         // batched replay: the current panel's slabs W and L = W / D (64 x np each)
+    // split form of the persistent factorisation (memory-tile sizes, a filter that has the GPU to itself): the slabs of every pivoted panel (gs_panels x 64 x np
+    // each), the side stream the tile launch runs on and the events that fork it off / join it to the filter's stream
+    double *gsW = nullptr, *gsL = nullptr; int gs_panels = 0;
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double* P1 = nullptr; int* pxy2_tiles = nullptr; int n_pxy2_tiles = 0, pxy2_split_b0 = 0;   // "table" mode: k_pxy2's second K half, its tile list
     int* nskip = nullptr; int ns_full = 0, ns_null = 0, ns_rows = 0;   // NullSkip lists (srukf_device.h): [dirs | nulls | rows] in one buffer
     int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
@@ -565,6 +570,43 @@ static std::atomic<int> g_dbg_shared_tenants{2};
 #define SRUKF_MAX_TENANTS 4                                    // 4 x (1 pivot + 63 workers with two register tiles each) fill 256 CUs at N = 200
 static int plan_tenants(const srukf_ctx* c) { return c->gmw_shared == 1 ? c->shared_tenants : 1; }
 static int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? c->shared_tenants : 0; }
+// "mem_split" 0: sizes beyond two tiles per worker keep the memory-tile instance of k_gmw_persist (round 3's form) instead of the split form
+static std::atomic<int> g_dbg_mem_split{1};
+// (2, measurements: also the plans whose workers own two register tiles each)
+static bool split_wanted(const GmwPlan& gp)
+{
+    if (!srukf_gmw_register_form(gp.T, gp.Tp, gp.ntiles, gp.workers)) return true;
+    return g_dbg_mem_split == 2 && gp.nreal > gp.workers;
+}
+// Buffers / side stream of the split form for a plan with Tp pivoted panels (not inside a capture).  Failure is not an error: the memory-tile form is used.
+static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
+{
+    if (!g_dbg_mem_split || gp.workers < 0 || gp.T < 16 || !split_wanted(gp)) return;
+    if (gp.T + 1 > gp.cus) return;                              // the pivot / slab launch must be resident as a whole with CUs left for the tiles
+    if (c->gs_panels < gp.Tp) {
+        if (c->gsW) srukf_dfree_on(c->gsW, c->stream);
+        if (c->gsL) srukf_dfree_on(c->gsL, c->stream);
+        c->gsW = c->gsL = nullptr; c->gs_panels = 0;
+        const size_t bytes = sizeof(double) * 64 * (size_t)c->d.np * gp.Tp;
+        if (srukf_dmalloc(&c->gsW, bytes) != hipSuccess || srukf_dmalloc(&c->gsL, bytes) != hipSuccess || hipMemset(c->gsW, 0, bytes) != hipSuccess || hipMemset(c->gsL, 0, bytes) != hipSuccess) {
+            if (c->gsW) srukf_dfree_on(c->gsW, c->stream);
+            if (c->gsL) srukf_dfree_on(c->gsL, c->stream);
+            c->gsW = c->gsL = nullptr; (void)hipGetLastError();
+            return;
+        }
+        c->gs_panels = gp.Tp;
+    }
+    if (!c->side) {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); return; }
+        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            hipStreamDestroy(c->side); c->side = nullptr; (void)hipGetLastError();
+        }
+    }
+}
+static bool split_form(const srukf_ctx* c, const GmwPlan& gp)
+{
+    return g_dbg_mem_split && c->gmw_shared == 0 && !c->debug_starve && c->side && c->gsW && c->gs_panels >= gp.Tp && gp.workers >= 0 && gp.T >= 16 && split_wanted(gp);
+}
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
 // fp32 storage: S, X and the permuted copy are rounded to the stored values first, and the trajectory row is taken from those
@@ -789,6 +831,15 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
         const int workers = c->debug_starve ? 0 : gp.workers;
+        if (split_form(c, gp)) {
+            // the tile launch depends on what produced Gbuf, not on the pivot / slab launch: fork before, join after (in a capture: two parallel branches)
+            hipEventRecord(c->ev_fork, c->stream);
+            hipStreamWaitEvent(c->side, c->ev_fork, 0);
+            srukf_launch_gmw_split(c->stream, c->side, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, c->fs, Tp, reduced ? ((c->red_r + 15) & ~15) : 0, c->gsW, c->gsL);
+            hipEventRecord(c->ev_join, c->side);
+            hipStreamWaitEvent(c->stream, c->ev_join, 0);
+            return;
+        }
         // (krows: where the kept pivots end — the last pivoted panel is not factored beyond them)
         srukf_launch_gmw_persist(c->stream, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, workers, c->fs, nullptr, nullptr, 0, 0, Tp,
                                  reduced ? ((c->red_r + 15) & ~15) : 0, gate_limit(c));
@@ -916,6 +967,7 @@ static int update_null_set(srukf_ctx* c)
                 const int rc = gmw_plan_create(c->gplan_red, np, c->stream, Tp, plan_tenants(c));
                 if (rc) { c->err = "rank-aware refactorisation: allocation failed"; return rc; }
             }
+            split_ensure(c, c->gplan_red);
             c->red_r = r; c->red_Tp = Tp;
             {
                 // algorithmic flop of the rank-aware refactorisation (DESIGN.md "flop model"): pivots j < rp update rows (j, rp) x
@@ -1048,6 +1100,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     ALLOC(c->vis, N > 0 ? N : 1); ALLOC(c->mcur, N > 0 ? N : 1); ALLOC(c->theta, np); ALLOC(c->fs, 1);
     { char* pb0 = nullptr; char* pb1 = nullptr; ALLOC(pb0, srukf_gmw_panel_bytes()); ALLOC(pb1, srukf_gmw_panel_bytes()); c->pan[0] = pb0; c->pan[1] = pb1; }
     { const int rcg = gmw_plan_create(c->gplan, d.np, c->stream); if (rcg) { g_create_error = "persistent GMW resources: allocation failed"; srukf_destroy(c); return rcg; } }
+    split_ensure(c, c->gplan);
     {
         // k_syrk: tile (row r, col c >= r); A panel = S columns of r, B panel = S columns of c.  XCD owns rows.
         std::vector<int> ts = build_tile_table(d.np / 32, d.np / 32, true, true, 0);
@@ -1110,10 +1163,11 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->own_stream && c->stream) hipStreamSynchronize(c->stream);
     if (c->hstage) {
         // keep ONE pinned staging buffer for the next context (pinning 16 MB costs milliseconds; map changes rebuild contexts)
@@ -1446,6 +1500,7 @@ static int set_shared(srukf_ctx* c, int shared, int tenants)
         gmw_plan_destroy(c->gplan, c->stream);
         const int rc = gmw_plan_create(c->gplan, c->d.np, c->stream, 0, plan_tenants(c));
         if (rc) { c->err = "set_exclusive: persistent GMW resources: allocation failed"; return rc; }
+        split_ensure(c, c->gplan);
         return update_null_set(c);                             // the rank-aware plan with the same limit
     }
     return SRUKF_OK;
@@ -2304,7 +2359,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
 {
     if (!key) return SRUKF_ERR_BAD_ARG;
     struct { const char* k; std::atomic<int>* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
-                                                    { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs }
+                                                    { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs }, { "mem_split", &g_dbg_mem_split }
                                                   };
     if (!strcmp(key, "batch_split")) { g_dbg_batch_split = value ? 1 : 0; for (int grp = 0; grp < SRUKF_BATCH_GROUPS_MAX; grp++) if (g_batches[grp]) { hipStreamSynchronize(batch_stream(grp)); batch_plan_drop_graphs(g_batches[grp]); } return SRUKF_OK; }
     if (!strcmp(key, "batch_groups")) { if (value < 0 || value > SRUKF_BATCH_GROUPS_MAX) return SRUKF_ERR_BAD_ARG; g_dbg_batch_groups = value; return SRUKF_OK; }
@@ -2316,7 +2371,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     }
     for (auto& g : globals)
         if (!strcmp(key, g.k)) {
-            g.v->store(value ? 1 : 0);
+            g.v->store(!strcmp(key, "mem_split") ? value : (value ? 1 : 0));
             if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); drop_graphs(c); if (!strcmp(key, "rank_aware")) return update_null_set(c); }
             return SRUKF_OK;
         }

@@ -302,12 +302,16 @@ struct GmwSync {
     unsigned long long* dbg;         // diagnostic builds: host-visible progress markers (null in the product)
     unsigned int head_done;          // head fold: 32 x 32 tiles of the head rows of S^T S - U U^T finished by the helper workgroups of this launch
     unsigned int head_crit;          // ... and the first ha.ncrit of them: what the pivot needs before its first panel
-    unsigned long long pad[60];
+    unsigned int resident;           // split form (k_gmw_pivslab_persist + k_gmw_tiles_persist): pivot / slab workgroups that have started — the tile launch waits for all of them
+    unsigned int pad32;
+    unsigned long long pad[59];
     unsigned long long panel_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];  // copy c at [c * STRIDE]: (epoch << SHIFT) + panels published
     unsigned long long half_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];   // same for the first half of a panel buffer (Tt1, E, pivots of sub-panel 1)
     // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)
+    // followed by unsigned long long slabver[T*T] (split form): (epoch << SHIFT) + 1 once the slabs of panel k for column block J are in Wslab / Lslab
 };
 __device__ __forceinline__ unsigned long long* gmw_sync_ver(GmwSync* sy) { return (unsigned long long*)(sy + 1); }
+__device__ __forceinline__ unsigned long long* gmw_sync_slabver(GmwSync* sy, int T) { return (unsigned long long*)(sy + 1) + (size_t)T * T; }
 
 #ifdef SRUKF_GMW_DBG
 #define GMW_DBG(sy, slot, val) do { if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0 && (sy)->dbg) __hip_atomic_store(&(sy)->dbg[blockIdx.x * 8 + (slot)], (unsigned long long)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)

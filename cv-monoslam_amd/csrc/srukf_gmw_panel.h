@@ -415,3 +415,84 @@ __device__ __forceinline__ void gmw_slab_to_global(int n, int ld, int j0, int n0
                 }
             }
 }
+
+// ---- split form of the persistent factorisation (srukf_gmw_persist.hip, N >= 340): a panel's slabs by SLAB workgroups, 16 columns per wave ----
+// The same three stages on a 16-column quarter (the per-element MFMA sequences do not depend on how many column blocks a wave carries: bit-identical to the
+// half-slab forms above).  DEV: the panel's G rows were written by a tile workgroup of the SAME launch pair (agent-scope loads), the slab rows are read by tile
+// workgroups of it (write-through stores).  rows32: the panel has only its first 32 pivots (last pivoted panel of the rank-aware form): S rows j0 .. j0+31 only.
+template <bool DEV>
+__device__ __forceinline__ void gmw_slab16_to_global(int n, int ld, int j0, int n0, const double* __restrict__ G, const GmwPanel64* __restrict__ cur,
+                                                     double* __restrict__ Sout, double* __restrict__ Wb, double* __restrict__ Lb, bool write_s, bool rows32, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    if (n0 >= ld) return;
+    d4 X2[2], W1[2], W2[2];
+    double fb[8], ta0[4], ta1[8], ea0[8], ea1[8], tb0[4], tb1[8], dr[2][4], dr2[2][4], sqr[4][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) X2[a][t] = rows32 ? 0.0 : ld_g<DEV>(&G[(size_t)(j0 + 32 + 16 * a + lk + 4 * t) * ld + n0 + lr]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) fb[u] = ld_g<DEV>(&G[(size_t)(j0 + 4 * u + lk) * ld + n0 + lr]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int o = (4 * u + lk) * 32 + lr;
+        if (u < 4) { ta0[u] = cur->Tt1[o]; tb0[u] = rows32 ? 0.0 : cur->Tt2[o]; }
+        ta1[u] = cur->Tt1[o + 16]; tb1[u] = rows32 ? 0.0 : cur->Tt2[o + 16];
+        ea0[u] = rows32 ? 0.0 : cur->E[o]; ea1[u] = rows32 ? 0.0 : cur->E[o + 16];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) { dr[q][t] = cur->rD[16 * q + lk + 4 * t]; dr2[q][t] = rows32 ? 0.0 : cur->rD[32 + 16 * q + lk + 4 * t]; }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) sqr[q][t] = (write_s && !(rows32 && q >= 2)) ? cur->sq[16 * q + lk + 4 * t] : 0.0;
+    W1[0] = (d4){0, 0, 0, 0}; W1[1] = (d4){0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (u < 4) W1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0[u], fb[u], W1[0], 0, 0, 0);
+        W1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1[u], fb[u], W1[1], 0, 0, 0);
+    }
+    if (rows32) {
+        if (write_s) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const int jj = 16 * a + lk + 4 * t; if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + n0 + lr] = W1[a][t] * sqr[a][t]; }
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int a2 = u >> 2, t = u & 3;
+        X2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea0[u], W1[a2][t], X2[0], 0, 0, 0);
+        X2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ea1[u], W1[a2][t], X2[1], 0, 0, 0);
+    }
+    W2[0] = (d4){0, 0, 0, 0}; W2[1] = (d4){0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int a2 = u >> 2, t = u & 3;
+        if (u < 4) W2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb0[u], X2[a2][t], W2[0], 0, 0, 0);
+        W2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb1[u], X2[a2][t], W2[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int jj = 16 * a + lk + 4 * t, col = n0 + lr;
+            const double w1 = W1[a][t], w2 = W2[a][t];
+            if constexpr (DEV) {
+                st_dev(&Wb[(size_t)jj * ld + col], w1);        st_dev(&Lb[(size_t)jj * ld + col], w1 * dr[a][t]);
+                st_dev(&Wb[(size_t)(32 + jj) * ld + col], w2); st_dev(&Lb[(size_t)(32 + jj) * ld + col], w2 * dr2[a][t]);
+            } else {
+                Wb[(size_t)jj * ld + col] = w1;        Lb[(size_t)jj * ld + col] = w1 * dr[a][t];
+                Wb[(size_t)(32 + jj) * ld + col] = w2; Lb[(size_t)(32 + jj) * ld + col] = w2 * dr2[a][t];
+            }
+            if (write_s) {
+                if (j0 + jj < n) Sout[(size_t)(j0 + jj) * ld + col] = w1 * sqr[a][t];
+                if (j0 + 32 + jj < n) Sout[(size_t)(j0 + 32 + jj) * ld + col] = w2 * sqr[2 + a][t];
+            }
+        }
+}

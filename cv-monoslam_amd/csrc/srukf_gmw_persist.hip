@@ -723,14 +723,191 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->head_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->head_crit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gated) atomicSub(&g_gmw_admitted, 1);
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split form (N >= 340: more tiles than two per worker).  The memory-tile instance above runs every tile through one accumulator set per step — read, two slabs
+// recomputed (80 of the 144 MFMAs of a step), update, written back: 10.1 GFLOP of MFMA and 784 MB of HBM traffic per launch at N = 500 for 4.67 GFLOP and 74 MB
+// of algorithm, ~8 us per tile step on a lone wave per SIMD, and its early panels are bound by the workers.  Here the factorisation is TWO kernels that run side
+// by side on two streams and talk through the same sync block:
+//   k_gmw_pivslab_persist  1 pivot workgroup (gmw_pivot_persist, unchanged) + one SLAB workgroup per column block J: for every pivoted panel k < J it waits for
+//                          the panel and for the finished row-panel tile (k, J), forms W_k(J) and L = W / D once (16 columns per wave) and leaves them in
+//                          Wslab[k] / Lslab[k] (+ the panel's final S rows for its columns), then raises slabver[k][J];
+//   k_gmw_tiles_persist    ONE lean workgroup per tile (few registers, no LDS: several per CU, all of the early rows resident at once): the tile stays in
+//                          registers from its first update to its last, a step is the plain K = 64 update from the two slab rows it needs (L2 hits), then it
+//                          is stored once and ver[I][J] raised — what the slab workgroups and the pivot wait for.
+// Dependencies only point to earlier block rows and workgroups are dispatched in list (= row) order per XCD, so the tile launch makes progress whatever part of it
+// is resident; the pivot / slab launch (T workgroups of one CU each) has to be resident as a whole: the tile launch sits behind k_gmw_split_gate, which waits for
+// sy->resident.  Same arithmetic as the other forms (per-element MFMA sequences, multiplications by 1 / D): bit-identical.  Every wait is bounded.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gmw_pivslab_persist(int n, int ld, int T, int Tp, double* __restrict__ G, GmwPanel64* __restrict__ pans,
+                                                             double* __restrict__ Sout, double* __restrict__ Dall, double eps, GmwSync* __restrict__ sy,
+                                                             FrameScalars* __restrict__ fs, int krows, double* __restrict__ Wslab, double* __restrict__ Lslab,
+                                                             unsigned int total_exits)
+{
+    __shared__ double Lr[64][G64_LS];
+    __shared__ double Wc[64][G64_LS];
+    __shared__ double facreg[2 * GMW_FAC_DOUBLES];
+    __shared__ double xreg[1024 + 1024 + 32 * 33];
+    __shared__ double keepreg[1024 + 64 + 64];
+    __shared__ int ok, halfcnt, stageok[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int frozen_now = fs->frozen;
+    unsigned long long epoch_now = sy->epoch;
+    asm volatile("" : "+s"(frozen_now), "+s"(epoch_now));
+    if (frozen_now) return;
+    const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
+    if (tid == 0) __hip_atomic_fetch_add(&sy->resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    if (blockIdx.x == 0) {
+        gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid, krows);
+    } else {
+        const int J = (int)blockIdx.x, wv = tid >> 6;
+        unsigned long long* ver = gmw_sync_ver(sy);
+        unsigned long long* slabver = gmw_sync_slabver(sy, T);
+        const bool half_last = (Tp < T) && (krows <= 64 * (Tp - 1) + 32);
+        const int kend = min(J, Tp);
+        bool good = true;
+        for (int k = 0; k < kend && good; k++) {
+            if (wv0) {
+                bool g2 = gmw_wait_ge(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
+                if (g2 && k >= 1) g2 = gmw_wait_ge(&ver[(size_t)k * T + J], ebase + k, &sy->abort);
+                ok = g2 ? 1 : 0;
+            }
+            __syncthreads();
+            good = ok != 0;
+            if (good) {
+                const bool r32 = half_last && k == Tp - 1;
+                gmw_slab16_to_global<true>(n, ld, 64 * k, 64 * J + 16 * wv, G, pans + k, Sout, Wslab + (size_t)k * 64 * ld, Lslab + (size_t)k * 64 * ld, J >= k + 2 || (Tp < T && k == Tp - 1), r32, lane);
+                gmw_publish(&slabver[(size_t)k * T + J], ebase + 1, wv0);
+            }
+            __syncthreads();
+        }
+        if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == total_exits - 1) {
+            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
+            __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// one lean workgroup per tile of the list (register-resident from its first update to its last); waves = 32 x 32 quadrants
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void k_gmw_tiles_persist(int ld, int T, double* __restrict__ G, GmwSync* __restrict__ sy, const GmwTile* __restrict__ tiles, FrameScalars* __restrict__ fs,
+                         const double* __restrict__ Wslab, const double* __restrict__ Lslab, unsigned int total_exits)
+{
+    __shared__ int ok;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const unsigned long long tq = ((const unsigned long long*)tiles)[blockIdx.x];
+    int frozen_now = fs->frozen;
+    unsigned long long epoch_now = sy->epoch;
+    if (frozen_now) return;
+    const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
+    const int I = (int)(short)(tq & 0xffff), J = (int)(short)((tq >> 16) & 0xffff), ns = (int)(short)((tq >> 32) & 0xffff);
+    const bool wv0 = __builtin_amdgcn_readfirstlane(wv) == 0;
+    unsigned long long* ver = gmw_sync_ver(sy);
+    const unsigned long long* slabver = gmw_sync_slabver(sy, T);
+    const int m0 = 64 * I + 32 * (wv >> 1), c0 = 64 * J + 32 * (wv & 1);
+    const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
+    d4 acc[2][2];
+    zero_acc(acc);
+    if (live) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[a][b][t] = G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr];
+    }
+    bool good = true;
+    for (int k = 0; k < ns && good; k++) {
+        if (wv0) {
+            const unsigned long long want = ebase + 1;
+            unsigned long long a = 0, b = 0;
+            for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+                a = gmw_uniform64(__hip_atomic_load(&slabver[(size_t)k * T + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b = gmw_uniform64(__hip_atomic_load(&slabver[(size_t)k * T + J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (a >= want && b >= want) break;
+                if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+                // rows k+1, k+2 feed the next panels: tight poll.  The ~800 others have slack and poll about once per microsecond (two requests each to a
+                // handful of flag lines: otherwise the pollers alone are a TB/s of fabric traffic in front of the pivot's loads)
+                if (I - k <= 2) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
+            }
+            ok = (a >= want && b >= want) ? 1 : 0;
+        }
+        __syncthreads();
+        good = ok != 0;
+        if (good && live) {
+            // (plain loads: the slab rows of panel k are written once per launch pair, before their flag, and read only behind it: no L2 can hold an older copy)
+            const double* __restrict__ Lb = Lslab + (size_t)k * 64 * ld + m0 + lr;
+            const double* __restrict__ Wb = Wslab + (size_t)k * 64 * ld + c0 + lr;
+#pragma unroll
+            for (int kk = 0; kk < 64; kk += 16) {
+                double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const size_t ro = (size_t)(kk + 4 * u + lk) * ld;
+                    a0[u] = Lb[ro]; a1[u] = Lb[ro + 16]; b0[u] = Wb[ro]; b1[u] = Wb[ro + 16];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[u], b0[u], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[u], b1[u], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[u], b0[u], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[u], b1[u], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                       // ok is rewritten by the next poll
+    }
+    if (good) {
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) st_dev(&G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr], acc[a][b][t]);
+        }
+        gmw_publish(&ver[(size_t)I * T + J], ebase + ns, wv0);
+    } else if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == total_exits - 1) {
+            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
+            __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// In front of k_gmw_tiles_persist on its stream: lets it start only when every workgroup of the pivot / slab launch is resident (their CUs are then taken; the
+// tile workgroups get the others).  One wave; gives up after ~50 ms and abandons the launch pair (the frame is flagged).
+__global__ void k_gmw_split_gate(GmwSync* __restrict__ sy, const FrameScalars* __restrict__ fs, unsigned int want)
+{
+    if (fs->frozen) return;
+    for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sy->resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= want) return;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 extern "C" {
-int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + sizeof(unsigned long long) * (size_t)T * T); }
+int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + 2 * sizeof(unsigned long long) * (size_t)T * T); }
 // host-side tile list of the persistent launch: every tile (I, J), 1 <= I <= J < T, with the number of panel updates
 // its owner applies (I off the diagonal; I - 1 on it: the pivot applies the last one itself), ordered by the step at
 // which it is finished, so that worker w and worker w + workers hold tiles that retire at different times.
@@ -809,6 +986,20 @@ void srukf_launch_syrk_own_b(hipStream_t st, int n, int ld, const void* tab, int
     if (nreal > 0) hipLaunchKernelGGL(k_syrk_own_b, dim3(nreal * B), dim3(256), 0, st, n, ld, (const SyrkOwnArgs*)tab, B, u0, u1, krows, (const GmwTile*)tiles, nreal);
 }
 int srukf_gmw_register_form(int T, int Tp, int ntiles, int workers) { return gmw_register_form(T, Tp, ntiles, workers) ? 1 : 0; }
+// split form: stA = the filter's stream (k_gmw_pivslab_persist), stB = its side stream (gate + k_gmw_tiles_persist); the caller orders stB behind whatever produced
+// G (event) and stA behind stB afterwards.  tiles / ntiles: the plan's list (the pass-on tiles at its end are not launched: the slab workgroups write their S rows).
+void srukf_launch_gmw_split(hipStream_t stA, hipStream_t stB, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout, void* sync,
+                            const void* tiles, int ntiles, void* fs, int Tp, int krows, double* Wslab, double* Lslab)
+{
+    const int T = ld / 64;
+    if (Tp <= 0 || Tp > T) Tp = T;
+    if (krows <= 0 || krows > ld) krows = ld;
+    const int nreal = ntiles - ((Tp < T) ? T - Tp : 0);
+    const unsigned int total = (unsigned)(T + nreal);
+    hipLaunchKernelGGL(k_gmw_pivslab_persist, dim3(T), dim3(256), 0, stA, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps, (GmwSync*)sync, (FrameScalars*)fs, krows, Wslab, Lslab, total);
+    hipLaunchKernelGGL(k_gmw_split_gate, dim3(1), dim3(64), 0, stB, (GmwSync*)sync, (const FrameScalars*)fs, (unsigned)T);
+    if (nreal > 0) hipLaunchKernelGGL(k_gmw_tiles_persist, dim3(nreal), dim3(256), 0, stB, ld, T, G, (GmwSync*)sync, (const GmwTile*)tiles, (FrameScalars*)fs, Wslab, Lslab, total);
+}
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }
 }  // extern "C"
