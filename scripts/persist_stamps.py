@@ -8,7 +8,8 @@ csrc = os.path.join(ROOT, "cv-monoslam_amd", "csrc")
 dbgdir = os.path.join(ROOT, "gpurun_out", "dbgobj"); os.makedirs(dbgdir, exist_ok=True)
 srcs = ["srukf_api", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank"]
 flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -DSRUKF_GMW_DBG -w".split()
-procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-c", f"{csrc}/{s}.hip", "-o", f"{dbgdir}/{s}.o"]) for s in srcs]
+extra = {"srukf_gmw_persist": ["-Os", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}      # (the Makefile's flags for that file: a representative timeline)
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + extra.get(s, []) + ["-c", f"{csrc}/{s}.hip", "-o", f"{dbgdir}/{s}.o"]) for s in srcs]
 assert all(p.wait() == 0 for p in procs)
 lib = os.path.join(dbgdir, "libsrukf_hip_dbg.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [f"{dbgdir}/{s}.o" for s in srcs])
