@@ -2405,7 +2405,7 @@ int srukf_debug_gmw_stamps(srukf_ctx* c, unsigned long long* buf)
     HIPCHK(c, hipMemcpy((char*)g.sync + offsetof(GmwSync, dbg), &hbuf, 8, hipMemcpyHostToDevice));      // armed for the launches that follow
     return SRUKF_OK;
 }
-// Diagnostic read-out of the device-resident frame scalars (synchronises the stream): "gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts"
+// Diagnostic read-out of the device-resident frame scalars (synchronises the stream): "gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts"; "gmw_shared", "split_form"
 int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
 {
     if (!c || !key || !value) return SRUKF_ERR_BAD_ARG;
@@ -2418,6 +2418,7 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     else if (!strcmp(key, "frozen")) *value = c->hfs->frozen;
     else if (!strcmp(key, "gate_timeouts")) *value = c->hfs->gate_timeouts;
     else if (!strcmp(key, "gmw_shared")) *value = c->gmw_shared;
+    else if (!strcmp(key, "split_form")) *value = split_form(c, c->red_r > 0 ? c->gplan_red : c->gplan) ? 1 : 0;       // would the next persistent factorisation be the split form?
     else return SRUKF_ERR_BAD_ARG;
     return SRUKF_OK;
 }

@@ -273,12 +273,14 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  *   their tiles of S^T S - U U^T themselves), "rank_aware", "graphs" (0: contexts created afterwards launch eagerly, which rocprofv3 --pmc needs),
  *   "shared_tenants" (2..8: persistent launches that share the GPU after srukf_set_exclusive(SRUKF_GPU_SHARED); srukf_run_frames_batch picks its own),
  *   "batch_wide" (0: srukf_run_frames_batch never takes the batched launches), "batch_groups" (1..4: groups the batched filters are cut into),
- *   "batch_split" (0: one launch per panel in the batched replay instead of slabs + plain trailing updates).
+ *   "batch_split" (0: one launch per panel in the batched replay instead of slabs + plain trailing updates),
+ *   "mem_split" (0: sizes beyond two register tiles per worker — N >= 400 — keep the memory-tile instance of k_gmw_persist instead of the split form
+ *   k_gmw_pivslab_persist + k_gmw_tiles_persist; 2: the split form also where a worker would own two register tiles).
  * Per-context keys: "use_graph" (0: eager launches), "fused_motion" (0: k_motion + k_project as two launches, 1: k_project_motion, 2: "table"
  *   mode), "pxy2" (0: k_pxy instead of k_pxy2), "nullskip", "head_fold" (0: k_syrk launch in front of the persistent launch), "tail_fuse"
  *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse".  See srukf_api.hip (srukf_ctx::DbgSwitches). */
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
-/* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared"). */
+/* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared", "split_form"). */
 int  srukf_debug_get(srukf_ctx* ctx, const char* key, long long* value);
 /* Diagnostic copy of a device work buffer (tests compare the launch sequences stage by stage): key = "Z", "DZ", "sigR", "Cmat", "Xr1",
  * "Utp", "P1", "h", "Si"; `count` doubles from the start of the buffer. */

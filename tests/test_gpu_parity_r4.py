@@ -155,3 +155,31 @@ def test_batched_filters_recover_from_flagged_frames(srukf, oracle, synth):
     assert rel[:2].max() <= 1e-8 and rel.max() <= 1e-5, rel.max(axis=1)
     for f in fs:
         f.close()
+
+
+@pytest.mark.parametrize("N,storage,rank_aware", [(400, "f64", 1), (400, "f64", 0), (500, "f32", 1)])
+def test_split_form_of_the_persistent_factorisation(srukf, synth, N, storage, rank_aware):
+    """Sizes beyond two register tiles per worker (N >= 400 in the rank-aware form): the factorisation is k_gmw_pivslab_persist + k_gmw_tiles_persist side by side (the split form), captured in the
+    frame graphs as two branches.  Same arithmetic as the memory-tile instance of k_gmw_persist it replaces (srukf_debug_set "mem_split" 0), which the oracle tests of
+    round 2 hold (test_oracle_frame_n500 now runs the split form): bit for bit over a staged run, no abandoned launch."""
+    p = synth.scene_params()
+    F = 14
+    sc = synth.make_scene(N, F, seed=21, p=p)
+    res = []
+    for split in (1, 0):
+        srukf.debug_set_global("mem_split", split)
+        try:
+            f = srukf.Filter(N, p)
+            if not rank_aware: f.set_rank_aware(0)
+            if storage == "f32": f.set_storage(srukf.STORAGE_F32)
+            f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+            tr = [f.run_frames(0, 2), f.run_frames(2, F - 2)]  # (graph replay: blocks of eight frames and single frames)
+            assert f.debug_get("split_form") == split          # (the plan in use: rank-aware once the null directions are known)
+            X, S = f.get_state()
+            assert f.debug_get("gmw_aborts") == 0 and f.debug_get("gmw_shared") == 0
+            res.append((np.vstack(tr), X, S))
+            f.close()
+        finally:
+            srukf.debug_set_global("mem_split", 1)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.abs(res[0][0][-1, :2] - sc["odo"][F, :2]).max() < 5e-3      # and it tracks
