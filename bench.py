@@ -77,6 +77,34 @@ def pmc_mfma(kernel, tag=None):
     return (k.get("mfma_busy_pct_of_kernel_time") if k else None), (k.get("mfma_gflop") if k else None), os.path.relpath(files[-1], ROOT)
 
 
+# the split form of the persistent factorisation (N >= 400) is two launches side by side: the library times them as one ("k_gmw_persist"), rocprofv3 lists both
+SPLIT_KERNELS = ("k_gmw_pivslab_persist", "k_gmw_tiles_persist")
+
+
+def pmc_traffic_split(tag):
+    """pmc_traffic for the pair of launches of the split form: bytes of both per factorisation."""
+    files = profile_files("*_pmc_traffic.json", tag)
+    if not files:
+        return None, None
+    ks = json.load(open(files[-1])).get("kernels", {})
+    if not all(k in ks for k in SPLIT_KERNELS):
+        return None, os.path.relpath(files[-1], ROOT)
+    return sum(ks[k]["traffic_bytes"] for k in SPLIT_KERNELS), os.path.relpath(files[-1], ROOT)
+
+
+def pmc_mfma_split(tag):
+    """pmc_mfma for the pair: matrix-pipe busy cycles of both over the duration of the longer one (they run concurrently), MFMA flops of both."""
+    files = profile_files("*_mfma.json", tag)
+    if not files:
+        return None, None, None
+    ks = json.load(open(files[-1])).get("kernels", {})
+    if not all(k in ks for k in SPLIT_KERNELS):
+        return None, None, os.path.relpath(files[-1], ROOT)
+    dur_us = max(ks[k]["avg_duration_us"] for k in SPLIT_KERNELS)
+    busy = sum(ks[k]["SQ_VALU_MFMA_BUSY_CYCLES"] for k in SPLIT_KERNELS)
+    return busy / (dur_us * 2.4e3 * 1024) * 100.0, sum(ks[k]["mfma_gflop"] for k in SPLIT_KERNELS), os.path.relpath(files[-1], ROOT)
+
+
 def dist_env():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -361,9 +389,18 @@ def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
     else:
         roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(dom, "n500")
-    roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma(dom, "n500")
-    roof.update({"kernel": dom, "avg_launch_us": avg_s * 1e6, "launches_per_frame": d["launches"] / PF})
+    split = dom == "k_gmw_persist" and f.debug_get("split_form") == 1
+    if split:
+        roof["traffic"], roof["traffic_source"] = pmc_traffic_split("n500")
+        roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma_split("n500")
+    else:
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(dom, "n500")
+        roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma(dom, "n500")
+    if split and roof["traffic"] is None:
+        roof["traffic_note"] = ("rocprofv3 --pmc serialises dispatches; the two launches of the split form wait for each other and cannot run under it, so the committed "
+                                "counters are the memory-tile form's (profiles/*n500*: 784 MB per launch, 10.1 GFLOP of MFMA) and say nothing about this pair")
+    roof.update({"kernel": "k_gmw_pivslab_persist + k_gmw_tiles_persist (one factorisation: two launches side by side)" if split else dom,
+                 "avg_launch_us": avg_s * 1e6, "launches_per_frame": d["launches"] / PF})
     out = {"workload": f"BASELINE configs[4]: {N} landmarks (n={6 * N + 4}), fp32 storage of X / S between frames, fp64 arithmetic, one GPU",
            "value": K / dt, "unit": "frames/s", "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "dtype": "f64 (state stored as f32)",
            "roofline": roof, "null_directions_skipped": f.null_directions(), "pose_err_vs_truth_m": err,
@@ -438,6 +475,8 @@ def main():
                     help="precision the filter state is STORED in between frames (f32 with --landmarks 500 = the configs4 workload as the profiled one: scripts/profile_round.sh)")
     ap.add_argument("--no-configs4", action="store_true", help="skip the N = 500 / fp32-storage leg (BASELINE configs[4]) of the 1-GPU line")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 --pmc passes need it)")
+    ap.add_argument("--pmc-serial", action="store_true", help="rocprofv3 --pmc serialises the dispatches: the split form of the factorisation (N >= 400: two launches that "
+                    "wait for each other) cannot run under it and is switched off — the counters of that pass are the memory-tile form's")
     ap.add_argument("--no-collectives-check", action="store_true",
                     help="skip the short --force-dist child run whose outcome the default 1-GPU line reports as `collectives_check`")
     args = ap.parse_args()
@@ -463,6 +502,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.pmc_serial:
+        srukf.debug_set_global("mem_split", 0)
     if args.eager:
         srukf.debug_set_global("graphs", 0)
     torch.cuda.set_device(local)

@@ -562,7 +562,10 @@ static void shadow_rebuild(srukf_ctx* c)
 {
     if (c->red_r > 0 && c->shadowA) srukf_launch_rank_shadow(c->stream, c->d.n, c->d.np, c->red_r, c->S, c->red_perm, c->shadowA);
 }
-static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c->gmw_shared != 2 && c->gplan.workers >= 0; }
+static bool split_form(const srukf_ctx* c, const GmwPlan& gp);
+// (a plan with workers < 0 — more tiles than the workers of k_gmw_persist can own — still has the split form)
+static bool gmw_plan_persists(const srukf_ctx* c, const GmwPlan& gp) { return gp.workers >= 0 || split_form(c, gp); }
+static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c->gmw_shared != 2 && gmw_plan_persists(c, c->gplan); }
 // SRUKF_GPU_SHARED: how many persistent launches share the GPU (each keeps to 1 / tenants of the CUs; the gate admits that many)
 // (per context: srukf_run_frames_batch picks it from the number of filters it runs — one tenant per filter up to SRUKF_MAX_TENANTS; srukf_set_exclusive alone uses the
 //  process-wide default of srukf_debug_set "shared_tenants")
@@ -581,7 +584,7 @@ static bool split_wanted(const GmwPlan& gp)
 // Buffers / side stream of the split form for a plan with Tp pivoted panels (not inside a capture).  Failure is not an error: the memory-tile form is used.
 static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
 {
-    if (!g_dbg_mem_split || gp.workers < 0 || gp.T < 16 || !split_wanted(gp)) return;
+    if (!g_dbg_mem_split || gp.T < 16 || !split_wanted(gp)) return;           // (gp.workers < 0 — more tiles than the memory-tile form can own — included: the split form has no such limit)
     if (gp.T + 1 > gp.cus) return;                              // the pivot / slab launch must be resident as a whole with CUs left for the tiles
     if (c->gs_panels < gp.Tp) {
         if (c->gsW) srukf_dfree_on(c->gsW, c->stream);
@@ -605,7 +608,7 @@ static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
 }
 static bool split_form(const srukf_ctx* c, const GmwPlan& gp)
 {
-    return g_dbg_mem_split && c->gmw_shared == 0 && !c->debug_starve && c->side && c->gsW && c->gs_panels >= gp.Tp && gp.workers >= 0 && gp.T >= 16 && split_wanted(gp);
+    return g_dbg_mem_split && c->gmw_shared == 0 && !c->debug_starve && c->side && c->gsW && c->gs_panels >= gp.Tp && gp.T >= 16 && gp.T + 1 <= gp.cus && split_wanted(gp);
 }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
@@ -743,7 +746,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
             c->dx_pending = false;
         }
         {
-            ProfScope ps(c, gmw_use_persist(c) && c->gplan_red.workers >= 0 ? KC_GMW_PERSIST : KC_GMW_TRAIL, c->red_fac_flop, 8.0 * 2.0 * rp * n);
+            ProfScope ps(c, gmw_use_persist(c) && gmw_plan_persists(c, c->gplan_red) ? KC_GMW_PERSIST : KC_GMW_TRAIL, c->red_fac_flop, 8.0 * 2.0 * rp * n);
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
         ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
@@ -781,7 +784,7 @@ static void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_back
         }
         {
             const double rr = 64.0 * c->red_Tp;
-            ProfScope ps(c, gmw_use_persist(c) && c->gplan_red.workers >= 0 ? KC_GMW_PERSIST : KC_GMW_TRAIL, rr * rr * rr / 3.0 + rr * rr * (nn - rr) + rr * (nn - rr) * (nn - rr) / 2.0,
+            ProfScope ps(c, gmw_use_persist(c) && gmw_plan_persists(c, c->gplan_red) ? KC_GMW_PERSIST : KC_GMW_TRAIL, rr * rr * rr / 3.0 + rr * rr * (nn - rr) + rr * (nn - rr) * (nn - rr) / 2.0,
                          8.0 * (rr * nn));
             launch_gmw_fast(c, c->Wf, c->G, true);
         }
@@ -827,7 +830,7 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
     const int np = c->d.np, n = c->d.n;
     const GmwPlan& gp = reduced ? c->gplan_red : c->gplan;
     const int Tp = reduced ? c->red_Tp : np / 64;
-    if (gmw_use_persist(c) && gp.workers >= 0) {
+    if (gmw_use_persist(c) && gmw_plan_persists(c, gp)) {
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
         const int workers = c->debug_starve ? 0 : gp.workers;
