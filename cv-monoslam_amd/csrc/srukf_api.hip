@@ -41,7 +41,7 @@ int srukf_gmw_build_tiles(int T, int Tp, short* out);
 int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
 void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
-void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
+void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*, int);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int);
@@ -562,9 +562,9 @@ static void shadow_rebuild(srukf_ctx* c)
 {
     if (c->red_r > 0 && c->shadowA) srukf_launch_rank_shadow(c->stream, c->d.n, c->d.np, c->red_r, c->S, c->red_perm, c->shadowA);
 }
-static bool split_form(const srukf_ctx* c, const GmwPlan& gp);
+static bool split_form(const srukf_ctx* c, const GmwPlan& gp, bool ignore_starve = false);
 // (a plan with workers < 0 — more tiles than the workers of k_gmw_persist can own — still has the split form)
-static bool gmw_plan_persists(const srukf_ctx* c, const GmwPlan& gp) { return gp.workers >= 0 || split_form(c, gp); }
+static bool gmw_plan_persists(const srukf_ctx* c, const GmwPlan& gp) { return gp.workers >= 0 || split_form(c, gp, true); }
 static bool gmw_use_persist(const srukf_ctx* c) { return gmw_persist_mode() && c->gmw_shared != 2 && gmw_plan_persists(c, c->gplan); }
 // SRUKF_GPU_SHARED: how many persistent launches share the GPU (each keeps to 1 / tenants of the CUs; the gate admits that many)
 // (per context: srukf_run_frames_batch picks it from the number of filters it runs — one tenant per filter up to SRUKF_MAX_TENANTS; srukf_set_exclusive alone uses the
@@ -606,9 +606,9 @@ static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
         }
     }
 }
-static bool split_form(const srukf_ctx* c, const GmwPlan& gp)
+static bool split_form(const srukf_ctx* c, const GmwPlan& gp, bool ignore_starve)
 {
-    return g_dbg_mem_split && c->gmw_shared == 0 && !c->debug_starve && c->side && c->gsW && c->gs_panels >= gp.Tp && gp.T >= 16 && gp.T + 1 <= gp.cus && split_wanted(gp);
+    return g_dbg_mem_split && c->gmw_shared == 0 && (ignore_starve || !c->debug_starve) && c->side && c->gsW && c->gs_panels >= gp.Tp && gp.T >= 16 && gp.T + 1 <= gp.cus && split_wanted(gp);
 }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
@@ -834,11 +834,11 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
         const int workers = c->debug_starve ? 0 : gp.workers;
-        if (split_form(c, gp)) {
+        if (split_form(c, gp, true)) {                         // (srukf_debug_starve_workers: the pair without its tile launch)
             // the tile launch depends on what produced Gbuf, not on the pivot / slab launch: fork before, join after (in a capture: two parallel branches)
             hipEventRecord(c->ev_fork, c->stream);
             hipStreamWaitEvent(c->side, c->ev_fork, 0);
-            srukf_launch_gmw_split(c->stream, c->side, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, c->fs, Tp, reduced ? ((c->red_r + 15) & ~15) : 0, c->gsW, c->gsL);
+            srukf_launch_gmw_split(c->stream, c->side, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, c->fs, Tp, reduced ? ((c->red_r + 15) & ~15) : 0, c->gsW, c->gsL, c->debug_starve ? 1 : 0);
             hipEventRecord(c->ev_join, c->side);
             hipStreamWaitEvent(c->stream, c->ev_join, 0);
             return;

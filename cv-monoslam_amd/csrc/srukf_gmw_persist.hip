@@ -989,16 +989,17 @@ int srukf_gmw_register_form(int T, int Tp, int ntiles, int workers) { return gmw
 // split form: stA = the filter's stream (k_gmw_pivslab_persist), stB = its side stream (gate + k_gmw_tiles_persist); the caller orders stB behind whatever produced
 // G (event) and stA behind stB afterwards.  tiles / ntiles: the plan's list (the pass-on tiles at its end are not launched: the slab workgroups write their S rows).
 void srukf_launch_gmw_split(hipStream_t stA, hipStream_t stB, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout, void* sync,
-                            const void* tiles, int ntiles, void* fs, int Tp, int krows, double* Wslab, double* Lslab)
+                            const void* tiles, int ntiles, void* fs, int Tp, int krows, double* Wslab, double* Lslab, int starve)
 {
     const int T = ld / 64;
     if (Tp <= 0 || Tp > T) Tp = T;
     if (krows <= 0 || krows > ld) krows = ld;
     const int nreal = ntiles - ((Tp < T) ? T - Tp : 0);
-    const unsigned int total = (unsigned)(T + nreal);
+    const unsigned int total = (unsigned)(T + (starve ? 0 : nreal));
     hipLaunchKernelGGL(k_gmw_pivslab_persist, dim3(T), dim3(256), 0, stA, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps, (GmwSync*)sync, (FrameScalars*)fs, krows, Wslab, Lslab, total);
     hipLaunchKernelGGL(k_gmw_split_gate, dim3(1), dim3(64), 0, stB, (GmwSync*)sync, (const FrameScalars*)fs, (unsigned)T);
-    if (nreal > 0) hipLaunchKernelGGL(k_gmw_tiles_persist, dim3(nreal), dim3(256), 0, stB, ld, T, G, (GmwSync*)sync, (const GmwTile*)tiles, (FrameScalars*)fs, Wslab, Lslab, total);
+    // starve (tests): the tile launch never arrives, as if the GPU were taken — the bounded waits of the pivot and the slab workgroups expire, the frame is flagged
+    if (nreal > 0 && !starve) hipLaunchKernelGGL(k_gmw_tiles_persist, dim3(nreal), dim3(256), 0, stB, ld, T, G, (GmwSync*)sync, (const GmwTile*)tiles, (FrameScalars*)fs, Wslab, Lslab, total);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }

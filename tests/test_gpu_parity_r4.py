@@ -183,3 +183,30 @@ def test_split_form_of_the_persistent_factorisation(srukf, synth, N, storage, ra
             srukf.debug_set_global("mem_split", 1)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     assert np.abs(res[0][0][-1, :2] - sc["odo"][F, :2]).max() < 5e-3      # and it tracks
+
+
+def test_split_form_without_its_tile_launch_falls_back(srukf, synth):
+    """The split form whose tile launch never arrives (srukf_debug_starve_workers: as if somebody else held the GPU) must not hang: the bounded waits of the pivot and of
+    the slab workgroups expire, the frame is flagged and repeated on the exact path, the filter goes on with one launch per panel — and ends where an undisturbed filter ends
+    (P to 1e-11: the repeated frame's exact column path rounds differently)."""
+    p = synth.scene_params()
+    N, F = 400, 5
+    sc = synth.make_scene(N, F, seed=22, p=p)
+    res = []
+    for starve in (True, False):
+        f = srukf.Filter(N, p)
+        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        tr = [f.run_frames(0, 1)]
+        assert f.debug_get("split_form") == 1
+        if starve: f.debug_starve_workers(True)
+        tr.append(f.run_frames(1, 2))
+        if starve:
+            assert f.debug_get("gmw_shared") == 2              # fell back to per-panel launches
+            f.debug_starve_workers(False)
+        tr.append(f.run_frames(3, F - 3))
+        X, S = f.get_state()
+        res.append((np.vstack(tr), X, S.T @ S))
+        f.close()
+    np.testing.assert_allclose(res[0][0][:, :4], res[1][0][:, :4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=1e-11)
