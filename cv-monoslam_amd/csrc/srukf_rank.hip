@@ -300,7 +300,10 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                                                      KDims d, KWeights w,
                                                      srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32)
 {
-    rank_expand_body<MODE>(n, ld, r, eps, Sp, D, perm, iperm, gdiag, fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, (int)blockIdx.x);
+    // dispatch order: the frame tail, the null checks and the noise rows (the longest chains of round trips: a column walk over every kept row) first, then the rows
+    const int extra = (int)gridDim.x - n;
+    const int bid = (int)blockIdx.x < extra ? n + (int)blockIdx.x : (int)blockIdx.x - extra;
+    rank_expand_body<MODE>(n, ld, r, eps, Sp, D, perm, iperm, gdiag, fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, bid);
 }
 // batched form (srukf_run_frames_batch; "fused tail" mode, fp64 storage): filter f owns workgroups [f per, (f + 1) per)
 __global__ __launch_bounds__(256) void k_rank_expand_b(int n, int ld, int r, double eps, const ExpandArgs* __restrict__ tab, int per, double gamma, KDims d, KWeights w, srukf_params p)
