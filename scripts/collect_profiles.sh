@@ -15,4 +15,5 @@ tail -1 gpurun_out/r04_bench_driver_style.json > profiles/r04_a_bench_driver_sty
 tail -1 gpurun_out/r04_bench_default.json > profiles/r04_a_bench.json
 cp gpurun_out/r04_batch_probe_groups.txt profiles/r04_batch_probe_groups.txt
 cp gpurun_out/r04_batch_soak.json profiles/r04_batch_soak.json 2>/dev/null
+cp gpurun_out/r04_split_soak.json profiles/r04_n500_split_soak.json 2>/dev/null
 ls -la profiles/ | grep r04
