@@ -104,18 +104,46 @@ template <int R, int RE, int NA> struct GmwRowUpd {
 // Pivot J.  Every DPP row of 16 lanes holds the whole block: lane c16 owns column c16 (P[r], rows 0..15 — the
 // lower-left 16x16 quarter is never needed) and column 16 + c16 (Q[r], rows 0..31), so the pivot row is
 // available to row_newbcast in every DPP row without any cross-row traffic.
+// Software-pipelined by one pivot: step J arrives with D_J and -1 / D_J already computed, updates ROW J + 1 first, starts pivot J + 1's chain (broadcast of the new
+// diagonal, clamp, reciprocal + Newton step: ~90 cycles of dependent instructions) and only then issues the other updates of pivot J, which fill those cycles — a
+// lone wave issues in order, so what is not interleaved in the instruction stream is not overlapped (the compiler keeps this order; it kept the serial one too:
+// chain, then 16 - 46 updates, per pivot).  Same operations on the same operands: bit-identical.
+// The updates of pivot J other than row J + 1, as one list with a compile-time index (so that the chain of pivot J + 1 can be threaded through it):
+//   J < 16:  P rows J+2..15 (src xp, nt ntp), Q rows J+2..15 (src xp, nt ntq), Q rows 16..31 (src xq, nt ntq; row 16 is "row J + 1" when J = 15)
+//   J >= 16: Q rows J+2..31 (src xq, nt ntq)
+template <int J> struct GmwOps {
+    static constexpr int NP = (J < 16) ? (14 - J > 0 ? 14 - J : 0) : 0;          // P rows J+2..15, and as many Q rows
+    static constexpr int Q16 = (J < 16) ? (J == 15 ? 15 : 16) : 0;               // Q rows 16..31 (17..31 when J = 15)
+    static constexpr int NQ = (J >= 16) ? (30 - J > 0 ? 30 - J : 0) : 0;         // Q rows J+2..31
+    static constexpr int N = (J < 16) ? 2 * NP + Q16 : NQ;
+    template <int I> static __device__ __forceinline__ void one(double (&P)[16], double (&Q)[32], double xp, double xq, double ntp, double ntq)
+    {
+        if constexpr (J < 16) {
+            if constexpr (I < NP) fmac_bcast16<((J + 2 + I) & 15)>(P[J + 2 + I], xp, ntp);
+            else if constexpr (I < 2 * NP) fmac_bcast16<((J + 2 + I - NP) & 15)>(Q[J + 2 + I - NP], xp, ntq);
+            else { constexpr int r = 32 - Q16 + (I - 2 * NP); fmac_bcast16<(r & 15)>(Q[r], xq, ntq); }
+        } else {
+            constexpr int r = J + 2 + I;
+            fmac_bcast16<(r & 15)>(Q[r], xq, ntq);
+        }
+    }
+    // ops [I0, I1) clipped to the list
+    template <int I0, int I1> static __device__ __forceinline__ void run(double (&P)[16], double (&Q)[32], double xp, double xq, double ntp, double ntq)
+    {
+        if constexpr (I0 < I1 && I0 < N) {
+            one<I0>(P, Q, xp, xq, ntp, ntq);
+            run<I0 + 1, I1>(P, Q, xp, xq, ntp, ntq);
+        }
+    }
+};
 template <int J> struct GmwPivot {
-    // lm: LDS offset of this lane's Lm strip, dv: LDS offset of Dv[0]
-    static __device__ __forceinline__ void run(double (&P)[16], double (&Q)[32], double eps, unsigned lm, unsigned dv)
+    // lm: LDS offset of this lane's Lm strip, dv: LDS offset of Dv[0]; D, nrc: pivot J and -1 / pivot J
+    static __device__ __forceinline__ void run(double (&P)[16], double (&Q)[32], double eps, unsigned lm, unsigned dv, double D, double nrc)
     {
         if constexpr (J < 32) {
             const double xq = Q[J];
             double xp = 0.0;
             if constexpr (J < 16) xp = P[J];
-            const double d = mov_bcast16<(J & 15)>(J < 16 ? xp : xq);
-            double D;
-            asm("v_max_f64 %0, %1, |%2|" : "=v"(D) : "v"(eps), "v"(d));     // NaN-proof: max(eps, NaN) = eps
-            const double nrc = -gmw_pivot_rcp(D);
             const double ntq = xq * nrc;
             double ntp = 0.0;
             if constexpr (J < 16) {
@@ -125,14 +153,34 @@ template <int J> struct GmwPivot {
                 lds_publish<16 * J + 8>(lm, ntq);
             }
             lds_publish<J * 8>(dv, D);
-            if constexpr (J < 16) {
-                GmwRowUpd<J + 1, 16, 16>::run(P, xp, ntp);
-                GmwRowUpd<J + 1, 16, 32>::run(Q, xp, ntq);
-                GmwRowUpd<16, 32, 32>::run(Q, xq, ntq);
-            } else {
-                GmwRowUpd<J + 1, 32, 32>::run(Q, xq, ntq);
+            double D1 = 0.0, nrc1 = 0.0;
+            using Ops = GmwOps<J>;
+            if constexpr (J + 1 < 32) {
+                // row J + 1, then the next pivot's chain, one link at a time with other updates of pivot J between the links (scheduling barriers: the compiler
+                // otherwise sinks the whole chain behind the updates again)
+                if constexpr (J + 1 < 16) { fmac_bcast16<((J + 1) & 15)>(P[J + 1], xp, ntp); fmac_bcast16<((J + 1) & 15)>(Q[J + 1], xp, ntq); }
+                else fmac_bcast16<((J + 1) & 15)>(Q[J + 1], xq, ntq);
+                Ops::template run<0, 2>(P, Q, xp, xq, ntp, ntq);
+                __builtin_amdgcn_sched_barrier(0);
+                const double d1 = mov_bcast16<((J + 1) & 15)>(J + 1 < 16 ? P[(J + 1) & 15] : Q[J + 1 < 32 ? J + 1 : 0]);
+                Ops::template run<2, 4>(P, Q, xp, xq, ntp, ntq);
+                __builtin_amdgcn_sched_barrier(0);
+                asm("v_max_f64 %0, %1, |%2|" : "=v"(D1) : "v"(eps), "v"(d1));     // NaN-proof: max(eps, NaN) = eps
+                Ops::template run<4, 6>(P, Q, xp, xq, ntp, ntq);
+                __builtin_amdgcn_sched_barrier(0);
+                double r = __builtin_amdgcn_rcp(D1);                // gmw_pivot_rcp's three links
+                Ops::template run<6, 10>(P, Q, xp, xq, ntp, ntq);
+                __builtin_amdgcn_sched_barrier(0);
+                const double e = fma(-D1, r, 1.0);
+                Ops::template run<10, 12>(P, Q, xp, xq, ntp, ntq);
+                __builtin_amdgcn_sched_barrier(0);
+                r = fma(e, r, r);
+                Ops::template run<12, 14>(P, Q, xp, xq, ntp, ntq);
+                __builtin_amdgcn_sched_barrier(0);
+                nrc1 = -r;
+                Ops::template run<14, 64>(P, Q, xp, xq, ntp, ntq);
             }
-            GmwPivot<J + 1>::run(P, Q, eps, lm, dv);
+            GmwPivot<J + 1>::run(P, Q, eps, lm, dv, D1, nrc1);
         }
     }
 };
@@ -146,7 +194,13 @@ __device__ __forceinline__ void gmw_cols_pivot_wave(const GmwColsLds& w, double 
     for (int r = 0; r < 16; r++) P[r] = w.Xm[r][c];
 #pragma unroll
     for (int r = 0; r < 32; r++) Q[r] = w.Xm[r][16 + c];
-    GmwPivot<0>::run(P, Q, eps, lds_off(&w.Lm[c * GMW_LM_STRIDE]), lds_off(w.Dv));
+    double D0, nrc0;
+    {
+        const double d0 = mov_bcast16<0>(P[0]);
+        asm("v_max_f64 %0, %1, |%2|" : "=v"(D0) : "v"(eps), "v"(d0));
+        nrc0 = -gmw_pivot_rcp(D0);
+    }
+    GmwPivot<0>::run(P, Q, eps, lds_off(&w.Lm[c * GMW_LM_STRIDE]), lds_off(w.Dv), D0, nrc0);
 }
 
 // ---- follower waves ----------------------------------------------------------------------------
