@@ -2398,14 +2398,16 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
 int srukf_debug_gmw_stamps(srukf_ctx* c, unsigned long long* buf)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;
-    static unsigned long long* hbuf = nullptr;
+    // (device memory: stamps written to pinned host memory cross PCIe, and every later s_waitcnt vmcnt(0) of the stamping wave waits for them — the timeline of the
+    //  diagnostic build then shows 17.9 us per panel where the product runs 14.5)
+    static unsigned long long* dbuf = nullptr;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     GmwPlan& g = c->red_r > 0 ? c->gplan_red : c->gplan;
     if (!g.sync) return SRUKF_ERR_SEQUENCE;
-    if (!hbuf) { HIPCHK(c, hipHostMalloc((void**)&hbuf, 8 * 4096, hipHostMallocCoherent)); memset(hbuf, 0, 8 * 4096); }
-    if (buf) memcpy(buf, hbuf, 8 * 4096);
-    HIPCHK(c, hipMemcpy((char*)g.sync + offsetof(GmwSync, dbg), &hbuf, 8, hipMemcpyHostToDevice));      // armed for the launches that follow
+    if (!dbuf) { HIPCHK(c, hipMalloc((void**)&dbuf, 8 * 4096)); HIPCHK(c, hipMemset(dbuf, 0, 8 * 4096)); }
+    if (buf) HIPCHK(c, hipMemcpy(buf, dbuf, 8 * 4096, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy((char*)g.sync + offsetof(GmwSync, dbg), &dbuf, 8, hipMemcpyHostToDevice));      // armed for the launches that follow
     return SRUKF_OK;
 }
 // Diagnostic read-out of the device-resident frame scalars (synchronises the stream): "gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts"; "gmw_shared", "split_form"

@@ -317,7 +317,7 @@ __device__ __forceinline__ unsigned long long* gmw_sync_slabver(GmwSync* sy, int
 #define GMW_DBG(sy, slot, val) do { if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0 && (sy)->dbg) __hip_atomic_store(&(sy)->dbg[blockIdx.x * 8 + (slot)], (unsigned long long)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 #define GMW_DBG2(sy, slot, val) do { if ((sy)->dbg) __hip_atomic_store(&(sy)->dbg[blockIdx.x * 8 + (slot)], (unsigned long long)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 // time stamp (s_memtime) of pivot iteration p, slot 0..7, written by whichever wave executes it
-#define GMW_TS(sy, p, slot) do { if ((sy)->dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __hip_atomic_store(&(sy)->dbg[2048 + (p) * 8 + (slot)], t_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
+#define GMW_TS(sy, p, slot) do { if ((sy)->dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); (sy)->dbg[2048 + (p) * 8 + (slot)] = t_; } } while (0)
 #else
 #define GMW_DBG(sy, slot, val)
 #define GMW_DBG2(sy, slot, val)

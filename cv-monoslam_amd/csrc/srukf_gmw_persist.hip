@@ -195,8 +195,8 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
         __syncthreads();
         if (wv0) GMW_TS(sy, p, 2);
         // ---- factor 1 (+ panel S rows, tiles (0,1), (1,1)) ----
-        if (wv0) gmw_cols_pivot_wave(ws, eps, lane);
-        else if (wvu == 2) gmw_cols_t_wave<0>(ws, lane, nullptr, kp.T1);
+        if (wv0) { gmw_cols_pivot_wave(ws, eps, lane); GMW_TS(sy, p + 64, 4); }
+        else if (wvu == 2) { gmw_cols_t_wave<0>(ws, lane, nullptr, kp.T1); GMW_TS(sy, p + 64, 5); }
         else {
             if (!first) {
 #pragma unroll
@@ -227,6 +227,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
                     *(d4*)&Sout[(size_t)(j0 + row) * ld + base + c4] = w;
                 }
             }
+            if (wv1) GMW_TS(sy, p + 64, 6); else GMW_TS(sy, p + 64, 7);
         }
         __syncthreads();
         if (wv0) GMW_TS(sy, p, 3);
@@ -284,6 +285,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
                 if (p == 0 || gmw_uniform64(fa) >= ebase + p) stageok[0] = 1;
                 if (p == 0 || gmw_uniform64(fb) >= ebase + p) stageok[1] = 1;
             });
+            GMW_TS(sy, p + 192, 0);
             }
         } else {
             const int c4 = (lane & 7) * 4;

@@ -36,6 +36,11 @@ for pnl in range(Tp):
     print(f"p={pnl:02d}: {d(t[1]):6d} {d(t[2]):6d} {d(t[3]):6d} {d(t[4]):6d} | {d(t[5]):6d} {d(t[6]):6d} | {d(u[0]):6d} {d(u[1]):6d} {d(u[2]):6d} | {d(t[7]):6d} | {int(t[0] - prev) if prev is not None else 0}")
     prev = t[0]
 
+print("factor 1, since afterB: pivot wave done, T wave done, wave 1 done, wave 3 done | factor 2, since afterC1: pivot wave done, T wave done, waves 1 / 3 done")
+for pnl in range(Tp):
+    t = st[2048 + 8 * pnl: 2048 + 8 * pnl + 8].astype(np.int64); u = st[2048 + 8 * (pnl + 64): 2048 + 8 * (pnl + 64) + 8].astype(np.int64); w = st[2048 + 8 * (pnl + 192): 2048 + 8 * (pnl + 192) + 8].astype(np.int64)
+    a = lambda x, ref: int(x - ref) if x else -1
+    print(f"p={pnl:02d}: {a(u[4], t[2]):6d} {a(u[5], t[2]):6d} {a(u[6], t[2]):6d} {a(u[7], t[2]):6d} | {a(u[0], t[4]):6d} {a(w[0], t[4]):6d} {a(u[1], t[4]):6d} {a(u[2], t[4]):6d}")
 g = lambda p_, s_: int(st[2048 + 8 * p_ + s_])
 t0 = g(128, 0)
 print("pivot: entry 0, head ready %d, loop end %d   (ticks of 10 ns since the pivot's entry)" % (g(128, 1) - t0, g(128, 2) - t0))
