@@ -581,6 +581,35 @@ static bool split_wanted(const GmwPlan& gp)
     if (!srukf_gmw_register_form(gp.T, gp.Tp, gp.ntiles, gp.workers)) return true;
     return g_dbg_mem_split == 2 && gp.nreal > gp.workers;
 }
+// Do kernels on streams a and b run side by side?  HIP maps streams onto a handful of hardware queues (four by default: GPU_MAX_HW_QUEUES) and two streams that share
+// one run their kernels one after the other — the split form's two launches wait for each other, so it must never be given such a pair (measured: with several
+// filters in a process the SECOND one's stream pair shared a queue; its first pair of launches sat out the 50 ms wait bound and the filter fell back to per-panel
+// launches).  Probe: a one-wave kernel on a that waits (bounded, ~2 ms) for a word a kernel on b sets.
+__global__ void k_stream_probe_wait(int* w)
+{
+    int seen = 0;
+    for (int spins = 0; spins < (1 << 15) && !seen; spins++) {
+        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (!seen) __builtin_amdgcn_s_sleep(2);
+    }
+    if (threadIdx.x == 0) w[1] = seen;
+}
+__global__ void k_stream_probe_set(int* w) { __hip_atomic_store(&w[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static bool streams_run_side_by_side(hipStream_t a, hipStream_t b)
+{
+    int* w = nullptr;
+    if (srukf_dmalloc(&w, 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    int seen = 0;
+    bool ok = hipMemsetAsync(w, 0, 2 * sizeof(int), a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_stream_probe_wait, dim3(1), dim3(64), 0, a, w);
+        hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(1), 0, b, w);
+        ok = hipStreamSynchronize(b) == hipSuccess && hipStreamSynchronize(a) == hipSuccess && hipMemcpy(&seen, w + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    srukf_dfree(w);
+    if (!ok) (void)hipGetLastError();
+    return ok && seen != 0;
+}
 // Buffers / side stream of the split form for a plan with Tp pivoted panels (not inside a capture).  Failure is not an error: the memory-tile form is used.
 static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
 {
@@ -600,7 +629,16 @@ static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
         c->gs_panels = gp.Tp;
     }
     if (!c->side) {
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); return; }
+        // a side stream whose kernels really run beside the filter's stream's: candidates are created until one passes the probe (they are kept alive until then,
+        // so that the runtime hands out another hardware queue), the others are destroyed; none in eight tries: no split form for this filter
+        hipStream_t tried[8]; int ntried = 0;
+        while (!c->side && ntried < 8) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (streams_run_side_by_side(c->stream, s)) c->side = s; else tried[ntried++] = s;
+        }
+        for (int q = 0; q < ntried; q++) hipStreamDestroy(tried[q]);
+        if (!c->side) return;
         if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
             hipStreamDestroy(c->side); c->side = nullptr; (void)hipGetLastError();
         }

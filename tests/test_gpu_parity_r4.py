@@ -210,3 +210,30 @@ def test_split_form_without_its_tile_launch_falls_back(srukf, synth):
     np.testing.assert_allclose(res[0][0][:, :4], res[1][0][:, :4], rtol=0, atol=1e-9)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-9)
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=1e-11)
+
+
+def test_batched_filters_at_n400_against_the_split_form_run_alone(srukf, synth):
+    """Beyond two register tiles per worker a filter run ALONE factors with the split form (k_gmw_pivslab_persist + k_gmw_tiles_persist) behind a split-K k_syrk over the
+    kept rows; the batched replay forms S^T S - U U^T in the owners' summation order (k_syrk_b + k_syrk_own_b: what makes it bit-identical to solo runs where the solo
+    path's owners fold, N <= 260) and factors with its per-panel launches.  Different summation order of the contraction, same factorisation arithmetic: the same
+    filter to rounding (X 1e-9, P 1e-11: the per-frame parity bounds), nothing abandoned — several split-form contexts alive in one process included."""
+    N, F, B = 400, 6, 2
+    p = synth.scene_params()
+    scs = [synth.make_scene(N, F, seed=0, p=p, obs_seed=7100 + b) for b in range(B)]
+    fs = []
+    for sc in scs:
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"]); fs.append(f)
+    tb = srukf.run_frames_batch(fs, 0, F)
+    for b, sc in enumerate(scs):
+        assert fs[b].debug_get("gmw_aborts") == 0 and fs[b].debug_get("clamp_rows") == 0 and fs[b].debug_get("gmw_shared") == 0
+        g = srukf.Filter(N, p); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        ts = g.run_frames(0, F)
+        assert g.debug_get("split_form") == 1 and g.debug_get("gmw_shared") == 0
+        Xs, Ss = g.get_state(); Xb, Sb = fs[b].get_state()
+        np.testing.assert_allclose(tb[b][:, :4], ts[:, :4], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(tb[b][:, 4:], ts[:, 4:], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Xb, Xs, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(Sb.T @ Sb, Ss.T @ Ss, rtol=0, atol=1e-11)
+        g.close()
+    for f in fs:
+        f.close()
