@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split form (N >= 340: more tiles than two per worker).  The memory-tile instance above runs every tile through one accumulator set per step — read, two slabs
+// Split form (plans with more than two register tiles per worker: N >= 400 in the rank-aware form, N >= 340 with every pivot factored).  The memory-tile instance above runs every tile through one accumulator set per step — read, two slabs
 // recomputed (80 of the 144 MFMAs of a step), update, written back: 10.1 GFLOP of MFMA and 784 MB of HBM traffic per launch at N = 500 for 4.67 GFLOP and 74 MB
 // of algorithm, ~8 us per tile step on a lone wave per SIMD, and its early panels are bound by the workers.  Here the factorisation is TWO kernels that run side
 // by side on two streams and talk through the same sync block:
@@ -746,6 +746,8 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
 // Dependencies only point to earlier block rows and workgroups are dispatched in list (= row) order per XCD, so the tile launch makes progress whatever part of it
 // is resident; the pivot / slab launch (T workgroups of one CU each) has to be resident as a whole: the tile launch sits behind k_gmw_split_gate, which waits for
 // sy->resident.  Same arithmetic as the other forms (per-element MFMA sequences, multiplications by 1 / D): bit-identical.  Every wait is bounded.
+// The two launches WAIT FOR EACH OTHER: their streams must sit on different hardware queues (two streams on one queue run their kernels one after the other) — the
+// host side probes the pair when it creates the side stream (srukf_api.hip: streams_run_side_by_side) and uses the memory-tile instance if it finds none.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gmw_pivslab_persist(int n, int ld, int T, int Tp, double* __restrict__ G, GmwPanel64* __restrict__ pans,
                                                              double* __restrict__ Sout, double* __restrict__ Dall, double eps, GmwSync* __restrict__ sy,
