@@ -149,7 +149,7 @@ def collectives_check(timeout=240):
     rank).  Never fails the line: the outcome is reported."""
     try:
         rc, line = spawn_ranks(1, ["--gpus", "1", "--force-dist", "--steps", "8", "--warmup", "2", "--profile-frames", "4", "--no-cpu-baseline",
-                                   "--sequences-per-gpu", "0", "--no-configs4"], timeout=timeout)
+                                   "--sequences-per-gpu", "0", "--no-configs4", "--no-step-api", "--repetitions", "1"], timeout=timeout)
         if rc != 0 or not line:
             return {"ok": False, "returncode": rc}
         d = json.loads(line)
@@ -390,6 +390,7 @@ def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
         roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     split = dom == "k_gmw_persist" and f.debug_get("split_form") == 1
+    fb = plan_keys(f)
     if split:
         roof["traffic"], roof["traffic_source"] = pmc_traffic_split("n500")
         roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma_split("n500")
@@ -403,7 +404,7 @@ def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
                  "avg_launch_us": avg_s * 1e6, "launches_per_frame": d["launches"] / PF})
     out = {"workload": f"BASELINE configs[4]: {N} landmarks (n={6 * N + 4}), fp32 storage of X / S between frames, fp64 arithmetic, one GPU",
            "value": K / dt, "unit": "frames/s", "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "dtype": "f64 (state stored as f32)",
-           "roofline": roof, "null_directions_skipped": f.null_directions(), "pose_err_vs_truth_m": err,
+           "roofline": roof, "launch_plan": fb, "null_directions_skipped": f.null_directions(), "pose_err_vs_truth_m": err,
            "kernels_us_per_frame": {k: round(v["ms"] / PF * 1e3, 1) for k, v in prof.items() if v["launches"]},
            "note": "the mixed-precision sqrt(S) downdate of configs[4] (SRUKF_STORAGE_F32_MIXED) is refused below epsilon = 1e-9: DESIGN.md, row g"}
     f.close()
@@ -454,6 +455,59 @@ def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local, reps=3, sm
     return out, identical, flagged
 
 
+STEP_BENCH = os.path.join(ROOT, "cv-monoslam_amd", "cslam_step_bench.bin")
+
+
+def plan_keys(f):
+    """Which launch plan the filter's staged frames take and whether anything fell back (srukf_debug_get): printed next to every rate, so that an abandoned
+    persistent launch or a side stream that was not found shows up as a cause, not only as a slower number."""
+    keys = ["split_form", "gmw_aborts", "gmw_shared", "clamp_rows", "gate_timeouts", "plan_persist", "plan_register_form", "plan_tiles_per_worker", "plan_fold",
+            "plan_head_fold", "plan_red_perm", "plan_motion", "plan_fuse"]
+    return {k: int(f.debug_get(k)) for k in keys}
+
+
+def step_api_leg(synth, sizes=(200, 50), K=200, W=20, timeout=300):
+    """The DROP-IN frame rate (SLAM.cpp:87-112 per frame: predict, host association, update), wall clock, through a C++ host (cv-monoslam_amd/host/
+    cslam_step_bench.cpp) in child processes: the C-ABI step by step (`capi`; `capi_hint`: the host announces the next frame's odometry, as a host that has its
+    odometry file loaded can), through monoslam::CSLAM::SLAM() (`facade`: display refresh and mirrors included, as the reference's SLAM() does them), and with
+    srukf_associate on a 640 x 480 gray frame between predict and update (`assoc`).  Not the headline value: a separate key."""
+    import struct
+    import subprocess
+    import tempfile
+    if not os.path.exists(STEP_BENCH):
+        return {"error": "cv-monoslam_amd/cslam_step_bench.bin is not built"}
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for N in sizes:
+            p = synth.scene_params()
+            sc = synth.make_scene(N, W + K, seed=0, p=p, obs_seed=1000)
+            with open(os.path.join(tmp, "scene.bin"), "wb") as fh:
+                fh.write(struct.pack("ii", N, W + K))
+                fh.write(np.array([p["a1"], p["a2"], p["a3"], p["a4"]], dtype=np.float64).tobytes())
+                fh.write(np.ascontiguousarray(sc["X0"]).tobytes()); fh.write(np.ascontiguousarray(sc["S0"]).tobytes()); fh.write(np.ascontiguousarray(sc["z"]).tobytes())
+            with open(os.path.join(tmp, "odo.txt"), "w") as fh:                     # the reference's odometry text format (SLAM.cpp:475)
+                for i, (x, y, th) in enumerate(sc["odo"]):
+                    fh.write(f"{i + 1} : {0.1 * i:.3f} {float(x)!r} {float(y)!r} {float(th)!r}\n")
+            res = {}
+            for name, args in (("capi", ["mode=capi"]), ("capi_hint", ["mode=capi", "hint=1"]), ("facade", ["mode=facade"]), ("assoc", ["mode=assoc", "hint=1"])):
+                if N != sizes[0] and name == "assoc":
+                    continue
+                try:
+                    r = subprocess.run([STEP_BENCH, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "odo.txt")] + args + [f"frames={K}", f"warmup={W}"],
+                                       capture_output=True, text=True, timeout=timeout)
+                    d = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr.strip()[-300:]}
+                except Exception as e:                                 # noqa: BLE001 - a report, not a gate
+                    d = {"error": f"{type(e).__name__}: {e}"}
+                res[name] = {k: d[k] for k in ("frames_per_s", "us_per_frame", "device_matches", "error") if k in d}
+                if "pose" in d:
+                    res[name]["pose_err_vs_truth_m"] = float(np.abs(np.asarray(d["pose"][:2]) - sc["odo"][W + K, :2]).max())
+            out[f"n{N}"] = res
+    out["frames"], out["warmup"] = K, W
+    out["note"] = ("wall clock of a C++ host calling srukf_predict_motion / srukf_predict_measurement / srukf_update (+ srukf_get_robot) once per frame with host buffers: "
+                   "what binding monoslam::CSLAM gives; the staged replay (`value`) has no host in the loop")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -477,6 +531,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay (rocprofv3 --pmc passes need it)")
     ap.add_argument("--pmc-serial", action="store_true", help="rocprofv3 --pmc serialises the dispatches: the split form of the factorisation (N >= 400: two launches that "
                     "wait for each other) cannot run under it and is switched off — the counters of that pass are the memory-tile form's")
+    ap.add_argument("--lib", default=None, help="measurement only: an A/B build of libsrukf_hip.so (scripts/build_variants.sh, scripts/ab_head.sh) instead of the in-tree one")
+    ap.add_argument("--repetitions", type=int, default=5, help="the timed block of K frames is run this many times (consecutive frames of the staged sequence); `value` is the median")
+    ap.add_argument("--no-step-api", action="store_true", help="skip the step_api leg (drop-in frame rate through the C++ host)")
     ap.add_argument("--no-collectives-check", action="store_true",
                     help="skip the short --force-dist child run whose outcome the default 1-GPU line reports as `collectives_check`")
     args = ap.parse_args()
@@ -499,6 +556,8 @@ def main():
     import __graft_entry__ as ge
     pkg = ge.load_package()
     synth, srukf = pkg.synth, pkg.srukf
+    if args.lib:
+        srukf.load_library(args.lib)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -515,8 +574,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     N, K, W, PF = args.landmarks, args.steps, args.warmup, args.profile_frames
+    R = max(1, args.repetitions)
+    KL = 300 if K < 300 else 0                                 # one longer block behind the repetitions: the two-point fit wall(K) = fixed + K * per_frame
     n = 6 * N + 4
-    F = W + K + PF + 4
+    F = W + R * K + KL + PF + 4
     sc = build_inputs(synth, N, F, rank)
     binfo = {}
     X0, S0 = broadcast_map(torch, dist, sc, n, rank, world, device, force=use_dist, info=binfo)
@@ -555,22 +616,41 @@ def main():
     # warmup (untimed)
     f.run_frames_async(PF0 + PF, W, srukf.UPDATE_BATCHED, traj[PF0 + PF:].data_ptr())
     f.synchronize()
-    # timed region: exactly K frames
-    sync_all()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    f.run_frames_async(PF0 + PF + W, K, srukf.UPDATE_BATCHED, traj[PF0 + PF + W:].data_ptr())
-    ev1.record()
-    f.synchronize()
-    sync_all()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    tt = torch.tensor([wall], dtype=torch.float64, device=device)
-    walls = per_rank_walls(torch, dist, tt, world, use_dist)
-    if use_dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    wall_max = float(tt.item())
+    # timed region: exactly K frames between barrier + synchronize on both sides, max over ranks — R times on consecutive blocks of the staged sequence (same
+    # captured graph); `value` is the median repetition, every repetition is printed (a block of 20 frames is a 4 ms sample)
+    walls_rep, dev_rep, per_rank_rep = [], [], []
+    for r in range(R):
+        first = PF0 + PF + W + r * K
+        sync_all()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        f.run_frames_async(first, K, srukf.UPDATE_BATCHED, traj[first:].data_ptr())
+        ev1.record()
+        f.synchronize()
+        sync_all()
+        wall = time.perf_counter() - t0
+        dev_rep.append(ev0.elapsed_time(ev1))
+        tt = torch.tensor([wall], dtype=torch.float64, device=device)
+        per_rank_rep.append(per_rank_walls(torch, dist, tt, world, use_dist))
+        if use_dist:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        walls_rep.append(float(tt.item()))
+    med = int(np.argsort(walls_rep)[len(walls_rep) // 2])
+    wall_max, walls, dev_ms = walls_rep[med], per_rank_rep[med], dev_rep[med]
+    run_fixed_us = None
+    if KL:
+        first = PF0 + PF + W + R * K
+        f.prepare_frames(KL)
+        sync_all()
+        t0 = time.perf_counter()
+        f.run_frames_async(first, KL, srukf.UPDATE_BATCHED, traj[first:].data_ptr())
+        f.synchronize()
+        sync_all()
+        wall_l = time.perf_counter() - t0
+        per_frame = (wall_l - wall_max) / (KL - K)
+        run_fixed_us = (wall_max - K * per_frame) * 1e6
+    fb = plan_keys(f)
 
     # gather trajectories (end-of-run all-gather, nothing per frame)
     if use_dist:
@@ -601,6 +681,11 @@ def main():
         out = {
             "metric": "srukf_updates_per_sec", "value": world * K / wall_max, "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall_max / K * 1e3,
+            # the timed block of K frames, R times back to back (each between its own barrier + synchronize); value / ms_per_step = the median one
+            "value_repetitions": [round(world * K / w, 1) for w in walls_rep], "repetitions": R,
+            # what a run of K frames costs besides its frames (first-frame projection launches, one graph launch, one synchronisation): two-point fit with a 300-frame block
+            "run_fixed_us": (round(run_fixed_us, 1) if run_fixed_us is not None else None),
+            "launch_plan": fb,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.storage == "f64" else "f64 (state stored as f32)", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: {N} inverse-depth landmarks (n={n}, Na={n + 5}, L={2 * (n + 5) + 1}), "
                                    "M=N matched, fp64, one batched refactor per frame, synthetic 640x480 figure-8 sequence",
@@ -678,6 +763,8 @@ def main():
                         "matched_same_algorithm is against those CPUs only"}
             out["pose_rmse_vs_oracle_m"] = float(np.sqrt(np.mean((gt[:, :2] - otraj[:, :2]) ** 2)))
             out["max_abs_dP_robot_vs_oracle"] = float(np.abs(gt[:, 4:] - otraj[:, 4:]).max())
+        if world == 1 and not use_dist and not args.no_step_api:
+            out["step_api"] = step_api_leg(synth)
         if world == 1 and not use_dist and not args.no_collectives_check:
             out["collectives_check"] = collectives_check()
         print(json.dumps(out))

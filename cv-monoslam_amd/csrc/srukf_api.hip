@@ -13,6 +13,7 @@
 #include <utility>
 #include <atomic>
 #include <mutex>
+#include <map>
 #include "srukf_device.h"
 #include "srukf_rank.h"
 
@@ -42,6 +43,7 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
 void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
 void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*, int);
+void srukf_launch_gmw_split_alone(hipStream_t, int, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
 void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int);
@@ -154,6 +156,37 @@ __global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* 
     if (clear_clamp) { fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0; }
 }
 
+// Step-wise API, fast path: start of a frame.  odo = (prev, cur[, next]) poses on the device: a staged sequence of one (two) frames the frame scalars point at.
+// fresh: nothing prepared this frame (the control, the flags of the constant rows); otherwise the previous frame's tail prepared fs->ctl and projected the frame.
+__global__ void k_set_step(FrameScalars* fs, const double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh)
+{
+    fs->odo_seq = odo; fs->seqF = seqF;
+    fs->a[0] = a1; fs->a[1] = a2; fs->a[2] = a3; fs->a[3] = a4;
+    fs->frame = 0;
+    fs->traj_base = nullptr;
+    fs->stat_count = 0;
+    for (int q = 0; q < SRUKF_STAT_GROUPS; q++) fs->stat_cnt[q] = 0;
+    fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0;
+    if (fresh) { srukf_prepare_control(fs); fs->const_rows_ok = 0; fs->const_rows_pending = 0; }
+}
+__global__ void k_set_frame_control(FrameScalars* fs) { srukf_prepare_control(fs); }
+// ... and the commit of its motion step on demand (a state getter or srukf_associate between predict and update; a frame without a match): what k_gain does with Cmat /
+// the state update with fs->Xr1 — the new last four columns of S (and of the permuted copy), the new robot mean.  Idempotent: k_gain / the update write the same values again.
+__global__ __launch_bounds__(256) void k_commit_motion(int n, int ld, double* __restrict__ X, double* __restrict__ S, const double* __restrict__ Cm, const FrameScalars* __restrict__ fs,
+                                                       double* __restrict__ A, const int* __restrict__ iperm, int rk)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const double4 v = *reinterpret_cast<const double4*>(Cm + (size_t)r * 4);
+    *reinterpret_cast<double2*>(S + (size_t)r * ld + (n - 4)) = make_double2(v.x, v.y);
+    *reinterpret_cast<double2*>(S + (size_t)r * ld + (n - 2)) = make_double2(v.z, v.w);
+    if (A) {
+        const int arow = (r < n - 4) ? iperm[r] : rk - 4 + (r - (n - 4));
+        if (arow < rk) { double* o = A + (size_t)arow * ld + (rk - 4); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    }
+    if (r >= n - 4) X[r] = fs->Xr1[r - (n - 4)];
+}
+
 // ---- NEED_REORDER helpers (GSLCholeskyUpdate, SLAM.cpp:2122-2138) -------------------------------
 // dst = P^T src P on the upper triangle of a symmetric matrix stored upper: dst[a][b] = src[ip[a]][ip[b]] (a <= b),
 // ip[a] = the row r of the source with perm[r] = a.  forward = 0 swaps the roles (dst[r][c] = src[perm[r]][perm[c]]).
@@ -206,6 +239,15 @@ __global__ __launch_bounds__(256) void k_quantize(int n, int ld, double* __restr
 static thread_local std::string g_create_error;
 static thread_local double* g_spare_stage = nullptr;       // one pinned staging buffer handed from a destroyed context to the next one
 static thread_local size_t g_spare_stage_bytes = 0;
+// ... and one verified side stream of the split form (with its events): a map change rebuilds the context on the SAME filter stream, and probing candidates again
+// (up to eight streams, two launches and three synchronisations each) would sit on the latency-critical path of every srukf_add_landmarks / srukf_delete_landmark
+struct SpareSide { int device = -1; hipStream_t main = nullptr, side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static thread_local SpareSide g_spare_side;
+static void spare_side_drop()
+{
+    if (g_spare_side.side) { hipStreamSynchronize(g_spare_side.side); hipStreamDestroy(g_spare_side.side); hipEventDestroy(g_spare_side.fork); hipEventDestroy(g_spare_side.join); }
+    g_spare_side = SpareSide();
+}
 
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_SYRK, KC_GMW_TRAIL, KC_GMW_PERSIST, KC_GMW_CHECK,
               KC_GMW_COL, KC_RANK_EXPAND, KC_PROJECT_MOTION, KC_PROJECT_TABLE, KC_PXY2, KC_MISC, KC_COUNT };
@@ -353,6 +395,8 @@ struct srukf_ctx {
     // each), the side stream the tile launch runs on and the events that fork it off / join it to the filter's stream
     double *gsW = nullptr, *gsL = nullptr; int gs_panels = 0;
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool split_off = false;                // a split-form pair of this context was abandoned (its two launches did not run side by side — e.g. the branches of a captured
+                                           // graph sharing a hardware queue): the context keeps to the memory-tile instance of k_gmw_persist (read_fs; srukf_debug_get "split_off")
     double* P1 = nullptr; int* pxy2_tiles = nullptr; int n_pxy2_tiles = 0, pxy2_split_b0 = 0;   // "table" mode: k_pxy2's second K half, its tile list
     int* nskip = nullptr; int ns_full = 0, ns_null = 0, ns_rows = 0;   // NullSkip lists (srukf_device.h): [dirs | nulls | rows] in one buffer
     int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
@@ -372,6 +416,8 @@ struct srukf_ctx {
         int head_fold = 1;                 // "head_fold": exclusive rank-aware replay without the k_syrk launch (helper workgroups of the persistent launch)
         int nullskip = 1;                  // "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
         int pxy2 = 1;                      // "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
+        int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
+        int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
     } dbg;
     bool null_canonical = false;           // every structurally null row of S is exactly sqrt(EPSILON) e_k (update_null_set checks; true behind every rank-aware frame tail)
     bool tail_ok = false;                  // "fused tail" mode is possible: directions 0 and 1 are kept rows (the Si factor names their Z rows: they are projected for every landmark, which
@@ -392,6 +438,19 @@ struct srukf_ctx {
     FrameScalars* hfs = nullptr;
     // state machine
     int phase = 0;   // 0 idle, 1 after predict_motion, 2 after predict_measurement
+    double next_odo[6] = { 0, 0, 0, 0, 0, 0 }; bool next_odo_valid = false;   // srukf_predict_motion_next: the pair the next srukf_predict_motion will bring
+    // Fast path of the step-wise API (step_* below): a frame of the staged replay's own launch sequence ("fused tail" mode) cut in two at the host's association step
+    double* odo_step = nullptr;            // device: (prev, cur, next) poses of the frame in flight — a three-pose "staged sequence" fs->odo_seq points at
+    double step_odo[6] = { 0, 0, 0, 0, 0, 0 };   // the pair srukf_predict_motion was called with (the fallback to the other path needs it again)
+    int step_seqF = 1;                     // 2: odo_step holds the next pose too (hint), the tail prepares and projects the next frame
+    bool step_fast = false;                // the frame in flight runs on the fast path
+    bool step_uncommitted = false;         // ... and its motion step still waits beside the state (fs->Xr1, Cmat): state getters commit it first (k_commit_motion)
+    bool step_chain = false;               // X, S, the permuted copy and the frame scalars are exactly what the last fast-path tail left: its constant rows stand
+    bool proj_valid = false; double proj_odo[6] = { 0, 0, 0, 0, 0, 0 };   // ... and that tail projected the frame with this odometry pair (Z, DZ, the table, fs->ctl)
+    bool fs_seq_step = false;              // fs->odo_seq points at odo_step (srukf_run_frames_async points it back at the staged sequence)
+    bool last_update_sequential = false;   // a host that updates in SRUKF_UPDATE_SEQUENTIAL mode never takes the fast path (decided at predict time)
+    bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
+    int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
     bool async_pending = false;
     std::string err;
     // one captured frame (BATCHED, staged inputs): replayed by srukf_run_frames_async
@@ -493,6 +552,10 @@ static std::vector<int> build_tile_table(int n_own, int n_other, bool upper, boo
 }
 
 // ---- launch sequences --------------------------------------------------------------------------
+static void step_commit_motion(srukf_ctx* c);
+static void step_invalidate(srukf_ctx* c);
+// the state is about to be replaced or read by somebody outside the step-wise fast path
+static void step_state_replaced(srukf_ctx* c) { c->step_uncommitted = false; c->step_fast = false; c->xr1_pending = false; step_invalidate(c); c->f32_stale = false; }
 static void quantize_state(srukf_ctx* c)
 {
     if (c->storage != SRUKF_STORAGE_F64)
@@ -628,6 +691,10 @@ static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
         }
         c->gs_panels = gp.Tp;
     }
+    if (!c->side && g_spare_side.side && g_spare_side.device == c->device && g_spare_side.main == c->stream) {
+        c->side = g_spare_side.side; c->ev_fork = g_spare_side.fork; c->ev_join = g_spare_side.join;      // probed against this very stream by the context that was just rebuilt
+        g_spare_side = SpareSide();
+    }
     if (!c->side) {
         // a side stream whose kernels really run beside the filter's stream's: candidates are created until one passes the probe (they are kept alive until then,
         // so that the runtime hands out another hardware queue), the others are destroyed; none in eight tries: no split form for this filter
@@ -646,7 +713,7 @@ static void split_ensure(srukf_ctx* c, const GmwPlan& gp)
 }
 static bool split_form(const srukf_ctx* c, const GmwPlan& gp, bool ignore_starve)
 {
-    return g_dbg_mem_split && c->gmw_shared == 0 && (ignore_starve || !c->debug_starve) && c->side && c->gsW && c->gs_panels >= gp.Tp && gp.T >= 16 && gp.T + 1 <= gp.cus && split_wanted(gp);
+    return g_dbg_mem_split && !c->split_off && c->gmw_shared == 0 && (ignore_starve || !c->debug_starve) && c->side && c->gsW && c->gs_panels >= gp.Tp && gp.T >= 16 && gp.T + 1 <= gp.cus && split_wanted(gp);
 }
 static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 // Tail of every rank-aware refactorisation: factor rows (c->G, permuted order) -> S and the permuted copy, checks, frame tail.
@@ -874,6 +941,7 @@ static void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduc
         const int workers = c->debug_starve ? 0 : gp.workers;
         if (split_form(c, gp, true)) {                         // (srukf_debug_starve_workers: the pair without its tile launch)
             // the tile launch depends on what produced Gbuf, not on the pivot / slab launch: fork before, join after (in a capture: two parallel branches)
+            if (c->dbg.split_record) hipMemcpyAsync(c->Gbak, Gbuf, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
             hipEventRecord(c->ev_fork, c->stream);
             hipStreamWaitEvent(c->side, c->ev_fork, 0);
             srukf_launch_gmw_split(c->stream, c->side, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, c->fs, Tp, reduced ? ((c->red_r + 15) & ~15) : 0, c->gsW, c->gsL, c->debug_starve ? 1 : 0);
@@ -941,28 +1009,35 @@ static int refactor_reorder(srukf_ctx* c, int ub, int ue)
 }
 // fused_motion: the frame's motion step ran inside k_project_motion: the statistics take the robot mean from fs->Xr1, k_gain commits Cmat
 // table: "table" mode of the replay — the product on the permuted operands (k_pxy2), k_gain takes it from there
-static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false)
+// first half: the cross covariances (and, riding on the launch, the measurement statistics h / Si / visible; in "fused tail" mode the frame's motion reduction)
+static void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false)
 {
     const KDims& d = c->d;
-    {
-        const double nn = d.n;
-        ProfScope ps(c, table ? KC_PXY2 : KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
-        MeasArgs ms = {};
-        // ("fused tail" mode: the statistics are centred on the centre point's robot part, row 0 of the table: the mean does not exist yet)
-        const double* xrob = fmode ? c->sigR : fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
-        if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{}, preamble ? 1 : 0,
-                                        fmode ? 1 : 0, c->Cmat };
-        if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
-        else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
-    }
-    {
-        ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
-        srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
-                          fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ,
-                          (fmode && c->storage == SRUKF_STORAGE_F32) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon),   // (the null rows of S as they are stored)
-                          c->sigR, fmode ? 1 : 0);
-        c->dx_pending = true;                         // applied by the next k_syrk launch (seq_refactor)
-    }
+    const double nn = d.n;
+    ProfScope ps(c, table ? KC_PXY2 : KC_PXY, nn * nn * 2.0 * d.N, 8.0 * (nn * nn / 2 + 2.0 * nn * 2 * d.N));
+    MeasArgs ms = {};
+    // ("fused tail" mode: the statistics are centred on the centre point's robot part, row 0 of the table: the mean does not exist yet)
+    const double* xrob = fmode ? c->sigR : fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
+    if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{}, preamble ? 1 : 0,
+                                    fmode ? 1 : 0, c->Cmat };
+    if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
+    else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
+}
+// second half: gains, U^T, slice partials of the state update; z_dev / m_dev: this frame's measurements and matches on the device (null: the staged sequence's)
+static void seq_gain_only(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_motion = false, bool table = false, bool fmode = false)
+{
+    const KDims& d = c->d;
+    ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
+    srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
+                      fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ,
+                      (fmode && c->storage == SRUKF_STORAGE_F32) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon),   // (the null rows of S as they are stored)
+                      c->sigR, fmode ? 1 : 0);
+    c->dx_pending = true;                             // applied by the next k_syrk launch (seq_refactor)
+}
+static void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false)
+{
+    seq_pxy(c, fused_stats, fused_motion, table, preamble, fmode);
+    seq_gain_only(c, z_dev, m_dev, fused_motion, table, fmode);
 }
 
 // Which directions of the state are structurally null (srukf_rank.hip)?  Called whenever a state arrives from outside
@@ -974,6 +1049,7 @@ static int update_null_set(srukf_ctx* c)
     const int enabled = g_dbg_rank_aware;
     const int n = c->d.n, np = c->d.np, T = np / 64;
     const int was = c->red_r;
+    step_invalidate(c);
     c->red_r = 0;
     if (enabled && c->rank_aware && n >= 128) {
         srukf_launch_row_energy(c->stream, n, np, c->S, c->D);
@@ -1204,7 +1280,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h, c->Si, c->PxyR, c->D,
                      c->zcur, c->odocur, c->small, c->vis, c->mcur, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->odo_step, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -1227,6 +1303,7 @@ int srukf_reset(srukf_ctx* c)
     HIPCHK(c, hipSetDevice(c->device));
     const KDims& d = c->d;
     const size_t np = d.np;
+    step_state_replaced(c);
     HIPCHK(c, hipMemsetAsync(c->X, 0, sizeof(double) * np, c->stream));
     HIPCHK(c, hipMemsetAsync(c->S, 0, sizeof(double) * np * np, c->stream));
     // initializeParameters, SLAM.cpp:226-231
@@ -1253,6 +1330,7 @@ int srukf_set_state(srukf_ctx* c, const double* X, const double* S)
     if (!c || !X || !S) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
+    step_state_replaced(c);
     double* hs = c->hstage;
     memset(hs, 0, sizeof(double) * np * np);
     for (int r = 0; r < n; r++) for (int cc = r; cc < n; cc++) hs[(size_t)r * np + cc] = S[(size_t)r * n + cc];   // upper triangle only
@@ -1272,6 +1350,7 @@ int srukf_get_state(srukf_ctx* c, double* X, double* S)
     if (!c) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
+    step_commit_motion(c);
     double* hs = c->hstage;
     if (X) {
         HIPCHK(c, hipMemcpyAsync(hs, c->X, sizeof(double) * np, hipMemcpyDeviceToHost, c->stream));
@@ -1291,6 +1370,7 @@ int srukf_set_state_device(srukf_ctx* c, const double* dX, const double* dS, int
     if (!c || !dX || !dS || S_ld < c->d.n) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
+    step_state_replaced(c);
     HIPCHK(c, hipMemsetAsync(c->S, 0, sizeof(double) * np * np, c->stream));
     HIPCHK(c, hipMemcpy2DAsync(c->S, sizeof(double) * np, dS, sizeof(double) * S_ld, sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->X, 0, sizeof(double) * np, c->stream));
@@ -1306,6 +1386,7 @@ int srukf_get_state_device(srukf_ctx* c, double* dX, double* dS, int S_ld)
     if (!c || S_ld < c->d.n) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
+    step_commit_motion(c);
     if (dX) HIPCHK(c, hipMemcpyAsync(dX, c->X, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     if (dS) HIPCHK(c, hipMemcpy2DAsync(dS, sizeof(double) * S_ld, c->S, sizeof(double) * np, sizeof(double) * n, n, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1326,6 +1407,7 @@ int srukf_get_robot(srukf_ctx* c, double pose4[4], double P4[16])
     if (!c) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n;
+    step_commit_motion(c);
     if (pose4) {
         HIPCHK(c, hipMemcpyAsync(c->hstage + 64, c->X + (n - 4), sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1339,6 +1421,7 @@ int srukf_get_landmark_block(srukf_ctx* c, int k, double X6[6], double P66[36])
 {
     if (!c || k < 0 || k >= c->d.N) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    step_commit_motion(c);
     if (X6) {
         HIPCHK(c, hipMemcpyAsync(c->hstage + 64, c->X + 6 * k, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1354,8 +1437,10 @@ int srukf_get_landmarks_cartesian(srukf_ctx* c, double* xyz, double* cov)
     const int N = c->d.N;
     if (N == 0) return SRUKF_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    // Z is scratch between frames (written by k_project before anything reads it): 12 N doubles for the results
-    double* dx = c->Z; double* dc = c->Z + 3 * (size_t)N;
+    step_commit_motion(c);
+    // G is scratch outside the refactorisation (the tail has consumed the factor rows it held): 12 N doubles for the results.  (Not Z: between predict and update the
+    // fast path of the step-wise API still needs the centre point's row there.)
+    double* dx = c->G; double* dc = c->G + 3 * (size_t)N;
     srukf_launch_landmarks_cartesian(c->stream, c->d, c->X, c->S, dx, dc);
     HIPCHK(c, hipMemcpyAsync(c->hstage, dx, sizeof(double) * 12 * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1371,6 +1456,7 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     if (!c || !P) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->d.n; const size_t np = c->d.np;
+    step_commit_motion(c);
     srukf_launch_syrk(c->stream, c->d, c->S, c->Ut, 0, 0, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, nullptr, c->X, RankArgs{}, nullptr);
     HIPCHK(c, hipMemcpyAsync(c->hstage, c->G, sizeof(double) * np * np, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1378,17 +1464,91 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
     return SRUKF_OK;
 }
 
-int srukf_predict_motion(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
+// ---- step-wise API: the fast path ---------------------------------------------------------------------------------------------------------------
+// The step-wise calls used to run launch sequences of their own (k_motion, k_project, k_meas_*, k_pxy, k_gain, a full k_syrk, the permutation pass, the persistent launch
+// reading its tiles from memory, k_rank_expand, the rebuild of the permuted copy): ~2 x the staged replay's time per frame before the host round trips.  Where the replay's
+// "fused tail" mode applies (replay_fuse_mode: rank-aware form with canonical null rows; BATCHED, NEEDNOT_REORDER) a step-wise frame now IS a frame of the staged replay, cut
+// in two at the host's association step:
+//   srukf_predict_motion       [k_set_step; unless the previous frame's tail projected this very odometry pair: k_sigr_rows + k_project_table;] k_pxy2 (motion reduction,
+//                              measurement statistics, cross covariances);  the state before the frame is kept (ckS / ckX)
+//   srukf_predict_measurement  D->H copies of h, Si, visible
+//   srukf_update               H->D z / matched; k_gain, the persistent factorisation launch, k_rank_expand<2> (which, when the host has announced the next frame's odometry —
+//                              srukf_predict_motion_next — also projects the next frame); the frame scalars come back, and a flagged frame (theta clamp, abandoned launch,
+//                              a null direction that is not) is rewound and repeated on the other path, as srukf_run_frames does
+// Same kernels on the same values as the staged replay: bit-identical states (tests/test_gpu_parity_r5.py::test_step_api_equals_staged_replay).
+static void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; }
+static bool step_fast_eligible(const srukf_ctx* c) { return c->dbg.step_fast && !c->last_update_sequential && c->d.N > 0 && replay_fuse_mode(c); }
+// a state getter between predict and update (or a frame that ends without an update): the motion step's results go where k_gain / the state update would put them
+static void step_commit_motion(srukf_ctx* c)
 {
-    if (!c || !odo_prev || !odo_cur) return SRUKF_ERR_BAD_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->step_uncommitted) return;
+    const RankArgs ra = rank_args(c);
+    hipLaunchKernelGGL(k_commit_motion, dim3((c->d.n + 255) / 256), dim3(256), 0, c->stream, c->d.n, c->d.np, c->X, c->S, c->Cmat, c->fs, ra.A, ra.iperm, ra.r);
+    c->step_uncommitted = false;
+}
+static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
+{
+    const KDims& d = c->d;
+    const size_t np = d.np;
+    if (!c->odo_step) HIPCHK(c, srukf_dmalloc(&c->odo_step, sizeof(double) * 16));
+    if (!c->ckS) {
+        if (srukf_dmalloc((void**)&c->ckS, sizeof(double) * np * np) != hipSuccess || srukf_dmalloc((void**)&c->ckX, sizeof(double) * np) != hipSuccess) { c->err = "predict_motion: out of device memory (checkpoint)"; return SRUKF_ERR_NOMEM; }
+    }
+    for (int e = 0; e < 3; e++) { c->step_odo[e] = odo_prev[e]; c->step_odo[3 + e] = odo_cur[e]; }
+    const bool projected = c->step_chain && c->proj_valid && memcmp(c->proj_odo, c->step_odo, sizeof c->step_odo) == 0;
+    // the next pose, if the host has announced it already (it may still do so before srukf_update)
+    const bool hint = c->next_odo_valid && memcmp(c->next_odo, odo_cur, sizeof(double) * 3) == 0;
+    double* hs = c->hstage;
+    for (int e = 0; e < 6; e++) hs[e] = c->step_odo[e];
+    for (int e = 0; e < 3; e++) hs[6 + e] = hint ? c->next_odo[3 + e] : 0.0;
+    c->step_seqF = hint ? 2 : 1;
+    HIPCHK(c, hipMemcpyAsync(c->odo_step, hs, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
+    // the state before the frame: a flagged frame is repeated from it on the other path
+    HIPCHK(c, hipMemcpyAsync(c->ckS, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ckX, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, c->stream, c->fs, c->odo_step, c->step_seqF, c->p.a1, c->p.a2, c->p.a3, c->p.a4, c->step_chain ? 0 : 1);
+    c->fs_seq_step = true;
+    if (!projected) {
+        if (c->step_chain) hipLaunchKernelGGL(k_set_frame_control, dim3(1), dim3(1), 0, c->stream, c->fs);      // (the tail prepared the control of ANOTHER pair, or none)
+        srukf_launch_sigr_rows(c->stream, d, c->w, c->X, c->S, c->sigR, c->fs, c->red_iperm, c->red_r);
+        seq_predict_fused(c, 2);
+    }
+    c->xr1_pending = true;
+    seq_pxy(c, true, true, true, true, true);
+    c->step_fast = true; c->step_uncommitted = true;
+    c->proj_valid = false;
+    HIPCHK(c, hipGetLastError());
+    c->phase = 1;
+    return SRUKF_OK;
+}
+static int step_predict_slow(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
+{
     double* hs = c->hstage;
     for (int e = 0; e < 3; e++) { hs[e] = odo_prev[e]; hs[3 + e] = odo_cur[e]; }
     HIPCHK(c, hipMemcpyAsync(c->odocur, hs, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
     seq_predict_motion(c, c->odocur);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    c->step_fast = false;
     c->phase = 1;
+    return SRUKF_OK;
+}
+int srukf_predict_motion(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
+{
+    if (!c || !odo_prev || !odo_cur) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->step_uncommitted) { step_commit_motion(c); step_invalidate(c); }      // a frame that was predicted and never updated: its motion step stands (as on the other path)
+    c->step_fast = false;
+    if (step_fast_eligible(c)) return step_predict_fast(c, odo_prev, odo_cur);
+    step_invalidate(c);
+    return step_predict_slow(c, odo_prev, odo_cur);
+}
+
+int srukf_predict_motion_next(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
+{
+    if (!c || !odo_prev || !odo_cur) return SRUKF_ERR_BAD_ARG;
+    for (int e = 0; e < 3; e++) { c->next_odo[e] = odo_prev[e]; c->next_odo[3 + e] = odo_cur[e]; }
+    c->next_odo_valid = true;
     return SRUKF_OK;
 }
 
@@ -1399,7 +1559,7 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->d.N;
     if (N == 0) { c->phase = 2; return SRUKF_OK; }                       // empty map: nothing to predict
-    seq_predict_measurement(c, false);
+    if (!c->step_fast) seq_predict_measurement(c, false);                // (fast path: the statistics rode on srukf_predict_motion's k_pxy2 launch: this call is a copy)
     double* hs = c->hstage;
     HIPCHK(c, hipMemcpyAsync(hs, c->h, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs + 2 * N, c->Si, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, c->stream));
@@ -1421,14 +1581,83 @@ static int read_fs(srukf_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->hfs->clamp_rows > 0 && c->hfs->clamp_frame == 0x7fffffff) c->hfs->clamp_frame = c->hfs->frame - 1;   // the run's last frame
     if (c->hfs->gmw_aborts > 0 && c->gmw_shared != 2) {
-        // a persistent launch did not get all its workgroups onto the GPU in time (somebody else is using it): the flagged
-        // frame is repeated on the exact path like a clamp frame, and this filter stays with one launch per panel
-        c->gmw_shared = 2;
+        // a persistent launch did not get all its workgroups onto the GPU in time (somebody else is using it, or the two launches of a split-form pair were not
+        // run side by side): the flagged frame is repeated on the exact path like a clamp frame, and the filter steps down ONE tier — from the split form to the
+        // memory-tile instance of k_gmw_persist (one launch, no second hardware queue needed), from any single persistent launch to one launch per panel
+        const GmwPlan& gp = c->red_r > 0 ? c->gplan_red : c->gplan;
+        if (split_form(c, gp, true)) { c->split_off = true; c->err = "a split-form factorisation pair was abandoned: this filter continues with the memory-tile persistent launch (srukf_debug_get \"split_off\")"; }
+        else { c->gmw_shared = 2; c->err = "a persistent factorisation launch was abandoned: this filter continues with one launch per panel (srukf_debug_get \"gmw_shared\" = 2)"; }
         drop_graphs(c);
     }
     return SRUKF_OK;
 }
 
+static int step_update_slow(srukf_ctx* c, const double* z, const int* matched, int reorder, int mode, int nm);
+// the frame in flight leaves the fast path: the state before the frame comes back and the frame's predict half runs again on the other path
+static int step_rewind_to_slow(srukf_ctx* c)
+{
+    const size_t np = c->d.np;
+    HIPCHK(c, hipMemcpyAsync(c->S, c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->X, c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream));
+    quantize_state(c); shadow_rebuild(c);
+    c->step_uncommitted = false; c->xr1_pending = false; c->dx_pending = false;
+    step_invalidate(c);
+    int rc = step_predict_slow(c, c->step_odo, c->step_odo + 3);
+    if (rc) return rc;
+    seq_predict_measurement(c, false);
+    c->phase = 2;
+    return SRUKF_OK;
+}
+static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, int nm)
+{
+    const KDims& d = c->d;
+    const int N = d.N;
+    c->step_fast = false;
+    if (nm == 0) {
+        // KalmanUpdate returns at once (SLAM.cpp:2050-2051): the frame ends with its motion step, which the fast path still holds beside the state
+        step_commit_motion(c);
+        c->xr1_pending = false;
+        step_invalidate(c);
+        c->step_fast_frames++;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        return SRUKF_OK;
+    }
+    double* hs = c->hstage;
+    memcpy(hs, z, sizeof(double) * 2 * N);
+    int* hm = (int*)(hs + 2 * N);
+    memcpy(hm, matched, sizeof(int) * N);
+    HIPCHK(c, hipMemcpyAsync(c->zcur, hs, sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->mcur, hm, sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
+    if (c->step_seqF == 1 && c->next_odo_valid && memcmp(c->next_odo, c->step_odo + 3, sizeof(double) * 3) == 0) {
+        // the host announced the next frame's odometry after srukf_predict_motion: the tail of this frame can still project it
+        double* ho = hs + 2 * N + N;                            // (behind z and matched in the pinned buffer)
+        for (int e = 0; e < 3; e++) ho[e] = c->next_odo[3 + e];
+        HIPCHK(c, hipMemcpyAsync(c->odo_step + 6, ho, sizeof(double) * 3, hipMemcpyHostToDevice, c->stream));
+        c->step_seqF = 2;
+        hipLaunchKernelGGL(k_set_seq, dim3(1), dim3(1), 0, c->stream, c->fs, c->odo_step, 2, c->p.a1, c->p.a2, c->p.a3, c->p.a4);
+    }
+    seq_gain_only(c, c->zcur, c->mcur, true, true, true);
+    c->step_uncommitted = false;                               // (k_gain and the state update commit the motion step)
+    seq_refactor(c, 0, d.mp, false, false, false, true, true, true);
+    int rc = read_fs(c); if (rc) return rc;
+    if (c->hfs->clamp_rows > 0) {
+        // flagged (the reference's theta clamp would have been active, a skipped direction was not null, a persistent launch was abandoned): the frame is repeated
+        // from the state before it on the path that evaluates the clamp pivot by pivot
+        rc = step_rewind_to_slow(c); if (rc) return rc;
+        c->phase = 0;
+        return step_update_slow(c, z, matched, SRUKF_NEEDNOT_REORDER, SRUKF_UPDATE_BATCHED, nm);
+    }
+    set_null_canonical(c);
+    c->step_chain = true;
+    c->proj_valid = c->step_seqF == 2 && c->hfs->ctl_next_valid != 0;
+    if (c->proj_valid) { for (int e = 0; e < 3; e++) { c->proj_odo[e] = c->step_odo[3 + e]; c->proj_odo[3 + e] = c->next_odo[3 + e]; } }
+    c->next_odo_valid = false;
+    c->f32_stale = c->storage == SRUKF_STORAGE_F32;
+    c->step_fast_frames++;
+    HIPCHK(c, hipGetLastError());
+    return SRUKF_OK;
+}
 int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder, int mode)
 {
     if (!c || !z || !matched) return SRUKF_ERR_BAD_ARG;
@@ -1437,10 +1666,23 @@ int srukf_update(srukf_ctx* c, const double* z, const int* matched, int reorder,
     if (reorder == SRUKF_NEED_REORDER && c->K_new <= 0) { c->err = "NEED_REORDER without srukf_set_new_landmarks (m_nFilters = 0)"; return SRUKF_ERR_SEQUENCE; }
     if (mode != SRUKF_UPDATE_SEQUENTIAL && mode != SRUKF_UPDATE_BATCHED) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->d.N;
+    int nm = 0; for (int k = 0; k < N; k++) nm += matched[k] ? 1 : 0;
+    c->last_update_sequential = mode == SRUKF_UPDATE_SEQUENTIAL;
+    if (c->step_fast) {
+        if (reorder == SRUKF_NEEDNOT_REORDER && mode == SRUKF_UPDATE_BATCHED) { c->phase = 0; return step_update_fast(c, z, matched, nm); }
+        const int rc = step_rewind_to_slow(c); if (rc) return rc;       // predicted on the fast path, updated in a mode it does not have
+        c->step_fast = false;
+    }
+    c->phase = 0;
+    return step_update_slow(c, z, matched, reorder, mode, nm);
+}
+static int step_update_slow(srukf_ctx* c, const double* z, const int* matched, int reorder, int mode, int nm)
+{
     const KDims& d = c->d;
     const int N = d.N;
-    int nm = 0; for (int k = 0; k < N; k++) nm += matched[k] ? 1 : 0;
-    c->phase = 0;
+    step_invalidate(c);
+    c->step_slow_frames++;
     if (nm == 0) return SRUKF_OK;                                        // SLAM.cpp:2050-2051
     double* hs = c->hstage;
     memcpy(hs, z, sizeof(double) * 2 * N);
@@ -1534,6 +1776,7 @@ static int set_shared(srukf_ctx* c, int shared, int tenants)
     if (tenants < 2) tenants = 2;
     if (shared == c->gmw_shared && (shared != 1 || tenants == c->shared_tenants)) return SRUKF_OK;
     const int was = plan_tenants(c);
+    step_invalidate(c);
     c->gmw_shared = shared;
     if (shared == 1) c->shared_tenants = tenants;
     drop_graphs(c);
@@ -1559,6 +1802,7 @@ int srukf_set_storage(srukf_ctx* c, int storage)
         return SRUKF_ERR_UNSUPPORTED;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    step_commit_motion(c); step_state_replaced(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t np = c->d.np, mp = c->d.mp;
     if (storage != SRUKF_STORAGE_F64 && !c->S32) {
@@ -1592,6 +1836,8 @@ int srukf_get_state_f32(srukf_ctx* c, float* X, float* S)
     if (!c) return SRUKF_ERR_BAD_ARG;
     if (c->storage == SRUKF_STORAGE_F64) { c->err = "get_state_f32: the context stores fp64 (srukf_set_storage)"; return SRUKF_ERR_SEQUENCE; }
     HIPCHK(c, hipSetDevice(c->device));
+    step_commit_motion(c);
+    if (c->f32_stale) { quantize_state(c); HIPCHK(c, hipStreamSynchronize(c->stream)); c->f32_stale = false; }      // (the step-wise fast path rounds S and X as it writes them; the float copies on demand)
     const int n = c->d.n; const size_t np = c->d.np;
     if (X) HIPCHK(c, hipMemcpy(X, c->X32, sizeof(float) * n, hipMemcpyDeviceToHost));
     if (S) HIPCHK(c, hipMemcpy2D(S, sizeof(float) * n, c->S32, sizeof(float) * np, sizeof(float) * n, n, hipMemcpyDeviceToHost));
@@ -1623,6 +1869,15 @@ int srukf_set_new_landmarks(srukf_ctx* c, int K_new)
 }
 
 static void adopt_context(srukf_ctx* c, srukf_ctx* c2);
+// a context about to be rebuilt (map change) offers its verified side stream to the context srukf_create builds next on the same filter stream (split_ensure)
+static void side_stream_lend(srukf_ctx* c)
+{
+    if (!c->side) return;
+    hipStreamSynchronize(c->side);
+    spare_side_drop();
+    g_spare_side.device = c->device; g_spare_side.main = c->stream; g_spare_side.side = c->side; g_spare_side.fork = c->ev_fork; g_spare_side.join = c->ev_join;
+    c->side = nullptr; c->ev_fork = c->ev_join = nullptr;
+}
 // ---- data association ------------------------------------------------------------------------------
 static int ensure_appearance(srukf_ctx* c)
 {
@@ -1694,7 +1949,8 @@ int srukf_associate(srukf_ctx* c, const unsigned char* gray, double* z, int* mat
     int rc = ensure_appearance(c); if (rc) return rc;
     const size_t img = (size_t)c->p.image_w * c->p.image_h;
     HIPCHK(c, hipMemcpyAsync(c->d_image, gray, img, hipMemcpyHostToDevice, c->stream));
-    double* dxyz = c->Z; double* dcov = c->Z + 3 * (size_t)N;            // Z is free between predict_measurement and the next frame
+    step_commit_motion(c);                                               // the warp uses the PREDICTED robot pose (wrapPatch reads m_X_k after predictMotion, SLAM.cpp:1812-1830)
+    double* dxyz = c->G; double* dcov = c->G + 3 * (size_t)N;            // G is free outside the refactorisation
     srukf_launch_landmarks_cartesian(c->stream, c->d, c->X, c->S, dxyz, dcov);                              // PointsMap::xyz (2574)
     srukf_launch_warp_patch(c->stream, c->d, c->p, c->X, dxyz, c->h, c->appR, c->appT, c->appPx, c->app_patch, c->has_app, c->app_tmpl);
     srukf_launch_associate(c->stream, c->d, c->p, c->d_image, c->h, c->Si, c->vis, c->has_app, c->app_tmpl, c->zcur, c->mcur, c->corr);
@@ -1718,10 +1974,12 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
 {
     if (!c || K < 1 || !uv) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    step_commit_motion(c); step_invalidate(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int dim = c->d.n, ld = c->d.np;
     const int Na = dim + 3 * K, L = 2 * Na + 1, dimn = dim + 6 * K;                          // 827-828
     srukf_ctx* c2 = nullptr;
+    side_stream_lend(c);
     int rc = srukf_create(&c2, c->d.N + K, &c->p, c->device, c->stream);
     if (rc) { c->err = std::string("add_landmarks: ") + g_create_error; return rc; }
     const int ldn = c2->d.np, rows_p = round_up(2 * Na, 16);
@@ -1787,7 +2045,7 @@ static void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     c->own_stream = own; c2->own_stream = false;
     c->profiling = c2->profiling; c->use_graph = c2->use_graph;
     // per-context switches the caller set on the handle survive the rebuild (before srukf_set_storage / update_null_set run on it)
-    c->rank_aware = c2->rank_aware; c->debug_allow_mixed = c2->debug_allow_mixed; c->debug_starve = c2->debug_starve; c->dbg = c2->dbg;
+    c->rank_aware = c2->rank_aware; c->debug_allow_mixed = c2->debug_allow_mixed; c->debug_starve = c2->debug_starve; c->dbg = c2->dbg; c->split_off = c2->split_off;
     const int shared = c2->gmw_shared, tenants = c2->shared_tenants;
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
@@ -1807,8 +2065,10 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     const int N = c->d.N, n = c->d.n, np = c->d.np;
     if (id < 0 || id >= N) { c->err = "delete_landmark: no such landmark"; return SRUKF_ERR_BAD_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    step_commit_motion(c); step_invalidate(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     srukf_ctx* c2 = nullptr;
+    side_stream_lend(c);
     int rc = srukf_create(&c2, N - 1, &c->p, c->device, c->stream);
     if (rc) { c->err = std::string("delete_landmark: ") + g_create_error; return rc; }
     const int nn = n - 6, ldn = c2->d.np;
@@ -1933,6 +2193,11 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
     if (mode != SRUKF_UPDATE_BATCHED) { c->err = "run_frames_async supports BATCHED only (SEQUENTIAL needs a host check per column)"; return SRUKF_ERR_UNSUPPORTED; }
     HIPCHK(c, hipSetDevice(c->device));
     const KDims& d = c->d;
+    step_commit_motion(c); step_state_replaced(c);
+    if (c->fs_seq_step) {                                      // the step-wise fast path pointed the frame scalars at its own three poses
+        hipLaunchKernelGGL(k_set_seq, dim3(1), dim3(1), 0, c->stream, c->fs, c->odo_seq, c->seqF, c->p.a1, c->p.a2, c->p.a3, c->p.a4);
+        c->fs_seq_step = false;
+    }
     // traj rows are indexed by the absolute frame counter; offset so that frame `first` lands in row 0
     double* traj = d_traj ? d_traj - (size_t)8 * first : nullptr;
     int clear = c->async_pending ? 0 : 1;
@@ -2071,17 +2336,22 @@ struct BatchPlan {
     hipGraph_t g1 = nullptr, g8 = nullptr; hipGraphExec_t e1 = nullptr, e8 = nullptr;
     std::vector<unsigned long long> sig;                    // what the captured launches depend on besides the tables' CONTENTS
 };
-// (one plan per group of filters: srukf_run_frames_batch cuts B filters into groups that run side by side, each on the stream of its first filter)
+// (one plan per group of filters: srukf_run_frames_batch cuts B filters into groups that run side by side, each on a stream of its own)
 #define SRUKF_BATCH_GROUPS_MAX 4
-static thread_local BatchPlan* g_batches[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr };
-// The groups' streams: created together, once, so that they sit on different hardware queues whatever the filters' own streams map to (streams that share a
-// queue serialise: with the groups on their first filters' streams, 4 + 4 filters ran slower than 4 alone).
-static thread_local hipStream_t g_batch_streams[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr };
-static hipStream_t batch_stream(int grp)
+// Plans and group streams are kept per host thread AND per device: a stream belongs to the device that was current when it was created, and a thread may run
+// batches for filters on several devices (round-4 advisor finding: streams created once on whichever device came first).
+// The groups' streams: created together, once per device, so that they sit on different hardware queues whatever the filters' own streams map to (streams that share a
+// queue serialise: with the groups on their first filters' streams, 4 + 4 filters ran slower than 4 alone).  They go when the device's last plan goes.
+struct BatchDev { BatchPlan* plans[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr }; hipStream_t streams[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr }; };
+static thread_local std::map<int, BatchDev> g_batch_dev;
+static hipStream_t batch_stream(int device, int grp)
 {
-    if (!g_batch_streams[0])
-        for (int q = 0; q < SRUKF_BATCH_GROUPS_MAX; q++) if (hipStreamCreateWithFlags(&g_batch_streams[q], hipStreamNonBlocking) != hipSuccess) g_batch_streams[q] = nullptr;
-    return g_batch_streams[grp];
+    BatchDev& bd = g_batch_dev[device];
+    if (!bd.streams[0]) {
+        if (hipSetDevice(device) != hipSuccess) return nullptr;
+        for (int q = 0; q < SRUKF_BATCH_GROUPS_MAX; q++) if (hipStreamCreateWithFlags(&bd.streams[q], hipStreamNonBlocking) != hipSuccess) bd.streams[q] = nullptr;
+    }
+    return bd.streams[grp];
 }
 static void batch_plan_drop_graphs(BatchPlan* bp)
 {
@@ -2090,20 +2360,38 @@ static void batch_plan_drop_graphs(BatchPlan* bp)
     if (bp->e8) { hipGraphExecDestroy(bp->e8); bp->e8 = nullptr; }
     if (bp->g8) { hipGraphDestroy(bp->g8); bp->g8 = nullptr; }
 }
-static void batch_plan_destroy(int grp)
+static void batch_plan_destroy(int device, int grp, bool keep_streams = false)
 {
-    BatchPlan* bp = g_batches[grp];
-    if (!bp) return;
-    batch_plan_drop_graphs(bp);
-    for (void* t : { bp->t_pxy2, bp->t_gain, bp->t_syrk, bp->t_own, bp->t_step, bp->t_exp }) if (t) srukf_dfree(t);
-    delete bp;
-    g_batches[grp] = nullptr;
+    auto it = g_batch_dev.find(device);
+    if (it == g_batch_dev.end()) return;
+    BatchDev& bd = it->second;
+    BatchPlan* bp = bd.plans[grp];
+    if (bp) {
+        hipSetDevice(device);
+        batch_plan_drop_graphs(bp);
+        for (void* t : { bp->t_pxy2, bp->t_gain, bp->t_syrk, bp->t_own, bp->t_step, bp->t_exp }) if (t) srukf_dfree(t);
+        delete bp;
+        bd.plans[grp] = nullptr;
+    }
+    if (keep_streams) return;
+    for (int q = 0; q < SRUKF_BATCH_GROUPS_MAX; q++) if (bd.plans[q]) return;
+    for (int q = 0; q < SRUKF_BATCH_GROUPS_MAX; q++) if (bd.streams[q]) { hipStreamSynchronize(bd.streams[q]); hipStreamDestroy(bd.streams[q]); }
+    g_batch_dev.erase(it);                                      // the device's last plan: its streams go too
 }
 static void batch_plan_forget(const srukf_ctx* c)
 {
+    auto it = g_batch_dev.find(c->device);
+    if (it == g_batch_dev.end()) return;
     for (int grp = 0; grp < SRUKF_BATCH_GROUPS_MAX; grp++) {
-        if (!g_batches[grp]) continue;
-        for (const srukf_ctx* q : g_batches[grp]->cs) if (q == c) { hipStreamSynchronize(batch_stream(grp)); batch_plan_destroy(grp); break; }
+        BatchPlan* bp = it->second.plans[grp];
+        if (!bp) continue;
+        bool mine = false;
+        for (const srukf_ctx* q : bp->cs) mine = mine || q == c;
+        if (!mine) continue;
+        if (it->second.streams[grp]) hipStreamSynchronize(it->second.streams[grp]);
+        batch_plan_destroy(c->device, grp);
+        it = g_batch_dev.find(c->device);
+        if (it == g_batch_dev.end()) return;
     }
 }
 // Can these filters run as one batch?  Same device and shape, the default launch sequence of a filter that has the GPU to itself ("fused tail" mode on the permuted
@@ -2118,6 +2406,8 @@ static bool batch_eligible(srukf_ctx* const* cs, int B, bool ignore_canonical = 
         if (c->device != a->device || c->d.N != a->d.N || c->d.N < 1 || c->storage != SRUKF_STORAGE_F64 || c->w.wc0 != c->w.wm0) return false;
         if (c->red_r <= 0 || c->red_r != a->red_r || c->red_Tp != a->red_Tp || !c->shadowA || (!c->null_canonical && !ignore_canonical) || !c->nskip || !c->tail_ok) return false;
         if (c->ns_full != a->ns_full || c->ns_null != a->ns_null || c->ns_rows != a->ns_rows || c->n_pxy2_tiles != a->n_pxy2_tiles) return false;
+        // (the batched launches take these from the group's first filter: shape-only quantities today — checked, not assumed)
+        if (c->n_syrk_head_tiles != a->n_syrk_head_tiles || c->gplan_red.ntiles != a->gplan_red.ntiles || c->pxy2_split_b0 != a->pxy2_split_b0 || memcmp(&c->w, &a->w, sizeof c->w) != 0) return false;
         if (!c->dbg.pxy2 || !c->dbg.nullskip || !c->dbg.tail_fuse || c->dbg.fused_motion != 2 || !c->dbg.table_perm || c->profiling || c->use_graph != a->use_graph || c->debug_starve) return false;
         if (memcmp(&c->p, &a->p, sizeof c->p) != 0 || c->gplan_red.T < 16 || (size_t)c->d.np * sizeof(double) > 48 * 1024 || !rank_fused_mode()) return false;
         if (!c->odo_seq || c->seqF != a->seqF) return false;
@@ -2161,19 +2451,20 @@ static int batch_capture(BatchPlan* bp, hipStream_t st, int nframes, hipGraph_t*
 static int batch_run(srukf_ctx* const* cs, int B, int first, int count, double* const* dt, int grp)
 {
     srukf_ctx* c0 = cs[0];
-    hipStream_t st = batch_stream(grp);
+    HIPCHK(c0, hipSetDevice(c0->device));
+    hipStream_t st = batch_stream(c0->device, grp);
     if (!st) { c0->err = "run_frames_batch: no stream for the group"; return SRUKF_ERR_HIP; }
-    BatchPlan* bp = g_batches[grp];
+    BatchPlan* bp = g_batch_dev[c0->device].plans[grp];
     bool same = bp && bp->B == B;
     for (int b = 0; same && b < B; b++) same = bp->cs[b] == cs[b];
     if (!same) {
-        batch_plan_destroy(grp);
-        bp = g_batches[grp] = new BatchPlan();
+        batch_plan_destroy(c0->device, grp, true);
+        bp = g_batch_dev[c0->device].plans[grp] = new BatchPlan();
         bp->B = B; bp->cs.assign(cs, cs + B);
         if (srukf_dmalloc(&bp->t_pxy2, sizeof(Pxy2Args) * B) != hipSuccess || srukf_dmalloc(&bp->t_gain, sizeof(GainArgs) * B) != hipSuccess ||
             srukf_dmalloc(&bp->t_syrk, sizeof(SyrkArgs) * B) != hipSuccess || srukf_dmalloc(&bp->t_own, sizeof(SyrkOwnArgs) * B) != hipSuccess ||
             srukf_dmalloc(&bp->t_step, sizeof(Step64Args) * B) != hipSuccess || srukf_dmalloc(&bp->t_exp, sizeof(ExpandArgs) * B) != hipSuccess) {
-            batch_plan_destroy(grp); c0->err = "run_frames_batch: out of device memory (argument tables)"; return SRUKF_ERR_NOMEM;
+            batch_plan_destroy(c0->device, grp); c0->err = "run_frames_batch: out of device memory (argument tables)"; return SRUKF_ERR_NOMEM;
         }
     }
     // the tables' contents (buffers may have been re-staged or rebuilt since the last call: rewritten every call, the captured launches only hold the tables' addresses)
@@ -2306,7 +2597,7 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
             }
             for (int grp = 0; grp < G; grp++) {
                 const int b0 = (int)((long long)nb * grp / G);
-                if (hipStreamSynchronize(batch_stream(grp)) != hipSuccess && rc == SRUKF_OK) { sub[b0]->err = "run_frames_batch: the batched launches failed"; rc = SRUKF_ERR_HIP; }
+                if (hipStreamSynchronize(batch_stream(sub[b0]->device, grp)) != hipSuccess && rc == SRUKF_OK) { sub[b0]->err = "run_frames_batch: the batched launches failed"; rc = SRUKF_ERR_HIP; }
             }
         } else {
             for (int q = 0; q < nb && rc == SRUKF_OK; q++) {
@@ -2389,6 +2680,7 @@ int srukf_debug_poke_state(srukf_ctx* c, int row, int col, double value)
 {
     if (!c || row < 0 || col < row || col >= c->d.n) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    step_commit_motion(c); step_invalidate(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->S + (size_t)row * c->d.np + col, &value, sizeof(double), hipMemcpyHostToDevice));
     return SRUKF_OK;
@@ -2402,7 +2694,12 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     struct { const char* k; std::atomic<int>* v; } globals[] = { { "gmw_persist", &g_dbg_gmw_persist }, { "gmw_fused", &g_dbg_gmw_fused }, { "rank_fused", &g_dbg_rank_fused },
                                                     { "rank_fold", &g_dbg_rank_fold }, { "rank_aware", &g_dbg_rank_aware }, { "graphs", &g_dbg_graphs }, { "mem_split", &g_dbg_mem_split }
                                                   };
-    if (!strcmp(key, "batch_split")) { g_dbg_batch_split = value ? 1 : 0; for (int grp = 0; grp < SRUKF_BATCH_GROUPS_MAX; grp++) if (g_batches[grp]) { hipStreamSynchronize(batch_stream(grp)); batch_plan_drop_graphs(g_batches[grp]); } return SRUKF_OK; }
+    if (!strcmp(key, "batch_split")) {
+        g_dbg_batch_split = value ? 1 : 0;
+        for (auto& kv : g_batch_dev)
+            for (int grp = 0; grp < SRUKF_BATCH_GROUPS_MAX; grp++) if (kv.second.plans[grp]) { hipSetDevice(kv.first); hipStreamSynchronize(kv.second.streams[grp]); batch_plan_drop_graphs(kv.second.plans[grp]); }
+        return SRUKF_OK;
+    }
     if (!strcmp(key, "batch_groups")) { if (value < 0 || value > SRUKF_BATCH_GROUPS_MAX) return SRUKF_ERR_BAD_ARG; g_dbg_batch_groups = value; return SRUKF_OK; }
     if (!strcmp(key, "batch_wide")) { g_dbg_batch_wide = value ? 1 : 0; return SRUKF_OK; }
     if (!strcmp(key, "shared_tenants")) {                      // applies to filters switched to SRUKF_GPU_SHARED afterwards
@@ -2413,11 +2710,12 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     for (auto& g : globals)
         if (!strcmp(key, g.k)) {
             g.v->store(!strcmp(key, "mem_split") ? value : (value ? 1 : 0));
-            if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); drop_graphs(c); if (!strcmp(key, "rank_aware")) return update_null_set(c); }
+            if (c) { hipSetDevice(c->device); step_commit_motion(c); step_invalidate(c); hipStreamSynchronize(c->stream); drop_graphs(c); if (!strcmp(key, "rank_aware")) return update_null_set(c); }
             return SRUKF_OK;
         }
     if (!c) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    step_commit_motion(c); step_invalidate(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!strcmp(key, "use_graph")) c->use_graph = value != 0;
     else if (!strcmp(key, "pxy2")) c->dbg.pxy2 = value ? 1 : 0;
@@ -2426,6 +2724,8 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "tail_fuse")) c->dbg.tail_fuse = value ? 1 : 0;
     else if (!strcmp(key, "table_perm")) c->dbg.table_perm = value ? 1 : 0;
     else if (!strcmp(key, "f32_fuse")) c->dbg.f32_fuse = value ? 1 : 0;
+    else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
+    else if (!strcmp(key, "step_fast")) c->dbg.step_fast = value ? 1 : 0;
     else if (!strcmp(key, "fused_motion")) c->dbg.fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);
@@ -2461,37 +2761,121 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     else if (!strcmp(key, "frozen")) *value = c->hfs->frozen;
     else if (!strcmp(key, "gate_timeouts")) *value = c->hfs->gate_timeouts;
     else if (!strcmp(key, "gmw_shared")) *value = c->gmw_shared;
+    else if (!strcmp(key, "split_off")) *value = c->split_off ? 1 : 0;
+    else if (!strcmp(key, "step_fast")) *value = c->step_fast_frames;          // frames the step-wise API ran on the staged replay's launch sequence / on its own
+    else if (!strcmp(key, "step_slow")) *value = c->step_slow_frames;
     else if (!strcmp(key, "split_form")) *value = split_form(c, c->red_r > 0 ? c->gplan_red : c->gplan) ? 1 : 0;       // would the next persistent factorisation be the split form?
+    else if (!strncmp(key, "plan_", 5)) {
+        // which launch plan the next staged frame takes (tests assert it next to the oracle comparison: every N is a product size, SLAM.cpp:552-562, 2443-2460)
+        const GmwPlan& gp = c->red_r > 0 ? c->gplan_red : c->gplan;
+        const bool persist = gmw_use_persist(c) && gmw_plan_persists(c, gp);
+        const char* k = key + 5;
+        if (!strcmp(k, "T")) *value = gp.T;
+        else if (!strcmp(k, "Tp")) *value = gp.Tp;
+        else if (!strcmp(k, "tiles")) *value = gp.nreal;
+        else if (!strcmp(k, "workers")) *value = gp.workers;
+        else if (!strcmp(k, "persist")) *value = persist ? 1 : 0;                                        // 0: one launch per 64-row panel
+        else if (!strcmp(k, "register_form")) *value = (persist && !split_form(c, gp) && srukf_gmw_register_form(gp.T, gp.Tp, gp.ntiles, gp.workers)) ? 1 : 0;
+        else if (!strcmp(k, "tiles_per_worker")) *value = gp.workers > 0 ? (gp.nreal + gp.workers - 1) / gp.workers : -1;
+        else if (!strcmp(k, "fold")) *value = replay_red_fused(c) ? 1 : 0;                               // the owners form their tiles of S^T S - U U^T themselves
+        else if (!strcmp(k, "head_fold")) *value = (replay_red_fused(c) && head_fold_ok(c)) ? 1 : 0;     // ... and the head tiles ride on the persistent launch
+        else if (!strcmp(k, "red_perm")) *value = (!replay_red_fused(c) && replay_red_perm(c)) ? 1 : 0;  // k_syrk over the kept rows in permuted order
+        else if (!strcmp(k, "motion")) *value = replay_motion_mode(c);                                   // 2: "table" mode
+        else if (!strcmp(k, "fuse")) *value = replay_fuse_mode(c) ? 1 : 0;                               // "fused tail" mode
+        else if (!strcmp(k, "kept")) *value = c->red_r;
+        else if (!strcmp(k, "sync_doubles")) *value = gp.sync ? srukf_gmw_sync_bytes(gp.T) / 8 : 0;      // sizes of the byte buffers srukf_debug_copy counts in doubles
+        else if (!strcmp(k, "pans_doubles")) *value = gp.pans ? (long long)srukf_gmw_panel_bytes() * gp.T / 8 : 0;
+        else if (!strcmp(k, "slab_panels")) *value = c->gs_panels;
+        else return SRUKF_ERR_BAD_ARG;
+    }
     else return SRUKF_ERR_BAD_ARG;
     return SRUKF_OK;
 }
 // Diagnostic copy of a device work buffer (synchronises the stream): "Z" (L x mp), "DZ" (np x mp), "sigR" ((L + 1) x 8), "Cmat" (n x 4),
 // "Xr1" (4), "Utp" / "P1" (mp x np), "h" (2N), "Si" (4N).  count doubles from the start of the buffer.
+static bool debug_buffer(srukf_ctx* c, const char* key, double** ptr, long long* cap)
+{
+    const KDims& d = c->d;
+    const GmwPlan& gp = c->red_r > 0 ? c->gplan_red : c->gplan;
+    double* src = nullptr; long long n = 0;
+    if (!strcmp(key, "Z")) { src = c->Z; n = (long long)d.L * d.mp; }
+    else if (!strcmp(key, "DZ")) { src = c->DZ; n = (long long)d.np * d.mp; }
+    else if (!strcmp(key, "sigR")) { src = c->sigR; n = (long long)(d.L + 1) * 8; }
+    else if (!strcmp(key, "Cmat")) { src = c->Cmat; n = (long long)d.n * 4; }
+    else if (!strcmp(key, "Xr1")) { src = (double*)((char*)c->fs + offsetof(FrameScalars, Xr1)); n = 4; }
+    else if (!strcmp(key, "Utp")) { src = c->Utp; n = c->Utp ? (long long)d.mp * d.np : 0; }
+    else if (!strcmp(key, "P1")) { src = c->P1; n = c->P1 ? (long long)d.mp * d.np : 0; }
+    else if (!strcmp(key, "h")) { src = c->h; n = 2LL * d.N; }
+    else if (!strcmp(key, "Si")) { src = c->Si; n = 4LL * d.N; }
+    // the operands of one factorisation (scripts/split_replay.py: a split-form pair recorded from a real frame, each launch then replayed alone under the counters)
+    else if (!strcmp(key, "Wf")) { src = c->Wf; n = (long long)d.np * d.np; }
+    else if (!strcmp(key, "Gbak")) { src = c->Gbak; n = (long long)d.np * d.np; }
+    else if (!strcmp(key, "G")) { src = c->G; n = (long long)d.np * d.np; }
+    else if (!strcmp(key, "D")) { src = c->D; n = d.np; }
+    else if (!strcmp(key, "gsW")) { src = c->gsW; n = c->gsW ? (long long)c->gs_panels * 64 * d.np : 0; }
+    else if (!strcmp(key, "gsL")) { src = c->gsL; n = c->gsL ? (long long)c->gs_panels * 64 * d.np : 0; }
+    else if (!strcmp(key, "pans")) { src = (double*)gp.pans; n = gp.pans ? (long long)srukf_gmw_panel_bytes() * gp.T / 8 : 0; }
+    else if (!strcmp(key, "sync")) { src = (double*)gp.sync; n = gp.sync ? (long long)srukf_gmw_sync_bytes(gp.T) / 8 : 0; }
+    else return false;
+    *ptr = src; *cap = n;
+    return true;
+}
 int srukf_debug_copy(srukf_ctx* c, const char* key, double* out, long long count)
 {
     if (!c || !key || !out || count < 0) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const KDims& d = c->d;
-    const double* src = nullptr; long long cap = 0;
-    if (!strcmp(key, "Z")) { src = c->Z; cap = (long long)d.L * d.mp; }
-    else if (!strcmp(key, "DZ")) { src = c->DZ; cap = (long long)d.np * d.mp; }
-    else if (!strcmp(key, "sigR")) { src = c->sigR; cap = (long long)(d.L + 1) * 8; }
-    else if (!strcmp(key, "Cmat")) { src = c->Cmat; cap = (long long)d.n * 4; }
-    else if (!strcmp(key, "Xr1")) { src = (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)); cap = 4; }
-    else if (!strcmp(key, "Utp")) { src = c->Utp; cap = c->Utp ? (long long)d.mp * d.np : 0; }
-    else if (!strcmp(key, "P1")) { src = c->P1; cap = c->P1 ? (long long)d.mp * d.np : 0; }
-    else if (!strcmp(key, "h")) { src = c->h; cap = 2LL * d.N; }
-    else if (!strcmp(key, "Si")) { src = c->Si; cap = 4LL * d.N; }
-    else return SRUKF_ERR_BAD_ARG;
+    double* src = nullptr; long long cap = 0;
+    if (!debug_buffer(c, key, &src, &cap)) return SRUKF_ERR_BAD_ARG;
     if (!src || count > cap) return SRUKF_ERR_DIM_MISMATCH;
     HIPCHK(c, hipMemcpy(out, src, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
     return SRUKF_OK;
+}
+// the other direction (same keys): `count` doubles to the start of the buffer
+int srukf_debug_upload(srukf_ctx* c, const char* key, const double* in, long long count)
+{
+    if (!c || !key || !in || count < 0) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double* dst = nullptr; long long cap = 0;
+    if (!debug_buffer(c, key, &dst, &cap)) return SRUKF_ERR_BAD_ARG;
+    if (!dst || count > cap) return SRUKF_ERR_DIM_MISMATCH;
+    HIPCHK(c, hipMemcpy(dst, in, sizeof(double) * (size_t)count, hipMemcpyHostToDevice));
+    return SRUKF_OK;
+}
+// Measurement only (scripts/split_replay.py).  The two launches of the split form wait for each other, and rocprofv3's counter passes serialise dispatches: the pair cannot
+// run under them.  Everything the launches exchange lives in HBM — G tiles and their version flags, the slabs of every panel and theirs, the panel buffers and flags — so
+// ONE launch of the pair can be replayed ALONE against the buffers a real frame left behind (uploaded with srukf_debug_upload: "Gbak" = the matrix before the factorisation,
+// "Wf" = its tiles after it, "gsW" / "gsL", "pans", "sync"): every wait finds its flag at its final value, every load the value the real run delivered, and the launch
+// executes the instructions and moves the bytes of the real one.  which = 0: k_gmw_pivslab_persist, 1: k_gmw_tiles_persist (its tiles restored from "Gbak" first); `reps` launches.
+int srukf_debug_split_replay(srukf_ctx* c, int which, int reps)
+{
+    if (!c || which < 0 || which > 1 || reps < 1) return SRUKF_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const bool reduced = c->red_r > 0;
+    const GmwPlan& gp = reduced ? c->gplan_red : c->gplan;
+    if (!split_form(c, gp, true)) { c->err = "split_replay: this context does not factor with the split form"; return SRUKF_ERR_SEQUENCE; }
+    const int np = c->d.np, n = c->d.n, Tp = reduced ? c->red_Tp : np / 64;
+    unsigned long long epoch = 0;
+    HIPCHK(c, hipMemcpy(&epoch, (char*)gp.sync + offsetof(GmwSync, epoch), sizeof epoch, hipMemcpyDeviceToHost));
+    if (epoch < 2) { c->err = "split_replay: the sync block holds no finished run"; return SRUKF_ERR_SEQUENCE; }
+    const unsigned long long prev = epoch - 1;                   // the run whose flags the block holds
+    for (int r = 0; r < reps; r++) {
+        HIPCHK(c, hipMemcpyAsync((char*)gp.sync + offsetof(GmwSync, epoch), &prev, sizeof prev, hipMemcpyHostToDevice, c->stream));
+        if (which == 1) HIPCHK(c, hipMemcpyAsync(c->Wf, c->Gbak, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));              // (&prev is pageable)
+        srukf_launch_gmw_split_alone(c->stream, which, n, np, c->p.epsilon, c->Wf, gp.pans, c->D, c->G, gp.sync, gp.tiles, gp.ntiles, c->fs, Tp, reduced ? ((c->red_r + 15) & ~15) : 0, c->gsW, c->gsL);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    return read_fs(c);
 }
 int srukf_debug_starve_workers(srukf_ctx* c, int on)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;
     c->debug_starve = on ? 1 : 0;
+    step_invalidate(c);
     drop_graphs(c);                                    // the captured frames contain one or the other launch sequence
     return SRUKF_OK;
 }

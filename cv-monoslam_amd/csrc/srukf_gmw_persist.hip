@@ -1005,6 +1005,18 @@ void srukf_launch_gmw_split(hipStream_t stA, hipStream_t stB, int n, int ld, dou
     // starve (tests): the tile launch never arrives, as if the GPU were taken — the bounded waits of the pivot and the slab workgroups expire, the frame is flagged
     if (nreal > 0 && !starve) hipLaunchKernelGGL(k_gmw_tiles_persist, dim3(nreal), dim3(256), 0, stB, ld, T, G, (GmwSync*)sync, (const GmwTile*)tiles, (FrameScalars*)fs, Wslab, Lslab, total);
 }
+// Measurement only (srukf_debug_split_replay): ONE launch of the pair, alone, against the buffers and flags a real run of the pair left behind (epoch set back by
+// the caller): which = 0 the pivot / slab launch, 1 the tile launch without its residency gate.  The last workgroup out re-arms the block as in the real pair.
+void srukf_launch_gmw_split_alone(hipStream_t st, int which, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout, void* sync,
+                                  const void* tiles, int ntiles, void* fs, int Tp, int krows, double* Wslab, double* Lslab)
+{
+    const int T = ld / 64;
+    if (Tp <= 0 || Tp > T) Tp = T;
+    if (krows <= 0 || krows > ld) krows = ld;
+    const int nreal = ntiles - ((Tp < T) ? T - Tp : 0);
+    if (which == 0) hipLaunchKernelGGL(k_gmw_pivslab_persist, dim3(T), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps, (GmwSync*)sync, (FrameScalars*)fs, krows, Wslab, Lslab, (unsigned)T);
+    else if (nreal > 0) hipLaunchKernelGGL(k_gmw_tiles_persist, dim3(nreal), dim3(256), 0, st, ld, T, G, (GmwSync*)sync, (const GmwTile*)tiles, (FrameScalars*)fs, Wslab, Lslab, (unsigned)nreal);
+}
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }
 }  // extern "C"

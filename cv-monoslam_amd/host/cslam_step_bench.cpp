@@ -1,0 +1,143 @@
+// cslam_step_bench — wall-clock frame rate of the DROP-IN path: what a host that binds this library the way the MFC view binds the reference's
+// CSLAM gets per frame (SLAM.cpp:87-112, called from MonoSLAMView.cpp:499-572): predict, host (or device) data association, update — one frame at a
+// time, with the host round trips in between.  bench.py's headline is the staged replay (inputs resident in HBM, no host in the loop); this is the other number.
+//   cslam_step_bench scene.bin odometry.txt mode=<capi|facade|assoc> [frames=K] [warmup=W] [hint=0|1]
+//     capi   : srukf_predict_motion -> srukf_predict_measurement (D->H h, Si, visible) -> host association (matched = visible, z from the scene)
+//              -> srukf_update (H->D) -> srukf_get_robot (the pose and robot block RobotPath.txt records, SLAM.cpp:3539-3556)
+//     facade : monoslam::CSLAM::SLAM() with the same association as a callback (what cslam_replay does), display refresh and mirrors included
+//     assoc  : capi with srukf_associate (wrapPatch + dataAssociation on the device, SLAM.cpp:1803-2009) on a 640 x 480 gray frame between predict and
+//              update.  The frame is a static synthetic texture the landmarks' init patches were cut from, so the templates stop correlating as the
+//              robot moves: the launches and their D->H copy are what is timed, the filter itself is driven by the scene's z / matched (stated in the output).
+//     hint=1 : capi / assoc announce the NEXT frame's odometry with srukf_predict_motion_next before every update (a host that has its odometry
+//              file loaded, as the reference has: loadOdometryData reads it whole, SLAM.cpp:363-496)
+// scene.bin: int32 N, int32 F, double a1..a4, double X0[n], double S0[n*n], double z[F][2N]   (the file cslam_replay reads)
+// Prints ONE JSON object.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "cslam.hpp"
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: %s scene.bin odometry.txt mode=<capi|facade|assoc> [frames=K] [warmup=W] [hint=0|1]\n", argv[0]); return 2; }
+    std::string mode = "capi";
+    int K = 200, W = 20, hint = 0;
+    for (int a = 3; a < argc; a++) {
+        if (!strncmp(argv[a], "mode=", 5)) mode = argv[a] + 5;
+        else if (!strncmp(argv[a], "frames=", 7)) K = atoi(argv[a] + 7);
+        else if (!strncmp(argv[a], "warmup=", 7)) W = atoi(argv[a] + 7);
+        else if (!strncmp(argv[a], "hint=", 5)) hint = atoi(argv[a] + 5);
+    }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 2; }
+    int N = 0, F = 0; double a4[4];
+    if (fread(&N, 4, 1, f) != 1 || fread(&F, 4, 1, f) != 1 || fread(a4, 8, 4, f) != 4) return 2;
+    const int n = 6 * N + 4;
+    std::vector<double> X0(n), S0((size_t)n * n), z((size_t)F * 2 * N);
+    if (fread(X0.data(), 8, n, f) != (size_t)n || fread(S0.data(), 8, (size_t)n * n, f) != (size_t)n * n || fread(z.data(), 8, z.size(), f) != z.size()) { fprintf(stderr, "short scene file\n"); return 2; }
+    fclose(f);
+    if (W + K > F) { fprintf(stderr, "scene has %d frames, need %d\n", F, W + K); return 2; }
+    // odometry: the reference's text format "%d : %*lf %lf %lf %lf" (SLAM.cpp:462-496)
+    std::vector<double> odo;
+    {
+        FILE* o = fopen(argv[2], "r");
+        if (!o) { perror(argv[2]); return 2; }
+        char line[500];
+        while (fgets(line, sizeof line, o)) { int id; double x, y, th; if (sscanf(line, "%d : %*f %lf %lf %lf", &id, &x, &y, &th) == 4) { odo.push_back(x); odo.push_back(y); odo.push_back(th); } }
+        fclose(o);
+    }
+    if ((int)odo.size() / 3 < F + 1) { fprintf(stderr, "odometry has %d poses, need %d\n", (int)odo.size() / 3, F + 1); return 2; }
+
+    double t_timed = 0.0, pose[4] = { 0, 0, 0, 0 }, P4[16] = { 0 };
+    long long matches_dev = 0;
+    if (mode == "facade") {
+        monoslam::CSLAM SLAM;
+        SLAM.m_params.a1 = a4[0]; SLAM.m_params.a2 = a4[1]; SLAM.m_params.a3 = a4[2]; SLAM.m_params.a4 = a4[3];
+        if (!SLAM.setMap(N, X0.data(), S0.data(), nullptr)) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+        SLAM.MIN_STEP_X = SLAM.MIN_STEP_Y = 0.0;
+        if (!SLAM.loadOdometryData(argv[2])) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+        SLAM.dataAssociation = [&](monoslam::CSLAM& s) {
+            const int fr = s.m_frame.counter - 1;
+            for (monoslam::PointsMap* mp = s.map; NULL != mp; mp = mp->next) {
+                const double* zz = &z[(size_t)fr * 2 * N + 2 * ((mp->ID - 1) % N)];
+                mp->isMatching = mp->isVisible; mp->matchLocation.x = zz[0]; mp->matchLocation.y = zz[1];
+            }
+        };
+        for (int fr = 0; fr < W; fr++) SLAM.SLAM();
+        const double t0 = now_s();
+        for (int fr = 0; fr < K; fr++) SLAM.SLAM();
+        t_timed = now_s() - t0;
+        if (!SLAM.lastError.empty()) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+        const int nn = SLAM.m_X_k.rows;
+        for (int e = 0; e < 4; e++) pose[e] = SLAM.m_X_k.at(nn - 4 + e, 0);
+        P4[0] = SLAM.m_P_k.at(nn - 4, nn - 4); P4[1] = SLAM.m_P_k.at(nn - 4, nn - 3); P4[4] = SLAM.m_P_k.at(nn - 3, nn - 4); P4[5] = SLAM.m_P_k.at(nn - 3, nn - 3);
+        if (SLAM.m_nMapFeatures != N) { fprintf(stderr, "the map changed size (%d landmarks left)\n", SLAM.m_nMapFeatures); return 1; }
+    } else {
+        srukf_params p;
+        srukf_default_params(&p);
+        p.a1 = a4[0]; p.a2 = a4[1]; p.a3 = a4[2]; p.a4 = a4[3];
+        srukf_ctx* c = nullptr;
+        int rc = srukf_create(&c, N, &p, 0, nullptr);
+        if (rc) { fprintf(stderr, "srukf_create: %d %s\n", rc, srukf_last_error(nullptr)); return 1; }
+#define CK(call) do { rc = (call); if (rc) { fprintf(stderr, "%s: %d %s\n", #call, rc, srukf_last_error(c)); return 1; } } while (0)
+        CK(srukf_set_state(c, X0.data(), S0.data()));
+        std::vector<double> h(2 * N), Si(4 * N), zc(2 * N), corr(N);
+        std::vector<int> vis(N), m(N), md(N);
+        std::vector<unsigned char> gray;
+        const bool assoc = mode == "assoc";
+        if (assoc) {
+            // texture: box-filtered noise (11 x 11), 640 x 480; every landmark's init patch is cut from it around its first predicted pixel, "created" at the start pose
+            const int Wd = 640, Hd = 480;
+            std::vector<double> t((size_t)Wd * Hd);
+            unsigned long long s = 88172645463325252ull;
+            for (auto& v : t) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s & 0xffff); }
+            std::vector<double> b((size_t)Wd * Hd, 0.0);
+            for (int y = 0; y < Hd; y++) for (int x = 0; x < Wd; x++) {
+                double acc = 0; for (int dy = -5; dy <= 5; dy++) for (int dx = -5; dx <= 5; dx++) acc += t[(size_t)((y + dy + Hd) % Hd) * Wd + (x + dx + Wd) % Wd];
+                b[(size_t)y * Wd + x] = acc;
+            }
+            double lo = b[0], hi = b[0]; for (double v : b) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+            gray.resize((size_t)Wd * Hd);
+            for (size_t q = 0; q < gray.size(); q++) gray[q] = (unsigned char)((b[q] - lo) / (hi - lo) * 255.0);
+            CK(srukf_predict_motion(c, &odo[0], &odo[3]));
+            CK(srukf_predict_measurement(c, h.data(), Si.data(), vis.data()));
+            for (int k = 0; k < N; k++) zc[2 * k] = z[2 * k], zc[2 * k + 1] = z[2 * k + 1];
+            for (int k = 0; k < N; k++) m[k] = vis[k];
+            const double th = X0[n - 1], R[9] = { cos(th), -sin(th), 0, sin(th), cos(th), 0, 0, 0, 1 }, tr[3] = { X0[n - 4], X0[n - 3], X0[n - 2] };
+            for (int k = 0; k < N; k++) {
+                double px[2] = { h[2 * k], h[2 * k + 1] };
+                int cu = (int)lround(px[0]), cv = (int)lround(px[1]);
+                if (!(cu >= 20 && cu < Wd - 20 && cv >= 20 && cv < Hd - 20)) { cu = 320; cv = 240; px[0] = 320; px[1] = 240; }
+                unsigned char patch[441];
+                for (int i = 0; i < 21; i++) for (int j = 0; j < 21; j++) patch[21 * i + j] = gray[(size_t)(cv - 10 + i) * Wd + cu - 10 + j];
+                CK(srukf_set_landmark_appearance(c, k, patch, R, tr, px));
+            }
+            CK(srukf_update(c, zc.data(), m.data(), SRUKF_NEEDNOT_REORDER, SRUKF_UPDATE_BATCHED));
+        }
+        const int f0 = assoc ? 1 : 0;
+        double t0 = 0.0;
+        for (int fr = f0; fr < W + K; fr++) {
+            if (fr == W) t0 = now_s();
+            CK(srukf_predict_motion(c, &odo[3 * fr], &odo[3 * fr + 3]));
+            CK(srukf_predict_measurement(c, h.data(), Si.data(), vis.data()));
+            if (assoc) { CK(srukf_associate(c, gray.data(), zc.data(), md.data(), corr.data())); for (int k = 0; k < N; k++) matches_dev += md[k]; }
+            const double* zz = &z[(size_t)fr * 2 * N];
+            for (int k = 0; k < N; k++) m[k] = vis[k];                 // the host's association: every visible landmark found where the scene put it
+            if (hint && fr + 2 <= F) CK(srukf_predict_motion_next(c, &odo[3 * fr + 3], &odo[3 * fr + 6]));
+            CK(srukf_update(c, zz, m.data(), SRUKF_NEEDNOT_REORDER, SRUKF_UPDATE_BATCHED));
+            CK(srukf_get_robot(c, pose, P4));
+        }
+        t_timed = now_s() - t0;
+        srukf_destroy(c);
+    }
+    printf("{\"mode\": \"%s\", \"hint\": %d, \"landmarks\": %d, \"frames\": %d, \"warmup\": %d, \"frames_per_s\": %.2f, \"us_per_frame\": %.2f, "
+           "\"pose\": [%.17g, %.17g, %.17g, %.17g], \"P_robot\": [%.17g, %.17g, %.17g, %.17g], \"device_matches\": %lld, \"filter_driven_by\": \"scene z / matched (host association)\"}\n",
+           mode.c_str(), hint, N, K, W, K / t_timed, t_timed / K * 1e6, pose[0], pose[1], pose[2], pose[3], P4[0], P4[1], P4[4], P4[5], matches_dev);
+    return 0;
+}

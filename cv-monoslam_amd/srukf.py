@@ -11,8 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SRUKF_LIB: an A/B build of the same library (scripts/build_variants.sh; measurement only)
-LIB_PATH = os.environ.get("SRUKF_LIB") or os.path.join(_HERE, "libsrukf_hip.so")
+LIB_PATH = os.path.join(_HERE, "libsrukf_hip.so")
 
 _DBL_FIELDS = ["cam_dx", "cam_dy", "cam_cx", "cam_cy", "cam_k1", "cam_k2", "cam_f", "image_w", "image_h",
                "a1", "a2", "a3", "a4", "sigma_measure", "rho0", "sigma_rho", "sigma_x", "sigma_y", "sigma_z",
@@ -23,9 +22,9 @@ _INT_FIELDS = ["weight_type", "noise_type", "newton_iters", "reserved_"]
 EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
-    "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_measurement",
+    "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_motion_next", "srukf_predict_measurement",
     "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_run_frames_batch", "srukf_prepare_frames", "srukf_debug_poke_state", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
-    "srukf_clamp_info", "srukf_debug_set", "srukf_debug_get", "srukf_debug_copy", "srukf_debug_gmw_stamps", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
+    "srukf_clamp_info", "srukf_debug_set", "srukf_debug_get", "srukf_debug_copy", "srukf_debug_upload", "srukf_debug_split_replay", "srukf_debug_gmw_stamps", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
 ]
 
@@ -67,11 +66,17 @@ _ip = C.POINTER(C.c_int)
 _lib = None
 
 
-def load_library():
-    """dlopen the in-tree libsrukf_hip.so; raises if it has not been built (no fallback)."""
-    global _lib
+def load_library(path=None):
+    """dlopen the in-tree libsrukf_hip.so; raises if it has not been built (no fallback).
+    path: measurement scripts only (bench.py --lib, scripts/ab_bench.sh) — an A/B build of the same library, named on the FIRST call; the product reads no
+    environment variable and loads nothing else."""
+    global _lib, LIB_PATH
     if _lib is not None:
+        if path and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is already loaded; an A/B library must be named on the first load_library call")
         return _lib
+    if path:
+        LIB_PATH = path
     # PyTorch-ROCm bundles its own libamdhip64.so; if ours (linked against /opt/rocm) initialises
     # HIP first, a later `import torch` in the same process finds no GPUs.  Loading torch first
     # makes both share one runtime.  torch is plumbing here (streams / RCCL), never compute.
@@ -98,6 +103,7 @@ def load_library():
     L.srukf_get_covariance.argtypes = [C.c_void_p, _dp]
     L.srukf_get_landmarks_cartesian.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_predict_motion.argtypes = [C.c_void_p, _dp, _dp]
+    L.srukf_predict_motion_next.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_predict_measurement.argtypes = [C.c_void_p, _dp, _dp, _ip]
     L.srukf_update.argtypes = [C.c_void_p, _dp, _ip, C.c_int, C.c_int]
     L.srukf_set_new_landmarks.argtypes = [C.c_void_p, C.c_int]
@@ -124,6 +130,8 @@ def load_library():
     L.srukf_debug_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.srukf_debug_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
     L.srukf_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_longlong]
+    L.srukf_debug_upload.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_longlong]
+    L.srukf_debug_split_replay.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.srukf_debug_gmw_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.srukf_debug_allow_mixed.argtypes = [C.c_void_p, C.c_int]
     L.srukf_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -228,6 +236,11 @@ class Filter:
     def predict_motion(self, odo_prev, odo_cur):
         a, b = _c(odo_prev), _c(odo_cur)
         self._chk(self._lib.srukf_predict_motion(self._h, _d(a), _d(b)))
+
+    def predict_motion_next(self, odo_prev, odo_cur):
+        """Look-ahead: the odometry pair of the NEXT frame (srukf_predict_motion_next)."""
+        a, b = _c(odo_prev), _c(odo_cur)
+        self._chk(self._lib.srukf_predict_motion_next(self._h, _d(a), _d(b)))
 
     def predict_measurement(self):
         h, Si, vis = np.empty(2 * self.N), np.empty((self.N, 2, 2)), np.empty(self.N, dtype=np.int32)
@@ -352,6 +365,15 @@ class Filter:
         out = np.empty(int(count), dtype=np.float64)
         self._chk(self._lib.srukf_debug_copy(self._h, key.encode(), out.ctypes.data_as(C.POINTER(C.c_double)), int(count)))
         return out
+
+    def debug_upload(self, key, arr):
+        """The other direction of debug_copy (measurement scripts)."""
+        a = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        self._chk(self._lib.srukf_debug_upload(self._h, key.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+
+    def debug_split_replay(self, which, reps=1):
+        """One launch of the split form's pair alone against recorded buffers (scripts/split_replay.py)."""
+        self._chk(self._lib.srukf_debug_split_replay(self._h, int(which), int(reps)))
 
     def debug_gmw_stamps(self):
         """Diagnostic builds only: the time stamps the persistent launch left since the last call (and arms the next launches)."""

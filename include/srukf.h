@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRUKF_ABI_VERSION 5
+#define SRUKF_ABI_VERSION 6
 
 
 typedef enum srukf_status {
@@ -131,6 +131,12 @@ int  srukf_get_covariance(srukf_ctx* ctx, double* P);
 /* predictMotion numeric tail (SLAM.cpp:1430-1465): control from two consecutive odometry
  * poses (x, y, theta), sigma points, motion model, re-triangularisation of S.            */
 int  srukf_predict_motion(srukf_ctx* ctx, const double odo_prev[3], const double odo_cur[3]);
+/* Optional look-ahead for hosts that know their odometry in advance (the reference does: loadOdometryData reads the whole file into m_odoXY / m_odoTheta
+ * before the first frame, SLAM.cpp:363-496): the pair srukf_predict_motion will be called with for the NEXT frame, announced any time before this frame's
+ * srukf_update.  The update's frame tail then also projects the next frame's sigma points (as the staged replay's tail does), and the next
+ * srukf_predict_motion / srukf_predict_measurement launch nothing but the reduction over them.  A next call whose pair differs from the announced one simply
+ * projects again: results never depend on the hint.  No reference counterpart (predictMotion reads m_odoXY[counter], SLAM.cpp:1444-1450). */
+int  srukf_predict_motion_next(srukf_ctx* ctx, const double odo_prev[3], const double odo_cur[3]);
 
 /* predictMeasurement (SLAM.cpp:1604-1608): h[2N] predicted pixels (m_allPredictSet),
  * Si[4N] per-landmark 2x2 upper-triangular sqrt innovation covariance (PointsMap::Si),
@@ -278,13 +284,23 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  *   k_gmw_pivslab_persist + k_gmw_tiles_persist; 2: the split form also where a worker would own two register tiles).
  * Per-context keys: "use_graph" (0: eager launches), "fused_motion" (0: k_motion + k_project as two launches, 1: k_project_motion, 2: "table"
  *   mode), "pxy2" (0: k_pxy instead of k_pxy2), "nullskip", "head_fold" (0: k_syrk launch in front of the persistent launch), "tail_fuse"
- *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse".  See srukf_api.hip (srukf_ctx::DbgSwitches). */
+ *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse", "step_fast" (0: the step-wise API keeps to its own launch sequences instead of the
+ *   staged replay's cut at the association step), "split_record".  See srukf_api.hip (srukf_ctx::DbgSwitches). */
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
-/* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared", "split_form"). */
+/* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared", "split_form", "split_off",
+ * "step_fast" / "step_slow": frames the step-wise API ran on the fast / the other path) and of the launch plan the next staged frame takes ("plan_persist",
+ * "plan_register_form", "plan_tiles_per_worker", "plan_fold", "plan_head_fold", "plan_red_perm", "plan_motion", "plan_fuse", "plan_T", "plan_Tp", "plan_tiles",
+ * "plan_workers", "plan_kept"). */
 int  srukf_debug_get(srukf_ctx* ctx, const char* key, long long* value);
 /* Diagnostic copy of a device work buffer (tests compare the launch sequences stage by stage): key = "Z", "DZ", "sigR", "Cmat", "Xr1",
  * "Utp", "P1", "h", "Si"; `count` doubles from the start of the buffer. */
 int  srukf_debug_copy(srukf_ctx* ctx, const char* key, double* out, long long count);
+/* ... and the other way (same keys, plus the operands of one factorisation: "Wf", "Gbak", "G", "D", "gsW", "gsL", "pans", "sync" — byte buffers counted in doubles).
+ * srukf_debug_split_replay: ONE launch of the split form's pair (0: k_gmw_pivslab_persist, 1: k_gmw_tiles_persist) `reps` times ALONE against the buffers and flags a
+ * real frame left behind (recorded with the "split_record" switch, moved between processes with debug_copy / debug_upload): the pair itself cannot run under
+ * rocprofv3's counter passes, which serialise dispatches (scripts/split_replay.py). */
+int  srukf_debug_upload(srukf_ctx* ctx, const char* key, const double* in, long long count);
+int  srukf_debug_split_replay(srukf_ctx* ctx, int which, int reps);
 /* Diagnostic builds (-DSRUKF_GMW_DBG) only: arms / reads the time stamps of the persistent factorisation launch (4096 values). */
 int  srukf_debug_gmw_stamps(srukf_ctx* ctx, unsigned long long* buf);
 

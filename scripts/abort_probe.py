@@ -1,0 +1,32 @@
+"""Why do staged frames at some sizes abandon their persistent launch?  (round 5: the plan sweep found gmw_shared = 2 at N = 267 .. 275)
+  python scripts/abort_probe.py N [head_fold] [frames]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.load_package()
+synth, srukf = pkg.synth, pkg.srukf
+
+N = int(sys.argv[1]); head_fold = int(sys.argv[2]) if len(sys.argv) > 2 else 1; F = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+p = synth.scene_params()
+sc = synth.make_scene(N, F, seed=3, p=p)
+f = srukf.Filter(N, p)
+f.debug_set("head_fold", head_fold); f.debug_set("use_graph", 0)
+f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+keys = ["plan_T", "plan_Tp", "plan_tiles", "plan_workers", "plan_persist", "plan_fold", "plan_head_fold", "plan_red_perm", "plan_fuse", "split_form"]
+print("N", N, "head_fold", head_fold, {k: f.debug_get(k) for k in keys})
+for t in range(F):
+    try:
+        f.run_frames_async(t, 1); f.synchronize()
+        st = "ok"
+    except srukf.SrukfError as e:
+        st = f"{e}"
+    print(" frame", t, st, {k: f.debug_get(k) for k in ("gmw_aborts", "clamp_rows", "gmw_shared", "plan_persist", "plan_fold", "plan_head_fold")}, "clamp_info", f.clamp_info())
+    if st != "ok":
+        break
+f.close()

@@ -1,0 +1,81 @@
+"""Counters for the split form of the factorisation (k_gmw_pivslab_persist + k_gmw_tiles_persist: BASELINE configs[4], N = 500, fp32 storage).
+
+The two launches wait for each other, and rocprofv3's counter passes serialise dispatches: the pair cannot run under --pmc.  Everything the pair exchanges lives
+in HBM (G tiles + version flags, the slabs of every panel + theirs, panel buffers + flags), so the operands of ONE factorisation are recorded from a real frame and
+each launch is then replayed ALONE against them (srukf_debug_split_replay): every wait finds its flag at its final value, every load the bytes the real run
+delivered, and the launch executes the instructions and moves the bytes of the real one.  Its DURATION alone is not the pair's (nothing waits): the pair's time
+comes from the kernel trace of the real run (profiles/*_n500_kernel_stats.csv).
+
+  python scripts/split_replay.py record  [N] [path]     a real run (no profiler): 4 frames, the 5th recorded -> path (.npz); replays both launches here too and
+                                                         checks that they reproduce the recorded outputs bit for bit
+  python scripts/split_replay.py replay  [N] [path] [reps]   under rocprofv3: uploads the record, replays each launch `reps` times
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.load_package()
+synth, srukf = pkg.synth, pkg.srukf
+KEYS = ["Gbak", "Wf", "gsW", "gsL", "pans", "sync", "G", "D"]
+
+
+def make_filter(N):
+    sc = synth.make_scene(N, 6, seed=0, p=synth.scene_params())
+    f = srukf.Filter(N, sc["params"])
+    f.set_state(sc["X0"], sc["S0"])
+    f.set_storage(srukf.STORAGE_F32)
+    f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    return f, sc
+
+
+def sizes(f):
+    npad = -(-f.n // 64) * 64
+    slabs = f.debug_get("plan_slab_panels") * 64 * npad
+    return {"Gbak": npad * npad, "Wf": npad * npad, "G": npad * npad, "D": npad, "gsW": slabs, "gsL": slabs, "pans": f.debug_get("plan_pans_doubles"), "sync": f.debug_get("plan_sync_doubles")}
+
+
+def replay_and_check(f, rec, reps):
+    out = {}
+    for which, name in ((0, "k_gmw_pivslab_persist"), (1, "k_gmw_tiles_persist")):
+        t0 = time.perf_counter()
+        f.debug_split_replay(which, reps)
+        out[name + "_alone_us"] = (time.perf_counter() - t0) / reps * 1e6
+        assert f.debug_get("gmw_aborts") == 0, "a replayed launch gave up"
+        if which == 0:
+            ok = np.array_equal(f.debug_copy("G", rec["G"].size), rec["G"]) and np.array_equal(f.debug_copy("D", rec["D"].size), rec["D"]) and \
+                 np.array_equal(f.debug_copy("gsW", rec["gsW"].size), rec["gsW"]) and np.array_equal(f.debug_copy("gsL", rec["gsL"].size), rec["gsL"])
+        else:
+            ok = np.array_equal(f.debug_copy("Wf", rec["Wf"].size), rec["Wf"])
+        out[name + "_reproduces_the_recorded_outputs"] = bool(ok)
+    return out
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "record"
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+    path = sys.argv[3] if len(sys.argv) > 3 else "/tmp/split_record.npz"
+    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+    f, sc = make_filter(N)
+    assert f.debug_get("split_form") == 1, "this size does not factor with the split form"
+    sz = sizes(f)
+    if mode == "record":
+        f.run_frames(0, 4)
+        f.debug_set("split_record", 1)
+        f.run_frames(4, 1)
+        assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0
+        rec = {k: f.debug_copy(k, sz[k]) for k in KEYS}
+        np.savez(path, **rec)
+        print("recorded", {k: v.size * 8 for k, v in rec.items()}, "->", path)
+        print(replay_and_check(f, rec, reps))
+    else:
+        rec = dict(np.load(path))
+        for k in ("Gbak", "Wf", "gsW", "gsL", "pans", "sync"):
+            f.debug_upload(k, rec[k])
+        print(replay_and_check(f, rec, reps))
+    f.close()

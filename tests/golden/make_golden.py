@@ -147,7 +147,58 @@ def g8_batched(N=200, F=40, seed=81):
                 V=V, PV=P @ V, P_absmax=np.abs(P).max(), clamps=np.array(list(o.clamp_stats().values())))
 
 
+def multi_frame_pin(N, F, seed, storage="f64", empty=None, single=None):
+    """F consecutive BATCHED oracle frames at a size whose launch plan differs from N = 200's (g9: N = 500 — split form, fused tail on the permuted operands, split-K
+    k_syrk; g10: N = 800 — more tiles than the memory-tile form can own), with a third of the landmarks unmatched per frame, optionally one frame without a match and
+    one with a single match.  storage = "f32" (BASELINE configs[4]): the state that lives from frame to frame is float — X and S are rounded to float before the first
+    frame and after every frame, exactly what srukf_set_storage(SRUKF_STORAGE_F32) keeps, and the trajectory row is read from the rounded state.
+    ~30 s (N = 500) / ~2.5 min (N = 800) of single-thread CPU per frame.  Stored like g7 / g8."""
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=seed, p=p)
+    rng = np.random.default_rng(seed)
+    matched = np.ones((F, N), dtype=np.int32)
+    for t in range(F):
+        matched[t, rng.permutation(N)[:N // 3]] = 0
+    if empty is not None:
+        matched[empty] = 0
+    if single is not None:
+        matched[single] = 0; matched[single, 5] = 1
+    f32 = storage == "f32"
+    rnd = (lambda a: a.astype(np.float32).astype(np.float64)) if f32 else (lambda a: a)
+    n = 6 * N + 4
+    o = O.Oracle(N, p); o.set_state(rnd(sc["X0"]), rnd(np.triu(sc["S0"])))
+    traj = np.zeros((F, 8))
+    for t in range(F):
+        tr = o.run_frames(sc["odo"][t:t + 2], sc["z"][t:t + 1], matched[t:t + 1], O.Oracle.BATCHED)
+        X, S = o.get_state()
+        if f32:
+            X, S = rnd(X), rnd(np.triu(S))
+            o.set_state(X, S)
+            Pr = S[:, n - 4:n - 2].T @ S[:, n - 4:n - 2]
+            traj[t, :4] = X[n - 4:]; traj[t, 4:] = Pr.ravel()
+        else:
+            traj[t] = tr[0]
+    X, S = o.get_state()
+    P = S.T @ S
+    V = np.random.default_rng(900 + N).choice([-1.0, 1.0], size=(n, 16))
+    blocks = np.stack([P[6 * k:6 * k + 6, 6 * k:6 * k + 6] for k in range(N)])
+    # |S|^T |S| of the final state on the stored entries: the scale of one float ulp per entry of S in P (fp32 storage bounds are relative to it)
+    A = np.abs(S)
+    AV = A.T @ (A @ np.ones((n, 1)))
+    return dict(N=N, F=F, seed=seed, storage=storage, matched=matched.astype(np.int8), traj=traj, X=X, P_diag=np.diag(P).copy(), P_robot_cols=P[:, n - 4:].copy(), P_blocks=blocks,
+                V=V, PV=P @ V, P_absmax=np.abs(P).max(), absS_diag=np.einsum("ki,ki->i", A, A), absS_rowsum=AV.ravel(), clamps=np.array(list(o.clamp_stats().values())))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        # separate (slow) target:  python tests/golden/make_golden.py g9 [f64|f32]   (N = 500, 8 frames: ~4 min each)
+        for st in (sys.argv[2:] or ["f64", "f32"]):
+            np.savez_compressed(os.path.join(OUT, f"g9_batched_n500_{st}.npz"), **multi_frame_pin(500, 8, 91, st, empty=3, single=5))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        # separate (slow) target:  python tests/golden/make_golden.py g10   (N = 800, 2 frames: ~5 min)
+        np.savez_compressed(os.path.join(OUT, "g10_batched_n800.npz"), **multi_frame_pin(800, 2, 101, "f64"))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         # separate (slow) target:  python tests/golden/make_golden.py g8
         np.savez_compressed(os.path.join(OUT, "g8_batched_n200.npz"), **g8_batched())

@@ -1,0 +1,332 @@
+"""GPU parity tests added in round 5 (-m gpu).
+
+Which kernels a staged frame launches depends on the landmark count through a handful of thresholds (srukf_api.hip: replay_red_fused / head_fold_ok /
+replay_fuse_mode / split_form; scripts/plan_sweep.py lists where each flips on a 256-CU device), and in the reference the landmark count changes every few
+frames (SLAM.cpp:552-562, 2443-2460): every N is a product size.  Here the DEFAULT staged replay is held to the live ORACLE on both sides of every threshold,
+each case asserting WHICH plan ran next to the comparison, and to multi-frame oracle fixtures at N = 500 (g9: fp64 and fp32 storage) and N = 800 (g10)."""
+import numpy as np
+import pytest
+
+from g7_check import g7_check
+
+pytestmark = pytest.mark.gpu
+
+# (N, what the default rank-aware plan must be there).  Keys of srukf_debug_get "plan_*" / "split_form":
+#   fuse      "fused tail" mode: k_pxy2, k_gain, persistent launch, k_rank_expand<2>
+#   fold      the owners of the persistent launch form their tiles of S^T S - U U^T themselves
+#   head_fold ... and the head tiles ride on that launch as helper workgroups (no k_syrk launch)
+#   red_perm  k_syrk over the kept rows in permuted order instead of the owners' fold
+#   tpw       register tiles per worker of the persistent launch (split form: one lean workgroup per tile)
+#   split     the split form (k_gmw_pivslab_persist + k_gmw_tiles_persist)
+PLAN_SWEEP = [
+    # from scripts/plan_sweep.py (profiles/r05_plan_sweep.txt: every N from 16 to 520 on a 256-CU device) — both sides of every flip of the rank-aware default
+    (20, dict(fuse=0, motion=1, persist=1, split=0)),                       # n < 128: no structurally null set is taken, k_project_motion + k_pxy
+    (21, dict(fuse=1, motion=2, red_perm=1, fold=0, split=0)),              # "fused tail" mode from here on; k_syrk over the kept rows (T < 16)
+    (159, dict(fuse=1, red_perm=1, fold=0, head_fold=0, tpw=1)),
+    (160, dict(fuse=1, fold=1, head_fold=1, red_perm=0, tpw=1)),            # T = 16: the owners' fold and the head fold (the headline's plan: N = 200)
+    (266, dict(fuse=1, fold=1, head_fold=1, tpw=1, persist=1)),
+    (276, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),             # fewer than 16 CUs left beside pivot + workers: k_syrk head launch in front
+    (277, dict(fuse=1, fold=1, head_fold=0, tpw=2, persist=1)),             # two register tiles per worker
+    (287, dict(fuse=1, fold=1, head_fold=0, tpw=2)),
+    (288, dict(fuse=1, fold=0, red_perm=1, tpw=2, split=0, persist=1)),     # more than 1.06 tiles per worker: k_syrk over the kept rows, register tiles read from G
+    (394, dict(fuse=1, red_perm=1, split=0, tpw=2, persist=1)),
+    (395, dict(fuse=1, red_perm=1, split=1, persist=1)),                    # more than two tiles per worker: the split form (configs[4]'s plan: N = 500)
+]
+
+
+def _run_two_frames_against_oracle(srukf, oracle, synth, N, rank_aware=1, storage="f64", F=2, seed=3):
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=seed, p=p)
+    rng = np.random.default_rng(1000 + N)
+    matched = np.ones((F, N), dtype=np.int32)
+    for t in range(F):
+        matched[t, rng.permutation(N)[:N // 4]] = 0            # a quarter of the landmarks unmatched per frame
+    X0, S0 = sc["X0"], np.triu(sc["S0"])
+    f = srukf.Filter(N, p)
+    if not rank_aware:
+        f.set_rank_aware(0)
+    if storage == "f32":
+        f.set_storage(srukf.STORAGE_F32)
+        X0, S0 = X0.astype(np.float32).astype(np.float64), S0.astype(np.float32).astype(np.float64)
+    f.set_state(X0, S0); f.stage_sequence(sc["odo"], sc["z"], matched)
+    traj = f.run_frames(0, F)
+    X, S = f.get_state()
+    o = oracle.Oracle(N, p); o.set_state(X0, S0)
+    n = 6 * N + 4
+    to = np.zeros((F, 8))
+    for t in range(F):
+        tr = o.run_frames(sc["odo"][t:t + 2], sc["z"][t:t + 1], matched[t:t + 1], oracle.Oracle.BATCHED)
+        to[t] = tr[0]
+        if storage == "f32":                                   # the state that lives from frame to frame is float
+            Xo, So = o.get_state()
+            Xo, So = Xo.astype(np.float32).astype(np.float64), np.triu(So).astype(np.float32).astype(np.float64)
+            o.set_state(Xo, So)
+            to[t, :4] = Xo[n - 4:]; to[t, 4:] = (So[:, n - 4:n - 2].T @ So[:, n - 4:n - 2]).ravel()
+    Xo, So = o.get_state()
+    return f, traj, X, S, to, Xo, So
+
+
+def _hold(traj, X, S, to, Xo, So, storage):
+    P, Po = S.T @ S, So.T @ So
+    if storage == "f64":
+        np.testing.assert_allclose(traj[:, :4], to[:, :4], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(traj[:, 4:], to[:, 4:], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(X, Xo, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(P, Po, rtol=0, atol=1e-11)
+    else:
+        # both states are float roundings of fp64 results that agree to ~1e-13: an entry that sits on a rounding boundary may round the other way —
+        # one float ulp of one entry of X or S, i.e. |dP_ij| <= eps32 (|S|^T |S|)_ij per such entry (test_oracle_frame_n500's bound)
+        eps32 = float(np.finfo(np.float32).eps)
+        np.testing.assert_allclose(X, Xo, rtol=2 * eps32, atol=1e-9)
+        np.testing.assert_allclose(traj[:, :4], to[:, :4], rtol=2 * eps32, atol=1e-9)
+        bound = eps32 * (np.abs(S).T @ np.abs(S)) * 3.0 + 1e-11
+        assert np.all(np.abs(P - Po) <= bound), float((np.abs(P - Po) / bound).max())
+
+
+@pytest.mark.parametrize("N,plan", PLAN_SWEEP)
+def test_default_replay_on_both_sides_of_every_plan_threshold(srukf, oracle, synth, N, plan):
+    f, traj, X, S, to, Xo, So = _run_two_frames_against_oracle(srukf, oracle, synth, N)
+    got = {"fuse": f.debug_get("plan_fuse"), "fold": f.debug_get("plan_fold"), "head_fold": f.debug_get("plan_head_fold"), "red_perm": f.debug_get("plan_red_perm"),
+           "tpw": f.debug_get("plan_tiles_per_worker"), "split": f.debug_get("split_form"), "persist": f.debug_get("plan_persist"), "motion": f.debug_get("plan_motion")}
+    assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("gmw_shared") == 0
+    f.close()
+    for k, v in plan.items():
+        assert got[k] == v, (N, k, got)
+    _hold(traj, X, S, to, Xo, So, "f64")
+
+
+@pytest.mark.parametrize("N,form", [(100, "full_rank"), (244, "full_rank"), (245, "full_rank"), (300, "full_rank"), (340, "full_rank"), (341, "full_rank"), (400, "full_rank"),
+                                    (100, "f32"), (300, "f32"), (400, "f32")])
+def test_other_forms_at_the_plan_boundaries(srukf, oracle, synth, N, form):
+    """The same two oracle frames with every pivot factored (srukf_set_rank_aware(0): the full-rank plans — owners' fold up to one tile per worker, memory tiles /
+    split form beyond: two register tiles per worker from N = 245, the split form from N = 341 in the sweep) and with fp32 storage of the state (configs[4]'s form: the
+    frame tail and the state update round what they write)."""
+    f, traj, X, S, to, Xo, So = _run_two_frames_against_oracle(srukf, oracle, synth, N, rank_aware=0 if form == "full_rank" else 1, storage="f32" if form == "f32" else "f64")
+    assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("gmw_shared") == 0
+    assert f.null_directions() == (0 if form == "full_rank" else 3 * (N - 1))
+    if form == "full_rank":
+        assert f.debug_get("plan_tiles_per_worker") == (1 if N < 245 else 2 if N < 341 else 3 if N < 416 else 4) and f.debug_get("split_form") == (1 if N >= 341 else 0)
+    if form == "f32":
+        X32, S32 = f.get_state_f32()
+        assert np.array_equal(X32.astype(np.float64), X) and np.array_equal(np.triu(S32).astype(np.float64), np.triu(S))     # the stored state IS float
+    f.close()
+    _hold(traj, X, S, to, Xo, So, "f32" if form == "f32" else "f64")
+
+
+def _pin_scene(g, synth):
+    N, F = int(g["N"]), int(g["F"])
+    p = synth.scene_params()
+    sc = synth.make_scene(N, F, seed=int(g["seed"]), p=p)
+    return N, F, p, sc, g["matched"].astype(np.int32)
+
+
+@pytest.mark.parametrize("variant", ["default", "mem_tiles", "split_calls"])
+def test_g9_n500_fp64_against_8_oracle_frames(srukf, golden, synth, variant):
+    """Fixture g9 (tests/golden/make_golden.py g9 f64): 8 consecutive BATCHED oracle frames at N = 500, a third of the landmarks unmatched per frame, frame 3 without
+    a match, frame 5 with a single one.  default: what bench.py's configs4 leg launches apart from the storage — split form of the factorisation, fused tail on the
+    permuted operands, split-K k_syrk over the kept rows; mem_tiles: the memory-tile instance of k_gmw_persist instead of the split form; split_calls: 1 + 3 + 4 frames."""
+    g = golden["g9_batched_n500_f64"]
+    N, F, p, sc, matched = _pin_scene(g, synth)
+    if variant == "mem_tiles":
+        srukf.debug_set_global("mem_split", 0)
+    try:
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], matched)
+        traj = np.vstack([f.run_frames(0, 1), f.run_frames(1, 3), f.run_frames(4, F - 4)]) if variant == "split_calls" else f.run_frames(0, F)
+        assert f.debug_get("split_form") == (0 if variant == "mem_tiles" else 1) and f.debug_get("plan_fuse") == 1 and f.debug_get("plan_red_perm") == 1
+        assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("gmw_shared") == 0
+        X, S = f.get_state(); f.close()
+    finally:
+        srukf.debug_set_global("mem_split", 1)
+    np.testing.assert_allclose(traj[:, :4], g["traj"][:, :4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(traj[:, 4:], g["traj"][:, 4:], rtol=0, atol=1e-12)
+    g7_check(g, X, S.T @ S, 1e-9, 1e-11)
+
+
+def test_g9_n500_fp32_storage_against_8_oracle_frames(srukf, golden, synth):
+    """BASELINE configs[4] as bench.py runs it (N = 500, X and S live as float between frames, fp64 arithmetic, split form + fused tail that rounds what it writes)
+    against 8 oracle frames whose state is rounded to float after every frame (fixture g9 f32).  Tolerance: a device entry and an oracle entry are float roundings
+    of fp64 values that agree to ~1e-13, so they are equal or — on a rounding boundary — one float ulp apart; such ulps feed the later frames.  Bound per entry of P:
+    c eps32 (|S|^T |S|)_ij with c = 4 (measured ratio printed), X and pose: 4 eps32 relative."""
+    g = golden["g9_batched_n500_f32"]
+    N, F, p, sc, matched = _pin_scene(g, synth)
+    f = srukf.Filter(N, p); f.set_storage(srukf.STORAGE_F32)
+    f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], matched)
+    traj = f.run_frames(0, F)
+    assert f.debug_get("split_form") == 1 and f.debug_get("plan_fuse") == 1
+    assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("gmw_shared") == 0
+    X, S = f.get_state()
+    X32, S32 = f.get_state_f32(); f.close()
+    assert np.array_equal(X32.astype(np.float64), X) and np.array_equal(np.triu(S32).astype(np.float64), np.triu(S))
+    eps32 = float(np.finfo(np.float32).eps)
+    n = 6 * N + 4
+    np.testing.assert_allclose(traj[:, :4], g["traj"][:, :4], rtol=4 * eps32, atol=1e-9)
+    np.testing.assert_allclose(X, g["X"], rtol=4 * eps32, atol=1e-9)
+    P = S.T @ S
+    B = eps32 * (np.abs(S).T @ np.abs(S))
+    worst = 0.0
+    for got, ref, b in ((np.diag(P), g["P_diag"], np.diag(B)), (P[:, n - 4:], g["P_robot_cols"], B[:, n - 4:]),
+                        (np.stack([P[6 * k:6 * k + 6, 6 * k:6 * k + 6] for k in range(N)]), g["P_blocks"], np.stack([B[6 * k:6 * k + 6, 6 * k:6 * k + 6] for k in range(N)])),
+                        (P @ g["V"], g["PV"], (B @ np.ones((n, 1))) * np.ones((1, 16)))):
+        worst = max(worst, float((np.abs(got - ref) / (b + 1e-11 / 4)).max()))
+    print(f"g9 f32: max |dP| / (eps32 |S|^T|S| + 2.5e-12) = {worst:.3f}; max |dtraj pose| = {np.abs(traj[:, :4] - g['traj'][:, :4]).max():.3e}")
+    assert worst <= 4.0, worst
+    np.testing.assert_allclose(traj[:, 4:], g["traj"][:, 4:], rtol=16 * eps32, atol=1e-12)
+
+
+@pytest.mark.parametrize("variant", ["default", "per_panel"])
+def test_g10_n800_against_oracle_frames(srukf, golden, synth, variant):
+    """Fixture g10: 2 consecutive BATCHED oracle frames at N = 800 (n = 4804, T = 76 block rows: more tiles than the memory-tile form of k_gmw_persist can own on 256 CUs).
+    default: the split form (any size); per_panel: one launch per 64-row panel (srukf_debug_set "gmw_persist" 0), what such sizes ran before round 4."""
+    g = golden["g10_batched_n800"]
+    N, F, p, sc, matched = _pin_scene(g, synth)
+    if variant == "per_panel":
+        srukf.debug_set_global("gmw_persist", 0)
+    try:
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], matched)
+        traj = f.run_frames(0, F)
+        assert f.debug_get("plan_persist") == (0 if variant == "per_panel" else 1)
+        if variant == "default":
+            assert f.debug_get("split_form") == 1
+        assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("gmw_shared") == 0
+        X, S = f.get_state(); f.close()
+    finally:
+        srukf.debug_set_global("gmw_persist", 1)
+    np.testing.assert_allclose(traj[:, :4], g["traj"][:, :4], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(traj[:, 4:], g["traj"][:, 4:], rtol=0, atol=1e-12)
+    g7_check(g, X, S.T @ S, 1e-9, 1e-11)
+
+
+def test_mixed_precision_downdate_n500(srukf, oracle, synth):
+    """Row g of the review (BASELINE configs[4]: "500 landmarks fp32 SRUKF with mixed-precision sqrt(S) downdate, tolerance study") at the config's own size:
+    one frame of SRUKF_STORAGE_F32_MIXED (S^T S - U U^T on the fp32 matrix pipe, K chunks summed in FP64) at N = 500 from the float-rounded state against the oracle's
+    fp64 frame, (a) with the clamp at 1e-8, where the mode is offered, and (b) at the reference's EPSILON = 1e-13 through the study hook srukf_debug_allow_mixed,
+    where it is refused: the measured error of ONE frame is printed and bounded for both (the divergence at 1e-13 needs a few frames: scripts/mixed_eps_study.py)."""
+    N = 500
+    res = {}
+    for eps, allow in ((1e-8, False), (1e-13, True)):
+        p = synth.scene_params(); p["epsilon"] = eps
+        sc = synth.make_scene(N, 1, seed=3, p=p)
+        X0 = sc["X0"].astype(np.float32).astype(np.float64); S0 = np.triu(sc["S0"]).astype(np.float32).astype(np.float64)
+        f = srukf.Filter(N, p)
+        if allow:
+            with pytest.raises(srukf.SrukfError) as e:
+                f.set_storage(srukf.STORAGE_F32_MIXED)
+            assert e.value.rc == -6
+            f.debug_allow_mixed(1)
+        f.set_storage(srukf.STORAGE_F32_MIXED); f.set_state(X0, S0)
+        o = oracle.Oracle(N, p); o.set_state(X0, S0)
+        f.predict_motion(sc["odo"][0], sc["odo"][1]); o.predict_motion(sc["odo"][0], sc["odo"][1])
+        f.predict_measurement(); o.predict_measurement()
+        f.update(sc["z"][0], sc["matched"][0]); o.update(sc["z"][0], sc["matched"][0], 1, 0, 1)
+        X, S = f.get_state(); Xo, So = o.get_state(); f.close()
+        P, Po = S.T @ S, So.T @ So
+        sd = np.sqrt(np.diag(Po))
+        rel = float((np.abs(P - Po) / (np.outer(sd, sd) + 1e-30)).max())
+        dx = float(np.abs(X - Xo).max())
+        res[eps] = (rel, dx)
+        print(f"mixed downdate N=500 eps={eps:g}: max |dP_ij| / sqrt(P_ii P_jj) = {rel:.3e}, max |dX| = {dx:.3e}, pose |d| = {np.abs(X[-4:] - Xo[-4:]).max():.3e}")
+    assert res[1e-8][0] < 4e-6 and res[1e-8][1] < 1e-5, res        # N = 200 measured 5e-7 (test_mixed_precision_downdate)
+    assert np.isfinite(res[1e-13][0]) and np.isfinite(res[1e-13][1])
+
+
+def test_native_multi_gpu_replay_host_runs_its_rccl_calls(tmp_path, srukf, synth):
+    """cv-monoslam_amd/host/cslam_replay_multi.cpp — the C++ product's own N-device driver (one thread and one srukf_ctx per device, ncclCommInitAll, ncclBroadcast of
+    the map from device 0, ncclAllGather of the trajectories) — with ONE device, so that every RCCL call executes on this box: the JSON line carries bench.py's
+    scaling keys, what the all-gather delivered is what the device computed, and the trajectory is, bit for bit, the staged replay's through the C-ABI from Python."""
+    import json
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cv-monoslam_amd", "cslam_replay_multi.bin")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    N, W, K = 50, 4, 20
+    p = synth.scene_params()
+    sc = synth.make_scene(N, W + K, seed=4, p=p)
+    tmp = str(tmp_path)
+    with open(f"{tmp}/scene.bin", "wb") as fh:
+        fh.write(struct.pack("ii", N, W + K)); fh.write(np.array([p["a1"], p["a2"], p["a3"], p["a4"]]).tobytes())
+        fh.write(np.ascontiguousarray(sc["X0"]).tobytes()); fh.write(np.ascontiguousarray(sc["S0"]).tobytes()); fh.write(np.ascontiguousarray(sc["z"]).tobytes())
+    with open(f"{tmp}/odo.txt", "w") as fh:
+        for i, (x, y, th) in enumerate(sc["odo"]):
+            fh.write(f"{i + 1} : {0.1 * i:.3f} {float(x)!r} {float(y)!r} {float(th)!r}\n")
+    r = subprocess.run([exe, f"{tmp}/scene.bin", f"{tmp}/odo.txt", "devices=0", f"frames={K}", f"warmup={W}", f"traj={tmp}/traj.bin"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["rccl_world_size"] == 1 and d["collectives"] == "rccl" and d["trajectory_allgather_ok"] is True
+    assert d["map_broadcast"]["bytes"] == 8 * ((6 * N + 4) + (6 * N + 4) ** 2) and len(d["per_rank_frames_per_s"]) == 1 and d["value"] > 0
+    traj = np.fromfile(f"{tmp}/traj.bin").reshape(1, W + K, 8)[0]
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    f.prepare_frames(K)
+    ref = np.vstack([f.run_frames(0, W), f.run_frames(W, K)]); f.close()
+    assert np.array_equal(traj, ref)
+
+
+@pytest.mark.parametrize("N,hint", [(200, True), (200, False), (50, True), (400, True)])
+def test_step_api_equals_staged_replay(srukf, synth, N, hint):
+    """The drop-in path (SLAM.cpp:87-112 per frame: srukf_predict_motion -> srukf_predict_measurement -> host -> srukf_update) runs, where the staged replay's "fused
+    tail" mode applies, the replay's OWN launch sequence cut at the association step (srukf_api.hip: step_predict_fast / step_update_fast): same kernels on the same
+    values, so the state after F step-wise frames equals the staged replay's bit for bit — with the next frame's odometry announced (srukf_predict_motion_next: the
+    update's tail projects the next frame, as the replay's does) and without (every predict projects: k_sigr_rows + k_project_table).  The host's view between predict
+    and update (h, Si, visible; the predicted pose) is held to the other path of the step-wise API (debug switch "step_fast" 0: round 4's launch sequences)."""
+    p = synth.scene_params()
+    F0, F = 3, 9
+    sc = synth.make_scene(N, F0 + F + 1, seed=17, p=p)
+    f0 = srukf.Filter(N, p); f0.set_state(sc["X0"], sc["S0"]); f0.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    f0.run_frames(0, F0)
+    X3, S3 = f0.get_state(); f0.close()
+    a = srukf.Filter(N, p); a.set_state(X3, S3); a.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+    ta = a.run_frames(F0, F)
+    Xa, Sa = a.get_state(); a.close()
+    b = srukf.Filter(N, p); b.set_state(X3, S3)
+    s = srukf.Filter(N, p); s.set_state(X3, S3); s.debug_set("step_fast", 0)
+    tb = np.zeros((F, 8))
+    for t in range(F0, F0 + F):
+        for q in (b, s):
+            q.predict_motion(sc["odo"][t], sc["odo"][t + 1])
+            if hint:
+                q.predict_motion_next(sc["odo"][t + 1], sc["odo"][t + 2])
+        (h, Si, vis), (hs, Sis, viss) = b.predict_measurement(), s.predict_measurement()
+        assert np.array_equal(vis, viss)
+        np.testing.assert_allclose(h, hs, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(Si, Sis, rtol=0, atol=1e-9)
+        if t == F0 + 1:                                          # a state getter between predict and update sees the PREDICTED pose on both paths
+            (pb, Pb), (ps, Ps) = b.get_robot(), s.get_robot()
+            np.testing.assert_allclose(pb, ps, rtol=0, atol=1e-12); np.testing.assert_allclose(Pb, Ps, rtol=0, atol=1e-13)
+        b.update(sc["z"][t], sc["matched"][t]); s.update(sc["z"][t], sc["matched"][t])
+        pose, P4 = b.get_robot()
+        tb[t - F0, :4] = pose; tb[t - F0, 4:] = np.asarray(P4).reshape(4, 4)[:2, :2].ravel()
+    assert b.debug_get("step_fast") == F and b.debug_get("step_slow") == 0 and s.debug_get("step_fast") == 0 and s.debug_get("step_slow") == F
+    assert b.debug_get("gmw_aborts") == 0 and b.debug_get("clamp_rows") == 0
+    Xb, Sb = b.get_state(); Xs, Ss = s.get_state(); b.close(); s.close()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Sa, Sb)
+    assert np.array_equal(ta[:, :4], tb[:, :4])
+    np.testing.assert_allclose(ta[:, 4:], tb[:, 4:], rtol=0, atol=1e-15)        # (the 2 x 2 block: the tail sums the robot columns of the factor rows, srukf_get_robot those of S)
+    np.testing.assert_allclose(Xs, Xb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Ss.T @ Ss, Sb.T @ Sb, rtol=0, atol=1e-11)
+
+
+def test_step_api_fast_path_falls_back_on_flagged_frames(srukf, oracle, synth):
+    """The shipped a1..a4 = 8 at N = 200: S^T S - U U^T turns indefinite within a few frames and the reference's theta clamp becomes active.  The fast path's tail flags the
+    frame; srukf_update rewinds to the state before the frame (kept by srukf_predict_motion) and repeats it on the path that evaluates the clamp pivot by pivot — the
+    state the other path of the step-wise API reaches, and the oracle's frames to what a diverging filter allows."""
+    p = synth.default_params()
+    N, F = 200, 4
+    sc = synth.make_scene(N, F, seed=1, p=p)
+    res = []
+    for fast in (1, 0):
+        f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"]); f.debug_set("step_fast", fast)
+        tr = np.zeros((F, 4))
+        for t in range(F):
+            f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); f.predict_measurement(); f.update(sc["z"][t], sc["matched"][t])
+            tr[t] = f.get_robot()[0]
+        res.append((tr, f.get_state(), f.debug_get("step_fast"), f.debug_get("step_slow")))
+        f.close()
+    assert res[0][3] >= 1 and res[1][2] == 0                     # (frame 0 of a fresh state is never fast; at least one later frame was flagged and repeated)
+    o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
+    to = o.run_frames(sc["odo"], sc["z"], sc["matched"], mode=oracle.Oracle.BATCHED)
+    assert o.clamp_stats()["theta"] > 0
+    rel = np.abs(res[0][0] - to[:, :4]) / np.maximum(1.0, np.abs(to[:, :4]))
+    assert rel[:2].max() <= 1e-8 and rel.max() <= 1e-5, rel.max(axis=1)
+    rel2 = np.abs(res[0][0] - res[1][0]) / np.maximum(1.0, np.abs(res[1][0]))
+    assert rel2.max() <= 1e-5, rel2.max(axis=1)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(lib, n), f"libsrukf_hip.so does not export {n}"
     assert sorted(pkg.srukf.EXPORTS) == names
-    assert lib.srukf_abi_version() == 5
+    assert lib.srukf_abi_version() == 6
 
 
 def test_default_params_match_reference_constants(pkg):
