@@ -49,6 +49,14 @@ __device__ __forceinline__ bool gmw_wait_ge(const unsigned long long* f, unsigne
     }
     return false;
 }
+// Abandon the launch (a bounded wait expired): everybody leaves, the frame is flagged.  The FIRST to give up also leaves who and where (site << 32 | blockIdx + 1) in the
+// sync block's pad word 0 (srukf_debug_get "abort_code"): cold path, diagnostic only.
+// sites: 1 pivot (operands of the next panel), 2 pivot (critical head tiles), 3 worker (head tiles), 4 worker (a tile step), 5 slab workgroup, 6 tile workgroup, 7 residency gate
+__device__ __forceinline__ void gmw_abandon(GmwSync* sy, unsigned int site)
+{
+    __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0) atomicCAS(&sy->pad[0], 0ull, ((unsigned long long)site << 32) | (unsigned long long)(blockIdx.x + 1));
+}
 __device__ __forceinline__ void gmw_set_flag(unsigned long long* f, unsigned long long v)
 {
     __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -344,7 +352,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
         __syncthreads();                                       // closes the iteration: staged tiles visible, LDS arrays reusable
         if (wv3 && p + 1 < T) { gmw_set_panel_flag(sy->panel_ready, ebase + p + 1, lane); GMW_TS(sy, p + 64, 3); }
         if (wv0) GMW_TS(sy, p, 7);
-        if (!*okp) { if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        if (!*okp) { if (wv0) gmw_abandon(sy, 1); return; }
     }
     // the last panel buffers are never read by a worker (steps T-2 and T-1 have no trailing tiles)
 }
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         }
         GMW_TS(sy, 128, 1);
         if (head_ok) gmw_pivot_persist(n, ld, T, Tp, eps, G, pans, Dall, Sout, sy, ebase, Lr, Wc, facreg, xreg, keepreg, &ok, &halfcnt, stageok, tid, krows);
-        else if (tid == 0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) gmw_abandon(sy, 2);
         GMW_TS(sy, 128, 2);
     } else {
         const bool wv0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
@@ -698,6 +706,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             if (wv0) ok = (gmw_wait_head(&sy->head_crit, (unsigned)ha.ncrit, &sy->abort) && gmw_wait_head(&sy->head_done, (unsigned)(ha.ntiles - ha.ncrit), &sy->abort)) ? 1 : 0;
             __syncthreads();
             good = ok != 0;
+            if (!good && wv0) gmw_abandon(sy, 3);
             __syncthreads();
         }
         if (role == 1) GMW_TS(sy, 129, 2);
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         // the pass-on slot: step Tp - 1 only, behind every step of the register tiles (which end at Tp - 2 at the latest); its accumulator values are never used
         if (good && tc.nsteps > 0) good = gmw_owner_step(n, ld, T, tc.kfirst, tc, acca, G, pans, Sout, sy, ebase, Lr, Wc, &ok, wv0, tid, false, half_last);
         }
-        if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!good && wv0) gmw_abandon(sy, 4);
         if (role == 1) GMW_TS(sy, 129, 3);
         if (role == nmain - 1) GMW_TS(sy, 130, 3);
     }
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(256) void k_gmw_pivslab_persist(int n, int ld, int 
             }
             __syncthreads();
         }
-        if (!good && wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!good && wv0) gmw_abandon(sy, 5);
     }
     __syncthreads();
     if (tid == 0) {
@@ -885,7 +894,7 @@ void k_gmw_tiles_persist(int ld, int T, double* __restrict__ G, GmwSync* __restr
                     for (int t = 0; t < 4; t++) st_dev(&G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr], acc[a][b][t]);
         }
         gmw_publish(&ver[(size_t)I * T + J], ebase + ns, wv0);
-    } else if (wv0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (wv0) gmw_abandon(sy, 6);
     __syncthreads();
     if (tid == 0) {
         const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -907,7 +916,7 @@ __global__ void k_gmw_split_gate(GmwSync* __restrict__ sy, const FrameScalars* _
         if ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sy->resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= want) return;
         __builtin_amdgcn_s_sleep(4);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&sy->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) gmw_abandon(sy, 7);
 }
 
 extern "C" {

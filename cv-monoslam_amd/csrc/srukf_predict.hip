@@ -632,10 +632,12 @@ __global__ __launch_bounds__(256) void k_traj(KDims d, const double* __restrict_
 
 // k_block_cov: small diagonal blocks of P = S^T S for the accessors (robot 4x4: SLAM.cpp:3539-3556;
 // landmark 6x6: 2748).  out[bs*bs], block starts at row/col `off`.  One workgroup.
-__global__ __launch_bounds__(256) void k_block_cov(KDims d, const double* __restrict__ S, int off, int bs, double* __restrict__ out)
+// X (may be null): the bs state entries of the block are appended behind the bs x bs values (the robot view the step-wise API hands back with a frame's status)
+__global__ __launch_bounds__(256) void k_block_cov(KDims d, const double* __restrict__ S, int off, int bs, double* __restrict__ out, const double* __restrict__ X)
 {
     __shared__ double red[16];
     const int ld = d.np;
+    if (X && (int)threadIdx.x < bs) out[bs * bs + threadIdx.x] = X[off + threadIdx.x];
     for (int a = 0; a < bs; a++)
         for (int b = a; b < bs; b++) {
             double v[1] = { 0.0 };
@@ -747,9 +749,9 @@ void srukf_launch_traj(hipStream_t st, KDims d, const double* X, const double* S
 {
     hipLaunchKernelGGL(k_traj, dim3(1), dim3(256), 0, st, d, X, S, fs, traj, advance);
 }
-void srukf_launch_block_cov(hipStream_t st, KDims d, const double* S, int off, int bs, double* out)
+void srukf_launch_block_cov(hipStream_t st, KDims d, const double* S, int off, int bs, double* out, const double* X)
 {
-    hipLaunchKernelGGL(k_block_cov, dim3(1), dim3(256), 0, st, d, S, off, bs, out);
+    hipLaunchKernelGGL(k_block_cov, dim3(1), dim3(256), 0, st, d, S, off, bs, out, X);
 }
 }  // extern "C"
 

@@ -104,6 +104,7 @@ bool CSLAM::integrateFeaturesInformation(int K, const double* kp)
 bool CSLAM::deleteOneFeature(int id)
 {
     if (!ctx_ || id < 0 || id >= m_nMapFeatures) { lastError = "deleteOneFeature: no such landmark"; return false; }
+    mirrorsFresh_ = false;
     if (!check(srukf_delete_landmark(ctx_, id))) return false;                                                  // 2643-2668
     mapStore.erase(mapStore.begin() + id); relinkMap();                                                                                // 2670-2705
     m_nMapFeatures--;                                                                                           // 2664
@@ -137,12 +138,21 @@ bool CSLAM::dataAssociationOnDevice(const unsigned char* gray)
 }
 
 // ---- display accessors -----------------------------------------------------------------------------------------
-bool CSLAM::refreshFeaturesDisplay()
+bool CSLAM::refreshFeaturesDisplay(bool withMirrors)
 {
     const int N = m_nMapFeatures;
     if (!ctx_ || N == 0) return true;
     std::vector<double> xyz(3 * (size_t)N), cov(9 * (size_t)N);
-    if (!check(srukf_get_landmarks_cartesian(ctx_, xyz.data(), cov.data()))) return false;
+    if (withMirrors && !fullCovariance) {
+        double pose[4], P4[16];
+        if (!check(srukf_get_frame_view(ctx_, m_X_k.data.data(), xyz.data(), cov.data(), pose, P4))) return false;
+        const int n = m_X_k.rows;
+        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) m_P_k.at(n - 4 + a, n - 4 + b) = P4[4 * a + b];
+        mirrorsFresh_ = true;
+    } else {
+        if (withMirrors && !check(srukf_get_state(ctx_, m_X_k.data.data(), nullptr))) return false;
+        if (!check(srukf_get_landmarks_cartesian(ctx_, xyz.data(), cov.data()))) return false;
+    }
     Mat c; c.create(3, 3);
     for (int k = 0; k < N; k++) {
         map[k].xyz.x = xyz[3 * k]; map[k].xyz.y = xyz[3 * k + 1]; map[k].xyz.z = xyz[3 * k + 2];
@@ -156,8 +166,9 @@ bool CSLAM::refreshFeaturesDisplay()
 bool CSLAM::updateFeaturesInformation()
 {
     if (!m_nMapFeatures || !ctx_) return true;                                                                  // 2399-2402
-    if (!check(srukf_get_state(ctx_, m_X_k.data.data(), nullptr))) return false;
-    if (!refreshFeaturesDisplay()) return false;                 // xyz / cov / axis / sigma from the posterior (2566-2567; also what an archived landmark takes along, 2528-2529)
+    // m_X_k, xyz / cov / axis / sigma from the posterior (2566-2567; also what an archived landmark takes along, 2528-2529) and the robot block the
+    // mirrors show (2404): one device round trip (srukf_get_frame_view)
+    if (!refreshFeaturesDisplay(true)) return false;
     const double imageWidth = m_params.image_w, imageHeight = m_params.image_h;
     m_nDeletes = 0; m_nStores = 0; m_deleteID.clear();                                                           // 2419-2422
     int id = 0;
@@ -449,6 +460,7 @@ void CSLAM::refreshMirrors()
 {
     if (!ctx_) return;
     const int n = m_X_k.rows;
+    if (mirrorsFresh_ && !fullCovariance) { mirrorsFresh_ = false; return; }      // updateFeaturesInformation fetched them with the display refresh, and the map has not changed since
     if (fullCovariance) {
         check(srukf_get_state(ctx_, m_X_k.data.data(), m_S_k.data.data()));
         check(srukf_get_covariance(ctx_, m_P_k.data.data()));                                                  // 2404
@@ -486,6 +498,7 @@ void CSLAM::SLAM()
 {
     const auto t0 = std::chrono::steady_clock::now();                                                          // startTimer 122-132
     m_showCounter++;
+    mirrorsFresh_ = false;
     predictMotion();
     predictMeasurement();
     if (dataAssociation) dataAssociation(*this);                                                               // loadPictures + dataAssociation (95-97)

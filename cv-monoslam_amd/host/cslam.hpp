@@ -121,7 +121,7 @@ public:
     bool updateFeaturesInformation();
     // the display part alone (2566-2580): xyz, cov, axis, sigma of every landmark of `map`, from ONE device call
     // (srukf_get_landmarks_cartesian) instead of a pass over the n x n m_P_k per landmark
-    bool refreshFeaturesDisplay();
+    bool refreshFeaturesDisplay(bool withMirrors = false);   // withMirrors: m_X_k and the robot block of m_P_k in the same device round trip
     // getFeatureCartesianInformation (2721-2751): xyz and cov (3x3) of landmark id from the last refresh; sr (the 6x6
     // diagonal block of m_S_k) only when fullCovariance mirrors are on, otherwise left empty
     void getFeatureCartesianInformation(Point3d& xyz, Mat& sr, Mat& cov, const int& id) const;
@@ -175,6 +175,7 @@ private:
     void refreshMirrors();
     bool check(int rc);
     srukf_ctx* ctx_ = nullptr;
+    bool mirrorsFresh_ = false;          // m_X_k / the robot block of m_P_k were fetched by this frame's display refresh
     int device_ = 0;
     FILE* robotFile_ = nullptr;
     double initOdo_[2] = {0, 0}, initPos_[2] = {0, 0};

@@ -22,7 +22,7 @@ _INT_FIELDS = ["weight_type", "noise_type", "newton_iters", "reserved_"]
 EXPORTS = [
     "srukf_abi_version", "srukf_default_params", "srukf_create", "srukf_destroy", "srukf_reset", "srukf_last_error",
     "srukf_set_state", "srukf_get_state", "srukf_set_state_device", "srukf_get_state_device", "srukf_get_robot",
-    "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_motion_next", "srukf_predict_measurement",
+    "srukf_get_landmark_block", "srukf_get_landmarks_cartesian", "srukf_get_frame_view", "srukf_get_covariance", "srukf_predict_motion", "srukf_predict_motion_next", "srukf_predict_measurement",
     "srukf_update", "srukf_set_new_landmarks", "srukf_add_landmarks", "srukf_delete_landmark", "srukf_set_storage", "srukf_set_exclusive", "srukf_set_rank_aware", "srukf_null_directions", "srukf_run_frames_batch", "srukf_prepare_frames", "srukf_debug_poke_state", "srukf_get_state_f32", "srukf_set_landmark_appearance", "srukf_associate", "srukf_get_match_patch", "srukf_stage_sequence", "srukf_run_frames_async", "srukf_run_frames", "srukf_synchronize", "srukf_set_profiling",
     "srukf_clamp_info", "srukf_debug_set", "srukf_debug_get", "srukf_debug_copy", "srukf_debug_upload", "srukf_debug_split_replay", "srukf_debug_gmw_stamps", "srukf_debug_starve_workers", "srukf_debug_allow_mixed", "srukf_profile_count", "srukf_profile_get", "srukf_profile_reset", "srukf_dims", "srukf_gmw_host",
     "srukf_project_host",
@@ -102,6 +102,7 @@ def load_library(path=None):
     L.srukf_get_landmark_block.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     L.srukf_get_covariance.argtypes = [C.c_void_p, _dp]
     L.srukf_get_landmarks_cartesian.argtypes = [C.c_void_p, _dp, _dp]
+    L.srukf_get_frame_view.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
     L.srukf_predict_motion.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_predict_motion_next.argtypes = [C.c_void_p, _dp, _dp]
     L.srukf_predict_measurement.argtypes = [C.c_void_p, _dp, _dp, _ip]
@@ -267,6 +268,12 @@ class Filter:
         xyz, cov = np.zeros((self.N, 3)), np.zeros((self.N, 3, 3))
         self._chk(self._lib.srukf_get_landmarks_cartesian(self._h, _d(xyz), _d(cov)))
         return xyz, cov
+
+    def get_frame_view(self):
+        """(X, xyz[N,3], cov[N,3,3], pose[4], P4[4,4]) in one device round trip (srukf_get_frame_view)."""
+        X, xyz, cov, pose, P4 = np.zeros(self.n), np.zeros((self.N, 3)), np.zeros((self.N, 3, 3)), np.zeros(4), np.zeros((4, 4))
+        self._chk(self._lib.srukf_get_frame_view(self._h, _d(X), _d(xyz), _d(cov), _d(pose), _d(P4)))
+        return X, xyz, cov, pose, P4
 
     def set_landmark_appearance(self, k, patch, R, t, px):
         """PointsMap::initPatch (21x21 uint8), initRotation (3x3), initTrans (3), initPixel (2) of landmark k."""

@@ -123,6 +123,10 @@ int  srukf_get_landmark_block(srukf_ctx* ctx, int k, double X6[6], double P66[36
  * every paint (OpenGlDisplay.cpp:449-583) without ever forming the n x n P.  Either pointer may be NULL. */
 int  srukf_get_landmarks_cartesian(srukf_ctx* ctx, double* xyz, double* cov);
 
+/* What CSLAM::SLAM() refreshes for the display after every update (updateFeaturesInformation 2397-2621: m_X_k, xyz / Cartesian covariance of every landmark;
+ * recordRobotInformation 3539-3556: the robot block) in ONE device round trip instead of one per accessor: X[n], xyz[3N], cov[9N], pose4[4], P4[16]; any may be NULL. */
+int  srukf_get_frame_view(srukf_ctx* ctx, double* X, double* xyz, double* cov, double pose4[4], double P4[16]);
+
 /* Full covariance m_P_k = S^T S (SLAM.cpp:2404), n*n row-major, for hosts that want it. */
 int  srukf_get_covariance(srukf_ctx* ctx, double* P);
 

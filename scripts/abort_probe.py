@@ -1,5 +1,5 @@
 """Why do staged frames at some sizes abandon their persistent launch?  (round 5: the plan sweep found gmw_shared = 2 at N = 267 .. 275)
-  python scripts/abort_probe.py N [head_fold] [frames]"""
+  python scripts/abort_probe.py N [head_fold] [frames] [head_fold_free: CUs the head fold asks for beside pivot + workers]"""
 import os
 import sys
 
@@ -15,6 +15,9 @@ synth, srukf = pkg.synth, pkg.srukf
 N = int(sys.argv[1]); head_fold = int(sys.argv[2]) if len(sys.argv) > 2 else 1; F = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 p = synth.scene_params()
 sc = synth.make_scene(N, F, seed=3, p=p)
+free = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+if free:
+    srukf.debug_set_global("head_fold_free", free)
 f = srukf.Filter(N, p)
 f.debug_set("head_fold", head_fold); f.debug_set("use_graph", 0)
 f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
@@ -26,7 +29,9 @@ for t in range(F):
         st = "ok"
     except srukf.SrukfError as e:
         st = f"{e}"
-    print(" frame", t, st, {k: f.debug_get(k) for k in ("gmw_aborts", "clamp_rows", "gmw_shared", "plan_persist", "plan_fold", "plan_head_fold")}, "clamp_info", f.clamp_info())
+    code = f.debug_get("abort_code")
+    print(" frame", t, st, {k: f.debug_get(k) for k in ("gmw_aborts", "clamp_rows", "gmw_shared", "plan_persist", "plan_fold", "plan_head_fold")}, "clamp_info", f.clamp_info(),
+          "abort site", code >> 32, "workgroup", (code & 0xffffffff) - 1)
     if st != "ok":
         break
 f.close()
