@@ -216,7 +216,14 @@ std::vector<int> build_tile_table(int n_own, int n_other, bool upper, bool own_i
 }
 
 // the state is about to be replaced or read by somebody outside the step-wise fast path
-void step_state_replaced(srukf_ctx* c) { c->step_uncommitted = false; c->step_fast = false; c->xr1_pending = false; step_invalidate(c); c->f32_stale = false; c->robot_cached = false; }
+// the checkpoint copy of the frame in flight (its own stream) must be complete before anything on the filter's stream changes S or X, or reads the checkpoint
+void step_ck_join(srukf_ctx* c)
+{
+    if (!c->ck_pending) return;
+    hipStreamWaitEvent(c->stream, c->ck_e2, 0);
+    c->ck_pending = false;
+}
+void step_state_replaced(srukf_ctx* c) { step_ck_join(c); c->step_uncommitted = false; c->step_fast = false; c->xr1_pending = false; step_invalidate(c); c->f32_stale = false; c->robot_cached = false; }
 
 }  // namespace srukf_impl
 
@@ -247,6 +254,7 @@ namespace srukf_impl {
 void step_commit_motion(srukf_ctx* c)
 {
     if (!c->step_uncommitted) return;
+    step_ck_join(c);
     const RankArgs ra = rank_args(c);
     launch_commit_motion(c->stream, c->d.n, c->d.np, c->X, c->S, c->Cmat, c->fs, ra.A, ra.iperm, ra.r);
     c->step_uncommitted = false;
@@ -266,15 +274,24 @@ static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const doubl
     const bool projected = c->step_chain && c->proj_valid && memcmp(c->proj_odo, c->step_odo, sizeof c->step_odo) == 0;
     // the next pose, if the host has announced it already (it may still do so before srukf_update)
     const bool hint = c->next_odo_valid && memcmp(c->next_odo, odo_cur, sizeof(double) * 3) == 0;
-    double* hs = c->hstage;
-    for (int e = 0; e < 6; e++) hs[e] = c->step_odo[e];
-    for (int e = 0; e < 3; e++) hs[6 + e] = hint ? c->next_odo[3 + e] : 0.0;
+    double poses[9];
+    for (int e = 0; e < 6; e++) poses[e] = c->step_odo[e];
+    for (int e = 0; e < 3; e++) poses[6 + e] = hint ? c->next_odo[3 + e] : 0.0;
     c->step_seqF = hint ? 2 : 1;
-    HIPCHK(c, hipMemcpyAsync(c->odo_step, hs, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
-    // the state before the frame: a flagged frame is repeated from it on the other path
-    HIPCHK(c, hipMemcpyAsync(c->ckS, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->ckX, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream));
-    launch_set_step(c->stream, c->fs, c->odo_step, c->step_seqF, c->p.a1, c->p.a2, c->p.a3, c->p.a4, c->step_chain ? 0 : 1);
+    // the state before the frame (a flagged frame is repeated from it on the other path): copied on a stream of its own, beside the frame's first launch and the host's
+    // association step — nothing writes S or X before k_gain, which waits for the copy (step_ck_join)
+    if (!c->ck_stream) {
+        if (hipStreamCreateWithFlags(&c->ck_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ck_e1, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ck_e2, hipEventDisableTiming) != hipSuccess) { c->err = "predict_motion: no stream for the checkpoint copy"; return SRUKF_ERR_HIP; }
+    }
+    step_ck_join(c);
+    HIPCHK(c, hipEventRecord(c->ck_e1, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->ck_stream, c->ck_e1, 0));
+    HIPCHK(c, hipMemcpyAsync(c->ckS, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->ck_stream));
+    HIPCHK(c, hipMemcpyAsync(c->ckX, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->ck_stream));
+    HIPCHK(c, hipEventRecord(c->ck_e2, c->ck_stream));
+    c->ck_pending = true;
+    launch_set_step(c->stream, c->fs, c->odo_step, c->step_seqF, c->p.a1, c->p.a2, c->p.a3, c->p.a4, c->step_chain ? 0 : 1, poses);
     c->fs_seq_step = true;
     if (!projected) {
         if (c->step_chain) launch_set_frame_control(c->stream, c->fs);      // (the tail prepared the control of ANOTHER pair, or none)
@@ -309,6 +326,7 @@ static int step_update_slow(srukf_ctx* c, const double* z, const int* matched, i
 static int step_rewind_to_slow(srukf_ctx* c)
 {
     const size_t np = c->d.np;
+    step_ck_join(c);
     HIPCHK(c, hipMemcpyAsync(c->S, c->ckS, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->X, c->ckX, sizeof(double) * np, hipMemcpyDeviceToDevice, c->stream));
     quantize_state(c); shadow_rebuild(c);
@@ -338,25 +356,24 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     }
     double* hs = c->hstage;
     const size_t mp = d.mp;
+    // z | matched stay in the pinned host buffer: k_gain reads its 2N doubles and N ints from there (the buffer is device-accessible and is not touched again before this call's
+    // synchronisation) — a host-to-device copy in front of it cost 12 us of stream time
     memcpy(hs, z, sizeof(double) * 2 * N);
-    memcpy(hs + mp, matched, sizeof(int) * N);                 // (z | matched are one device allocation: one copy)
-    HIPCHK(c, hipMemcpyAsync(c->zcur, hs, sizeof(double) * mp + sizeof(int) * N, hipMemcpyHostToDevice, c->stream));
+    memcpy(hs + mp, matched, sizeof(int) * N);
     if (c->step_seqF == 1 && c->next_odo_valid && memcmp(c->next_odo, c->step_odo + 3, sizeof(double) * 3) == 0) {
         // the host announced the next frame's odometry after srukf_predict_motion: the tail of this frame can still project it
-        double* ho = hs + mp + N;                               // (behind z and matched in the pinned buffer)
-        for (int e = 0; e < 3; e++) ho[e] = c->next_odo[3 + e];
-        HIPCHK(c, hipMemcpyAsync(c->odo_step + 6, ho, sizeof(double) * 3, hipMemcpyHostToDevice, c->stream));
+        launch_set_next_pose(c->stream, c->fs, c->odo_step, c->next_odo + 3);
         c->step_seqF = 2;
-        launch_set_seq(c->stream, c->fs, c->odo_step, 2, c->p.a1, c->p.a2, c->p.a3, c->p.a4);
     }
-    seq_gain_only(c, c->zcur, c->mcur, true, true, true);
+    step_ck_join(c);
+    seq_gain_only(c, hs, (const int*)(hs + mp), true, true, true);
     c->step_uncommitted = false;                               // (k_gain and the state update commit the motion step)
     seq_refactor(c, 0, d.mp, false, false, false, true, true, true);
     // the robot view (pose, 4 x 4 block of P: what the host records per frame, SLAM.cpp:3539-3556) comes back with the frame's status: srukf_get_robot then costs no round trip
-    double* hrobot = (double*)((char*)c->hfs + sizeof(FrameScalars));
     srukf_launch_block_cov(c->stream, d, c->S, d.n - 4, 4, c->small, c->X);
-    HIPCHK(c, hipMemcpyAsync(hrobot, c->small, sizeof(double) * 20, hipMemcpyDeviceToHost, c->stream));
-    int rc = read_fs(c); if (rc) return rc;
+    launch_export(c->stream, c->fs, sizeof(FrameScalars), c->small, sizeof(double) * 20, c->hfs);       // status + robot view: one short launch, no copies
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = read_fs_host(c); if (rc) return rc;
     if (c->hfs->clamp_rows > 0) {
         // flagged (the reference's theta clamp would have been active, a skipped direction was not null, a persistent launch was abandoned): the frame is repeated
         // from the state before it on the path that evaluates the clamp pivot by pivot
@@ -597,6 +614,7 @@ int srukf_destroy(srukf_ctx* c)
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
+    if (c->ck_stream) { hipStreamSynchronize(c->ck_stream); hipStreamDestroy(c->ck_stream); hipEventDestroy(c->ck_e1); hipEventDestroy(c->ck_e2); }
     if (c->own_stream && c->stream) hipStreamSynchronize(c->stream);
     if (c->hstage) {
         // keep ONE pinned staging buffer for the next context (pinning 16 MB costs milliseconds; map changes rebuild contexts)
@@ -828,8 +846,10 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     if (N == 0) { c->phase = 2; return SRUKF_OK; }                       // empty map: nothing to predict
     if (!c->step_fast) seq_predict_measurement(c, false);                // (fast path: the statistics rode on srukf_predict_motion's k_pxy2 launch: this call is a copy)
     double* hs = c->hstage;
-    const size_t mp = c->d.mp;                                           // (h | Si | visible are one device allocation: one copy)
-    HIPCHK(c, hipMemcpyAsync(hs, c->h, sizeof(double) * (mp + 4 * (size_t)N) + sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
+    const size_t mp = c->d.mp;                                           // (h | Si | visible are one device allocation: one transfer)
+    const size_t out_bytes = sizeof(double) * (mp + 4 * (size_t)N) + sizeof(int) * N;
+    if (c->step_fast) launch_export(c->stream, c->h, out_bytes, nullptr, 0, hs);       // a kernel writes the pinned buffer: no blit, no gap behind it
+    else HIPCHK(c, hipMemcpyAsync(hs, c->h, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (h) memcpy(h, hs, sizeof(double) * 2 * N);

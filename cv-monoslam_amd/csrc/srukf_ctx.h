@@ -201,6 +201,8 @@ struct srukf_ctx {
     bool proj_valid = false; double proj_odo[6] = { 0, 0, 0, 0, 0, 0 };   // ... and that tail projected the frame with this odometry pair (Z, DZ, the table, fs->ctl)
     bool fs_seq_step = false;              // fs->odo_seq points at odo_step (srukf_run_frames_async points it back at the staged sequence)
     bool last_update_sequential = false;   // a host that updates in SRUKF_UPDATE_SEQUENTIAL mode never takes the fast path (decided at predict time)
+    hipStream_t ck_stream = nullptr; hipEvent_t ck_e1 = nullptr, ck_e2 = nullptr; bool ck_pending = false;   // the copy of the state before the frame runs BESIDE the frame's
+                                           // first launch on a stream of its own (it only has to be complete before k_gain touches S): step_ck_join
     bool robot_cached = false;             // the 20 doubles behind *hfs hold P4 and the pose of the CURRENT state (fast path: fetched with the frame's status)
     bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
@@ -246,7 +248,9 @@ void launch_set_seq(hipStream_t st, FrameScalars* fs, const double* odo_seq, int
 void launch_set_frame(hipStream_t st, FrameScalars* fs, int frame, int clear_clamp);
 void launch_set_traj(hipStream_t st, FrameScalars* fs, double* traj_base);
 void launch_set_run(hipStream_t st, FrameScalars* fs, int frame, int clear_clamp, double* traj_base);
-void launch_set_step(hipStream_t st, FrameScalars* fs, const double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh);
+void launch_set_step(hipStream_t st, FrameScalars* fs, double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh, const double poses[9]);
+void launch_set_next_pose(hipStream_t st, FrameScalars* fs, double* odo, const double pose[3]);
+void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned);   // device -> pinned host memory, two segments of 8-byte words
 void launch_set_frame_control(hipStream_t st, FrameScalars* fs);
 void launch_commit_motion(hipStream_t st, int n, int ld, double* X, double* S, const double* Cm, const FrameScalars* fs, double* A, const int* iperm, int rk);
 void launch_sym_permute(hipStream_t st, int n, int ld, const double* src, int lds, double* dst, const int* map);
@@ -279,6 +283,7 @@ struct ProfScope {
 void step_commit_motion(srukf_ctx* c);
 void step_invalidate(srukf_ctx* c);
 void step_state_replaced(srukf_ctx* c);
+void step_ck_join(srukf_ctx* c);
 
 // ---- launch sequences (srukf_replay.hip) ----
 void quantize_state(srukf_ctx* c);
@@ -314,6 +319,7 @@ int update_null_set(srukf_ctx* c);
 void drop_graphs(srukf_ctx* c);
 void set_null_canonical(srukf_ctx* c);
 int read_fs(srukf_ctx* c);
+int read_fs_host(srukf_ctx* c);
 int set_shared(srukf_ctx* c, int shared, int tenants);
 void replay_one_frame(srukf_ctx* c);
 

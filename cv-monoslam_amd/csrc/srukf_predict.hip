@@ -635,18 +635,37 @@ __global__ __launch_bounds__(256) void k_traj(KDims d, const double* __restrict_
 // X (may be null): the bs state entries of the block are appended behind the bs x bs values (the robot view the step-wise API hands back with a frame's status)
 __global__ __launch_bounds__(256) void k_block_cov(KDims d, const double* __restrict__ S, int off, int bs, double* __restrict__ out, const double* __restrict__ X)
 {
-    __shared__ double red[16];
+    // one pass over the rows k <= off + bs - 1 for all bs (bs + 1) / 2 column pairs at once (bs <= 6: 21 sums), one block reduction — round 4 ran one reduction per pair,
+    // ten dependent passes for the robot block that the step-wise API hands back with every frame's status
+    __shared__ double red[16 * 21];
     const int ld = d.np;
     if (X && (int)threadIdx.x < bs) out[bs * bs + threadIdx.x] = X[off + threadIdx.x];
-    for (int a = 0; a < bs; a++)
-        for (int b = a; b < bs; b++) {
-            double v[1] = { 0.0 };
-            const int kmax = off + a;   // S upper triangular: S[k][off+a] = 0 for k > off+a
-            for (int k = threadIdx.x; k <= kmax; k += blockDim.x) v[0] += S[(size_t)k * ld + off + a] * S[(size_t)k * ld + off + b];
-            block_sum<1>(v, red);
-            if (threadIdx.x == 0) { out[a * bs + b] = v[0]; out[b * bs + a] = v[0]; }
-            __syncthreads();
+    double v[21];
+#pragma unroll
+    for (int q = 0; q < 21; q++) v[q] = 0.0;
+    // eight rows per thread and trip, all their loads requested before the first product (a row per trip was one memory round trip per 256 rows: 12 us at n = 1204)
+    for (int k0 = threadIdx.x; k0 < off + bs; k0 += 8 * 256) {  // S upper triangular: S[k][off + a] = 0 for k > off + a
+        double s[8][6];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + 256 * u;
+#pragma unroll
+            for (int e = 0; e < 6; e++) s[u][e] = (e < bs && k < off + bs && off + e >= k) ? S[(size_t)k * ld + off + e] : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a; b < 6; b++) v[q++] += s[u][a] * s[u][b];
+        }
+    }
+    block_sum<21>(v, red);
+    if (threadIdx.x != 0) return;
+    int q = 0;
+    for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) { if (a < bs && b < bs) { out[a * bs + b] = v[q]; out[b * bs + a] = v[q]; } q++; }
 }
 
 // k_landmarks_cartesian: getFeatureCartesianInformation (SLAM.cpp:2721-2751) for ALL landmarks in one launch — the

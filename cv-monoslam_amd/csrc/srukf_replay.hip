@@ -47,8 +47,12 @@ __global__ void k_set_run(FrameScalars* fs, int frame, int clear_clamp, double* 
 
 // Step-wise API, fast path: start of a frame.  odo = (prev, cur[, next]) poses on the device: a staged sequence of one (two) frames the frame scalars point at.
 // fresh: nothing prepared this frame (the control, the flags of the constant rows); otherwise the previous frame's tail prepared fs->ctl and projected the frame.
-__global__ void k_set_step(FrameScalars* fs, const double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh)
+// (the poses arrive as kernel arguments and are written to the device buffer here: a 72-byte host-to-device copy in front of the frame's first launch cost 12 us of stream
+//  time — 4.5 for the blit kernel, 7.5 of gap behind it; scripts/profile_step.sh)
+struct StepPoses { double v[9]; };
+__global__ void k_set_step(FrameScalars* fs, double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh, StepPoses po)
 {
+    for (int e = 0; e < 9; e++) odo[e] = po.v[e];
     fs->odo_seq = odo; fs->seqF = seqF;
     fs->a[0] = a1; fs->a[1] = a2; fs->a[2] = a3; fs->a[3] = a4;
     fs->frame = 0;
@@ -60,6 +64,14 @@ __global__ void k_set_step(FrameScalars* fs, const double* odo, int seqF, double
 }
 
 __global__ void k_set_frame_control(FrameScalars* fs) { srukf_prepare_control(fs); }
+// the next frame's pose announced after srukf_predict_motion (srukf_predict_motion_next): third pose of the step-wise sequence, which then has two frames
+__global__ void k_set_next_pose(FrameScalars* fs, double* odo, double x, double y, double th) { odo[6] = x; odo[7] = y; odo[8] = th; fs->odo_seq = odo; fs->seqF = 2; }
+// Small results for the host (h | Si | visible after the predict half; frame scalars + robot view after the update half) written straight into its pinned buffer by a kernel:
+// a hipMemcpyAsync of a few KB is a blit kernel plus ~7.5 us of gap behind it on the stream (scripts/profile_step.sh); this is one short launch.  Two segments, 8-byte words.
+__global__ __launch_bounds__(256) void k_export(const unsigned long long* __restrict__ a, int na, const unsigned long long* __restrict__ b, int nb, unsigned long long* __restrict__ dst)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb; i += gridDim.x * 256) dst[i] = i < na ? a[i] : b[i - na];
+}
 
 // ... and the commit of its motion step on demand (a state getter or srukf_associate between predict and update; a frame without a match): what k_gain does with Cmat /
 // the state update with fs->Xr1 — the new last four columns of S (and of the permuted copy), the new robot mean.  Idempotent: k_gain / the update write the same values again.
@@ -133,7 +145,17 @@ void launch_set_seq(hipStream_t st, FrameScalars* fs, const double* odo_seq, int
 void launch_set_frame(hipStream_t st, FrameScalars* fs, int frame, int clear_clamp) { hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, st, fs, frame, clear_clamp); }
 void launch_set_traj(hipStream_t st, FrameScalars* fs, double* traj_base) { hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, st, fs, traj_base); }
 void launch_set_run(hipStream_t st, FrameScalars* fs, int frame, int clear_clamp, double* traj_base) { hipLaunchKernelGGL(k_set_run, dim3(1), dim3(1), 0, st, fs, frame, clear_clamp, traj_base); }
-void launch_set_step(hipStream_t st, FrameScalars* fs, const double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh) { hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, fs, odo, seqF, a1, a2, a3, a4, fresh); }
+void launch_set_step(hipStream_t st, FrameScalars* fs, double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh, const double poses[9])
+{
+    StepPoses po; for (int e = 0; e < 9; e++) po.v[e] = poses[e];
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, fs, odo, seqF, a1, a2, a3, a4, fresh, po);
+}
+void launch_set_next_pose(hipStream_t st, FrameScalars* fs, double* odo, const double pose[3]) { hipLaunchKernelGGL(k_set_next_pose, dim3(1), dim3(1), 0, st, fs, odo, pose[0], pose[1], pose[2]); }
+void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned)
+{
+    const int na = (int)((bytes_a + 7) / 8), nb = (int)((bytes_b + 7) / 8);
+    hipLaunchKernelGGL(k_export, dim3((na + nb + 255) / 256 > 8 ? 8 : (na + nb + 255) / 256), dim3(256), 0, st, (const unsigned long long*)a, na, (const unsigned long long*)b, nb, (unsigned long long*)host_pinned);
+}
 void launch_set_frame_control(hipStream_t st, FrameScalars* fs) { hipLaunchKernelGGL(k_set_frame_control, dim3(1), dim3(1), 0, st, fs); }
 void launch_commit_motion(hipStream_t st, int n, int ld, double* X, double* S, const double* Cm, const FrameScalars* fs, double* A, const int* iperm, int rk) { hipLaunchKernelGGL(k_commit_motion, dim3((n + 255) / 256), dim3(256), 0, st, n, ld, X, S, Cm, fs, A, iperm, rk); }
 void launch_sym_permute(hipStream_t st, int n, int ld, const double* src, int lds, double* dst, const int* map) { hipLaunchKernelGGL(k_sym_permute, dim3(ld), dim3(256), 0, st, n, ld, src, lds, dst, map); }
@@ -312,9 +334,9 @@ bool replay_fuse_mode(const srukf_ctx* c)
 }  // namespace srukf_impl
 
 // (Round 5: the plan sweep over every N found the launch ABANDONED with 22 CUs free — N = 267 .. 275: pivot + 233 workers, ~290 helper jobs behind them — and fine with 34
-//  — N = 266 —: the head fold is kept to plans that leave a whole XCD's worth of CUs to the helpers; the others run the k_syrk head launch in front.  16 was never exercised
-//  between 9 and 34 before that sweep.)
-#define SRUKF_HEAD_FOLD_MIN_FREE_CUS 32
+//  — N = 266 —; the first to give up is a worker waiting for the head tiles (srukf_debug_get "abort_code": site 3), why the helpers do not get there in time is not established.
+//  The head fold is kept to plans that leave at least the 34 CUs measured good; the others run the k_syrk head launch in front.  16 was never exercised between 9 and 34 before.)
+#define SRUKF_HEAD_FOLD_MIN_FREE_CUS 34
 
 namespace srukf_impl {
 
@@ -707,6 +729,11 @@ int read_fs(srukf_ctx* c)
 {
     HIPCHK(c, hipMemcpyAsync(c->hfs, c->fs, sizeof(FrameScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return read_fs_host(c);
+}
+// the frame scalars are in *c->hfs already (the step-wise fast path has a kernel write them there with the robot view)
+int read_fs_host(srukf_ctx* c)
+{
     if (c->hfs->clamp_rows > 0 && c->hfs->clamp_frame == 0x7fffffff) c->hfs->clamp_frame = c->hfs->frame - 1;   // the run's last frame
     if (c->hfs->gmw_aborts > 0 && c->gmw_shared != 2) {
         // a persistent launch did not get all its workgroups onto the GPU in time (somebody else is using it, or the two launches of a split-form pair were not

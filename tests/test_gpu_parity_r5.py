@@ -25,7 +25,7 @@ PLAN_SWEEP = [
     (159, dict(fuse=1, red_perm=1, fold=0, head_fold=0, tpw=1)),
     (160, dict(fuse=1, fold=1, head_fold=1, red_perm=0, tpw=1)),            # T = 16: the owners' fold and the head fold (the headline's plan: N = 200)
     (266, dict(fuse=1, fold=1, head_fold=1, tpw=1, persist=1)),
-    (267, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),             # fewer than 32 CUs left beside pivot + workers (here 22): k_syrk head launch in front
+    (267, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),             # fewer than 34 CUs left beside pivot + workers (here 22): k_syrk head launch in front
     (276, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),
     (277, dict(fuse=1, fold=1, head_fold=0, tpw=2, persist=1)),             # two register tiles per worker
     (287, dict(fuse=1, fold=1, head_fold=0, tpw=2)),
