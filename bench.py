@@ -11,6 +11,10 @@ configs[2] (the configuration the metric's target is quoted on): 200 inverse-dep
 n = 1204, L = 2419 sigma points, fp64.  With --gpus N every rank runs its own independent
 sequence (Monte-Carlo run: shared initial map broadcast from rank 0 over RCCL, own measurement
 noise) — weak scaling, no per-frame collective.  Rank 0 prints ONE JSON line.
+
+The timed region is EXACTLY K frames between barrier + synchronize on both sides, max over ranks; it is run --repetitions times (default 5) on consecutive blocks of the
+staged sequence and `value` / `ms_per_step` are the MEDIAN repetition (`value_repetitions` lists all of them; `run_fixed_us` = what a run of K frames costs besides its frames).
+`launch_plan` names the kernels' plan and every fallback counter; `step_api` is the drop-in rate (one frame at a time through a C++ host: not the headline value).
 """
 from __future__ import annotations
 

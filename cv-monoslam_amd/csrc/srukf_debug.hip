@@ -223,7 +223,7 @@ int srukf_debug_upload(srukf_ctx* c, const char* key, const double* in, long lon
 int srukf_debug_starve_workers(srukf_ctx* c, int on)
 {
     if (!c) return SRUKF_ERR_BAD_ARG;
-    c->debug_starve = on ? 1 : 0;
+    c->debug_starve = on == 2 ? 2 : on ? 1 : 0;              // 2: only split-form pairs start without their tile launch (the single persistent launch below them is not starved)
     step_invalidate(c);
     drop_graphs(c);                                    // the captured frames contain one or the other launch sequence
     return SRUKF_OK;

@@ -35,7 +35,9 @@
 // get merged by the structurizer into a lane-divergent loop around the workgroup barrier (wave 0 then executes
 // s_barrier more often than the other waves: hang).  Uniform branches leave EXEC alone; 64 lanes loading or storing
 // the same flag word are one memory request.
+#ifndef GMW_XWG_LIMIT
 #define GMW_XWG_LIMIT (1 << 16)                 // ~50 ms; a legitimate wait is over in microseconds
+#endif
 __device__ __forceinline__ unsigned long long gmw_uniform64(unsigned long long v)
 {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);

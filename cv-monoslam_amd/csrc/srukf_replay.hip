@@ -507,7 +507,7 @@ void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced)
     if (gmw_use_persist(c) && gmw_plan_persists(c, gp)) {
         // srukf_debug_starve_workers (tests only): launch without workers, as if the GPU were taken — the pivot's bounded wait
         // expires, the frame is flagged and repeated on the exact path, and the context falls back to one launch per panel
-        const int workers = c->debug_starve ? 0 : gp.workers;
+        const int workers = c->debug_starve == 1 ? 0 : gp.workers;   // (2: only a split-form pair is starved — the tier below it then runs undisturbed)
         if (split_form(c, gp, true)) {                         // (srukf_debug_starve_workers: the pair without its tile launch)
             // the tile launch depends on what produced Gbuf, not on the pivot / slab launch: fork before, join after (in a capture: two parallel branches)
             if (c->dbg.split_record) hipMemcpyAsync(c->Gbak, Gbuf, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);

@@ -272,7 +272,7 @@ int  srukf_profile_reset(srukf_ctx* ctx);
  * factorisation launches of this context start without their worker workgroups, as if another process held the GPU (exercises the
  * bounded waits and the fallback to per-panel launches). */
 int  srukf_debug_poke_state(srukf_ctx* ctx, int row, int col, double value);
-int  srukf_debug_starve_workers(srukf_ctx* ctx, int on);
+int  srukf_debug_starve_workers(srukf_ctx* ctx, int on);      /* on = 2: only the split form's pair is starved (the tier it falls back to runs undisturbed) */
 /* Study hook, not for hosts: lets srukf_set_storage accept SRUKF_STORAGE_F32_MIXED below its epsilon floor (where the filter
  * diverges; scripts/mixed_eps_study.py documents exactly that). */
 int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);

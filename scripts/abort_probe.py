@@ -11,6 +11,9 @@ import __graft_entry__ as ge  # noqa: E402
 
 pkg = ge.load_package()
 synth, srukf = pkg.synth, pkg.srukf
+if len(sys.argv) > 5:
+    srukf.load_library(sys.argv[5])                            # an A/B build (scripts/build_variants.sh), e.g. with a longer wait bound
+import time
 
 N = int(sys.argv[1]); head_fold = int(sys.argv[2]) if len(sys.argv) > 2 else 1; F = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 p = synth.scene_params()
@@ -24,14 +27,16 @@ f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matche
 keys = ["plan_T", "plan_Tp", "plan_tiles", "plan_workers", "plan_persist", "plan_fold", "plan_head_fold", "plan_red_perm", "plan_fuse", "split_form"]
 print("N", N, "head_fold", head_fold, {k: f.debug_get(k) for k in keys})
 for t in range(F):
+    t0 = time.perf_counter()
     try:
         f.run_frames_async(t, 1); f.synchronize()
-        st = "ok"
+        st = "ok %.1f ms" % ((time.perf_counter() - t0) * 1e3)
     except srukf.SrukfError as e:
         st = f"{e}"
     code = f.debug_get("abort_code")
     print(" frame", t, st, {k: f.debug_get(k) for k in ("gmw_aborts", "clamp_rows", "gmw_shared", "plan_persist", "plan_fold", "plan_head_fold")}, "clamp_info", f.clamp_info(),
           "abort site", code >> 32, "workgroup", (code & 0xffffffff) - 1)
-    if st != "ok":
+    if not st.startswith("ok"):
+        print("   (%.1f ms)" % ((time.perf_counter() - t0) * 1e3))
         break
 f.close()
