@@ -26,6 +26,9 @@ f.debug_set("head_fold", head_fold); f.debug_set("use_graph", 0)
 f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
 keys = ["plan_T", "plan_Tp", "plan_tiles", "plan_workers", "plan_persist", "plan_fold", "plan_head_fold", "plan_red_perm", "plan_fuse", "split_form"]
 print("N", N, "head_fold", head_fold, {k: f.debug_get(k) for k in keys})
+dbg = len(sys.argv) > 5 and "DBG" in sys.argv[5]
+if dbg:
+    f.debug_gmw_stamps()                                      # arms the time stamps of the diagnostic build (10 ns ticks of s_memrealtime)
 for t in range(F):
     t0 = time.perf_counter()
     try:
@@ -35,7 +38,18 @@ for t in range(F):
         st = f"{e}"
     code = f.debug_get("abort_code")
     print(" frame", t, st, {k: f.debug_get(k) for k in ("gmw_aborts", "clamp_rows", "gmw_shared", "plan_persist", "plan_fold", "plan_head_fold")}, "clamp_info", f.clamp_info(),
-          "abort site", code >> 32, "workgroup", (code & 0xffffffff) - 1)
+          "abort site", code >> 32, "workgroup", (code & 0xffffffff) - 1, "| diagnostic build: helpers started / finished", f.debug_get("pad1"), f.debug_get("pad2"),
+          "head_done / head_crit at the last exit", f.debug_get("pad3"), f.debug_get("pad4"), "grid", f.debug_get("pad5"), "helpers", f.debug_get("pad6"))
+    if dbg:
+        st_ = f.debug_gmw_stamps().astype(np.int64)
+        def row(p):
+            r = st_[2048 + 8 * p:2048 + 8 * p + 8]
+            return r
+        base = row(128)[0]
+        def rel(r):
+            return [round((int(v) - int(base)) / 100.0, 1) if v else None for v in r]
+        print("   stamps (us after the pivot's start): pivot [start, head tiles seen, end]", rel(row(128))[:3], "| worker 1 [start, own tiles formed, head tiles seen, end]", rel(row(129))[:4],
+              "| last worker", rel(row(130))[:4], "| helpers [first start, first end, last end]", rel(row(131))[:3], "| helper job 0 [start, S part, U part, split-K sum, stores, barrier]", rel(row(132))[:7])
     if not st.startswith("ok"):
         print("   (%.1f ms)" % ((time.perf_counter() - t0) * 1e3))
         break

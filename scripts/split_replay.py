@@ -62,7 +62,8 @@ if __name__ == "__main__":
     path = sys.argv[3] if len(sys.argv) > 3 else "/tmp/split_record.npz"
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     f, sc = make_filter(N)
-    assert f.debug_get("split_form") == 1, "this size does not factor with the split form"
+    # (replay: under rocprofv3 --pmc the side-stream probe fails — dispatches are serialised — so split_form reads 0 there; the replay only needs the slab buffers)
+    assert (f.debug_get("split_form") == 1) if mode == "record" else (f.debug_get("plan_slab_panels") > 0), "this size does not factor with the split form"
     sz = sizes(f)
     if mode == "record":
         f.run_frames(0, 4)
