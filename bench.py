@@ -96,15 +96,16 @@ def pmc_traffic_split(tag):
     return sum(ks[k]["traffic_bytes"] for k in SPLIT_KERNELS), os.path.relpath(files[-1], ROOT)
 
 
-def pmc_mfma_split(tag):
-    """pmc_mfma for the pair: matrix-pipe busy cycles of both over the duration of the longer one (they run concurrently), MFMA flops of both."""
+def pmc_mfma_split(tag, pair_us=None):
+    """pmc_mfma for the pair: matrix-pipe busy cycles of both over the pair's duration — pair_us, measured live in this run (the counters come from each launch
+    replayed ALONE, scripts/split_replay.py: their own durations are not the pair's); without it the longer of the two alone —, MFMA flops of both."""
     files = profile_files("*_mfma.json", tag)
     if not files:
         return None, None, None
     ks = json.load(open(files[-1])).get("kernels", {})
     if not all(k in ks for k in SPLIT_KERNELS):
         return None, None, os.path.relpath(files[-1], ROOT)
-    dur_us = max(ks[k]["avg_duration_us"] for k in SPLIT_KERNELS)
+    dur_us = pair_us or max(ks[k]["avg_duration_us"] for k in SPLIT_KERNELS)
     busy = sum(ks[k]["SQ_VALU_MFMA_BUSY_CYCLES"] for k in SPLIT_KERNELS)
     return busy / (dur_us * 2.4e3 * 1024) * 100.0, sum(ks[k]["mfma_gflop"] for k in SPLIT_KERNELS), os.path.relpath(files[-1], ROOT)
 
@@ -397,7 +398,12 @@ def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
     fb = plan_keys(f)
     if split:
         roof["traffic"], roof["traffic_source"] = pmc_traffic_split("n500")
-        roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma_split("n500")
+        roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma_split("n500", avg_s * 1e6)
+        if roof["traffic"]:
+            # compulsory bytes of the factorisation: the kept rows of the matrix read once and the factor rows written once (2 rp n doubles: srukf_replay.hip's model)
+            roof["traffic_over_compulsory"] = roof["traffic"] / by
+            roof["counters_note"] = ("rocprofv3 --pmc serialises dispatches and the pair's two launches wait for each other: the counters are from each launch replayed ALONE against the "
+                                     "operands and flags of one recorded frame (scripts/split_replay.py; both reproduce the recorded outputs bit for bit)")
     else:
         roof["traffic"], roof["traffic_source"] = pmc_traffic(dom, "n500")
         roof["mfma_busy_pct"], roof["mfma_gflop_counted"], roof["mfma_source"] = pmc_mfma(dom, "n500")

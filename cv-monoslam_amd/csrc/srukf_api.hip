@@ -262,6 +262,21 @@ void step_commit_motion(srukf_ctx* c)
 
 }  // namespace srukf_impl
 
+// Wait for an export of the fast path: spin on the pinned flag word the export kernel writes behind its data (a completion signal through hipStreamSynchronize costs
+// ~10 us more per round trip); after ~2 ms without it — or with the switch off — the stream is synchronised the ordinary way (which also surfaces a faulted launch).
+static unsigned long long* step_flag(srukf_ctx* c) { return (unsigned long long*)((char*)c->hfs + sizeof(FrameScalars) + sizeof(double) * 32); }
+static int step_wait_export(srukf_ctx* c, unsigned long long seq)
+{
+    if (c->dbg.step_spin) {
+        volatile unsigned long long* f = step_flag(c);
+        for (int spins = 0; spins < 400000; spins++) {
+            if (*f == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return SRUKF_OK; }
+            __builtin_ia32_pause();
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SRUKF_OK;
+}
 static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
 {
     const KDims& d = c->d;
@@ -371,9 +386,10 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     seq_refactor(c, 0, d.mp, false, false, false, true, true, true);
     // the robot view (pose, 4 x 4 block of P: what the host records per frame, SLAM.cpp:3539-3556) comes back with the frame's status: srukf_get_robot then costs no round trip
     srukf_launch_block_cov(c->stream, d, c->S, d.n - 4, 4, c->small, c->X);
-    launch_export(c->stream, c->fs, sizeof(FrameScalars), c->small, sizeof(double) * 20, c->hfs);       // status + robot view: one short launch, no copies
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = read_fs_host(c); if (rc) return rc;
+    const unsigned long long seq = ++c->step_seq;
+    launch_export(c->stream, c->fs, sizeof(FrameScalars), c->small, sizeof(double) * 20, c->hfs, c->dbg.step_spin ? step_flag(c) : nullptr, seq);       // status + robot view: one short launch, no copies
+    int rc = step_wait_export(c, seq); if (rc) return rc;
+    rc = read_fs_host(c); if (rc) return rc;
     if (c->hfs->clamp_rows > 0) {
         // flagged (the reference's theta clamp would have been active, a skipped direction was not null, a persistent launch was abandoned): the frame is repeated
         // from the state before it on the path that evaluates the clamp pivot by pivot
@@ -585,9 +601,10 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     if (g_spare_stage && g_spare_stage_bytes >= c->hstage_bytes) {         // pinned staging of a context that was just rebuilt (map change)
         c->hstage = g_spare_stage; c->hstage_bytes = g_spare_stage_bytes; g_spare_stage = nullptr; g_spare_stage_bytes = 0;
     }
-    if ((!c->hstage && hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess) || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars) + sizeof(double) * 32) != hipSuccess) {
+    if ((!c->hstage && hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess) || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars) + sizeof(double) * 40) != hipSuccess) {
         g_create_error = "hipHostMalloc failed"; srukf_destroy(c); return SRUKF_ERR_NOMEM;
     }
+    memset(c->hfs, 0, sizeof(FrameScalars) + sizeof(double) * 40);      // (the flag word behind the robot view starts below every sequence number)
     int rc = srukf_reset(c);
     if (rc) { g_create_error = c->err; srukf_destroy(c); return rc; }
     *out = c;
@@ -848,9 +865,14 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     double* hs = c->hstage;
     const size_t mp = c->d.mp;                                           // (h | Si | visible are one device allocation: one transfer)
     const size_t out_bytes = sizeof(double) * (mp + 4 * (size_t)N) + sizeof(int) * N;
-    if (c->step_fast) launch_export(c->stream, c->h, out_bytes, nullptr, 0, hs);       // a kernel writes the pinned buffer: no blit, no gap behind it
-    else HIPCHK(c, hipMemcpyAsync(hs, c->h, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->step_fast) {                                                  // a kernel writes the pinned buffer: no blit, no gap behind it
+        const unsigned long long seq = ++c->step_seq;
+        launch_export(c->stream, c->h, out_bytes, nullptr, 0, hs, c->dbg.step_spin ? step_flag(c) : nullptr, seq);
+        const int rcw = step_wait_export(c, seq); if (rcw) return rcw;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(hs, c->h, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     HIPCHK(c, hipGetLastError());
     if (h) memcpy(h, hs, sizeof(double) * 2 * N);
     if (Si) memcpy(Si, hs + mp, sizeof(double) * 4 * N);

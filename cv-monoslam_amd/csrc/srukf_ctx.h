@@ -168,6 +168,7 @@ struct srukf_ctx {
         int head_fold = 1;                 // "head_fold": exclusive rank-aware replay without the k_syrk launch (helper workgroups of the persistent launch)
         int nullskip = 1;                  // "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
         int pxy2 = 1;                      // "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
+        int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
     } dbg;
@@ -203,6 +204,7 @@ struct srukf_ctx {
     bool last_update_sequential = false;   // a host that updates in SRUKF_UPDATE_SEQUENTIAL mode never takes the fast path (decided at predict time)
     hipStream_t ck_stream = nullptr; hipEvent_t ck_e1 = nullptr, ck_e2 = nullptr; bool ck_pending = false;   // the copy of the state before the frame runs BESIDE the frame's
                                            // first launch on a stream of its own (it only has to be complete before k_gain touches S): step_ck_join
+    unsigned long long step_seq = 0;       // sequence number of the step-wise fast path's exports: the host spins on a pinned word (behind the robot view) that receives it
     bool robot_cached = false;             // the 20 doubles behind *hfs hold P4 and the pose of the CURRENT state (fast path: fetched with the frame's status)
     bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
@@ -250,7 +252,8 @@ void launch_set_traj(hipStream_t st, FrameScalars* fs, double* traj_base);
 void launch_set_run(hipStream_t st, FrameScalars* fs, int frame, int clear_clamp, double* traj_base);
 void launch_set_step(hipStream_t st, FrameScalars* fs, double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh, const double poses[9]);
 void launch_set_next_pose(hipStream_t st, FrameScalars* fs, double* odo, const double pose[3]);
-void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned);   // device -> pinned host memory, two segments of 8-byte words
+// device -> pinned host memory, two segments of 8-byte words; flag (pinned too, may be null) receives seq behind the data
+void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned, unsigned long long* flag = nullptr, unsigned long long seq = 0);
 void launch_set_frame_control(hipStream_t st, FrameScalars* fs);
 void launch_commit_motion(hipStream_t st, int n, int ld, double* X, double* S, const double* Cm, const FrameScalars* fs, double* A, const int* iperm, int rk);
 void launch_sym_permute(hipStream_t st, int n, int ld, const double* src, int lds, double* dst, const int* map);

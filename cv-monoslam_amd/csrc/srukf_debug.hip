@@ -117,6 +117,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "f32_fuse")) c->dbg.f32_fuse = value ? 1 : 0;
     else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
     else if (!strcmp(key, "step_fast")) c->dbg.step_fast = value ? 1 : 0;
+    else if (!strcmp(key, "step_spin")) c->dbg.step_spin = value ? 1 : 0;
     else if (!strcmp(key, "fused_motion")) c->dbg.fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
     else { c->err = std::string("srukf_debug_set: unknown key ") + key; return SRUKF_ERR_BAD_ARG; }
     drop_graphs(c);
@@ -155,6 +156,14 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     else if (!strcmp(key, "gate_timeouts")) *value = c->hfs->gate_timeouts;
     else if (!strcmp(key, "gmw_shared")) *value = c->gmw_shared;
     else if (!strcmp(key, "split_off")) *value = c->split_off ? 1 : 0;
+    else if (!strncmp(key, "pad", 3) && key[3] >= '1' && key[3] <= '7' && !key[4]) {
+        // diagnostic builds (-DSRUKF_GMW_DBG): words 1..7 of the sync block's pad (helpers started / finished, head counters at the last exit, grid, helpers); cleared by the read
+        const GmwPlan& gp = c->red_r > 0 ? c->gplan_red : c->gplan;
+        unsigned long long v = 0, zero = 0;
+        const size_t off = offsetof(GmwSync, pad) + 8 * (size_t)(key[3] - '0');
+        if (gp.sync) { HIPCHK(c, hipMemcpy(&v, (char*)gp.sync + off, sizeof v, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy((char*)gp.sync + off, &zero, sizeof zero, hipMemcpyHostToDevice)); }
+        *value = (long long)v;
+    }
     else if (!strcmp(key, "abort_code")) {
         // who abandoned a persistent launch first, and where (gmw_abandon, srukf_gmw_persist.hip: site << 32 | blockIdx + 1; 0: nobody since the last read); cleared by the read
         const GmwPlan& gp = c->red_r > 0 ? c->gplan_red : c->gplan;

@@ -635,6 +635,9 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         const int nhead = ha.ntiles + ha.ndx + ha.ngd;
         const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const int job = (int)blockIdx.x - nmain;
+#ifdef SRUKF_GMW_DBG
+        if (tid == 0) atomicAdd(&sy->pad[1], 1ull);             // diagnostic builds: helpers started / finished (srukf_debug_get "pad1" / "pad2")
+#endif
         if ((int)blockIdx.x == nmain) GMW_TS(sy, 131, 0);
         if (job < ha.ntiles) {
             if (job == 0) GMW_TS(sy, 132, 0);
@@ -652,6 +655,10 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         } else if (job < nhead) srukf_rank_gdiag_job(n, ld, u1, ha.ra, &fs->gmax_bits, job - ha.ntiles - ha.ndx);
         if ((int)blockIdx.x == nmain) GMW_TS(sy, 131, 1);
         if ((int)blockIdx.x == (int)gridDim.x - 1) GMW_TS(sy, 131, 2);
+#ifdef SRUKF_GMW_DBG
+        __syncthreads();
+        if (tid == 0) atomicAdd(&sy->pad[2], 1ull);
+#endif
         }
     } else if (role == 0) {
         bool head_ok = true;
@@ -732,6 +739,10 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1) {
             if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
+#ifdef SRUKF_GMW_DBG
+            sy->pad[3] = __hip_atomic_load(&sy->head_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sy->pad[4] = __hip_atomic_load(&sy->head_crit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sy->pad[5] = gridDim.x; sy->pad[6] = (unsigned long long)nhelp;
+#endif
             __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->head_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -68,9 +68,17 @@ __global__ void k_set_frame_control(FrameScalars* fs) { srukf_prepare_control(fs
 __global__ void k_set_next_pose(FrameScalars* fs, double* odo, double x, double y, double th) { odo[6] = x; odo[7] = y; odo[8] = th; fs->odo_seq = odo; fs->seqF = 2; }
 // Small results for the host (h | Si | visible after the predict half; frame scalars + robot view after the update half) written straight into its pinned buffer by a kernel:
 // a hipMemcpyAsync of a few KB is a blit kernel plus ~7.5 us of gap behind it on the stream (scripts/profile_step.sh); this is one short launch.  Two segments, 8-byte words.
-__global__ __launch_bounds__(256) void k_export(const unsigned long long* __restrict__ a, int na, const unsigned long long* __restrict__ b, int nb, unsigned long long* __restrict__ dst)
+// flag (may be null): a word of the same pinned buffer that receives `seq` AFTER the data — every wave's stores made visible at system scope first — so that the host can
+// spin on it instead of going through hipStreamSynchronize (one workgroup then: the flag needs a barrier over all stores).
+__global__ __launch_bounds__(256) void k_export(const unsigned long long* __restrict__ a, int na, const unsigned long long* __restrict__ b, int nb, unsigned long long* __restrict__ dst,
+                                                unsigned long long* flag, unsigned long long seq)
 {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb; i += gridDim.x * 256) dst[i] = i < na ? a[i] : b[i - na];
+    if (flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ... and the commit of its motion step on demand (a state getter or srukf_associate between predict and update; a frame without a match): what k_gain does with Cmat /
@@ -151,10 +159,11 @@ void launch_set_step(hipStream_t st, FrameScalars* fs, double* odo, int seqF, do
     hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, fs, odo, seqF, a1, a2, a3, a4, fresh, po);
 }
 void launch_set_next_pose(hipStream_t st, FrameScalars* fs, double* odo, const double pose[3]) { hipLaunchKernelGGL(k_set_next_pose, dim3(1), dim3(1), 0, st, fs, odo, pose[0], pose[1], pose[2]); }
-void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned)
+void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned, unsigned long long* flag, unsigned long long seq)
 {
     const int na = (int)((bytes_a + 7) / 8), nb = (int)((bytes_b + 7) / 8);
-    hipLaunchKernelGGL(k_export, dim3((na + nb + 255) / 256 > 8 ? 8 : (na + nb + 255) / 256), dim3(256), 0, st, (const unsigned long long*)a, na, (const unsigned long long*)b, nb, (unsigned long long*)host_pinned);
+    const int blocks = flag ? 1 : ((na + nb + 255) / 256 > 8 ? 8 : (na + nb + 255) / 256);
+    hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, st, (const unsigned long long*)a, na, (const unsigned long long*)b, nb, (unsigned long long*)host_pinned, flag, seq);
 }
 void launch_set_frame_control(hipStream_t st, FrameScalars* fs) { hipLaunchKernelGGL(k_set_frame_control, dim3(1), dim3(1), 0, st, fs); }
 void launch_commit_motion(hipStream_t st, int n, int ld, double* X, double* S, const double* Cm, const FrameScalars* fs, double* A, const int* iperm, int rk) { hipLaunchKernelGGL(k_commit_motion, dim3((n + 255) / 256), dim3(256), 0, st, n, ld, X, S, Cm, fs, A, iperm, rk); }
@@ -333,17 +342,26 @@ bool replay_fuse_mode(const srukf_ctx* c)
 
 }  // namespace srukf_impl
 
-// (Round 5: the plan sweep over every N found the launch ABANDONED with 22 CUs free — N = 267 .. 275: pivot + 233 workers, ~290 helper jobs behind them — and fine with 34
-//  — N = 266 —; the first to give up is a worker waiting for the head tiles (srukf_debug_get "abort_code": site 3), why the helpers do not get there in time is not established.
-//  The head fold is kept to plans that leave at least the 34 CUs measured good; the others run the k_syrk head launch in front.  16 was never exercised between 9 and 34 before.)
-#define SRUKF_HEAD_FOLD_MIN_FREE_CUS 34
+// Round 5 measured where the head fold pays and where it cannot run at all (scripts/head_fold_sweep.py, scripts/abort_probe.py with the diagnostic build's time stamps):
+//   * every worker's first step waits for ALL head tiles, and the helpers only get the CUs that pivot + workers leave free: with 261 helper jobs on 34 free CUs (N = 266) the
+//     last one ends 125 us into the launch, the workers idle from 57 us on and the pivot behind them — frames/s with / without the fold: N = 200 5 269 / 5 098, 215 4 847 / 4 713,
+//     230 4 488 / 4 487, 240 4 256 / 4 299, 250 3 681 / 4 179, 266 3 224 / 3 790.  The fold is kept while the helpers are at most 2.25 rounds on the free CUs (N <= 223);
+//   * with 22 free CUs (N = 267 .. 275, pivot + 233 workers) the launch never completes by itself: some helpers run, then no further one starts until the workers give up
+//     (all 270 finish right after the 10.7 ms bound: stamps).  29 or 30 main workgroups on an XCD's 32 CUs leave one of its shader engines without a free CU, and the
+//     dispatcher, which deals workgroups round-robin to the engines, apparently does not skip a full one: with at most 28 per XCD (7 per engine: <= 224 main workgroups, >= 32
+//     CUs free) it never happened.  Until this sweep the threshold was 16 free CUs and nothing between 9 and 34 had ever run: N = 267 .. 275 fell back to one launch per
+//     panel without saying so.
+#define SRUKF_HEAD_FOLD_MIN_FREE_CUS 32
 
 namespace srukf_impl {
 
 bool head_fold_ok(const srukf_ctx* c)
 {
     const int need = g_dbg_head_fold_free.load() > 0 ? g_dbg_head_fold_free.load() : SRUKF_HEAD_FOLD_MIN_FREE_CUS;
-    return c->dbg.head_fold && c->gmw_shared == 0 && c->gplan_red.cus - 1 - c->gplan_red.workers >= need;
+    const int free_cus = c->gplan_red.cus - 1 - c->gplan_red.workers;
+    const int nhelp = c->n_syrk_head_tiles + (c->d.n + 255) / 256 + (c->d.n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;       // as seq_refactor counts them
+    const bool pays = g_dbg_head_fold_free.load() > 0 || 4 * nhelp <= 9 * free_cus;      // (the A/B switch "head_fold_free" overrides the rounds rule: measurements)
+    return c->dbg.head_fold && c->gmw_shared == 0 && free_cus >= need && pays;
 }
 
 void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table, bool fuse)

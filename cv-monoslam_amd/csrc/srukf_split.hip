@@ -127,7 +127,8 @@ int srukf_debug_split_replay(srukf_ctx* c, int which, int reps)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const bool reduced = c->red_r > 0;
     const GmwPlan& gp = reduced ? c->gplan_red : c->gplan;
-    if (!split_form(c, gp, true)) { c->err = "split_replay: this context does not factor with the split form"; return SRUKF_ERR_SEQUENCE; }
+    // (not split_form(): under a profiler that serialises dispatches the side-stream probe fails, and the replay needs no side stream — only the slab buffers)
+    if (!c->gsW || !c->gsL || c->gs_panels < gp.Tp || gp.T < 16) { c->err = "split_replay: this context has no slab buffers (its size does not factor with the split form)"; return SRUKF_ERR_SEQUENCE; }
     const int np = c->d.np, n = c->d.n, Tp = reduced ? c->red_Tp : np / 64;
     unsigned long long epoch = 0;
     HIPCHK(c, hipMemcpy(&epoch, (char*)gp.sync + offsetof(GmwSync, epoch), sizeof epoch, hipMemcpyDeviceToHost));

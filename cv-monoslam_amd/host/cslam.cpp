@@ -410,13 +410,13 @@ void CSLAM::predictMotion()
     const int c = m_frame.counter;
     const double prev[3] = { m_odoXY[2 * c - 2], m_odoXY[2 * c - 1], m_odoTheta.at(1, c - 1) };               // 1444-1450
     const double cur[3]  = { m_odoXY[2 * c], m_odoXY[2 * c + 1], m_odoTheta.at(1, c) };
-    if (!check(srukf_predict_motion(ctx_, prev, cur))) return;
     // the odometry file is loaded whole before the first frame (loadOdometryData): the next frame's pair is known, and announcing it lets this frame's
     // update leave the next frame's sigma points projected (include/srukf.h: srukf_predict_motion_next).  Not across a redirection restart.
     if (c + 1 < m_odoCounter && c + 1 <= CAPACITY && m_odoTheta.at(2, c + 1) != 1) {
         const double next[3] = { m_odoXY[2 * c + 2], m_odoXY[2 * c + 3], m_odoTheta.at(1, c + 1) };
-        check(srukf_predict_motion_next(ctx_, cur, next));
+        if (!check(srukf_predict_motion_next(ctx_, cur, next))) return;
     }
+    check(srukf_predict_motion(ctx_, prev, cur));
 }
 
 // SLAM.cpp:1604-1608 + the bookkeeping of QrAndCholeskyForMeasurement (1724-1745)

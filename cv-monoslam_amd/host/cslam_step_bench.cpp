@@ -124,12 +124,12 @@ int main(int argc, char** argv)
         double t0 = 0.0;
         for (int fr = f0; fr < W + K; fr++) {
             if (fr == W) t0 = now_s();
+            if (hint && fr + 2 <= F) CK(srukf_predict_motion_next(c, &odo[3 * fr + 3], &odo[3 * fr + 6]));      // (before the predict: its first launch then carries the third pose too)
             CK(srukf_predict_motion(c, &odo[3 * fr], &odo[3 * fr + 3]));
             CK(srukf_predict_measurement(c, h.data(), Si.data(), vis.data()));
             if (assoc) { CK(srukf_associate(c, gray.data(), zc.data(), md.data(), corr.data())); for (int k = 0; k < N; k++) matches_dev += md[k]; }
             const double* zz = &z[(size_t)fr * 2 * N];
             for (int k = 0; k < N; k++) m[k] = vis[k];                 // the host's association: every visible landmark found where the scene put it
-            if (hint && fr + 2 <= F) CK(srukf_predict_motion_next(c, &odo[3 * fr + 3], &odo[3 * fr + 6]));
             CK(srukf_update(c, zz, m.data(), SRUKF_NEEDNOT_REORDER, SRUKF_UPDATE_BATCHED));
             CK(srukf_get_robot(c, pose, P4));
         }

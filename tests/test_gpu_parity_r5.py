@@ -1,6 +1,6 @@
 """GPU parity tests added in round 5 (-m gpu).
 
-Which kernels a staged frame launches depends on the landmark count through a handful of thresholds (srukf_api.hip: replay_red_fused / head_fold_ok /
+Which kernels a staged frame launches depends on the landmark count through a handful of thresholds (srukf_replay.hip: replay_red_fused / head_fold_ok /
 replay_fuse_mode / split_form; scripts/plan_sweep.py lists where each flips on a 256-CU device), and in the reference the landmark count changes every few
 frames (SLAM.cpp:552-562, 2443-2460): every N is a product size.  Here the DEFAULT staged replay is held to the live ORACLE on both sides of every threshold,
 each case asserting WHICH plan ran next to the comparison, and to multi-frame oracle fixtures at N = 500 (g9: fp64 and fp32 storage) and N = 800 (g10)."""
@@ -24,8 +24,10 @@ PLAN_SWEEP = [
     (21, dict(fuse=1, motion=2, red_perm=1, fold=0, split=0)),              # "fused tail" mode from here on; k_syrk over the kept rows (T < 16)
     (159, dict(fuse=1, red_perm=1, fold=0, head_fold=0, tpw=1)),
     (160, dict(fuse=1, fold=1, head_fold=1, red_perm=0, tpw=1)),            # T = 16: the owners' fold and the head fold (the headline's plan: N = 200)
-    (266, dict(fuse=1, fold=1, head_fold=1, tpw=1, persist=1)),
-    (267, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),             # fewer than 34 CUs left beside pivot + workers (here 22): k_syrk head launch in front
+    (223, dict(fuse=1, fold=1, head_fold=1, tpw=1, persist=1)),             # the head fold's helpers still fit 2.25 rounds on the CUs pivot + workers leave free
+    (224, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),             # ... from here they do not (measured: the fold loses from N ~ 240): k_syrk head launch in front
+    (266, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),
+    (267, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),             # 22 CUs left beside pivot + 233 workers: the head fold could not run here at all (< 32 free)
     (276, dict(fuse=1, fold=1, head_fold=0, tpw=1, persist=1)),
     (277, dict(fuse=1, fold=1, head_fold=0, tpw=2, persist=1)),             # two register tiles per worker
     (287, dict(fuse=1, fold=1, head_fold=0, tpw=2)),
@@ -423,3 +425,42 @@ def test_abandoned_split_pair_steps_down_one_tier(srukf, synth):
     np.testing.assert_allclose(res[0][0][:, :4], res[1][0][:, :4], rtol=0, atol=1e-9)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-9)
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("mode", ["capi", "capi_hint", "facade"])
+def test_cpp_step_host_equals_the_python_step_api(tmp_path, srukf, synth, mode):
+    """cv-monoslam_amd/host/cslam_step_bench.cpp (what bench.py's `step_api` leg times: a C++ host that calls the C-ABI / monoslam::CSLAM::SLAM() once per frame) ends, bit for
+    bit, where the same calls through the Python binding end: the pose and the robot block it prints against srukf_get_robot after the same F frames."""
+    import json
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cv-monoslam_amd", "cslam_step_bench.bin")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    N, W, K = 60, 3, 12
+    p = synth.scene_params()
+    sc = synth.make_scene(N, W + K, seed=6, p=p)
+    tmp = str(tmp_path)
+    with open(f"{tmp}/scene.bin", "wb") as fh:
+        fh.write(struct.pack("ii", N, W + K)); fh.write(np.array([p["a1"], p["a2"], p["a3"], p["a4"]]).tobytes())
+        fh.write(np.ascontiguousarray(sc["X0"]).tobytes()); fh.write(np.ascontiguousarray(sc["S0"]).tobytes()); fh.write(np.ascontiguousarray(sc["z"]).tobytes())
+    with open(f"{tmp}/odo.txt", "w") as fh:
+        for i, (x, y, th) in enumerate(sc["odo"]):
+            fh.write(f"{i + 1} : {0.1 * i:.3f} {float(x)!r} {float(y)!r} {float(th)!r}\n")
+    args = {"capi": ["mode=capi"], "capi_hint": ["mode=capi", "hint=1"], "facade": ["mode=facade"]}[mode]
+    r = subprocess.run([exe, f"{tmp}/scene.bin", f"{tmp}/odo.txt"] + args + [f"frames={K}", f"warmup={W}"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    f = srukf.Filter(N, p); f.set_state(sc["X0"], sc["S0"])
+    # (the facade starts the robot heading at the first odometry sample's, as loadOdometryData does: SLAM.cpp:397 — zero here, as in X0)
+    for t in range(W + K):
+        f.predict_motion(sc["odo"][t], sc["odo"][t + 1])
+        if mode != "capi" and t + 2 <= W + K:
+            f.predict_motion_next(sc["odo"][t + 1], sc["odo"][t + 2])
+        h, Si, vis = f.predict_measurement()
+        f.update(sc["z"][t], vis.astype(np.int32))
+        pose, P4 = f.get_robot()
+    f.close()
+    assert list(pose) == d["pose"], (list(pose), d["pose"])
+    assert [P4[0, 0], P4[0, 1], P4[1, 0], P4[1, 1]] == d["P_robot"]

@@ -135,3 +135,13 @@ def test_pxy2_tile_list_covers_every_tile_once(pkg):
             for slot, (mt, bt, h, halves) in enumerate(tl):
                 if mt >= 0:
                     assert xcd.setdefault((bt, h), slot % 8) == slot % 8
+
+
+@pytest.mark.parametrize("exe", ["cslam_replay.bin", "cslam_step_bench.bin", "cslam_replay_multi.bin"])
+def test_cpp_hosts_are_built_and_print_their_usage(exe):
+    """The C++ hosts of cv-monoslam_amd/host (the reference's language) link against the in-tree libraries and start without a GPU: no arguments -> usage, exit code 2."""
+    import subprocess
+    path = os.path.join(ROOT, "cv-monoslam_amd", exe)
+    assert os.path.exists(path), "run __graft_entry__.build() first"
+    r = subprocess.run([path], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
