@@ -242,7 +242,7 @@ void step_state_replaced(srukf_ctx* c) { step_ck_join(c); c->step_uncommitted = 
 
 namespace srukf_impl {
 
-void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; c->robot_cached = false; }
+void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; c->robot_cached = false; c->view_cached = false; }
 
 }  // namespace srukf_impl
 
@@ -314,7 +314,12 @@ static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const doubl
         seq_predict_fused(c, 2);
     }
     c->xr1_pending = true;
+    // h | Si | visible reach the host's pinned buffer from the statistics jobs of this very launch (their final passes: the first ~10 us of it), flag behind them: the host
+    // runs its association, and queues the update's launches, while the cross-covariance tiles are still being formed
+    c->meas_seq = c->dbg.step_fuse_export ? ++c->step_seq : 0;
+    c->mirror_next = c->meas_seq != 0;
     seq_pxy(c, true, true, true, true, true);
+    c->mirror_next = false;
     c->step_fast = true; c->step_uncommitted = true;
     c->proj_valid = false;
     HIPCHK(c, hipGetLastError());
@@ -383,11 +388,28 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     step_ck_join(c);
     seq_gain_only(c, hs, (const int*)(hs + mp), true, true, true);
     c->step_uncommitted = false;                               // (k_gain and the state update commit the motion step)
-    seq_refactor(c, 0, d.mp, false, false, false, true, true, true);
-    // the robot view (pose, 4 x 4 block of P: what the host records per frame, SLAM.cpp:3539-3556) comes back with the frame's status: srukf_get_robot then costs no round trip
-    srukf_launch_block_cov(c->stream, d, c->S, d.n - 4, 4, c->small, c->X);
+    // The frame's status and the robot view (pose, 4 x 4 block of P: what the host records per frame, SLAM.cpp:3539-3556; srukf_get_robot then costs no round trip) reach the
+    // pinned buffer from the frame's LAST launch: k_rank_expand<2>'s frame tail forms the block from the factor rows it walks anyway, the last workgroup through exports
+    // (StepExport).  A host that fetched the display view (srukf_get_frame_view: the facade's refreshFeaturesDisplay, SLAM.cpp:2721-2751 per landmark) after its last update
+    // gets it with this one: the landmark launch and one export launch behind the tail, which then raises the flag — no round trip and no copies of its own.
     const unsigned long long seq = ++c->step_seq;
-    launch_export(c->stream, c->fs, sizeof(FrameScalars), c->small, sizeof(double) * 20, c->hfs, c->dbg.step_spin ? step_flag(c) : nullptr, seq);       // status + robot view: one short launch, no copies
+    const bool view = c->dbg.step_fuse_export && c->view_auto && c->dbg.view_auto && c->hview && c->hview_doubles >= 12 * (size_t)N + d.n;
+    if (c->dbg.step_fuse_export && !c->export_cnt) {
+        if (srukf_dmalloc((void**)&c->export_cnt, sizeof(int) * 64 * 64) == hipSuccess) HIPCHK(c, hipMemsetAsync(c->export_cnt, 0, sizeof(int) * 64 * 64, c->stream));
+        else { (void)hipGetLastError(); c->export_cnt = nullptr; }
+    }
+    if (c->dbg.step_fuse_export && c->export_cnt) c->step_export = StepExport{ (unsigned long long*)c->hfs, (int)(sizeof(FrameScalars) / 8), c->small, view ? nullptr : step_flag(c), seq, c->export_cnt };
+    c->step_export_attached = false;
+    seq_refactor(c, 0, d.mp, false, false, false, true, true, true);
+    c->step_export = StepExport{};
+    if (!c->step_export_attached) {                            // (the form with launches of their own: "step_fuse_export" 0, or a tail that is not k_rank_expand<2>)
+        srukf_launch_block_cov(c->stream, d, c->S, d.n - 4, 4, c->small, c->X);
+        launch_export(c->stream, c->fs, sizeof(FrameScalars), c->small, sizeof(double) * 20, c->hfs, (c->dbg.step_spin && !view) ? step_flag(c) : nullptr, seq);
+    }
+    if (view) {
+        srukf_launch_landmarks_cartesian(c->stream, d, c->X, c->S, c->G, c->G + 3 * (size_t)N);
+        launch_export(c->stream, c->G, sizeof(double) * 12 * (size_t)N, c->X, sizeof(double) * d.n, c->hview, step_flag(c), seq);
+    }
     int rc = step_wait_export(c, seq); if (rc) return rc;
     rc = read_fs_host(c); if (rc) return rc;
     if (c->hfs->clamp_rows > 0) {
@@ -403,6 +425,8 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     if (c->proj_valid) { for (int e = 0; e < 3; e++) { c->proj_odo[e] = c->step_odo[3 + e]; c->proj_odo[3 + e] = c->next_odo[3 + e]; } }
     c->next_odo_valid = false;
     c->robot_cached = true;
+    c->view_cached = view;
+    if (view && ++c->view_unused >= 3) c->view_auto = false;   // (nobody reads them)
     c->f32_stale = c->storage == SRUKF_STORAGE_F32;
     c->step_fast_frames++;
     HIPCHK(c, hipGetLastError());
@@ -626,7 +650,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h /* + Si, vis */, c->PxyR, c->D,
                      c->zcur /* + mcur */, c->odocur, c->small, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->odo_step, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -639,6 +663,7 @@ int srukf_destroy(srukf_ctx* c)
         else hipHostFree(c->hstage);
     }
     if (c->hfs) hipHostFree(c->hfs);
+    if (c->hview) hipHostFree(c->hview);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return SRUKF_OK;
@@ -801,6 +826,25 @@ int srukf_get_frame_view(srukf_ctx* c, double* X, double* xyz, double* cov, doub
     if (!c) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->d.N, n = c->d.n;
+    if (c->view_cached) {                                      // exported with the last update's status (step_update_fast)
+        c->view_unused = 0; c->view_hits++;
+        const double* hv = c->hview; const double* hr = (const double*)((const char*)c->hfs + sizeof(FrameScalars));
+        if (xyz) memcpy(xyz, hv, sizeof(double) * 3 * (size_t)N);
+        if (cov) memcpy(cov, hv + 3 * (size_t)N, sizeof(double) * 9 * (size_t)N);
+        if (X) memcpy(X, hv + 12 * (size_t)N, sizeof(double) * n);
+        if (P4) memcpy(P4, hr, sizeof(double) * 16);
+        if (pose4) memcpy(pose4, hr + 16, sizeof(double) * 4);
+        return SRUKF_OK;
+    }
+    if (c->robot_cached && c->dbg.view_auto && N > 0) {        // asked right after an update of the fast path: the next updates bring the view along
+        if (c->hview_doubles < 12 * (size_t)N + n) {
+            if (c->hview) hipHostFree(c->hview);
+            c->hview = nullptr; c->hview_doubles = 0;
+            if (hipHostMalloc((void**)&c->hview, sizeof(double) * (12 * (size_t)N + c->d.np)) == hipSuccess) c->hview_doubles = 12 * (size_t)N + c->d.np;
+            else (void)hipGetLastError();
+        }
+        c->view_auto = c->hview != nullptr; c->view_unused = 0;
+    }
     step_commit_motion(c);
     double* dx = c->G; double* dc = c->G + 3 * (size_t)N; double* dr = c->G + 12 * (size_t)N;        // G is scratch outside the refactorisation
     if (N > 0 && (xyz || cov)) srukf_launch_landmarks_cartesian(c->stream, c->d, c->X, c->S, dx, dc);
@@ -840,7 +884,7 @@ int srukf_predict_motion(srukf_ctx* c, const double odo_prev[3], const double od
     if (!c || !odo_prev || !odo_cur) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->step_uncommitted) { step_commit_motion(c); step_invalidate(c); }      // a frame that was predicted and never updated: its motion step stands (as on the other path)
-    c->step_fast = false; c->robot_cached = false;
+    c->step_fast = false; c->robot_cached = false; c->view_cached = false;
     if (step_fast_eligible(c)) return step_predict_fast(c, odo_prev, odo_cur);
     step_invalidate(c);
     return step_predict_slow(c, odo_prev, odo_cur);
@@ -865,7 +909,9 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     double* hs = c->hstage;
     const size_t mp = c->d.mp;                                           // (h | Si | visible are one device allocation: one transfer)
     const size_t out_bytes = sizeof(double) * (mp + 4 * (size_t)N) + sizeof(int) * N;
-    if (c->step_fast) {                                                  // a kernel writes the pinned buffer: no blit, no gap behind it
+    if (c->step_fast && c->meas_seq) {                                   // the statistics jobs of k_pxy2 have written (or are writing) the pinned buffer themselves
+        const int rcw = step_wait_export(c, c->meas_seq); if (rcw) return rcw;
+    } else if (c->step_fast) {                                           // a kernel writes the pinned buffer: no blit, no gap behind it
         const unsigned long long seq = ++c->step_seq;
         launch_export(c->stream, c->h, out_bytes, nullptr, 0, hs, c->dbg.step_spin ? step_flag(c) : nullptr, seq);
         const int rcw = step_wait_export(c, seq); if (rcw) return rcw;

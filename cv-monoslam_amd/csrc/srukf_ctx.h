@@ -52,7 +52,7 @@ void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*,
 void srukf_launch_gmw_split_alone(hipStream_t, int, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int, const StepExport*);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
@@ -168,6 +168,9 @@ struct srukf_ctx {
         int head_fold = 1;                 // "head_fold": exclusive rank-aware replay without the k_syrk launch (helper workgroups of the persistent launch)
         int nullskip = 1;                  // "nullskip": with pxy2, structurally null directions are projected for their own landmark only (NullSkip)
         int pxy2 = 1;                      // "pxy2": "table" mode forms the cross covariances on the permuted operands (k_pxy2); 0: k_pxy
+        int step_fuse_export = 1;          // "step_fuse_export": the step-wise fast path's results reach the host from the launches that form them (the statistics' final passes inside
+                                           // k_pxy2, the status + robot view from k_block_cov) instead of two k_export launches behind them (0: round 5's first form, for A/B)
+        int view_auto = 1;                 // "view_auto": a host that fetched srukf_get_frame_view after its last update gets the view exported with the next update's status (0: never)
         int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
@@ -204,7 +207,16 @@ struct srukf_ctx {
     bool last_update_sequential = false;   // a host that updates in SRUKF_UPDATE_SEQUENTIAL mode never takes the fast path (decided at predict time)
     hipStream_t ck_stream = nullptr; hipEvent_t ck_e1 = nullptr, ck_e2 = nullptr; bool ck_pending = false;   // the copy of the state before the frame runs BESIDE the frame's
                                            // first launch on a stream of its own (it only has to be complete before k_gain touches S): step_ck_join
+    unsigned long long meas_seq = 0;       // != 0: k_pxy2's statistics jobs mirror h | Si | visible into hstage and raise the flag word with this number (srukf_predict_measurement waits for it)
+    bool step_export_attached = false;     // the last rank_expand carried step_export
+    int* export_cnt = nullptr;             // 64 x 64 ints (zero): first-level counters of the exporting launch (StepExport::cnt)
+    StepExport step_export = {};           // dst != null: the next rank_expand is the step-wise fast path's and exports the frame's status + robot view itself
+    bool mirror_next = false;              // the next seq_pxy is the step-wise fast path's: its MeasArgs carry the host mirror
     unsigned long long step_seq = 0;       // sequence number of the step-wise fast path's exports: the host spins on a pinned word (behind the robot view) that receives it
+    double* hview = nullptr; size_t hview_doubles = 0;      // pinned: xyz (3N) | cov (9N) | X (n) of the state an update of the fast path left, when the host is known to ask for it
+    bool view_auto = false; int view_unused = 0;   // the host called srukf_get_frame_view after its last update -> the following updates export the view with their status; three views nobody read end it
+    int view_hits = 0;
+    bool view_cached = false;              // *hview is the view of the CURRENT state (same lifetime as robot_cached)
     bool robot_cached = false;             // the 20 doubles behind *hfs hold P4 and the pose of the CURRENT state (fast path: fetched with the frame's status)
     bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"

@@ -41,7 +41,7 @@ struct FrameScalars {
     int clamp_rows;            // rows where the GMW theta clamp would have been active
     int clamp_first;           // first such row
     int frame;                 // frame counter for staged sequences
-    int stat_count;            // (unused since round 3: per-group counters below)
+    int stat_count;            // landmark groups whose final pass has reached the host mirror (MeasArgs::hmirror; step-wise API only; the last one clears it)
     int stat_cnt[SRUKF_STAT_GROUPS];          // measurement-statistics jobs finished per landmark group of 32 in the current contraction launch: the last one
                                // of a group runs its final pass
     double* traj_base;         // device trajectory buffer of the current replay (row = absolute frame), or null
@@ -62,6 +62,7 @@ struct FrameScalars {
     int frozen;                // staged replay: a frame was flagged -> k_motion and the persistent factorisation of the later frames of the run
                                // return at once (three quarters of a frame's time; the other kernels would pay a memory round trip per launch
                                // for the test); cleared with the clamp counters (k_set_frame) and by the step-wise API
+    int export_cnt;            // step-wise API: workgroups of the frame's last launch (k_rank_expand<2>) that are through; the last one exports status + robot view (StepExport)
 };
 
 // control from two odometry poses (SLAM.cpp:1444-1458): Ut = (rot1, trans, rot2), Mt = control-noise sigmas
@@ -274,7 +275,17 @@ struct MeasArgs {
                                                                // has run); the statistics are centred on the CENTRE point's robot part (xrob = sigR row 0) and their final pass leaves the raw
                                                                // sums (PxyR rows 0..3) and wi * sum(Z_c - Z_0) (row 4): k_gain, which runs after the reduction, re-centres them on the mean
     double* Cm;                                                // fmode: where the motion reduction leaves R12 / R22 (k_gain commits them)
+    // step-wise API (null / 0 in the replay): h | Si | visible are ONE device allocation starting at h; hmirror is a pinned HOST buffer of the same layout that every landmark
+    // group's final pass fills as well, and the last group stores hseq to *hflag behind it (system scope): the host has the statistics while the launch still forms its tiles
+    char* hmirror; unsigned long long* hflag; unsigned long long hseq;
 };
+
+// Step-wise API (dst null in the replay): the frame's LAST launch hands the frame's status and robot view to the host itself.  Its frame-tail workgroup forms the 4 x 4 robot
+// block of P = S^T S from the factor rows it walks anyway and leaves it, with the pose, in `view` (20 doubles); every workgroup counts itself (cnt, then fs->export_cnt) when its
+// updates of *fs are through, and the last one copies *fs (nfs 8-byte words) and the view to the pinned host buffer dst and stores seq to *flag behind them (system scope).
+// cnt: 64 counters 256 B apart (zero between launches) in front of fs->export_cnt: ~1 250 relaxed device-scope increments of ONE word cost the launch 29 us (they
+// serialise at the memory side); 64 words take ~20 each, the last arrival of each word then counts in fs->export_cnt.
+struct StepExport { unsigned long long* dst; int nfs; double* view; unsigned long long* flag; unsigned long long seq; int* cnt; };
 
 // ---- agent-scope (device-coherent) accesses: data handed from one workgroup to another INSIDE a launch ----
 // The eight XCDs have private, mutually non-coherent L2s; plain stores stay dirty in the writer's L2 until the kernel

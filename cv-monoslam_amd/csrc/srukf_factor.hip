@@ -32,6 +32,28 @@ __device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w,
     __syncthreads();
     if (!last) return;
     meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode);
+    if (!ms.hmirror) return;
+    // step-wise API: the 32 lanes that stored this group's h / Si / visible (one wave; each reads back its own stores) repeat them into the host's pinned buffer; the
+    // group that completes the count raises the flag.  A wave's fence covers all its lanes' stores, and every group fences at system scope BEFORE it counts.
+    if (threadIdx.x >= 32) return;
+    const int k = bx * 32 + (int)threadIdx.x;
+    if (k < d.N) {
+        double* hh = (double*)ms.hmirror;
+        double* hSi = (double*)(ms.hmirror + ((const char*)ms.Si - (const char*)ms.h));
+        int* hvis = (int*)(ms.hmirror + ((const char*)ms.vis - (const char*)ms.h));
+        const double2 hv = *(const double2*)(ms.h + 2 * k);
+        const double2 s0 = *(const double2*)(ms.Si + 4 * k), s1 = *(const double2*)(ms.Si + 4 * k + 2);
+        *(double2*)(hh + 2 * k) = hv; *(double2*)(hSi + 4 * k) = s0; *(double2*)(hSi + 4 * k + 2) = s1;
+        hvis[k] = ms.vis[k];
+    }
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(&ms.fs->stat_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == ms.gx - 1) {
+            __hip_atomic_store(&ms.fs->stat_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ms.hflag, ms.hseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -72,7 +72,7 @@ __device__ __forceinline__ void rank_expand_body(int n, int ld, int r, double ep
                                                  FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
                                                  double* __restrict__ A, double* __restrict__ sigR, double gamma,
                                                  const KDims& d, const KWeights& w,
-                                                 const srukf_params& p, double* __restrict__ Z, double* __restrict__ DZ, int f32, const int bid)
+                                                 const srukf_params& p, double* __restrict__ Z, double* __restrict__ DZ, int f32, const int bid, const StepExport& ex)
 {
     constexpr bool PROJ = MODE == 2;
     // f32 (fp32 storage, "fused tail" mode): every value this launch writes into S / the permuted copy — and reads back for the table, the projection and
@@ -172,6 +172,34 @@ __device__ __forceinline__ void rank_expand_body(int n, int ld, int r, double ep
             v[0] += p * p; v[1] += p * q; v[2] += q * q;
         }
         block_sum<3>(v, red);
+        if (ex.dst) {
+            // step-wise API: the whole 4 x 4 robot block (what srukf_get_robot hands out, SLAM.cpp:3539-3556) from the same walk over the kept rows, and the pose: the view
+            // the host gets with the frame's status.  Device-scope stores: the workgroup that exports them may sit on another XCD.
+            __shared__ double red4[16 * 10];
+            int bc[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) bc[e] = iperm[n - 4 + e];
+            double v4[10];
+#pragma unroll
+            for (int q = 0; q < 10; q++) v4[q] = 0.0;
+            for (int a = threadIdx.x; a < r; a += 256) {
+                double s4[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) s4[e] = (bc[e] >= a) ? rnd(Sp[(size_t)a * ld + bc[e]]) : 0.0;
+                int q = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int g = e; g < 4; g++) v4[q++] += s4[e] * s4[g];
+            }
+            block_sum<10>(v4, red4);
+            if (threadIdx.x == 0) {
+                int q = 0;
+                for (int e = 0; e < 4; e++)
+                    for (int g = e; g < 4; g++) { st_dev(ex.view + 4 * e + g, v4[q]); st_dev(ex.view + 4 * g + e, v4[q]); q++; }
+                for (int e = 0; e < 4; e++) st_dev(ex.view + 16 + e, X[n - 4 + e]);
+            }
+        }
         if (threadIdx.x == 0 && do_traj) {
             double* traj = fs->traj_base;
             if (traj) {
@@ -179,8 +207,13 @@ __device__ __forceinline__ void rank_expand_body(int n, int ld, int r, double ep
                 for (int e = 0; e < 4; e++) t[e] = X[n - 4 + e];
                 t[4] = v[0]; t[5] = v[1]; t[6] = v[1]; t[7] = v[2];
             }
-            fs->frame += 1;
-            fs->const_rows_pending = 1;                         // this launch wrote (or found) every structurally null row of S as sqrt(EPSILON) e_k
+            if (ex.dst) {                                      // (the workgroup that exports *fs may sit on another XCD: device-scope stores)
+                __hip_atomic_store(&fs->frame, fs->frame + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&fs->const_rows_pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                fs->frame += 1;
+                fs->const_rows_pending = 1;                     // this launch wrote (or found) every structurally null row of S as sqrt(EPSILON) e_k
+            }
             if (!sigR) srukf_prepare_control(fs);              // control of the next staged frame (k_project_motion); "table" mode: k_gain did it
         }
         return;
@@ -298,19 +331,45 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                                                      FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
                                                      double* __restrict__ A, double* __restrict__ sigR, double gamma,
                                                      KDims d, KWeights w,
-                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32)
+                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32, StepExport ex)
 {
     // dispatch order: the frame tail, the null checks and the noise rows (the longest chains of round trips: a column walk over every kept row) first, then the rows
     const int extra = (int)gridDim.x - n;
     const int bid = (int)blockIdx.x < extra ? n + (int)blockIdx.x : (int)blockIdx.x - extra;
-    rank_expand_body<MODE>(n, ld, r, eps, Sp, D, perm, iperm, gdiag, fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, bid);
+    rank_expand_body<MODE>(n, ld, r, eps, Sp, D, perm, iperm, gdiag, fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, bid, ex);
+    if (!ex.dst) return;
+    // step-wise API: this is the frame's last launch.  A workgroup's updates of *fs are device-scope atomics (the clamp counters) or device-scope stores (the frame
+    // tail's), complete once its s_waitcnt returns.  The last workgroup through copies *fs and the view to the host with loads that bypass its own L2.
+    __shared__ int last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int g = (int)blockIdx.x & 63, gsize = ((int)gridDim.x - g + 63) >> 6, groups = (int)gridDim.x < 64 ? (int)gridDim.x : 64;
+        int* c1 = ex.cnt + 64 * g;
+        last = 0;
+        if (__hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            __hip_atomic_store(c1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(&fs->export_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
+                __hip_atomic_store(&fs->export_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    const unsigned long long* fw = (const unsigned long long*)fs;
+    for (int i = threadIdx.x; i < ex.nfs; i += 256) ex.dst[i] = __hip_atomic_load(fw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 20) ((double*)(ex.dst + ex.nfs))[threadIdx.x] = ld_dev(ex.view + threadIdx.x);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && ex.flag) __hip_atomic_store(ex.flag, ex.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // batched form (srukf_run_frames_batch; "fused tail" mode, fp64 storage): filter f owns workgroups [f per, (f + 1) per)
 __global__ __launch_bounds__(256) void k_rank_expand_b(int n, int ld, int r, double eps, const ExpandArgs* __restrict__ tab, int per, double gamma, KDims d, KWeights w, srukf_params p)
 {
     const int f = (int)blockIdx.x / per, bid = (int)blockIdx.x - f * per;
     const ExpandArgs a = tab[f];
-    rank_expand_body<2>(n, ld, r, eps, a.Sp, a.D, a.perm, a.iperm, a.gdiag, a.fs, a.X, 1, a.S, a.A, a.sigR, gamma, d, w, p, a.Z, a.DZ, 0, bid);
+    rank_expand_body<2>(n, ld, r, eps, a.Sp, a.D, a.perm, a.iperm, a.gdiag, a.fs, a.X, 1, a.S, a.A, a.sigR, gamma, d, w, p, a.Z, a.DZ, 0, bid, StepExport{});
 }
 
 // fp32 storage: the permuted copy holds what the stored (float) state holds, like S after k_quantize
@@ -335,13 +394,14 @@ void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, cons
 }
 void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
                               const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A, double* sigR, double gamma,
-                              int fuse, KDims d, KWeights w, srukf_params p, double* Z, double* DZ, int f32)
+                              int fuse, KDims d, KWeights w, srukf_params p, double* Z, double* DZ, int f32, const StepExport* exp)
 {
+    const StepExport ex = (exp && fuse) ? *exp : StepExport{};
     // fuse: "fused tail" mode (projection of the next frame: five more workgroups, the row in LDS)
     const int nchk = (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
     const dim3 grid(n + 1 + nchk + (fuse ? 5 : 0));
-    if (fuse) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32);
-    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, 0);
+    if (fuse) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, ex);
+    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, 0, StepExport{});
 }
 void srukf_launch_rank_expand_b(hipStream_t st, int n, int ld, int r, double eps, const void* tab, int B, double gamma, KDims d, KWeights w, srukf_params p)
 {

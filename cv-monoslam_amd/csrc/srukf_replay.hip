@@ -285,8 +285,10 @@ void rank_expand(srukf_ctx* c, bool frame_tail, bool table, bool fuse)
     const bool f32fuse = f32s && fuse && table && frame_tail;      // fp32 storage in "fused tail" mode: the launch rounds what it writes (no k_quantize / k_rank_round / k_traj behind it)
     const bool f32 = f32s && !f32fuse;
     const bool tt = table && frame_tail && !f32;
+    const bool exports = c->step_export.dst && tt && fuse;         // step-wise fast path: this launch is the frame's last and hands status + robot view to the host itself
     srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
-                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 1 : 0, c->d, c->w, c->p, c->Z, c->DZ, f32fuse ? 1 : 0);
+                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 1 : 0, c->d, c->w, c->p, c->Z, c->DZ, f32fuse ? 1 : 0, exports ? &c->step_export : nullptr);
+    c->step_export_attached = exports;
     if (f32) {
         quantize_state(c);
         srukf_launch_rank_round(c->stream, np, c->red_r, c->shadowA);
@@ -609,6 +611,11 @@ void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion, bool table, bool
     const double* xrob = fmode ? c->sigR : fused_motion ? (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) : c->X + (d.n - 4);
     if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{}, preamble ? 1 : 0,
                                     fmode ? 1 : 0, c->Cmat };
+    if (fused_stats && c->mirror_next) {                       // step-wise API: the host's pinned copy of h | Si | visible is filled by the statistics jobs themselves
+        ms.hmirror = (char*)c->hstage;
+        ms.hflag = (unsigned long long*)((char*)c->hfs + sizeof(FrameScalars) + sizeof(double) * 32);
+        ms.hseq = c->meas_seq;
+    }
     if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
     else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
 }

@@ -1,7 +1,7 @@
 // cslam_step_bench — wall-clock frame rate of the DROP-IN path: what a host that binds this library the way the MFC view binds the reference's
 // CSLAM gets per frame (SLAM.cpp:87-112, called from MonoSLAMView.cpp:499-572): predict, host (or device) data association, update — one frame at a
 // time, with the host round trips in between.  bench.py's headline is the staged replay (inputs resident in HBM, no host in the loop); this is the other number.
-//   cslam_step_bench scene.bin odometry.txt mode=<capi|facade|assoc> [frames=K] [warmup=W] [hint=0|1]
+//   cslam_step_bench scene.bin odometry.txt mode=<capi|facade|assoc> [frames=K] [warmup=W] [hint=0|1] [set=key:value ...]
 //     capi   : srukf_predict_motion -> srukf_predict_measurement (D->H h, Si, visible) -> host association (matched = visible, z from the scene)
 //              -> srukf_update (H->D) -> srukf_get_robot (the pose and robot block RobotPath.txt records, SLAM.cpp:3539-3556)
 //     facade : monoslam::CSLAM::SLAM() with the same association as a callback (what cslam_replay does), display refresh and mirrors included
@@ -10,6 +10,7 @@
 //              robot moves: the launches and their D->H copy are what is timed, the filter itself is driven by the scene's z / matched (stated in the output).
 //     hint=1 : capi / assoc announce the NEXT frame's odometry with srukf_predict_motion_next before every update (a host that has its odometry
 //              file loaded, as the reference has: loadOdometryData reads it whole, SLAM.cpp:363-496)
+//     set=key:value : srukf_debug_set(ctx, key, value) after the context exists (capi / assoc; measurement switches, e.g. set=step_fuse_export:0)
 // scene.bin: int32 N, int32 F, double a1..a4, double X0[n], double S0[n*n], double z[F][2N]   (the file cslam_replay reads)
 // Prints ONE JSON object.
 #include <chrono>
@@ -18,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 #include "cslam.hpp"
 
@@ -28,11 +30,13 @@ int main(int argc, char** argv)
     if (argc < 4) { fprintf(stderr, "usage: %s scene.bin odometry.txt mode=<capi|facade|assoc> [frames=K] [warmup=W] [hint=0|1]\n", argv[0]); return 2; }
     std::string mode = "capi";
     int K = 200, W = 20, hint = 0;
+    std::vector<std::pair<std::string, int>> sets;
     for (int a = 3; a < argc; a++) {
         if (!strncmp(argv[a], "mode=", 5)) mode = argv[a] + 5;
         else if (!strncmp(argv[a], "frames=", 7)) K = atoi(argv[a] + 7);
         else if (!strncmp(argv[a], "warmup=", 7)) W = atoi(argv[a] + 7);
         else if (!strncmp(argv[a], "hint=", 5)) hint = atoi(argv[a] + 5);
+        else if (!strncmp(argv[a], "set=", 4)) { const char* q = strchr(argv[a] + 4, ':'); if (!q) { fprintf(stderr, "set=key:value\n"); return 2; } sets.emplace_back(std::string((const char*)argv[a] + 4, (size_t)(q - (argv[a] + 4))), atoi(q + 1)); }
     }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
@@ -86,6 +90,7 @@ int main(int argc, char** argv)
         int rc = srukf_create(&c, N, &p, 0, nullptr);
         if (rc) { fprintf(stderr, "srukf_create: %d %s\n", rc, srukf_last_error(nullptr)); return 1; }
 #define CK(call) do { rc = (call); if (rc) { fprintf(stderr, "%s: %d %s\n", #call, rc, srukf_last_error(c)); return 1; } } while (0)
+        for (auto& kv : sets) CK(srukf_debug_set(c, kv.first.c_str(), kv.second));
         CK(srukf_set_state(c, X0.data(), S0.data()));
         std::vector<double> h(2 * N), Si(4 * N), zc(2 * N), corr(N);
         std::vector<int> vis(N), m(N), md(N);

@@ -349,6 +349,43 @@ def test_step_api_equals_staged_replay(srukf, synth, N, hint, storage):
         assert np.abs(Xs - Xb).max() <= 1e-6 and ratio <= 4.0 and small <= 1e-11 * (F + 1), (ratio, small)
 
 
+@pytest.mark.parametrize("N", [40, 200])
+def test_step_results_exported_by_the_launches_that_form_them(srukf, synth, N):
+    """The fast path's two results per frame reach the host without a launch of their own: h / Si / visible are written into the pinned buffer by the final passes of the
+    statistics jobs inside k_pxy2 (the host continues while the tiles are still formed), the frame's status and robot view by k_block_cov.  Against the form with two
+    k_export launches behind them (debug switch "step_fuse_export" 0) and against waiting with hipStreamSynchronize ("step_spin" 0): the same bits everywhere."""
+    p = synth.scene_params()
+    F = 6
+    sc = synth.make_scene(N, F + 2, seed=23, p=p)
+    fs = [srukf.Filter(N, p) for _ in range(3)]
+    fs[1].debug_set("step_fuse_export", 0); fs[2].debug_set("step_spin", 0)
+    for f in fs:
+        f.set_state(sc["X0"], sc["S0"])
+    for t in range(F):
+        views = []
+        for f in fs:
+            f.predict_motion_next(sc["odo"][t + 1], sc["odo"][t + 2]) if t % 2 else None
+            f.predict_motion(sc["odo"][t], sc["odo"][t + 1])
+            views.append(f.predict_measurement())
+        for v in views[1:]:
+            assert all(np.array_equal(a, b) for a, b in zip(views[0], v))
+        assert views[0][2].sum() > 0
+        robots = []
+        for f in fs:
+            f.update(sc["z"][t], sc["matched"][t] * views[0][2])
+            robots.append(f.get_robot())
+        assert np.array_equal(robots[2][0], robots[0][0]) and np.array_equal(robots[2][1], robots[0][1])
+        # (the exported robot block is summed by k_rank_expand's frame tail over the factor rows, the other form's by k_block_cov over S: the same products in another order)
+        assert np.array_equal(robots[1][0], robots[0][0]); np.testing.assert_allclose(robots[1][1], robots[0][1], rtol=1e-13, atol=1e-19)
+    states = [f.get_state() for f in fs]
+    counts = [(f.debug_get("step_fast"), f.debug_get("step_slow")) for f in fs]
+    for f in fs:
+        f.close()
+    assert counts[0] == counts[1] == counts[2] and counts[0][0] >= 1 and sum(counts[0]) >= F, counts        # (a flagged frame is repeated on the other path: it counts on both)
+    for X, S in states[1:]:
+        assert np.array_equal(X, states[0][0]) and np.array_equal(S, states[0][1])
+
+
 def test_step_api_fast_path_falls_back_on_flagged_frames(srukf, oracle, synth):
     """The shipped a1..a4 = 8 at N = 200: S^T S - U U^T turns indefinite within a few frames and the reference's theta clamp becomes active.  The fast path's tail flags the
     frame; srukf_update rewinds to the state before the frame (kept by srukf_predict_motion) and repeats it on the path that evaluates the clamp pivot by pivot — the
@@ -392,6 +429,34 @@ def test_frame_view_is_the_accessors_in_one_round_trip(srukf, synth):
         assert np.array_equal(X, Xs) and np.array_equal(xyz, xyz2) and np.array_equal(cov, cov2) and np.array_equal(pose, pose2) and np.array_equal(P4, P42)
         np.testing.assert_allclose(P4, (Ss.T @ Ss)[-4:, -4:], rtol=0, atol=1e-15)
     f.close()
+
+
+def test_frame_view_rides_on_the_update_once_the_host_asks_for_it(srukf, synth):
+    """A host that fetches srukf_get_frame_view after every update (the facade: refreshFeaturesDisplay in SLAM(), SLAM.cpp:2721-2751 per landmark) gets the view exported
+    with the next updates' status — the landmark launch and one export behind the frame tail, no round trip of its own — and the call becomes a copy from the pinned
+    buffer (srukf_debug_get "view_hits").  Held bit for bit to a filter with that switched off ("view_auto" 0); three views nobody reads end it."""
+    p = synth.scene_params()
+    N, F = 60, 9
+    sc = synth.make_scene(N, F + 1, seed=31, p=p)
+    a, b = srukf.Filter(N, p), srukf.Filter(N, p)
+    b.debug_set("view_auto", 0)
+    for f in (a, b):
+        f.set_state(sc["X0"], sc["S0"])
+    for t in range(F):
+        for f in (a, b):
+            f.predict_motion(sc["odo"][t], sc["odo"][t + 1]); f.predict_measurement(); f.update(sc["z"][t], sc["matched"][t])
+        if t < 4 or t == F - 1:
+            va, vb = a.get_frame_view(), b.get_frame_view()
+            assert all(np.array_equal(x, y) for x, y in zip(va, vb))
+            Xs, _ = a.get_state(); xyz2, cov2 = a.get_landmarks_cartesian()
+            assert np.array_equal(va[0], Xs) and np.array_equal(va[1], xyz2) and np.array_equal(va[2], cov2)
+        if t == 3:
+            assert a.debug_get("view_hits") == 3 and a.debug_get("view_auto") == 1 and b.debug_get("view_hits") == 0
+    assert a.debug_get("view_hits") == 3 and a.debug_get("view_auto") == 1        # (frames 4 .. 6 exported views nobody read: off; the call after frame 8 asks again)
+    assert a.debug_get("step_fast") == F and b.debug_get("step_fast") == F
+    Xa, Sa = a.get_state(); Xb, Sb = b.get_state()
+    a.close(); b.close()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Sa, Sb)
 
 
 def test_abandoned_split_pair_steps_down_one_tier(srukf, synth):
