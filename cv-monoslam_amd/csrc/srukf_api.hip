@@ -242,7 +242,7 @@ void step_state_replaced(srukf_ctx* c) { step_ck_join(c); c->step_uncommitted = 
 
 namespace srukf_impl {
 
-void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; c->robot_cached = false; c->view_cached = false; }
+void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; c->robot_cached = false; c->view_cached = false; c->ck_valid = false; c->setstep_done = false; c->next_pose_pending = false; }
 
 }  // namespace srukf_impl
 
@@ -299,14 +299,21 @@ static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const doubl
         if (hipStreamCreateWithFlags(&c->ck_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ck_e1, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ck_e2, hipEventDisableTiming) != hipSuccess) { c->err = "predict_motion: no stream for the checkpoint copy"; return SRUKF_ERR_HIP; }
     }
-    step_ck_join(c);
-    HIPCHK(c, hipEventRecord(c->ck_e1, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->ck_stream, c->ck_e1, 0));
-    HIPCHK(c, hipMemcpyAsync(c->ckS, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->ck_stream));
-    HIPCHK(c, hipMemcpyAsync(c->ckX, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->ck_stream));
-    HIPCHK(c, hipEventRecord(c->ck_e2, c->ck_stream));
-    c->ck_pending = true;
-    launch_set_step(c->stream, c->fs, c->odo_step, c->step_seqF, c->p.a1, c->p.a2, c->p.a3, c->p.a4, c->step_chain ? 0 : 1, poses);
+    if (c->ck_valid && c->step_chain) {
+        // the update that produced this state submitted the copy behind its last launch (ck_pending / ck_e2 are that copy's)
+        c->ck_valid = false;
+    } else {
+        step_ck_join(c);
+        HIPCHK(c, hipEventRecord(c->ck_e1, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->ck_stream, c->ck_e1, 0));
+        HIPCHK(c, hipMemcpyAsync(c->ckS, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->ck_stream));
+        HIPCHK(c, hipMemcpyAsync(c->ckX, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->ck_stream));
+        HIPCHK(c, hipEventRecord(c->ck_e2, c->ck_stream));
+        c->ck_pending = true;
+    }
+    const bool preset = projected && c->setstep_done && memcmp(c->setstep_odo, c->step_odo, sizeof c->step_odo) == 0;
+    c->setstep_done = false;
+    if (!preset) launch_set_step(c->stream, c->fs, c->odo_step, c->step_seqF, c->p.a1, c->p.a2, c->p.a3, c->p.a4, c->step_chain ? 0 : 1, poses);
     c->fs_seq_step = true;
     if (!projected) {
         if (c->step_chain) launch_set_frame_control(c->stream, c->fs);      // (the tail prepared the control of ANOTHER pair, or none)
@@ -320,6 +327,7 @@ static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const doubl
     c->mirror_next = c->meas_seq != 0;
     seq_pxy(c, true, true, true, true, true);
     c->mirror_next = false;
+    c->next_pose_pending = preset && hint;                     // (k_set_step went out with two poses; the third rides on the update's k_gain launch: its successor needs it)
     c->step_fast = true; c->step_uncommitted = true;
     c->proj_valid = false;
     HIPCHK(c, hipGetLastError());
@@ -382,7 +390,7 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     memcpy(hs + mp, matched, sizeof(int) * N);
     if (c->step_seqF == 1 && c->next_odo_valid && memcmp(c->next_odo, c->step_odo + 3, sizeof(double) * 3) == 0) {
         // the host announced the next frame's odometry after srukf_predict_motion: the tail of this frame can still project it
-        launch_set_next_pose(c->stream, c->fs, c->odo_step, c->next_odo + 3);
+        c->next_pose_pending = true;                           // (rides on k_gain)
         c->step_seqF = 2;
     }
     step_ck_join(c);
@@ -410,6 +418,31 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
         srukf_launch_landmarks_cartesian(c->stream, d, c->X, c->S, c->G, c->G + 3 * (size_t)N);
         launch_export(c->stream, c->G, sizeof(double) * 12 * (size_t)N, c->X, sizeof(double) * d.n, c->hview, step_flag(c), seq);
     }
+    // While the host waits anyway: what the NEXT srukf_predict_motion would have to submit in front of its first launch.  The copy of the state this frame leaves (the
+    // checkpoint of the next frame; second pair of buffers: this frame's own checkpoint is still needed if it turns out flagged), and, when the host has announced the next
+    // frame's odometry, that frame's k_set_step.
+    bool early_ck = false, early_set = false;
+    if (c->dbg.step_early && c->ck_stream) {
+        const size_t np = d.np;
+        if (!c->ckS2 && (srukf_dmalloc((void**)&c->ckS2, sizeof(double) * np * np) != hipSuccess || srukf_dmalloc((void**)&c->ckX2, sizeof(double) * np) != hipSuccess || hipEventCreateWithFlags(&c->ck_e3, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipGetLastError();
+            if (c->ckS2) { srukf_dfree_on(c->ckS2, c->stream); c->ckS2 = nullptr; }
+        }
+        if (c->ckS2 && c->ckX2 && c->ck_e3) {
+            HIPCHK(c, hipEventRecord(c->ck_e1, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->ck_stream, c->ck_e1, 0));
+            HIPCHK(c, hipMemcpyAsync(c->ckS2, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->ck_stream));
+            HIPCHK(c, hipMemcpyAsync(c->ckX2, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->ck_stream));
+            HIPCHK(c, hipEventRecord(c->ck_e3, c->ck_stream));
+            early_ck = true;
+        }
+        if (c->step_seqF == 2) {                                // this frame's tail projects the pair (cur, next): the next frame's poses are known
+            double poses[9];
+            for (int e = 0; e < 3; e++) { poses[e] = c->step_odo[3 + e]; poses[3 + e] = c->next_odo[3 + e]; poses[6 + e] = 0.0; }
+            launch_set_step(c->stream, c->fs, c->odo_step, 1, c->p.a1, c->p.a2, c->p.a3, c->p.a4, 0, poses);
+            early_set = true;
+        }
+    }
     int rc = step_wait_export(c, seq); if (rc) return rc;
     rc = read_fs_host(c); if (rc) return rc;
     if (c->hfs->clamp_rows > 0) {
@@ -423,6 +456,12 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     c->step_chain = true;
     c->proj_valid = c->step_seqF == 2 && c->hfs->ctl_next_valid != 0;
     if (c->proj_valid) { for (int e = 0; e < 3; e++) { c->proj_odo[e] = c->step_odo[3 + e]; c->proj_odo[3 + e] = c->next_odo[3 + e]; } }
+    if (early_ck) {                                            // the frame is clean: its end state's copy becomes the next frame's checkpoint
+        std::swap(c->ckS, c->ckS2); std::swap(c->ckX, c->ckX2); std::swap(c->ck_e2, c->ck_e3);
+        c->ck_pending = true; c->ck_valid = true;
+    }
+    c->setstep_done = early_set && c->proj_valid;
+    if (c->setstep_done) memcpy(c->setstep_odo, c->proj_odo, sizeof c->setstep_odo);
     c->next_odo_valid = false;
     c->robot_cached = true;
     c->view_cached = view;
@@ -650,12 +689,12 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h /* + Si, vis */, c->PxyR, c->D,
                      c->zcur /* + mcur */, c->odocur, c->small, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
-    if (c->ck_stream) { hipStreamSynchronize(c->ck_stream); hipStreamDestroy(c->ck_stream); hipEventDestroy(c->ck_e1); hipEventDestroy(c->ck_e2); }
+    if (c->ck_stream) { hipStreamSynchronize(c->ck_stream); hipStreamDestroy(c->ck_stream); hipEventDestroy(c->ck_e1); hipEventDestroy(c->ck_e2); if (c->ck_e3) hipEventDestroy(c->ck_e3); }
     if (c->own_stream && c->stream) hipStreamSynchronize(c->stream);
     if (c->hstage) {
         // keep ONE pinned staging buffer for the next context (pinning 16 MB costs milliseconds; map changes rebuild contexts)

@@ -243,6 +243,7 @@ int srukf_run_frames_batch(srukf_ctx* const* ctxs, int B, int first, int count, 
     for (int b = 0; b < B && rc == SRUKF_OK; b++) {
         srukf_ctx* c = ctxs[b];
         if (hipSetDevice(c->device) != hipSuccess) rc = SRUKF_ERR_HIP;
+        if (rc == SRUKF_OK) { step_commit_motion(c); step_state_replaced(c); }      // (a filter that was stepped frame by frame before: nothing of that chain survives a replay)
         if (rc == SRUKF_OK && srukf_dmalloc((void**)&dt[b], sizeof(double) * 8 * (size_t)count) != hipSuccess) { c->err = "run_frames_batch: out of device memory"; rc = SRUKF_ERR_NOMEM; }
         if (rc == SRUKF_OK && !c->ckS) {                        // the state before the block, for the recovery of a flagged filter
             const size_t np = c->d.np;

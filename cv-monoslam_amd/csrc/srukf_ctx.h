@@ -30,7 +30,7 @@ void srukf_launch_meas_stats(hipStream_t, KDims, KWeights, const double*, const 
 int srukf_meas_part_doubles(int);
 void srukf_launch_gain(hipStream_t, KDims, KWeights, double*, const double*, const double*, const int*, const double*, const double*,
                        const double*, const int*, const int*, FrameScalars*, double*, double*, const double*, RankArgs, const double*, double*,
-                       const double*, int, const double*, double, const double*, int);
+                       const double*, int, const double*, double, const double*, int, const double*, double*);
 void srukf_launch_project_motion(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs);
 int srukf_gain_part_doubles(int);
 void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameScalars*, double*, int);
@@ -171,6 +171,7 @@ struct srukf_ctx {
         int step_fuse_export = 1;          // "step_fuse_export": the step-wise fast path's results reach the host from the launches that form them (the statistics' final passes inside
                                            // k_pxy2, the status + robot view from k_block_cov) instead of two k_export launches behind them (0: round 5's first form, for A/B)
         int view_auto = 1;                 // "view_auto": a host that fetched srukf_get_frame_view after its last update gets the view exported with the next update's status (0: never)
+        int step_early = 1;                // "step_early": the update submits the next frame's checkpoint copy and (announced odometry) its k_set_step behind its own last launch (0: the predict does)
         int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
@@ -205,6 +206,11 @@ struct srukf_ctx {
     bool proj_valid = false; double proj_odo[6] = { 0, 0, 0, 0, 0, 0 };   // ... and that tail projected the frame with this odometry pair (Z, DZ, the table, fs->ctl)
     bool fs_seq_step = false;              // fs->odo_seq points at odo_step (srukf_run_frames_async points it back at the staged sequence)
     bool last_update_sequential = false;   // a host that updates in SRUKF_UPDATE_SEQUENTIAL mode never takes the fast path (decided at predict time)
+    // The copy for the NEXT frame is submitted by the update that ends this one, right behind its last launch (into the second pair of buffers; pair and event swap
+    // when the frame turns out clean): the next srukf_predict_motion then finds its checkpoint made (ck_valid) and submits its first launch at once
+    double *ckS2 = nullptr, *ckX2 = nullptr; hipEvent_t ck_e3 = nullptr; bool ck_valid = false;
+    bool next_pose_pending = false;        // the next k_gain launch carries next_odo[3..5] as the sequence's third pose (no launch of its own)
+    bool setstep_done = false; double setstep_odo[6] = { 0, 0, 0, 0, 0, 0 };   // k_set_step for the announced next frame went out behind this frame's tail (poses: prev, cur)
     hipStream_t ck_stream = nullptr; hipEvent_t ck_e1 = nullptr, ck_e2 = nullptr; bool ck_pending = false;   // the copy of the state before the frame runs BESIDE the frame's
                                            // first launch on a stream of its own (it only has to be complete before k_gain touches S): step_ck_join
     unsigned long long meas_seq = 0;       // != 0: k_pxy2's statistics jobs mirror h | Si | visible into hstage and raise the flag word with this number (srukf_predict_measurement waits for it)
@@ -263,7 +269,6 @@ void launch_set_frame(hipStream_t st, FrameScalars* fs, int frame, int clear_cla
 void launch_set_traj(hipStream_t st, FrameScalars* fs, double* traj_base);
 void launch_set_run(hipStream_t st, FrameScalars* fs, int frame, int clear_clamp, double* traj_base);
 void launch_set_step(hipStream_t st, FrameScalars* fs, double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh, const double poses[9]);
-void launch_set_next_pose(hipStream_t st, FrameScalars* fs, double* odo, const double pose[3]);
 // device -> pinned host memory, two segments of 8-byte words; flag (pinned too, may be null) receives seq behind the data
 void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned, unsigned long long* flag = nullptr, unsigned long long seq = 0);
 void launch_set_frame_control(hipStream_t st, FrameScalars* fs);

@@ -118,6 +118,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
     else if (!strcmp(key, "step_fast")) c->dbg.step_fast = value ? 1 : 0;
     else if (!strcmp(key, "step_spin")) c->dbg.step_spin = value ? 1 : 0;
+    else if (!strcmp(key, "step_early")) c->dbg.step_early = value ? 1 : 0;
     else if (!strcmp(key, "view_auto")) { c->dbg.view_auto = value ? 1 : 0; if (!value) { c->view_auto = false; c->view_cached = false; } }
     else if (!strcmp(key, "step_fuse_export")) c->dbg.step_fuse_export = value ? 1 : 0;
     else if (!strcmp(key, "fused_motion")) c->dbg.fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;

@@ -529,6 +529,7 @@ __device__ __forceinline__ void gain_body(const KDims& d, const KWeights& w,
     __syncthreads();
     if (sl == 0) dxp[(size_t)by * ld + r] = (red[0][rl] + red[1][rl]) + (red[2][rl] + red[3][rl]);
 }
+struct GainNextPose { double v[3]; double* odo; };
 __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               double* __restrict__ Ut, const double* __restrict__ PxyR,
                                               const double* __restrict__ Si, const int* __restrict__ vis,
@@ -537,8 +538,11 @@ __global__ __launch_bounds__(256) void k_gain(KDims d, KWeights w,
                                               FrameScalars* __restrict__ fs, double* __restrict__ dxp /* [GAIN_SLICES][np] */, const RankArgs ra,
                                               const double* __restrict__ Cm, double* __restrict__ S,
                                               const double* __restrict__ P1, int split_b0, const double* __restrict__ DZp, double sqeps,
-                                              const double* __restrict__ sigR, const double* __restrict__ Z0, int fmode)
+                                              const double* __restrict__ sigR, const double* __restrict__ Z0, int fmode, GainNextPose np3)
 {
+    // step-wise API: the pose after this frame's, announced by the host after the frame's first launch had gone out (third pose of the two-frame sequence the frame scalars
+    // point at; the state-update job of the NEXT launch prepares the next control from it).  Nothing in this launch reads the sequence.
+    if (np3.odo && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { np3.odo[6] = np3.v[0]; np3.odo[7] = np3.v[1]; np3.odo[8] = np3.v[2]; fs->odo_seq = np3.odo; fs->seqF = 2; }
     gain_body(d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra, Cm, S, P1, split_b0, DZp, sqeps, sigR, Z0, fmode, (int)blockIdx.x, (int)blockIdx.y);
 }
 // batched form (srukf_run_frames_batch): grid (np / 64, GAIN_SLICES B), filter f = blockIdx.y / GAIN_SLICES; staged inputs only, "fused tail" mode
@@ -680,15 +684,24 @@ __global__ __launch_bounds__(256) void k_landmarks_cartesian(KDims d, const doub
     double v[21];
 #pragma unroll
     for (int q = 0; q < 21; q++) v[q] = 0.0;
-    for (int k = threadIdx.x; k < off + 6; k += 256) {          // S upper triangular: rows below the block do not contribute
-        double s[6];
+    // S upper triangular: rows below the block do not contribute.  Four rows per thread and trip, their loads requested before the first product (a row per trip is one
+    // memory round trip per 256 rows; the order of a thread's sums is unchanged)
+    for (int k0 = threadIdx.x; k0 < off + 6; k0 += 4 * 256) {
+        double s[4][6];
 #pragma unroll
-        for (int e = 0; e < 6; e++) s[e] = (off + e >= k) ? S[(size_t)k * ld + off + e] : 0.0;
-        int q = 0;
+        for (int u = 0; u < 4; u++) {
+            const int k = k0 + 256 * u;
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+            for (int e = 0; e < 6; e++) s[u][e] = (k < off + 6 && off + e >= k) ? S[(size_t)k * ld + off + e] : 0.0;
+        }
 #pragma unroll
-            for (int b = a; b < 6; b++) v[q++] += s[a] * s[b];
+        for (int u = 0; u < 4; u++) {
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a; b < 6; b++) v[q++] += s[u][a] * s[u][b];
+        }
     }
     block_sum<21>(v, red);
     if (threadIdx.x != 0) return;
@@ -756,10 +769,12 @@ void srukf_launch_gain_b(hipStream_t st, KDims d, KWeights w, const void* tab, i
 void srukf_launch_gain(hipStream_t st, KDims d, KWeights w, double* Ut, const double* PxyR, const double* Si, const int* vis,
                        const double* h, const double* z_seq, const double* z_cur, const int* m_seq, const int* m_cur,
                        FrameScalars* fs, double* dxp, double* X, const double* Z, RankArgs ra, const double* Cm, double* S,
-                       const double* P1, int split_b0, const double* DZp, double sqeps, const double* sigR, int fmode)
+                       const double* P1, int split_b0, const double* DZp, double sqeps, const double* sigR, int fmode, const double* next_pose, double* odo_dev)
 {
+    GainNextPose np3 = { { 0, 0, 0 }, nullptr };
+    if (next_pose && odo_dev) { np3.v[0] = next_pose[0]; np3.v[1] = next_pose[1]; np3.v[2] = next_pose[2]; np3.odo = odo_dev; }
     hipLaunchKernelGGL(k_gain, dim3(d.np / 64, GAIN_SLICES), dim3(256), 0, st, d, w, Ut, PxyR, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp, ra, Cm, S,
-                       P1, split_b0, DZp, sqeps, sigR, Z, fmode);
+                       P1, split_b0, DZp, sqeps, sigR, Z, fmode, np3);
     if (w.wc0 != w.wm0)
         hipLaunchKernelGGL(k_gain_center, dim3(d.np / 256 + 1), dim3(256), 0, st, d, w, Ut, Z, Si, vis, h, z_seq, z_cur, m_seq, m_cur, fs, dxp);
 }

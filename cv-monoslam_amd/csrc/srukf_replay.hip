@@ -64,8 +64,6 @@ __global__ void k_set_step(FrameScalars* fs, double* odo, int seqF, double a1, d
 }
 
 __global__ void k_set_frame_control(FrameScalars* fs) { srukf_prepare_control(fs); }
-// the next frame's pose announced after srukf_predict_motion (srukf_predict_motion_next): third pose of the step-wise sequence, which then has two frames
-__global__ void k_set_next_pose(FrameScalars* fs, double* odo, double x, double y, double th) { odo[6] = x; odo[7] = y; odo[8] = th; fs->odo_seq = odo; fs->seqF = 2; }
 // Small results for the host (h | Si | visible after the predict half; frame scalars + robot view after the update half) written straight into its pinned buffer by a kernel:
 // a hipMemcpyAsync of a few KB is a blit kernel plus ~7.5 us of gap behind it on the stream (scripts/profile_step.sh); this is one short launch.  Two segments, 8-byte words.
 // flag (may be null): a word of the same pinned buffer that receives `seq` AFTER the data — every wave's stores made visible at system scope first — so that the host can
@@ -158,7 +156,6 @@ void launch_set_step(hipStream_t st, FrameScalars* fs, double* odo, int seqF, do
     StepPoses po; for (int e = 0; e < 9; e++) po.v[e] = poses[e];
     hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, fs, odo, seqF, a1, a2, a3, a4, fresh, po);
 }
-void launch_set_next_pose(hipStream_t st, FrameScalars* fs, double* odo, const double pose[3]) { hipLaunchKernelGGL(k_set_next_pose, dim3(1), dim3(1), 0, st, fs, odo, pose[0], pose[1], pose[2]); }
 void launch_export(hipStream_t st, const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* host_pinned, unsigned long long* flag, unsigned long long seq)
 {
     const int na = (int)((bytes_a + 7) / 8), nb = (int)((bytes_b + 7) / 8);
@@ -628,7 +625,8 @@ void seq_gain_only(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fus
     srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
                       fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ,
                       (fmode && c->storage == SRUKF_STORAGE_F32) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon),   // (the null rows of S as they are stored)
-                      c->sigR, fmode ? 1 : 0);
+                      c->sigR, fmode ? 1 : 0, c->next_pose_pending ? c->next_odo + 3 : nullptr, c->odo_step);
+    c->next_pose_pending = false;
     c->dx_pending = true;                             // applied by the next k_syrk launch (seq_refactor)
 }
 
