@@ -242,7 +242,7 @@ void step_state_replaced(srukf_ctx* c) { step_ck_join(c); c->step_uncommitted = 
 
 namespace srukf_impl {
 
-void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; c->robot_cached = false; c->view_cached = false; c->ck_valid = false; c->setstep_done = false; c->next_pose_pending = false; }
+void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; c->robot_cached = false; c->view_cached = false; c->ck_valid = false; c->setstep_done = false; c->next_pose_pending = false; c->pre_issued = false; }
 
 }  // namespace srukf_impl
 
@@ -270,7 +270,7 @@ static int step_wait_export(srukf_ctx* c, unsigned long long seq)
     if (c->dbg.step_spin) {
         volatile unsigned long long* f = step_flag(c);
         for (int spins = 0; spins < 400000; spins++) {
-            if (*f == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return SRUKF_OK; }
+            if (*f >= seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return SRUKF_OK; }      // (>=: the next frame's pre-issued first launch may already have raised it further)
             __builtin_ia32_pause();
         }
     }
@@ -313,6 +313,8 @@ static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const doubl
     }
     const bool preset = projected && c->setstep_done && memcmp(c->setstep_odo, c->step_odo, sizeof c->step_odo) == 0;
     c->setstep_done = false;
+    const bool pre = preset && c->pre_issued && memcmp(c->pre_odo, c->step_odo, sizeof c->step_odo) == 0;      // k_pxy2 of this very frame is in flight already
+    c->pre_issued = false;
     if (!preset) launch_set_step(c->stream, c->fs, c->odo_step, c->step_seqF, c->p.a1, c->p.a2, c->p.a3, c->p.a4, c->step_chain ? 0 : 1, poses);
     c->fs_seq_step = true;
     if (!projected) {
@@ -323,10 +325,12 @@ static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const doubl
     c->xr1_pending = true;
     // h | Si | visible reach the host's pinned buffer from the statistics jobs of this very launch (their final passes: the first ~10 us of it), flag behind them: the host
     // runs its association, and queues the update's launches, while the cross-covariance tiles are still being formed
-    c->meas_seq = c->dbg.step_fuse_export ? ++c->step_seq : 0;
-    c->mirror_next = c->meas_seq != 0;
-    seq_pxy(c, true, true, true, true, true);
-    c->mirror_next = false;
+    if (!pre) {
+        c->meas_seq = c->dbg.step_fuse_export ? ++c->step_seq : 0;
+        c->mirror_next = c->meas_seq != 0;
+        seq_pxy(c, true, true, true, true, true);
+        c->mirror_next = false;
+    }
     c->next_pose_pending = preset && hint;                     // (k_set_step went out with two poses; the third rides on the update's k_gain launch: its successor needs it)
     c->step_fast = true; c->step_uncommitted = true;
     c->proj_valid = false;
@@ -406,9 +410,19 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
         if (srukf_dmalloc((void**)&c->export_cnt, sizeof(int) * 64 * 64) == hipSuccess) HIPCHK(c, hipMemsetAsync(c->export_cnt, 0, sizeof(int) * 64 * 64, c->stream));
         else { (void)hipGetLastError(); c->export_cnt = nullptr; }
     }
-    if (c->dbg.step_fuse_export && c->export_cnt) c->step_export = StepExport{ (unsigned long long*)c->hfs, (int)(sizeof(FrameScalars) / 8), c->small, view ? nullptr : step_flag(c), seq, c->export_cnt };
+    bool early_set = false;
+    if (c->dbg.step_fuse_export && c->export_cnt) {
+        c->step_export = StepExport{ (unsigned long long*)c->hfs, (int)(sizeof(FrameScalars) / 8), c->small, view ? nullptr : step_flag(c), seq, c->export_cnt, 0, nullptr, { 0, 0, 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+        if (c->dbg.step_early && c->step_seqF == 2) {         // this frame's tail projects the pair (cur, next): the next frame's poses are known, its scalars start in the exporter
+            StepExport& ex = c->step_export;
+            ex.set = 1; ex.odo = c->odo_step;
+            for (int e = 0; e < 3; e++) { ex.poses[e] = c->step_odo[3 + e]; ex.poses[3 + e] = c->next_odo[3 + e]; }
+            ex.a[0] = c->p.a1; ex.a[1] = c->p.a2; ex.a[2] = c->p.a3; ex.a[3] = c->p.a4;
+        }
+    }
     c->step_export_attached = false;
     seq_refactor(c, 0, d.mp, false, false, false, true, true, true);
+    early_set = c->step_export_attached && c->step_export.set;
     c->step_export = StepExport{};
     if (!c->step_export_attached) {                            // (the form with launches of their own: "step_fuse_export" 0, or a tail that is not k_rank_expand<2>)
         srukf_launch_block_cov(c->stream, d, c->S, d.n - 4, 4, c->small, c->X);
@@ -421,7 +435,7 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     // While the host waits anyway: what the NEXT srukf_predict_motion would have to submit in front of its first launch.  The copy of the state this frame leaves (the
     // checkpoint of the next frame; second pair of buffers: this frame's own checkpoint is still needed if it turns out flagged), and, when the host has announced the next
     // frame's odometry, that frame's k_set_step.
-    bool early_ck = false, early_set = false;
+    bool early_ck = false, early_pxy = false;
     if (c->dbg.step_early && c->ck_stream) {
         const size_t np = d.np;
         if (!c->ckS2 && (srukf_dmalloc((void**)&c->ckS2, sizeof(double) * np * np) != hipSuccess || srukf_dmalloc((void**)&c->ckX2, sizeof(double) * np) != hipSuccess || hipEventCreateWithFlags(&c->ck_e3, hipEventDisableTiming) != hipSuccess)) {
@@ -437,10 +451,21 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
             early_ck = true;
         }
         if (c->step_seqF == 2) {                                // this frame's tail projects the pair (cur, next): the next frame's poses are known
-            double poses[9];
-            for (int e = 0; e < 3; e++) { poses[e] = c->step_odo[3 + e]; poses[3 + e] = c->next_odo[3 + e]; poses[6 + e] = 0.0; }
-            launch_set_step(c->stream, c->fs, c->odo_step, 1, c->p.a1, c->p.a2, c->p.a3, c->p.a4, 0, poses);
-            early_set = true;
+            if (!early_set) {                                  // (the tail did not export: a launch of its own)
+                double poses[9];
+                for (int e = 0; e < 3; e++) { poses[e] = c->step_odo[3 + e]; poses[3 + e] = c->next_odo[3 + e]; poses[6 + e] = 0.0; }
+                launch_set_step(c->stream, c->fs, c->odo_step, 1, c->p.a1, c->p.a2, c->p.a3, c->p.a4, 0, poses);
+                early_set = true;
+            }
+            if (c->dbg.step_early >= 2 && early_ck) {
+                // ... and that frame's first launch: it reads what this frame's tail leaves (the table, the projected sigma points) and writes per-frame scratch only —
+                // nothing of the state — so a host that then does something else (another pair, a new state, a map change) just has it ignored and repeated
+                c->meas_seq = c->dbg.step_fuse_export ? ++c->step_seq : 0;
+                c->mirror_next = c->meas_seq != 0;
+                seq_pxy(c, true, true, true, true, true);
+                c->mirror_next = false;
+                early_pxy = true;
+            }
         }
     }
     int rc = step_wait_export(c, seq); if (rc) return rc;
@@ -462,6 +487,8 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     }
     c->setstep_done = early_set && c->proj_valid;
     if (c->setstep_done) memcpy(c->setstep_odo, c->proj_odo, sizeof c->setstep_odo);
+    c->pre_issued = early_pxy && c->setstep_done;
+    if (c->pre_issued) memcpy(c->pre_odo, c->proj_odo, sizeof c->pre_odo);
     c->next_odo_valid = false;
     c->robot_cached = true;
     c->view_cached = view;
@@ -664,10 +691,12 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
     if (g_spare_stage && g_spare_stage_bytes >= c->hstage_bytes) {         // pinned staging of a context that was just rebuilt (map change)
         c->hstage = g_spare_stage; c->hstage_bytes = g_spare_stage_bytes; g_spare_stage = nullptr; g_spare_stage_bytes = 0;
     }
-    if ((!c->hstage && hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess) || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars) + sizeof(double) * 40) != hipSuccess) {
+    if ((!c->hstage && hipHostMalloc((void**)&c->hstage, c->hstage_bytes) != hipSuccess) || hipHostMalloc((void**)&c->hfs, sizeof(FrameScalars) + sizeof(double) * (40 + c->d.mp + 5 * (size_t)c->d.N + 8)) != hipSuccess) {
         g_create_error = "hipHostMalloc failed"; srukf_destroy(c); return SRUKF_ERR_NOMEM;
     }
     memset(c->hfs, 0, sizeof(FrameScalars) + sizeof(double) * 40);      // (the flag word behind the robot view starts below every sequence number)
+    c->hmeas = (double*)((char*)c->hfs + sizeof(FrameScalars) + sizeof(double) * 40);      // h | Si | visible as the statistics jobs of the fast path's k_pxy2 leave them (a buffer of its own:
+                                                                                          // hstage is every accessor's staging area, and an accessor may run between predict_motion and predict_measurement)
     int rc = srukf_reset(c);
     if (rc) { g_create_error = c->err; srukf_destroy(c); return rc; }
     *out = c;
@@ -950,6 +979,7 @@ int srukf_predict_measurement(srukf_ctx* c, double* h, double* Si, int* visible)
     const size_t out_bytes = sizeof(double) * (mp + 4 * (size_t)N) + sizeof(int) * N;
     if (c->step_fast && c->meas_seq) {                                   // the statistics jobs of k_pxy2 have written (or are writing) the pinned buffer themselves
         const int rcw = step_wait_export(c, c->meas_seq); if (rcw) return rcw;
+        hs = c->hmeas;
     } else if (c->step_fast) {                                           // a kernel writes the pinned buffer: no blit, no gap behind it
         const unsigned long long seq = ++c->step_seq;
         launch_export(c->stream, c->h, out_bytes, nullptr, 0, hs, c->dbg.step_spin ? step_flag(c) : nullptr, seq);

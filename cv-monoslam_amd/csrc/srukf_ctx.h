@@ -171,7 +171,10 @@ struct srukf_ctx {
         int step_fuse_export = 1;          // "step_fuse_export": the step-wise fast path's results reach the host from the launches that form them (the statistics' final passes inside
                                            // k_pxy2, the status + robot view from k_block_cov) instead of two k_export launches behind them (0: round 5's first form, for A/B)
         int view_auto = 1;                 // "view_auto": a host that fetched srukf_get_frame_view after its last update gets the view exported with the next update's status (0: never)
-        int step_early = 1;                // "step_early": the update submits the next frame's checkpoint copy and (announced odometry) its k_set_step behind its own last launch (0: the predict does)
+        int step_early = 2;                // "step_early": the update submits the next frame's checkpoint copy and (announced odometry) its k_set_step behind its own last launch (0: the predict
+                                           // does), 2: and that frame's first launch, k_pxy2, too — srukf_predict_motion for the announced pair then has nothing left to submit
+                                           // (the statistics as a launch of their own in front of it were tried: alone they still take 16 us — eight dependent memory round trips —, and
+                                           //  16 + 25 us of launches lose to 25 us + the 12-us round trip they were meant to hide)
         int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
@@ -193,6 +196,7 @@ struct srukf_ctx {
     // pinned staging
     double* hstage = nullptr; size_t hstage_bytes = 0;
     FrameScalars* hfs = nullptr;
+    double* hmeas = nullptr;               // inside the hfs allocation, behind the robot view and the flag word
     // state machine
     int phase = 0;   // 0 idle, 1 after predict_motion, 2 after predict_measurement
     double next_odo[6] = { 0, 0, 0, 0, 0, 0 }; bool next_odo_valid = false;   // srukf_predict_motion_next: the pair the next srukf_predict_motion will bring
@@ -209,6 +213,7 @@ struct srukf_ctx {
     // The copy for the NEXT frame is submitted by the update that ends this one, right behind its last launch (into the second pair of buffers; pair and event swap
     // when the frame turns out clean): the next srukf_predict_motion then finds its checkpoint made (ck_valid) and submits its first launch at once
     double *ckS2 = nullptr, *ckX2 = nullptr; hipEvent_t ck_e3 = nullptr; bool ck_valid = false;
+    bool pre_issued = false; double pre_odo[6] = { 0, 0, 0, 0, 0, 0 };   // the NEXT frame's first launch (k_pxy2) went out behind this frame's tail, for this odometry pair
     bool next_pose_pending = false;        // the next k_gain launch carries next_odo[3..5] as the sequence's third pose (no launch of its own)
     bool setstep_done = false; double setstep_odo[6] = { 0, 0, 0, 0, 0, 0 };   // k_set_step for the announced next frame went out behind this frame's tail (poses: prev, cur)
     hipStream_t ck_stream = nullptr; hipEvent_t ck_e1 = nullptr, ck_e2 = nullptr; bool ck_pending = false;   // the copy of the state before the frame runs BESIDE the frame's

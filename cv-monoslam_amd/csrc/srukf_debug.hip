@@ -118,7 +118,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
     else if (!strcmp(key, "step_fast")) c->dbg.step_fast = value ? 1 : 0;
     else if (!strcmp(key, "step_spin")) c->dbg.step_spin = value ? 1 : 0;
-    else if (!strcmp(key, "step_early")) c->dbg.step_early = value ? 1 : 0;
+    else if (!strcmp(key, "step_early")) c->dbg.step_early = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(key, "view_auto")) { c->dbg.view_auto = value ? 1 : 0; if (!value) { c->view_auto = false; c->view_cached = false; } }
     else if (!strcmp(key, "step_fuse_export")) c->dbg.step_fuse_export = value ? 1 : 0;
     else if (!strcmp(key, "fused_motion")) c->dbg.fused_motion = value < 0 ? 0 : value > 2 ? 2 : value;
@@ -179,6 +179,7 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     }
     else if (!strcmp(key, "step_fast")) *value = c->step_fast_frames;          // frames the step-wise API ran on the staged replay's launch sequence / on its own
     else if (!strcmp(key, "step_slow")) *value = c->step_slow_frames;
+    else if (!strcmp(key, "meas_flag_ticks")) { const unsigned long long* t = (const unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N); *value = (long long)(t[1] - t[0]); }   // last fast-path k_pxy2: first workgroup's start -> statistics flag, 10 ns ticks
     else if (!strcmp(key, "view_hits")) *value = c->view_hits;                     // srukf_get_frame_view calls served from the view an update exported with its status
     else if (!strcmp(key, "view_auto")) *value = c->view_auto ? 1 : 0;
     else if (!strcmp(key, "split_form")) *value = split_form(c, c->red_r > 0 ? c->gplan_red : c->gplan) ? 1 : 0;       // would the next persistent factorisation be the split form?

@@ -278,6 +278,7 @@ struct MeasArgs {
     // step-wise API (null / 0 in the replay): h | Si | visible are ONE device allocation starting at h; hmirror is a pinned HOST buffer of the same layout that every landmark
     // group's final pass fills as well, and the last group stores hseq to *hflag behind it (system scope): the host has the statistics while the launch still forms its tiles
     char* hmirror; unsigned long long* hflag; unsigned long long hseq;
+    unsigned long long* hstamp;                                // (may be null) two pinned words: s_memrealtime when the launch's first workgroup starts / when the flag is raised
 };
 
 // Step-wise API (dst null in the replay): the frame's LAST launch hands the frame's status and robot view to the host itself.  Its frame-tail workgroup forms the 4 x 4 robot
@@ -285,7 +286,20 @@ struct MeasArgs {
 // updates of *fs are through, and the last one copies *fs (nfs 8-byte words) and the view to the pinned host buffer dst and stores seq to *flag behind them (system scope).
 // cnt: 64 counters 256 B apart (zero between launches) in front of fs->export_cnt: ~1 250 relaxed device-scope increments of ONE word cost the launch 29 us (they
 // serialise at the memory side); 64 words take ~20 each, the last arrival of each word then counts in fs->export_cnt.
-struct StepExport { unsigned long long* dst; int nfs; double* view; unsigned long long* flag; unsigned long long seq; int* cnt; };
+// set: the exporting workgroup — the last thing that runs in the frame — also starts the NEXT frame's scalars (what k_set_step does: the host has announced that frame's
+// odometry, poses = prev | cur): no launch for it between this frame's tail and the next frame's first launch.
+struct StepExport { unsigned long long* dst; int nfs; double* view; unsigned long long* flag; unsigned long long seq; int* cnt; int set; double* odo; double poses[6]; double a[4]; };
+// start of a step-wise frame whose predecessor's tail prepared the control and projected it (k_set_step with fresh = 0; one thread)
+__device__ __forceinline__ void srukf_step_scalars(FrameScalars* fs, double* odo, int seqF, const double (&a)[4])
+{
+    fs->odo_seq = odo; fs->seqF = seqF;
+    fs->a[0] = a[0]; fs->a[1] = a[1]; fs->a[2] = a[2]; fs->a[3] = a[3];
+    fs->frame = 0;
+    fs->traj_base = nullptr;
+    fs->stat_count = 0;
+    for (int q = 0; q < SRUKF_STAT_GROUPS; q++) fs->stat_cnt[q] = 0;
+    fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0;
+}
 
 // ---- agent-scope (device-coherent) accesses: data handed from one workgroup to another INSIDE a launch ----
 // The eight XCDs have private, mutually non-coherent L2s; plain stores stay dirty in the writer's L2 until the kernel

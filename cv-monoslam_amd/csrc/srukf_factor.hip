@@ -51,6 +51,7 @@ __device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w,
         const int done = __hip_atomic_fetch_add(&ms.fs->stat_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == ms.gx - 1) {
             __hip_atomic_store(&ms.fs->stat_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ms.hstamp) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[1] = t_; }      // (10 ns ticks; scripts: where in the launch the host gets its statistics)
             __hip_atomic_store(ms.hflag, ms.hseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -129,6 +130,7 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
     if (ms.preamble && bid == 0 && threadIdx.x == 0) srukf_frame_preamble(ms.fs);   // "tail" mode: nothing of this frame runs before this launch
     const int nmot = ms.fmode ? 1 : 0;                         // "fused tail" mode: workgroup 0 is the frame's motion step (sums over the table the previous frame's tail completed)
     if (nmot && bid == 0) {
+        if (ms.hstamp && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[0] = t_; }
         if (threadIdx.x >= 256) return;
         const RankArgs ra0 = {};
         motion_reduce_body<256, false>(d, w, const_cast<double*>(ms.X), nullptr, const_cast<double*>(ms.sigR), ms.Cm, ms.fs, ra0, shm);

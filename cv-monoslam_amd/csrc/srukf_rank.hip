@@ -362,7 +362,13 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     if (threadIdx.x < 20) ((double*)(ex.dst + ex.nfs))[threadIdx.x] = ld_dev(ex.view + threadIdx.x);
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0 && ex.flag) __hip_atomic_store(ex.flag, ex.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        if (ex.set) {                                          // every other workgroup of the frame's last launch is through, *fs is with the host: the next frame starts here
+            for (int e = 0; e < 6; e++) ex.odo[e] = ex.poses[e];
+            srukf_step_scalars(fs, ex.odo, 1, ex.a);
+        }
+        if (ex.flag) __hip_atomic_store(ex.flag, ex.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // batched form (srukf_run_frames_batch; "fused tail" mode, fp64 storage): filter f owns workgroups [f per, (f + 1) per)
 __global__ __launch_bounds__(256) void k_rank_expand_b(int n, int ld, int r, double eps, const ExpandArgs* __restrict__ tab, int per, double gamma, KDims d, KWeights w, srukf_params p)

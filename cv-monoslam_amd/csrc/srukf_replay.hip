@@ -53,13 +53,8 @@ struct StepPoses { double v[9]; };
 __global__ void k_set_step(FrameScalars* fs, double* odo, int seqF, double a1, double a2, double a3, double a4, int fresh, StepPoses po)
 {
     for (int e = 0; e < 9; e++) odo[e] = po.v[e];
-    fs->odo_seq = odo; fs->seqF = seqF;
-    fs->a[0] = a1; fs->a[1] = a2; fs->a[2] = a3; fs->a[3] = a4;
-    fs->frame = 0;
-    fs->traj_base = nullptr;
-    fs->stat_count = 0;
-    for (int q = 0; q < SRUKF_STAT_GROUPS; q++) fs->stat_cnt[q] = 0;
-    fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0;
+    const double a[4] = { a1, a2, a3, a4 };
+    srukf_step_scalars(fs, odo, seqF, a);
     if (fresh) { srukf_prepare_control(fs); fs->const_rows_ok = 0; fs->const_rows_pending = 0; }
 }
 
@@ -609,9 +604,10 @@ void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion, bool table, bool
     if (fused_stats) ms = MeasArgs{ c->X, xrob, c->sigR, c->Z, c->mpart, c->h, c->Si, c->vis, c->PxyR, c->fs, (d.N + 31) / 32, table ? null_skip(c) : NullSkip{}, preamble ? 1 : 0,
                                     fmode ? 1 : 0, c->Cmat };
     if (fused_stats && c->mirror_next) {                       // step-wise API: the host's pinned copy of h | Si | visible is filled by the statistics jobs themselves
-        ms.hmirror = (char*)c->hstage;
+        ms.hmirror = (char*)c->hmeas;
         ms.hflag = (unsigned long long*)((char*)c->hfs + sizeof(FrameScalars) + sizeof(double) * 32);
         ms.hseq = c->meas_seq;
+        ms.hstamp = (unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N);       // (the spare words behind h | Si | visible)
     }
     if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
     else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);

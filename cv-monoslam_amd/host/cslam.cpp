@@ -228,7 +228,7 @@ void CSLAM::getFeatureCartesianInformation(Point3d& xyz, Mat& sr, Mat& cov, cons
 
 void CSLAM::get3DdisplayInformation(Quaternion& axis, Point3d& sigma, const Mat& matrix) const
 {
-    Mat values, vectors;
+    static thread_local Mat values, vectors;                   // (called once per landmark and frame: the buffers are kept)
     calculateEigenvaluesAndEigenvectors(matrix, values, vectors);
     matrix2Quaternion(axis, vectors);
     sigma.x = sqrt(values.at(0, 0)); sigma.y = sqrt(values.at(1, 1)); sigma.z = sqrt(values.at(2, 2));       // 1-sigma semi-axes
@@ -238,7 +238,7 @@ void CSLAM::get3DdisplayInformation(Quaternion& axis, Point3d& sigma, const Mat&
 // magnitude with a plane rotation A <- R^T A R, accumulating V <- V R.  On return the diagonal of `eigenvalues` holds
 // the eigenvalues (in the positions the rotations left them, not sorted) and column j of `eigenvectors` is the
 // eigenvector of eigenvalues(j, j).  Stops when every off-diagonal magnitude is below EPSILON (false after 30 n^2 sweeps).
-bool CSLAM::calculateEigenvaluesAndEigenvectors(Mat src, Mat& eigenvalues, Mat& eigenvectors) const
+bool CSLAM::calculateEigenvaluesAndEigenvectors(const Mat& src, Mat& eigenvalues, Mat& eigenvectors) const
 {
     const int n = src.rows;
     eigenvalues = src;

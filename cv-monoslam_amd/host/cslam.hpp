@@ -128,7 +128,7 @@ public:
     // get3DdisplayInformation (2791-2802), calculateEigenvaluesAndEigenvectors (2816-2891: classical Jacobi rotations,
     // largest off-diagonal pivot, eigenvalues left on the diagonal in place), matrix2Quaternion (2902-2948)
     void get3DdisplayInformation(Quaternion& axis, Point3d& sigma, const Mat& matrix) const;
-    bool calculateEigenvaluesAndEigenvectors(Mat src, Mat& eigenvalues, Mat& eigenvectors) const;
+    bool calculateEigenvaluesAndEigenvectors(const Mat& src, Mat& eigenvalues, Mat& eigenvectors) const;
     void matrix2Quaternion(Quaternion& quaternion, const Mat& matrix) const;
 
     // the reference's loadPictures()+dataAssociation() slot (SLAM.cpp:95-97)

@@ -59,7 +59,9 @@ int main(int argc, char** argv)
     if ((int)odo.size() / 3 < F + 1) { fprintf(stderr, "odometry has %d poses, need %d\n", (int)odo.size() / 3, F + 1); return 2; }
 
     double t_timed = 0.0, pose[4] = { 0, 0, 0, 0 }, P4[16] = { 0 };
+    double tcall[5] = { 0, 0, 0, 0, 0 };                      // capi / assoc: host time inside predict_motion, predict_measurement, the association, update, get_robot
     long long matches_dev = 0;
+    long long flag_ticks = -1;                                       // last frame: start of the frame's first launch -> h / Si / visible flagged to the host (10 ns ticks)
     if (mode == "facade") {
         monoslam::CSLAM SLAM;
         SLAM.m_params.a1 = a4[0]; SLAM.m_params.a2 = a4[1]; SLAM.m_params.a3 = a4[2]; SLAM.m_params.a4 = a4[3];
@@ -129,20 +131,29 @@ int main(int argc, char** argv)
         double t0 = 0.0;
         for (int fr = f0; fr < W + K; fr++) {
             if (fr == W) t0 = now_s();
+            const double s0 = now_s();
             if (hint && fr + 2 <= F) CK(srukf_predict_motion_next(c, &odo[3 * fr + 3], &odo[3 * fr + 6]));      // (before the predict: its first launch then carries the third pose too)
             CK(srukf_predict_motion(c, &odo[3 * fr], &odo[3 * fr + 3]));
+            const double s1 = now_s();
             CK(srukf_predict_measurement(c, h.data(), Si.data(), vis.data()));
+            const double s2 = now_s();
             if (assoc) { CK(srukf_associate(c, gray.data(), zc.data(), md.data(), corr.data())); for (int k = 0; k < N; k++) matches_dev += md[k]; }
             const double* zz = &z[(size_t)fr * 2 * N];
             for (int k = 0; k < N; k++) m[k] = vis[k];                 // the host's association: every visible landmark found where the scene put it
+            const double s3 = now_s();
             CK(srukf_update(c, zz, m.data(), SRUKF_NEEDNOT_REORDER, SRUKF_UPDATE_BATCHED));
+            const double s4 = now_s();
             CK(srukf_get_robot(c, pose, P4));
+            if (fr >= W) { tcall[0] += s1 - s0; tcall[1] += s2 - s1; tcall[2] += s3 - s2; tcall[3] += s4 - s3; tcall[4] += now_s() - s4; }
         }
         t_timed = now_s() - t0;
+        srukf_debug_get(c, "meas_flag_ticks", &flag_ticks);
         srukf_destroy(c);
     }
     printf("{\"mode\": \"%s\", \"hint\": %d, \"landmarks\": %d, \"frames\": %d, \"warmup\": %d, \"frames_per_s\": %.2f, \"us_per_frame\": %.2f, "
-           "\"pose\": [%.17g, %.17g, %.17g, %.17g], \"P_robot\": [%.17g, %.17g, %.17g, %.17g], \"device_matches\": %lld, \"filter_driven_by\": \"scene z / matched (host association)\"}\n",
-           mode.c_str(), hint, N, K, W, K / t_timed, t_timed / K * 1e6, pose[0], pose[1], pose[2], pose[3], P4[0], P4[1], P4[4], P4[5], matches_dev);
+           "\"pose\": [%.17g, %.17g, %.17g, %.17g], \"P_robot\": [%.17g, %.17g, %.17g, %.17g], \"device_matches\": %lld, \"stats_flag_us_into_first_launch\": %.2f, \"host_us_per_call\": {\"predict_motion\": %.2f, \"predict_measurement\": %.2f, \"association\": %.2f, \"update\": %.2f, \"get_robot\": %.2f}, "
+           "\"filter_driven_by\": \"scene z / matched (host association)\"}\n",
+           mode.c_str(), hint, N, K, W, K / t_timed, t_timed / K * 1e6, pose[0], pose[1], pose[2], pose[3], P4[0], P4[1], P4[4], P4[5], matches_dev, flag_ticks * 0.01,
+           tcall[0] / K * 1e6, tcall[1] / K * 1e6, tcall[2] / K * 1e6, tcall[3] / K * 1e6, tcall[4] / K * 1e6);
     return 0;
 }
