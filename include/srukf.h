@@ -124,7 +124,9 @@ int  srukf_get_landmark_block(srukf_ctx* ctx, int k, double X6[6], double P66[36
 int  srukf_get_landmarks_cartesian(srukf_ctx* ctx, double* xyz, double* cov);
 
 /* What CSLAM::SLAM() refreshes for the display after every update (updateFeaturesInformation 2397-2621: m_X_k, xyz / Cartesian covariance of every landmark;
- * recordRobotInformation 3539-3556: the robot block) in ONE device round trip instead of one per accessor: X[n], xyz[3N], cov[9N], pose4[4], P4[16]; any may be NULL. */
+ * recordRobotInformation 3539-3556: the robot block) in ONE device round trip instead of one per accessor: X[n], xyz[3N], cov[9N], pose4[4], P4[16]; any may be NULL.
+ * A host that calls it right after srukf_update gets the view exported with the status of its following updates (the call is then a copy from pinned memory; three
+ * views nobody fetched end that).  Same values either way. */
 int  srukf_get_frame_view(srukf_ctx* ctx, double* X, double* xyz, double* cov, double pose4[4], double P4[16]);
 
 /* Full covariance m_P_k = S^T S (SLAM.cpp:2404), n*n row-major, for hosts that want it. */
@@ -137,9 +139,10 @@ int  srukf_get_covariance(srukf_ctx* ctx, double* P);
 int  srukf_predict_motion(srukf_ctx* ctx, const double odo_prev[3], const double odo_cur[3]);
 /* Optional look-ahead for hosts that know their odometry in advance (the reference does: loadOdometryData reads the whole file into m_odoXY / m_odoTheta
  * before the first frame, SLAM.cpp:363-496): the pair srukf_predict_motion will be called with for the NEXT frame, announced any time before this frame's
- * srukf_update.  The update's frame tail then also projects the next frame's sigma points (as the staged replay's tail does), and the next
- * srukf_predict_motion / srukf_predict_measurement launch nothing but the reduction over them.  A next call whose pair differs from the announced one simply
- * projects again: results never depend on the hint.  No reference counterpart (predictMotion reads m_odoXY[counter], SLAM.cpp:1444-1450). */
+ * srukf_update.  The update's frame tail then also projects the next frame's sigma points (as the staged replay's tail does) and srukf_update submits the
+ * next frame's first launch behind its own: the next srukf_predict_motion has nothing left to launch and srukf_predict_measurement only waits for the
+ * statistics.  A next call whose pair differs from the announced one (or a state / map change in between) has that work ignored and projects again:
+ * results never depend on the hint.  No reference counterpart (predictMotion reads m_odoXY[counter], SLAM.cpp:1444-1450). */
 int  srukf_predict_motion_next(srukf_ctx* ctx, const double odo_prev[3], const double odo_cur[3]);
 
 /* predictMeasurement (SLAM.cpp:1604-1608): h[2N] predicted pixels (m_allPredictSet),
