@@ -179,6 +179,7 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     }
     else if (!strcmp(key, "step_fast")) *value = c->step_fast_frames;          // frames the step-wise API ran on the staged replay's launch sequence / on its own
     else if (!strcmp(key, "step_slow")) *value = c->step_slow_frames;
+    else if (!strncmp(key, "pxy2_stamp", 10) && key[10] >= '1' && key[10] <= '7') { const unsigned long long* t = (const unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N); *value = (long long)(t[key[10] - '0'] - t[0]); }   // diagnostic build (-DSRUKF_PXY2_DBG): 2 motion end, 4..7 sampled tiles' ends
     else if (!strcmp(key, "meas_flag_ticks")) { const unsigned long long* t = (const unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N); *value = (long long)(t[1] - t[0]); }   // last fast-path k_pxy2: first workgroup's start -> statistics flag, 10 ns ticks
     else if (!strcmp(key, "view_hits")) *value = c->view_hits;                     // srukf_get_frame_view calls served from the view an update exported with its status
     else if (!strcmp(key, "view_auto")) *value = c->view_auto ? 1 : 0;

@@ -134,6 +134,9 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
         if (threadIdx.x >= 256) return;
         const RankArgs ra0 = {};
         motion_reduce_body<256, false>(d, w, const_cast<double*>(ms.X), nullptr, const_cast<double*>(ms.sigR), ms.Cm, ms.fs, ra0, shm);
+#ifdef SRUKF_PXY2_DBG
+        if (ms.hstamp && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[2] = t_; }
+#endif
         return;
     }
     // order of the grid: motion job, statistics jobs, tiles (PXY2_STATS_LAST = 1: the statistics behind the tiles)
@@ -220,6 +223,13 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 P[(size_t)(m0 + mo + 16 * a + lk + 4 * t) * d.np + b0 + bo + 16 * b + lr] = acc[a][b][t] + ho[wv][lane][(a * 2 + b) * 4 + t];
+#ifdef SRUKF_PXY2_DBG
+    if (ms.hstamp && threadIdx.x == 0) {
+        const int ti = bid - tile0;
+        const int slot = ti == ntiles - 1 ? 4 : ti == ntiles - 9 ? 5 : ti == ntiles / 2 ? 6 : ti == 0 ? 7 : -1;
+        if (slot >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[slot] = t_; }
+    }
+#endif
 }
 __global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
                                               const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
