@@ -22,6 +22,19 @@
 __device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w, const MeasArgs& ms, int bx, double* shm)
 {
     __shared__ int last;
+    // what the final pass will want from memory besides the partial sums — rows 0, 1, 2 of Z at the group's columns — is requested by EVERY job before it counts itself:
+    // for the one that turns out last it has arrived with the counter's reply (a dependent round trip less on the launch's longest chain)
+#ifdef SRUKF_PXY2_DBG
+#define PXY2_TS(slot) do { if (ms.hstamp && bx == 0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[slot] = t_; } } while (0)
+#else
+#define PXY2_TS(slot) do { } while (0)
+#endif
+    PXY2_TS(4);                                                // (group 0: the last writer is the last job to get here)
+    MeasPre pre;
+    const int kq = bx * 32 + (int)threadIdx.x;
+    const bool mine = threadIdx.x < 32 && kq < d.N;
+#pragma unroll
+    for (int e = 0; e < 3; e++) pre.z[e] = mine ? *reinterpret_cast<const double2*>(ms.Z + (size_t)e * d.mp + 2 * kq) : make_double2(0.0, 0.0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's device-scope stores have landed ...
     __syncthreads();                                           // ... and so have the whole workgroup's, before the count
     if (threadIdx.x == 0) {
@@ -31,20 +44,21 @@ __device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w,
     }
     __syncthreads();
     if (!last) return;
-    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode);
+    PXY2_TS(5);
+    MeasOut mo;
+    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode, &pre, ms.hmirror ? &mo : nullptr);
+    PXY2_TS(3);
     if (!ms.hmirror) return;
-    // step-wise API: the 32 lanes that stored this group's h / Si / visible (one wave; each reads back its own stores) repeat them into the host's pinned buffer; the
-    // group that completes the count raises the flag.  A wave's fence covers all its lanes' stores, and every group fences at system scope BEFORE it counts.
+    // step-wise API: the 32 lanes that stored this group's h / Si / visible (one wave) repeat them into the host's pinned buffer; the group that completes the count raises
+    // the flag.  A wave's fence covers all its lanes' stores, and every group fences at system scope BEFORE it counts.
     if (threadIdx.x >= 32) return;
-    const int k = bx * 32 + (int)threadIdx.x;
-    if (k < d.N) {
+    if (mine) {
         double* hh = (double*)ms.hmirror;
         double* hSi = (double*)(ms.hmirror + ((const char*)ms.Si - (const char*)ms.h));
         int* hvis = (int*)(ms.hmirror + ((const char*)ms.vis - (const char*)ms.h));
-        const double2 hv = *(const double2*)(ms.h + 2 * k);
-        const double2 s0 = *(const double2*)(ms.Si + 4 * k), s1 = *(const double2*)(ms.Si + 4 * k + 2);
-        *(double2*)(hh + 2 * k) = hv; *(double2*)(hSi + 4 * k) = s0; *(double2*)(hSi + 4 * k + 2) = s1;
-        hvis[k] = ms.vis[k];
+        *(double2*)(hh + 2 * kq) = make_double2(mo.h[0], mo.h[1]);
+        *(double2*)(hSi + 4 * kq) = make_double2(mo.si[0], mo.si[1]); *(double2*)(hSi + 4 * kq + 2) = make_double2(mo.si[2], mo.si[3]);
+        hvis[kq] = mo.vis;
     }
     __threadfence_system();
     if (threadIdx.x == 0) {
@@ -146,6 +160,9 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
     const int stat0 = PXY2_STATS_LAST ? nmot + ntiles : nmot, tile0 = PXY2_STATS_LAST ? nmot : nmot + nstat;
     if (bid >= stat0 && bid < stat0 + nstat) {
         if (threadIdx.x >= 256) return;
+#ifdef SRUKF_PXY2_DBG
+        if (ms.hstamp && bid == stat0 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[6] = t_; }
+#endif
         const int job = bid - stat0;               // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
         meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm, ms.ns);
         meas_job_done(d, w, ms, job % ms.gx, shm);
@@ -226,7 +243,7 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
 #ifdef SRUKF_PXY2_DBG
     if (ms.hstamp && threadIdx.x == 0) {
         const int ti = bid - tile0;
-        const int slot = ti == ntiles - 1 ? 4 : ti == ntiles - 9 ? 5 : ti == ntiles / 2 ? 6 : ti == 0 ? 7 : -1;
+        const int slot = ti == 0 ? 7 : -1;
         if (slot >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[slot] = t_; }
     }
 #endif

@@ -37,19 +37,42 @@ __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights&
     // touches the first — one memory round trip per chunk (one row per trip was a round trip per row: 9.8 us per job, the long
     // pole of the launch the statistics ride on).
     double (*rs)[4] = (double (*)[4])(smem + 8 * 32 * MEAS_NS);
+    // slice 0 also takes the landmark's own structurally null directions (below, behind the chunks: the order of the sums is what it was).  Their loads go out HERE, with
+    // the first chunk's — the row index does not depend on the test, only the decision does: behind the loop they were two more dependent round trips on the job every
+    // group's final pass waits for, and the statistics are the long pole of the launch they ride on (24 of its 25 us; scripts/pxy2_stamps.py)
+    const bool own = ns.rows && by == 0 && sl < 6 && k < d.N && 6 * k + (sl >> 1) >= 2;
+    int own_ip = 0; double2 own_z = make_double2(0.0, 0.0); double4 own_r = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (own) {
+        const int i = 6 * k + (sl >> 1), c = 1 + (sl & 1) * d.Na + i;
+        own_ip = ns.iperm[i];
+        own_z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * k);
+        own_r = *reinterpret_cast<const double4*>(sigR + (size_t)c * 8);
+    }
     for (int cb = c_beg; cb < c_end; cb += 8 * MEAS_CHUNK) {
         const int cn = min(8 * MEAS_CHUNK, c_end - cb);
         __syncthreads();
-        for (int e = threadIdx.x; e < cn * 4; e += 256) {
-            const int cp = cb + (e >> 2), c = ns.rows ? ns.rows[cp] : cp;
-            rs[e >> 2][e & 3] = sigR[(size_t)c * 8 + (e & 3)];
+        // Two memory round trips per chunk — every row index this thread needs first (list mode), then every value —, in that order in the program: written as a
+        // staging loop (index -> value -> LDS, twice) followed by the Z rows (index -> value) it was SIX dependent round trips, 13 of the launch's 25 us (scripts/pxy2_stamps.py)
+        static_assert(8 * MEAS_CHUNK * 4 <= 2 * 256, "two staging elements per thread");
+        int ce[2], cz[MEAS_CHUNK];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int e = threadIdx.x + 256 * j, cp = cb + (e >> 2);
+            ce[j] = (e < cn * 4) ? (ns.rows ? ns.rows[cp] : cp) : -1;
         }
-        double2 zz[MEAS_CHUNK];
 #pragma unroll
         for (int u = 0; u < MEAS_CHUNK; u++) {
-            const int cp = min(cb + sl + 8 * u, c_end - 1), c = ns.rows ? ns.rows[cp] : cp;
-            zz[u] = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * kk);
+            const int cp = min(cb + sl + 8 * u, c_end - 1);
+            cz[u] = ns.rows ? ns.rows[cp] : cp;
         }
+        double rv[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) rv[j] = (ce[j] >= 0) ? sigR[(size_t)ce[j] * 8 + (threadIdx.x & 3)] : 0.0;
+        double2 zz[MEAS_CHUNK];
+#pragma unroll
+        for (int u = 0; u < MEAS_CHUNK; u++) zz[u] = *reinterpret_cast<const double2*>(Z + (size_t)cz[u] * mp + 2 * kk);
+#pragma unroll
+        for (int j = 0; j < 2; j++) { const int e = threadIdx.x + 256 * j; if (ce[j] >= 0) rs[e >> 2][e & 3] = rv[j]; }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < MEAS_CHUNK; u++) {
@@ -67,13 +90,11 @@ __device__ __forceinline__ void meas_partial_job(const KDims& d, const KWeights&
             }
         }
     }
-    if (ns.rows && by == 0 && sl < 6 && k < d.N) {
+    if (own) {
         // the landmark's own null directions (anchor coordinates 6 k + e): sub-slice sl takes (e, sign) = (sl >> 1, sl & 1)
-        const int i = 6 * k + (sl >> 1);
-        if (i >= 2 && ns.iperm[i] >= ns.r) {
-            const int c = 1 + (sl & 1) * d.Na + i;
-            const double2 z = *reinterpret_cast<const double2*>(Z + (size_t)c * mp + 2 * k);
-            const double4 rr = *reinterpret_cast<const double4*>(sigR + (size_t)c * 8);
+        if (own_ip >= ns.r) {
+            const double2 z = own_z;
+            const double4 rr = own_r;
             const double r[4] = { rr.x, rr.y, rr.z, rr.w };
             const double dx = z.x - z0.x, dy = z.y - z0.y;
             s[0] += dx; s[1] += dy;
@@ -113,10 +134,14 @@ __device__ __forceinline__ double meas_slice_pair(const double* __restrict__ par
     return *s0 + *s1;
 }
 // landmark k, given the reduced sums t[]: h, Si, visible, PxyR
+// pre (may be null): rows 0, 1, 2 of Z at the landmark's columns, requested by the caller before it learnt that the final pass is its to run (one memory round trip less
+// behind the last partial sum); out (may be null): what was stored to h / Si / visible, for a caller that passes it on (the step-wise API's host mirror)
+struct MeasPre { double2 z[3]; };
+struct MeasOut { double h[2]; double si[4]; int vis; };
 __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                 const double* __restrict__ Z, const double (&t)[MEAS_NS],
                                                 double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                double* __restrict__ PxyR, int k, int defer = 0);
+                                                double* __restrict__ PxyR, int k, int defer = 0, const MeasPre* pre = nullptr, MeasOut* out = nullptr);
 // landmark k: reduce the slices, finish h, Si, visible, PxyR
 template <bool COHERENT>
 __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w, const double* __restrict__ X, const double* __restrict__ sigR,
@@ -140,15 +165,23 @@ __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w
 __device__ __forceinline__ void meas_final_group(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                  const double* __restrict__ Z, const double* __restrict__ part,
                                                  double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                 double* __restrict__ PxyR, int bx, double* smem, int defer = 0)
+                                                 double* __restrict__ PxyR, int bx, double* smem, int defer = 0, const MeasPre* pre = nullptr, MeasOut* out = nullptr)
 {
     double (*sm)[32][MEAS_NS] = (double (*)[32][MEAS_NS])smem;
     const int lx = threadIdx.x & 31, pr = threadIdx.x >> 5;
     const int k = bx * 32 + lx, half = d.mp / 2;
     __syncthreads();                                           // the partial job's use of the scratch is over
     if (k < d.N) {
+        // all 26 device-scope loads go out before the first sum (the compiler keeps atomic loads where they are written: pair by pair it was 13 dependent round trips,
+        // 5.8 us of the launch's longest chain)
+        double p0[MEAS_NS], p1[MEAS_NS];
 #pragma unroll
-        for (int q = 0; q < MEAS_NS; q++) sm[pr][lx][q] = meas_slice_pair<true>(part, half, k, q, pr);
+        for (int q = 0; q < MEAS_NS; q++) {
+            p0[q] = __hip_atomic_load(&part[((size_t)(2 * pr) * MEAS_NS + q) * half + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p1[q] = __hip_atomic_load(&part[((size_t)(2 * pr + 1) * MEAS_NS + q) * half + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < MEAS_NS; q++) sm[pr][lx][q] = p0[q] + p1[q];        // (meas_slice_pair's sum)
     }
     __syncthreads();
     if (threadIdx.x < 32 && k < d.N) {
@@ -160,19 +193,19 @@ __device__ __forceinline__ void meas_final_group(const KDims& d, const KWeights&
             for (int u = 0; u < 8; u++) acc += sm[u][lx][q];
             t[q] = acc;
         }
-        meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k, defer);
+        meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k, defer, pre, out);
     }
 }
 __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                 const double* __restrict__ Z, const double (&t)[MEAS_NS],
                                                 double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                double* __restrict__ PxyR, int k, int defer)
+                                                double* __restrict__ PxyR, int k, int defer, const MeasPre* pre, MeasOut* out)
 {
 #pragma clang fp contract(off)
     // (every fused multiply-add written out, contraction off: this function is compiled into three kernels — k_meas_final, k_pxy, k_pxy2 — and which of two
     //  products the compiler fuses depends on the code around an inlined call; the step-wise API and the replay must give the same bits)
     const int mp = d.mp;
-    const double2 z0 = *reinterpret_cast<const double2*>(Z + 2 * k);
+    const double2 z0 = pre ? pre->z[0] : *reinterpret_cast<const double2*>(Z + 2 * k);
     // h = wm0*Z0 + wi*sum_{c>=1} Z_c = Z0*(wm0 + 2Na*wi) + wi*sum (Z_c - Z0)      (SLAM.cpp:1678-1681)
     const double wsum = w.wm0 + 2.0 * d.Na * w.wi;
     const double hx = fma(wsum, z0.x, w.wi * t[0]), hy = fma(wsum, z0.y, w.wi * t[1]);
@@ -199,8 +232,8 @@ __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& 
         }
     }
     // Householder R of the 2Na x 2 matrix [a b] (GSL: beta = -sign(alpha) hypot(alpha, xnorm); tau = 0 if xnorm == 0)
-    const double2 z1 = *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * k);
-    const double2 z2 = *reinterpret_cast<const double2*>(Z + (size_t)2 * mp + 2 * k);
+    const double2 z1 = pre ? pre->z[1] : *reinterpret_cast<const double2*>(Z + (size_t)1 * mp + 2 * k);
+    const double2 z2 = pre ? pre->z[2] : *reinterpret_cast<const double2*>(Z + (size_t)2 * mp + 2 * k);
     const double a0 = w.wi_sr * (z1.x - z0.x), b0 = w.wi_sr * (z1.y - z0.y);
     const double a1 = w.wi_sr * (z2.x - z0.x), b1 = w.wi_sr * (z2.y - z0.y);
     const double saa = t[2], sab = t[3], sbb = t[4];
@@ -222,5 +255,6 @@ __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& 
     double R11 = bp1;
     if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(nrm2);
     Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;
+    if (out) { out->h[0] = hx; out->h[1] = hy; out->si[0] = v ? R00 : 0.0; out->si[1] = v ? R01 : 0.0; out->si[2] = 0.0; out->si[3] = v ? R11 : 0.0; out->vis = v ? 1 : 0; }
 }
 

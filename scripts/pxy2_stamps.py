@@ -1,6 +1,6 @@
 """Where inside the step-wise fast path's first launch (k_pxy2) do its three kinds of workgroups end?  Diagnostic build only:
   bash scripts/build_variants.sh srukf_factor.hip SRUKF_PXY2_DBG 1;  python scripts/pxy2_stamps.py [N] [lib]
-Prints, for the last frames, microseconds from the start of the motion workgroup: statistics flag, motion reduction end, four sampled tiles' ends."""
+Prints, for the last frames, microseconds from the start of the motion workgroup: the motion reduction's end, a tile's end, and the stations of landmark group 0's statistics."""
 import os
 import sys
 
@@ -26,8 +26,9 @@ for early in (2, 0):
         f.predict_motion(sc["odo"][t], sc["odo"][t + 1])
         h, Si, vis = f.predict_measurement()
         f.update(sc["z"][t], sc["matched"][t] * vis)
-        rows.append([f.debug_get("meas_flag_ticks")] + [f.debug_get(f"pxy2_stamp{k}") for k in (2, 4, 5, 6, 7)])
+        rows.append([f.debug_get("meas_flag_ticks")] + [f.debug_get(f"pxy2_stamp{k}") for k in (2, 6, 4, 5, 3, 7)])
     r = np.array(rows[6:], dtype=np.float64) * 0.01
-    print(f"N={N} step_early={early}: us from the motion workgroup's start (median over {len(r)} frames): stats flag {np.median(r[:,0]):.1f}, motion end {np.median(r[:,1]):.1f}, "
-          f"tiles: last {np.median(r[:,2]):.1f}, last-8 {np.median(r[:,3]):.1f}, middle {np.median(r[:,4]):.1f}, first {np.median(r[:,5]):.1f}", flush=True)
+    m = np.median(r, axis=0)
+    print(f"N={N} step_early={early}: us from the motion workgroup's start (median over {len(r)} frames): motion end {m[1]:.1f}, first tile's end {m[6]:.1f} | statistics of group 0: "
+          f"first job starts {m[2]:.1f}, last partial job done {m[3]:.1f}, last arrival knows it is last {m[4]:.1f}, final pass done {m[5]:.1f}; flag to the host (all groups) {m[0]:.1f}", flush=True)
     f.close()
