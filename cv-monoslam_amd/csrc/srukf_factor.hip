@@ -46,7 +46,7 @@ __device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w,
     if (!last) return;
     PXY2_TS(5);
     MeasOut mo;
-    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode, &pre, ms.hmirror ? &mo : nullptr);
+    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode, &pre, &mo);      // (always handed over: a conditional pointer keeps the struct in scratch)
     PXY2_TS(3);
     if (!ms.hmirror) return;
     // step-wise API: the 32 lanes that stored this group's h / Si / visible (one wave) repeat them into the host's pinned buffer; the group that completes the count raises
@@ -248,14 +248,16 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
     }
 #endif
 }
-__global__ __launch_bounds__(512) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
+// (four waves per SIMD = two of these workgroups per CU: 128 VGPRs.  The tiles need 124; the statistics jobs' loads-in-flight would take 142 and halve the tiles' occupancy —
+//  N = 500: 122 -> 142 us — so the cap is stated and the few registers over it in the statistics path go to scratch)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
                                               const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
 {
     pxy2_body(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x);
 }
 // Batched form (srukf_run_frames_batch, B filters of one shape in ONE launch per stage): filter f owns workgroups [f per, (f + 1) per) — per is a multiple of 8, so
 // the XCD-aware tile list keeps its meaning — and takes its pointers from tab[f] (device memory: one scalar load round trip at the head of the launch).
-__global__ __launch_bounds__(512) void k_pxy2_b(KDims d, const Pxy2Args* __restrict__ tab, int per, const int4* __restrict__ tiles, int ntiles, int kr, KWeights w)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pxy2_b(KDims d, const Pxy2Args* __restrict__ tab, int per, const int4* __restrict__ tiles, int ntiles, int kr, KWeights w)
 {
     const int f = (int)blockIdx.x / per, bid = (int)blockIdx.x - f * per;
     const Pxy2Args a = tab[f];

@@ -6,13 +6,15 @@ sys.path.insert(0, ".")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "cv-monoslam_amd", "csrc")
 dbgdir = os.path.join(ROOT, "gpurun_out", "dbgobj"); os.makedirs(dbgdir, exist_ok=True)
-srcs = ["srukf_api", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank"]
+srcs = ["srukf_api", "srukf_replay", "srukf_split", "srukf_batch", "srukf_map", "srukf_debug", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank"]      # (csrc/Makefile: SRCS)
 flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -DSRUKF_GMW_DBG -w".split()
 extra = {"srukf_gmw_persist": ["-Os", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}      # (the Makefile's flags for that file: a representative timeline)
-procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + extra.get(s, []) + ["-c", f"{csrc}/{s}.hip", "-o", f"{dbgdir}/{s}.o"]) for s in srcs]
-assert all(p.wait() == 0 for p in procs)
-lib = os.path.join(dbgdir, "libsrukf_hip_dbg.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [f"{dbgdir}/{s}.o" for s in srcs])
+lib = os.path.join(ROOT, "cv-monoslam_amd", "libsrukf_hip_dbg.so")          # built beforehand (hipcc cross-compiles without a GPU: the same flags as below) ...
+if not os.path.exists(lib):                                                    # ... or here
+    procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + extra.get(s, []) + ["-c", f"{csrc}/{s}.hip", "-o", f"{dbgdir}/{s}.o"]) for s in srcs]
+    assert all(p.wait() == 0 for p in procs)
+    lib = os.path.join(dbgdir, "libsrukf_hip_dbg.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [f"{dbgdir}/{s}.o" for s in srcs])
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package(); synth, srukf = pkg.synth, pkg.srukf
