@@ -646,6 +646,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tile stores have landed ...
             __syncthreads();
             if (job == 0) GMW_TS(sy, 132, 5);
+            if (job < ha.ncrit && job < 32) GMW_TS(sy, 140 + job, 0);      // (diagnostic builds: when each critical tile has landed)
             // the list starts with the ha.ncrit tiles the pivot needs before its first panel ((0,0), (0,1), (1,1) in 64 x 64 terms)
             if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(job < ha.ncrit ? &sy->head_crit : &sy->head_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         } else if (job < ha.ntiles + ha.ndx) {

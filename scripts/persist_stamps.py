@@ -50,3 +50,6 @@ for nm, q in (("first worker", 129), ("last worker", 130)):
     print(f"{nm}: entry {g(q, 0) - t0}, own tiles formed {g(q, 1) - t0}, head seen {g(q, 2) - t0}, done {g(q, 3) - t0}")
 print("first helper: entry %d, out %d; last helper (by index) out %d" % (g(131, 0) - t0, g(131, 1) - t0, g(131, 2) - t0))
 print("head job 0 (critical tile): entry %d, wave 0 after S^T S part %d, after its U U^T part %d, wave 3 after its part %d, after the split-K sum %d, stores issued %d, landed %d" % tuple(g(132, q) - t0 for q in (0, 1, 2, 6, 3, 4, 5)))
+crit = [g(140 + q, 0) - t0 for q in range(32) if g(140 + q, 0)]
+print("critical head tiles landed (ticks since the pivot's entry):", crit)
+
