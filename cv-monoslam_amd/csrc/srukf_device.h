@@ -335,6 +335,10 @@ struct GmwSync {
     // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)
     // followed by unsigned long long slabver[T*T] (split form): (epoch << SHIFT) + 1 once the slabs of panel k for column block J are in Wslab / Lslab
 };
+// The two head-fold counters live in words of their own, 2 KB behind copy 0 of the panel flags / of the half flags (unused padding of those arrays: zero like the rest of the
+// block): as fields next to epoch / exited / abort they shared one line with everything every workgroup of the launch touches.
+__device__ __forceinline__ unsigned int* gmw_head_crit(GmwSync* sy) { return (unsigned int*)&sy->panel_ready[GMW_FLAG_STRIDE / 2]; }
+__device__ __forceinline__ unsigned int* gmw_head_done(GmwSync* sy) { return (unsigned int*)&sy->half_ready[GMW_FLAG_STRIDE / 2]; }
 __device__ __forceinline__ unsigned long long* gmw_sync_ver(GmwSync* sy) { return (unsigned long long*)(sy + 1); }
 __device__ __forceinline__ unsigned long long* gmw_sync_slabver(GmwSync* sy, int T) { return (unsigned long long*)(sy + 1) + (size_t)T * T; }
 

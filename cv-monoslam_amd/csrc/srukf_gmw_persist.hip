@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
             if (job == 0) GMW_TS(sy, 132, 5);
             if (job < ha.ncrit && job < 32) GMW_TS(sy, 140 + job, 0);      // (diagnostic builds: when each critical tile has landed)
             // the list starts with the ha.ncrit tiles the pivot needs before its first panel ((0,0), (0,1), (1,1) in 64 x 64 terms)
-            if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(job < ha.ncrit ? &sy->head_crit : &sy->head_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (wvu == 0) { if (lane == 0) __hip_atomic_fetch_add(job < ha.ncrit ? gmw_head_crit(sy) : gmw_head_done(sy), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         } else if (job < ha.ntiles + ha.ndx) {
             const int dj = job - ha.ntiles;
             if (ha.ra.prep_next && dj == 0 && tid == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         bool head_ok = true;
         GMW_TS(sy, 128, 0);
         if (ha.ntiles > 0) {                                   // region R_0 and the two tiles behind it come from the helpers of this launch
-            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) ok = gmw_wait_head(&sy->head_crit, (unsigned)ha.ncrit, &sy->abort) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) ok = gmw_wait_head(gmw_head_crit(sy), (unsigned)ha.ncrit, &sy->abort) ? 1 : 0;
             __syncthreads();
             head_ok = ok != 0;
             __syncthreads();
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         if (role == 1) GMW_TS(sy, 129, 1);
         if (role == nmain - 1) GMW_TS(sy, 130, 1);
         if (ha.ntiles > 0) {                                   // step 0 reads the head rows of G (and a row-1 / 2 x 2-block tile is loaded from there)
-            if (wv0) ok = (gmw_wait_head(&sy->head_crit, (unsigned)ha.ncrit, &sy->abort) && gmw_wait_head(&sy->head_done, (unsigned)(ha.ntiles - ha.ncrit), &sy->abort)) ? 1 : 0;
+            if (wv0) ok = (gmw_wait_head(gmw_head_crit(sy), (unsigned)ha.ncrit, &sy->abort) && gmw_wait_head(gmw_head_done(sy), (unsigned)(ha.ntiles - ha.ncrit), &sy->abort)) ? 1 : 0;
             __syncthreads();
             good = ok != 0;
             if (!good && wv0) gmw_abandon(sy, 3);
@@ -741,13 +741,13 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         if (done == gridDim.x - 1) {
             if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
 #ifdef SRUKF_GMW_DBG
-            sy->pad[3] = __hip_atomic_load(&sy->head_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sy->pad[4] = __hip_atomic_load(&sy->head_crit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sy->pad[3] = __hip_atomic_load(gmw_head_done(sy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sy->pad[4] = __hip_atomic_load(gmw_head_crit(sy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sy->pad[5] = gridDim.x; sy->pad[6] = (unsigned long long)nhelp;
 #endif
             __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->head_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sy->head_crit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gmw_head_done(sy), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gmw_head_crit(sy), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gated) atomicSub(&g_gmw_admitted, 1);
