@@ -264,8 +264,9 @@ void step_commit_motion(srukf_ctx* c)
 
 // Wait for an export of the fast path: spin on the pinned flag word the export kernel writes behind its data (a completion signal through hipStreamSynchronize costs
 // ~10 us more per round trip); after ~2 ms without it — or with the switch off — the stream is synchronised the ordinary way (which also surfaces a faulted launch).
-static unsigned long long* step_flag(srukf_ctx* c) { return (unsigned long long*)((char*)c->hfs + sizeof(FrameScalars) + sizeof(double) * 32); }
-static int step_wait_export(srukf_ctx* c, unsigned long long seq)
+namespace srukf_impl {
+unsigned long long* step_flag(srukf_ctx* c) { return (unsigned long long*)((char*)c->hfs + sizeof(FrameScalars) + sizeof(double) * 32); }
+int step_wait_export(srukf_ctx* c, unsigned long long seq)
 {
     if (c->dbg.step_spin) {
         volatile unsigned long long* f = step_flag(c);
@@ -277,6 +278,7 @@ static int step_wait_export(srukf_ctx* c, unsigned long long seq)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SRUKF_OK;
 }
+}  // namespace srukf_impl
 static int step_predict_fast(srukf_ctx* c, const double odo_prev[3], const double odo_cur[3])
 {
     const KDims& d = c->d;

@@ -218,6 +218,17 @@ __global__ __launch_bounds__(256) void k_associate(KDims d, srukf_params p, cons
     half_x = min(HP_INIT, max(HP_MATCH, half_x)); half_y = min(HP_INIT, max(HP_MATCH, half_y));         // 1955-1956
     const int wx = 2 * half_x + 1, wy = 2 * half_y + 1;
     const int x0 = (int)px - half_x, y0 = (int)py - half_y;
+    // The pixels every candidate of this landmark can touch — the window plus the template's half width on every side, <= 37 x 37 — go to LDS once (as doubles: what the sums
+    // take); the candidates' two passes over their 17 x 17 patch then read LDS instead of issuing 578 single-byte global loads each.  Same values, same order of the sums.
+    // Pixels outside the image are staged as 0: a candidate whose patch would touch them is skipped by the border test below.
+    constexpr int RG_W = 2 * HP_INIT + 1 + 2 * HP_MATCH;       // 37
+    __shared__ double rg[RG_W * RG_W];
+    const int rw = wx + 2 * HP_MATCH, rh = wy + 2 * HP_MATCH, rx0 = x0 - HP_MATCH, ry0 = y0 - HP_MATCH;
+    for (int e = tid; e < rw * rh; e += 256) {
+        const int yy = ry0 + e / rw, xx = rx0 + e % rw;
+        rg[(e / rw) * RG_W + e % rw] = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? (double)image[(size_t)yy * W + xx] : 0.0;
+    }
+    __syncthreads();
     double bv = -1.0; int bi = 0x7fffffff;
     for (int c = tid; c < wx * wy; c += 256) {
         const int j = y0 + c / wx, i = x0 + c % wx;                                                     // row-major index of `correlation`
@@ -226,12 +237,12 @@ __global__ __launch_bounds__(256) void k_associate(KDims d, srukf_params p, cons
             const double ex = i - px, ey = j - py;
             const double pii = (ex * i00 + ey * i10) * ex + (ex * i01 + ey * i11) * ey;                 // 1975
             if (pii < 5.99146454710798) {                                                               // 1977
-                const unsigned char* roi = image + (size_t)(j - HP_MATCH) * W + (i - HP_MATCH);         // 1979
+                const double* roi = rg + (j - y0) * RG_W + (i - x0);                                    // 1979: image(j - HP_MATCH .., i - HP_MATCH ..) = rg(j - y0 .., i - x0 ..)
                 double s1 = 0.0;
-                for (int r = 0; r < TMPL_W; r++) for (int cl = 0; cl < TMPL_W; cl++) s1 += roi[r * W + cl];
+                for (int r = 0; r < TMPL_W; r++) for (int cl = 0; cl < TMPL_W; cl++) s1 += roi[r * RG_W + cl];
                 const double a1 = s1 / NP;
                 double q1 = 0.0, dot = 0.0;
-                for (int r = 0; r < TMPL_W; r++) for (int cl = 0; cl < TMPL_W; cl++) { const double v1 = roi[r * W + cl] - a1; q1 += v1 * v1; dot += v1 * tm[r * TMPL_W + cl]; }
+                for (int r = 0; r < TMPL_W; r++) for (int cl = 0; cl < TMPL_W; cl++) { const double v1 = roi[r * RG_W + cl] - a1; q1 += v1 * v1; dot += v1 * tm[r * TMPL_W + cl]; }
                 const double std1 = sqrt(q1);
                 cc = (std1 == 0.0 || std2 == 0.0) ? 0.0 : dot / std1 / std2;                            // 3163-3166
             }

@@ -306,6 +306,8 @@ struct ProfScope {
 
 // ---- the step-wise fast path's bookkeeping (srukf_api.hip) ----
 void step_commit_motion(srukf_ctx* c);
+unsigned long long* step_flag(srukf_ctx* c);          // the pinned word exports raise behind their data
+int step_wait_export(srukf_ctx* c, unsigned long long seq);   // spin on it ("step_spin"), or synchronise the stream
 void step_invalidate(srukf_ctx* c);
 void step_state_replaced(srukf_ctx* c);
 void step_ck_join(srukf_ctx* c);

@@ -102,21 +102,31 @@ int srukf_associate(srukf_ctx* c, const unsigned char* gray, double* z, int* mat
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_appearance(c); if (rc) return rc;
     const size_t img = (size_t)c->p.image_w * c->p.image_h;
-    HIPCHK(c, hipMemcpyAsync(c->d_image, gray, img, hipMemcpyHostToDevice, c->stream));
-    step_commit_motion(c);                                               // the warp uses the PREDICTED robot pose (wrapPatch reads m_X_k after predictMotion, SLAM.cpp:1812-1830)
-    double* dxyz = c->G; double* dcov = c->G + 3 * (size_t)N;            // G is free outside the refactorisation
-    srukf_launch_landmarks_cartesian(c->stream, c->d, c->X, c->S, dxyz, dcov);                              // PointsMap::xyz (2574)
+    const size_t mp = c->d.mp, zm = mp + ((size_t)N + 1) / 2;             // zcur | mcur: one device allocation of zm doubles
+    // What does not need the frame goes out first — the warp uses the PREDICTED robot pose (wrapPatch reads m_X_k after predictMotion, SLAM.cpp:1812-1830) — and runs while
+    // the host copies the frame into pinned memory: a hipMemcpyAsync from the caller's pageable buffer is staged by the runtime, synchronously, in front of everything.
+    step_commit_motion(c);
+    double* dxyz = c->G;                                                 // G is free outside the refactorisation
+    srukf_launch_landmarks_cartesian(c->stream, c->d, c->X, c->S, dxyz, nullptr);                           // PointsMap::xyz (2574): the points only, no covariances
     srukf_launch_warp_patch(c->stream, c->d, c->p, c->X, dxyz, c->h, c->appR, c->appT, c->appPx, c->app_patch, c->has_app, c->app_tmpl);
-    srukf_launch_associate(c->stream, c->d, c->p, c->d_image, c->h, c->Si, c->vis, c->has_app, c->app_tmpl, c->zcur, c->mcur, c->corr);
     double* hs = c->hstage;
-    HIPCHK(c, hipMemcpyAsync(hs, c->zcur, sizeof(double) * 2 * N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hs + 2 * N, c->corr, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hs + 3 * N, c->mcur, sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t img_off = (zm + (size_t)N + 7) & ~(size_t)7;           // (doubles) behind the results' place in the staging buffer
+    if ((img_off + (img + 7) / 8) * sizeof(double) <= c->hstage_bytes) {
+        unsigned char* himg = (unsigned char*)(hs + img_off);
+        memcpy(himg, gray, img);
+        HIPCHK(c, hipMemcpyAsync(c->d_image, himg, img, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_image, gray, img, hipMemcpyHostToDevice, c->stream));
+    }
+    srukf_launch_associate(c->stream, c->d, c->p, c->d_image, c->h, c->Si, c->vis, c->has_app, c->app_tmpl, c->zcur, c->mcur, c->corr);
+    // z | matched | corr written into the pinned buffer by ONE short launch, flag behind them: three small device-to-host copies were three blit kernels with their gaps
+    const unsigned long long seq = ++c->step_seq;
+    launch_export(c->stream, c->zcur, sizeof(double) * zm, c->corr, sizeof(double) * N, hs, c->dbg.step_spin ? step_flag(c) : nullptr, seq);
+    rc = step_wait_export(c, seq); if (rc) return rc;
     HIPCHK(c, hipGetLastError());
     if (z) memcpy(z, hs, sizeof(double) * 2 * N);
-    if (corr) memcpy(corr, hs + 2 * N, sizeof(double) * N);
-    if (matched) memcpy(matched, hs + 3 * N, sizeof(int) * N);
+    if (matched) memcpy(matched, hs + mp, sizeof(int) * N);
+    if (corr) memcpy(corr, hs + zm, sizeof(double) * N);
     return SRUKF_OK;
 }
 

@@ -686,6 +686,8 @@ __global__ __launch_bounds__(256) void k_landmarks_cartesian(KDims d, const doub
     for (int q = 0; q < 21; q++) v[q] = 0.0;
     // S upper triangular: rows below the block do not contribute.  Four rows per thread and trip, their loads requested before the first product (a row per trip is one
     // memory round trip per 256 rows; the order of a thread's sums is unchanged)
+    // (cov == null — srukf_associate, whose warp needs the points only: no walk over S, the same xyz code)
+    if (cov)
     for (int k0 = threadIdx.x; k0 < off + 6; k0 += 4 * 256) {
         double s[4][6];
 #pragma unroll
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256) void k_landmarks_cartesian(KDims d, const doub
                 for (int b = a; b < 6; b++) v[q++] += s[u][a] * s[u][b];
         }
     }
-    block_sum<21>(v, red);
+    if (cov) block_sum<21>(v, red);
     if (threadIdx.x != 0) return;
     double P[6][6];
     { int q = 0; for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { P[a][b] = v[q]; P[b][a] = v[q]; q++; } }
@@ -713,6 +715,7 @@ __global__ __launch_bounds__(256) void k_landmarks_cartesian(KDims d, const doub
     xyz[3 * id + 0] = xi + cph * sth / rho;                                                      // 2738-2740
     xyz[3 * id + 1] = yi - sph / rho;
     xyz[3 * id + 2] = zi + cph * cth / rho;
+    if (!cov) return;
     double J[3][6] = { { 1, 0, 0,  cph * cth / rho, -sph * sth / rho, -cph * sth / (rho * rho) },   // 2742-2747
                        { 0, 1, 0,  0.0,             -cph / rho,        sph / (rho * rho) },
                        { 0, 0, 1, -cph * sth / rho, -sph * cth / rho, -cph * cth / (rho * rho) } };
