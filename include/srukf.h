@@ -292,10 +292,14 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  * Per-context keys: "use_graph" (0: eager launches), "fused_motion" (0: k_motion + k_project as two launches, 1: k_project_motion, 2: "table"
  *   mode), "pxy2" (0: k_pxy instead of k_pxy2), "nullskip", "head_fold" (0: k_syrk launch in front of the persistent launch), "tail_fuse"
  *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse", "step_fast" (0: the step-wise API keeps to its own launch sequences instead of the
- *   staged replay's cut at the association step), "split_record".  See srukf_api.hip (srukf_ctx::DbgSwitches). */
+ *   staged replay's cut at the association step), "step_fuse_export" (0: the fast path's results leave through export launches of their own instead of from the
+ *   launches that form them), "step_early" (what srukf_update submits of the NEXT frame behind its own tail: 0 nothing, 1 checkpoint copy + frame scalars, 2 (default)
+ *   also the announced frame's first launch), "step_spin" (0: wait with hipStreamSynchronize instead of spinning on the pinned flag word), "view_auto" (0: the display
+ *   view is never exported with an update's status), "split_record".  See srukf_ctx.h (srukf_ctx::DbgSwitches). */
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
 /* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared", "split_form", "split_off",
- * "step_fast" / "step_slow": frames the step-wise API ran on the fast / the other path) and of the launch plan the next staged frame takes ("plan_persist",
+ * "step_fast" / "step_slow": frames the step-wise API ran on the fast / the other path, "view_hits": srukf_get_frame_view calls served from an exported view,
+ * "meas_flag_ticks": 10-ns ticks from the start of the fast path's last k_pxy2 to the moment the host had its statistics) and of the launch plan the next staged frame takes ("plan_persist",
  * "plan_register_form", "plan_tiles_per_worker", "plan_fold", "plan_head_fold", "plan_red_perm", "plan_motion", "plan_fuse", "plan_T", "plan_Tp", "plan_tiles",
  * "plan_workers", "plan_kept"). */
 int  srukf_debug_get(srukf_ctx* ctx, const char* key, long long* value);
