@@ -340,11 +340,14 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     if (!ex.dst) return;
     // step-wise API: this is the frame's last launch.  A workgroup's updates of *fs are device-scope atomics (the clamp counters) or device-scope stores (the frame
     // tail's), complete once its s_waitcnt returns.  The last workgroup through copies *fs and the view to the host with loads that bypass its own L2.
+    // (The workgroups of the dropped rows — dispatch indices from extra + r on — never write *fs: they are not counted, and do not wait for their stores.)
+    const int ncount = extra + r;
+    if ((int)blockIdx.x >= ncount) return;
     __shared__ int last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int g = (int)blockIdx.x & 63, gsize = ((int)gridDim.x - g + 63) >> 6, groups = (int)gridDim.x < 64 ? (int)gridDim.x : 64;
+        const int g = (int)blockIdx.x & 63, gsize = (ncount - g + 63) >> 6, groups = ncount < 64 ? ncount : 64;
         int* c1 = ex.cnt + 64 * g;
         last = 0;
         if (__hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
