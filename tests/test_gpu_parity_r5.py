@@ -389,6 +389,41 @@ def test_step_results_exported_by_the_launches_that_form_them(srukf, synth, N):
         assert np.array_equal(X, states[0][0]) and np.array_equal(S, states[0][1])
 
 
+def test_work_submitted_ahead_is_ignored_when_the_host_does_something_else(srukf, synth):
+    """With the next frame's odometry announced, srukf_update submits that frame's checkpoint copy, frame scalars and first launch behind its own tail.  A host that then
+    calls srukf_predict_motion with ANOTHER pair, replaces the state, or reads and writes it back in between must get what a host that never announced anything gets:
+    the work submitted ahead only reads the tail's outputs and writes per-frame scratch."""
+    p = synth.scene_params()
+    N, F = 120, 8
+    sc = synth.make_scene(N, F + 3, seed=41, p=p)
+    a, b = srukf.Filter(N, p), srukf.Filter(N, p)
+    for f in (a, b):
+        f.set_state(sc["X0"], sc["S0"])
+    for t in range(F):
+        o0, o1 = sc["odo"][t], sc["odo"][t + 1]
+        if t == 3:                                               # frame 2 announced (odo[3], odo[4]); the host now moves to a pose slightly off the announced one
+            o1 = o1 + np.array([1e-3, -2e-3, 5e-4])
+        if t == 4:
+            o0 = sc["odo"][4] + np.array([1e-3, -2e-3, 5e-4])
+        a.predict_motion_next(sc["odo"][t + 1], sc["odo"][t + 2])         # (a announces the nominal next pair every frame; b never)
+        for f in (a, b):
+            f.predict_motion(o0, o1)
+        va, vb = a.predict_measurement(), b.predict_measurement()
+        assert np.array_equal(va[2], vb[2])
+        np.testing.assert_allclose(va[0], vb[0], rtol=0, atol=1e-8)      # (projected by the tail vs by k_project_table: the same points, other launches)
+        for f in (a, b):
+            f.update(sc["z"][t], sc["matched"][t] * va[2])
+        if t == 5:                                               # the state goes out and comes back in between (everything submitted ahead for frame 6 is void)
+            for f in (a, b):
+                X, S = f.get_state(); f.set_state(X, S)
+    Xa, Sa = a.get_state(); Xb, Sb = b.get_state()
+    fa, fb = a.debug_get("step_fast"), b.debug_get("step_fast")
+    a.close(); b.close()
+    assert fa >= F - 3 and fb >= F - 3, (fa, fb)            # (the first frame of a state that came from outside is not a fast-path frame)
+    np.testing.assert_allclose(Xa, Xb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Sa.T @ Sa, Sb.T @ Sb, rtol=0, atol=1e-11)
+
+
 @pytest.mark.parametrize("hint", [False, True])
 def test_step_api_fast_path_falls_back_on_flagged_frames(srukf, oracle, synth, hint):
     """The shipped a1..a4 = 8 at N = 200: S^T S - U U^T turns indefinite within a few frames and the reference's theta clamp becomes active.  The fast path's tail flags the
