@@ -332,7 +332,7 @@ struct GmwSync {
     unsigned long long pad[59];
     unsigned long long panel_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];  // copy c at [c * STRIDE]: (epoch << SHIFT) + panels published
     unsigned long long half_ready[GMW_FLAG_COPIES * GMW_FLAG_STRIDE];   // same for the first half of a panel buffer (Tt1, E, pivots of sub-panel 1)
-    // followed by unsigned long long ver[T*T]: (epoch << SHIFT) + number of panel updates applied to tile (I, J)
+    // followed by unsigned long long ver[T*T] (one word per 128-byte line: GMW_VIDX): (epoch << SHIFT) + number of panel updates applied to tile (I, J)
     // followed by unsigned long long slabver[T*T] (split form): (epoch << SHIFT) + 1 once the slabs of panel k for column block J are in Wslab / Lslab
 };
 // The two head-fold counters live in words of their own, 2 KB behind copy 0 of the panel flags / of the half flags (unused padding of those arrays: zero like the rest of the
@@ -340,7 +340,11 @@ struct GmwSync {
 __device__ __forceinline__ unsigned int* gmw_head_crit(GmwSync* sy) { return (unsigned int*)&sy->panel_ready[GMW_FLAG_STRIDE / 2]; }
 __device__ __forceinline__ unsigned int* gmw_head_done(GmwSync* sy) { return (unsigned int*)&sy->half_ready[GMW_FLAG_STRIDE / 2]; }
 __device__ __forceinline__ unsigned long long* gmw_sync_ver(GmwSync* sy) { return (unsigned long long*)(sy + 1); }
-__device__ __forceinline__ unsigned long long* gmw_sync_slabver(GmwSync* sy, int T) { return (unsigned long long*)(sy + 1) + (size_t)T * T; }
+// Every version word has a 128-byte line to itself: published by one workgroup, polled by others, and neighbours in one line queue at the memory side behind each
+// other's polls (the head fold's counters: 10 us).  GMW_VIDX(I, J, T): index of tile (I, J)'s word.
+#define GMW_VER_STRIDE 16
+#define GMW_VIDX(I, J, T) (((size_t)(I) * (T) + (J)) * GMW_VER_STRIDE)
+__device__ __forceinline__ unsigned long long* gmw_sync_slabver(GmwSync* sy, int T) { return (unsigned long long*)(sy + 1) + (size_t)T * T * GMW_VER_STRIDE; }
 
 #ifdef SRUKF_GMW_DBG
 #define GMW_DBG(sy, slot, val) do { if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0 && (sy)->dbg) __hip_atomic_store(&(sy)->dbg[blockIdx.x * 8 + (slot)], (unsigned long long)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)

@@ -288,8 +288,8 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
             // round trip at the end of the iteration
             unsigned long long fa = 0, fb = 0;
             if (p >= 1 && p + 1 < Tp) {
-                fa = __hip_atomic_load(&ver[(size_t)p * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fb = __hip_atomic_load(&ver[(size_t)(p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fa = __hip_atomic_load(&ver[GMW_VIDX(p, p + 1, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fb = __hip_atomic_load(&ver[GMW_VIDX((p + 1), p + 1, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             gmw_cols_t_wave<2>(ws2, lane, nxt->Tt2, kp.T2, [&] {
                 if (p == 0 || gmw_uniform64(fa) >= ebase + p) stageok[0] = 1;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
             }
             gmw_cols_out_wave<true>(ws, wv1 ? 0 : 1, lane, n, ld, base, nxt->D, nxt->sq, nxt->rD, Dall, Sout, kp.sq, kp.rD);
             if (!half_only) gmw_cols_out_wave<true>(ws2, wv1 ? 0 : 1, lane, n, ld, base + 32, nxt->D + 32, nxt->sq + 32, nxt->rD + 32, Dall, Sout, kp.sq + 32, kp.rD + 32,
-                                                    [&] { if (p >= 1 && p + 1 < Tp) early = __hip_atomic_load(&ver[(size_t)(wv1 ? p : p + 1) * T + p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+                                                    [&] { if (p >= 1 && p + 1 < Tp) early = __hip_atomic_load(&ver[GMW_VIDX((wv1 ? p : p + 1), p + 1, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
             if (wv1) GMW_TS(sy, p + 64, 1); else GMW_TS(sy, p + 64, 2);
         }
         if (p + 1 < Tp) {
@@ -337,7 +337,7 @@ __device__ __forceinline__ void gmw_pivot_persist(int n, int ld, int T, int Tp, 
             const int tr = tileA ? p : p + 1, r0 = (wvu & 1) ? 0 : 32;
             if (wv1) GMW_TS(sy, p, 5);
             const bool ready = p == 0 || gmw_uniform64(early) >= ebase + p || __builtin_amdgcn_readfirstlane(stageok[tileA ? 0 : 1]) != 0 ||
-                               gmw_wait_ge(&ver[(size_t)tr * T + p + 1], ebase + p, &sy->abort);
+                               gmw_wait_ge(&ver[GMW_VIDX(tr, p + 1, T)], ebase + p, &sy->abort);
             if (wv1) GMW_TS(sy, p, 6);
             if (!ready) *okp = 0;
             else {
@@ -388,8 +388,8 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
         unsigned long long a = want, b = want, pr = 0;
         for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
             if (k > 0) {
-                a = __hip_atomic_load(&ver[(size_t)k * T + tl.I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b = __hip_atomic_load(&ver[(size_t)k * T + tl.J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a = __hip_atomic_load(&ver[GMW_VIDX(k, tl.I, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b = __hip_atomic_load(&ver[GMW_VIDX(k, tl.J, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             pr = __hip_atomic_load(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a = gmw_uniform64(a); b = gmw_uniform64(b); pr = gmw_uniform64(pr);
@@ -416,7 +416,7 @@ __device__ __forceinline__ bool gmw_owner_step(int n, int ld, int T, int k, cons
             __syncthreads();
             return *okp != 0;
         },
-        [&] { if (last && !tl.passon) gmw_publish(&ver[(size_t)tl.I * T + tl.J], ebase + tl.nsteps, wv0); },
+        [&] { if (last && !tl.passon) gmw_publish(&ver[GMW_VIDX(tl.I, tl.J, T)], ebase + tl.nsteps, wv0); },
         behind && (!memtile || GMW_MEM_EARLY2 > 0), rows32 && tl.passon, memtile && GMW_MEM_EARLY2 == 1);
 }
 
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void k_gmw_pivslab_persist(int n, int ld, int 
         for (int k = 0; k < kend && good; k++) {
             if (wv0) {
                 bool g2 = gmw_wait_ge(&sy->panel_ready[(blockIdx.x % GMW_FLAG_COPIES) * GMW_FLAG_STRIDE], ebase + k + 1, &sy->abort);
-                if (g2 && k >= 1) g2 = gmw_wait_ge(&ver[(size_t)k * T + J], ebase + k, &sy->abort);
+                if (g2 && k >= 1) g2 = gmw_wait_ge(&ver[GMW_VIDX(k, J, T)], ebase + k, &sy->abort);
                 ok = g2 ? 1 : 0;
             }
             __syncthreads();
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void k_gmw_pivslab_persist(int n, int ld, int 
             if (good) {
                 const bool r32 = half_last && k == Tp - 1;
                 gmw_slab16_to_global<true>(n, ld, 64 * k, 64 * J + 16 * wv, G, pans + k, Sout, Wslab + (size_t)k * 64 * ld, Lslab + (size_t)k * 64 * ld, J >= k + 2 || (Tp < T && k == Tp - 1), r32, lane);
-                gmw_publish(&slabver[(size_t)k * T + J], ebase + 1, wv0);
+                gmw_publish(&slabver[GMW_VIDX(k, J, T)], ebase + 1, wv0);
             }
             __syncthreads();
         }
@@ -863,8 +863,8 @@ void k_gmw_tiles_persist(int ld, int T, double* __restrict__ G, GmwSync* __restr
             const unsigned long long want = ebase + 1;
             unsigned long long a = 0, b = 0;
             for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
-                a = gmw_uniform64(__hip_atomic_load(&slabver[(size_t)k * T + I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                b = gmw_uniform64(__hip_atomic_load(&slabver[(size_t)k * T + J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                a = gmw_uniform64(__hip_atomic_load(&slabver[GMW_VIDX(k, I, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b = gmw_uniform64(__hip_atomic_load(&slabver[GMW_VIDX(k, J, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (a >= want && b >= want) break;
                 if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
                 // rows k+1, k+2 feed the next panels: tight poll.  The ~800 others have slack and poll about once per microsecond (two requests each to a
@@ -907,7 +907,7 @@ void k_gmw_tiles_persist(int ld, int T, double* __restrict__ G, GmwSync* __restr
 #pragma unroll
                     for (int t = 0; t < 4; t++) st_dev(&G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr], acc[a][b][t]);
         }
-        gmw_publish(&ver[(size_t)I * T + J], ebase + ns, wv0);
+        gmw_publish(&ver[GMW_VIDX(I, J, T)], ebase + ns, wv0);
     } else if (wv0) gmw_abandon(sy, 6);
     __syncthreads();
     if (tid == 0) {
@@ -934,7 +934,7 @@ __global__ void k_gmw_split_gate(GmwSync* __restrict__ sy, const FrameScalars* _
 }
 
 extern "C" {
-int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + 2 * sizeof(unsigned long long) * (size_t)T * T); }
+int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + 2 * sizeof(unsigned long long) * (size_t)T * T * GMW_VER_STRIDE); }
 // host-side tile list of the persistent launch: every tile (I, J), 1 <= I <= J < T, with the number of panel updates
 // its owner applies (I off the diagonal; I - 1 on it: the pivot applies the last one itself), ordered by the step at
 // which it is finished, so that worker w and worker w + workers hold tiles that retire at different times.
