@@ -233,11 +233,14 @@ void step_state_replaced(srukf_ctx* c) { step_ck_join(c); c->step_uncommitted = 
 // "fused tail" mode applies (replay_fuse_mode: rank-aware form with canonical null rows; BATCHED, NEEDNOT_REORDER) a step-wise frame now IS a frame of the staged replay, cut
 // in two at the host's association step:
 //   srukf_predict_motion       [k_set_step; unless the previous frame's tail projected this very odometry pair: k_sigr_rows + k_project_table;] k_pxy2 (motion reduction,
-//                              measurement statistics, cross covariances);  the state before the frame is kept (ckS / ckX)
-//   srukf_predict_measurement  D->H copies of h, Si, visible
-//   srukf_update               H->D z / matched; k_gain, the persistent factorisation launch, k_rank_expand<2> (which, when the host has announced the next frame's odometry —
-//                              srukf_predict_motion_next — also projects the next frame); the frame scalars come back, and a flagged frame (theta clamp, abandoned launch,
-//                              a null direction that is not) is rewound and repeated on the other path, as srukf_run_frames does
+//                              measurement statistics, cross covariances);  the state before the frame is kept (ckS / ckX, copied on a stream of its own).  Nothing at
+//                              all when the previous srukf_update submitted this frame ahead (announced odometry, below)
+//   srukf_predict_measurement  waits on a pinned flag word: the statistics jobs inside k_pxy2 write h, Si, visible to the host themselves (MeasArgs::hmirror)
+//   srukf_update               k_gain (z / matched read in place from pinned memory), the persistent factorisation launch, k_rank_expand<2> — which, when the host has
+//                              announced the next frame's odometry (srukf_predict_motion_next), also projects the next frame, and whose last workgroup hands the frame
+//                              scalars and the robot view to the host (StepExport) —; then, while the host waits for that: the NEXT frame's checkpoint copy, and with
+//                              announced odometry its frame scalars and first launch ("step_early").  A flagged frame (theta clamp, abandoned launch, a null direction
+//                              that is not) is rewound and repeated on the other path, as srukf_run_frames does; what was submitted ahead is then ignored
 // Same kernels on the same values as the staged replay: bit-identical states (tests/test_gpu_parity_r5.py::test_step_api_equals_staged_replay).
 
 namespace srukf_impl {
