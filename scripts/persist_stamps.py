@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "cv-monoslam_amd", "csrc")
 dbgdir = os.path.join(ROOT, "gpurun_out", "dbgobj"); os.makedirs(dbgdir, exist_ok=True)
-srcs = ["srukf_api", "srukf_replay", "srukf_split", "srukf_batch", "srukf_map", "srukf_debug", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank"]      # (csrc/Makefile: SRCS)
+srcs = ["srukf_api", "srukf_step", "srukf_replay", "srukf_split", "srukf_batch", "srukf_map", "srukf_debug", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank"]      # (csrc/Makefile: SRCS)
 flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -DSRUKF_GMW_DBG -w".split()
 extra = {"srukf_gmw_persist": ["-Os", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}      # (the Makefile's flags for that file: a representative timeline)
 lib = os.path.join(ROOT, "cv-monoslam_amd", "libsrukf_hip_dbg.so")          # built beforehand (hipcc cross-compiles without a GPU: the same flags as below) ...

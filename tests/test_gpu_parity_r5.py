@@ -293,7 +293,7 @@ def test_native_multi_gpu_replay_host_runs_its_rccl_calls(tmp_path, srukf, synth
 @pytest.mark.parametrize("N,hint,storage", [(200, True, "f64"), (200, False, "f64"), (50, True, "f64"), (400, True, "f64"), (500, True, "f32")])
 def test_step_api_equals_staged_replay(srukf, synth, N, hint, storage):
     """The drop-in path (SLAM.cpp:87-112 per frame: srukf_predict_motion -> srukf_predict_measurement -> host -> srukf_update) runs, where the staged replay's "fused
-    tail" mode applies, the replay's OWN launch sequence cut at the association step (srukf_api.hip: step_predict_fast / step_update_fast): same kernels on the same
+    tail" mode applies, the replay's OWN launch sequence cut at the association step (srukf_step.hip: step_predict_fast / step_update_fast): same kernels on the same
     values, so the state after F step-wise frames equals the staged replay's bit for bit — with the next frame's odometry announced (srukf_predict_motion_next: the
     update's tail projects the next frame, as the replay's does) and without (every predict projects: k_sigr_rows + k_project_table).  The host's view between predict
     and update (h, Si, visible; the predicted pose) is held to the other path of the step-wise API (debug switch "step_fast" 0: round 4's launch sequences)."""
