@@ -353,6 +353,10 @@ int srukf_destroy(srukf_ctx* c)
     hipSetDevice(c->device);
     batch_plan_forget(c);
     if (c->stream) hipStreamSynchronize(c->stream);
+    // the side streams too, BEFORE any buffer goes back to the pool: the step-wise fast path returns as soon as the tail raises its pinned flag and has by then queued
+    // the S -> ckS2 copy on ck_stream behind that tail; nothing on c->stream follows it, so the synchronisation above can return while the copy still reads S
+    if (c->ck_stream) hipStreamSynchronize(c->ck_stream);
+    if (c->side) hipStreamSynchronize(c->side);
     prof_collect(c);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->graph) hipGraphDestroy(c->graph);

@@ -213,6 +213,8 @@ struct srukf_ctx {
     // The copy for the NEXT frame is submitted by the update that ends this one, right behind its last launch (into the second pair of buffers; pair and event swap
     // when the frame turns out clean): the next srukf_predict_motion then finds its checkpoint made (ck_valid) and submits its first launch at once
     double *ckS2 = nullptr, *ckX2 = nullptr; hipEvent_t ck_e3 = nullptr; bool ck_valid = false;
+    bool ck3_inflight = false;             // ... and until then the copy is in flight on ck_stream with nothing but ck_e3 to wait on (step_ck_join)
+    unsigned spin_ok = 0;                  // successful spin waits (step_wait_export queries the stream every 256th)
     bool pre_issued = false; double pre_odo[6] = { 0, 0, 0, 0, 0, 0 };   // the NEXT frame's first launch (k_pxy2) went out behind this frame's tail, for this odometry pair
     bool next_pose_pending = false;        // the next k_gain launch carries next_odo[3..5] as the sequence's third pose (no launch of its own)
     bool setstep_done = false; double setstep_odo[6] = { 0, 0, 0, 0, 0, 0 };   // k_set_step for the announced next frame went out behind this frame's tail (poses: prev, cur)

@@ -290,7 +290,7 @@ struct MeasArgs {
 // odometry, poses = prev | cur): no launch for it between this frame's tail and the next frame's first launch.
 struct StepExport { unsigned long long* dst; int nfs; double* view; unsigned long long* flag; unsigned long long seq; int* cnt; int set; double* odo; double poses[6]; double a[4]; };
 // start of a step-wise frame whose predecessor's tail prepared the control and projected it (k_set_step with fresh = 0; one thread)
-__device__ __forceinline__ void srukf_step_scalars(FrameScalars* fs, double* odo, int seqF, const double (&a)[4])
+__device__ __forceinline__ void srukf_step_scalars(FrameScalars* fs, double* odo, int seqF, const double (&a)[4], bool clear_frozen = true)
 {
     fs->odo_seq = odo; fs->seqF = seqF;
     fs->a[0] = a[0]; fs->a[1] = a[1]; fs->a[2] = a[2]; fs->a[3] = a[3];
@@ -298,7 +298,8 @@ __device__ __forceinline__ void srukf_step_scalars(FrameScalars* fs, double* odo
     fs->traj_base = nullptr;
     fs->stat_count = 0;
     for (int q = 0; q < SRUKF_STAT_GROUPS; q++) fs->stat_cnt[q] = 0;
-    fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->frozen = 0; fs->gmw_aborts = 0;
+    fs->clamp_rows = 0; fs->clamp_first = 0x7fffffff; fs->clamp_frame = 0x7fffffff; fs->gmw_aborts = 0;
+    if (clear_frozen) fs->frozen = 0;
 }
 
 // ---- agent-scope (device-coherent) accesses: data handed from one workgroup to another INSIDE a launch ----

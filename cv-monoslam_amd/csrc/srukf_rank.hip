@@ -366,9 +366,12 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (ex.set) {                                          // every other workgroup of the frame's last launch is through, *fs is with the host: the next frame starts here
+        // every other COUNTED workgroup of the frame's last launch is through, *fs is with the host: the next frame starts here.  The workgroups of the dropped rows
+        // are not counted and may still be starting: what they read of *fs (ctl, ctl_next_valid, frozen, const_rows_ok) is not touched here — `frozen` is left as it is
+        // (it can only be set behind a flagged frame, and a flagged frame's successor is set up by k_set_step after the rewind, not here)
+        if (ex.set && __hip_atomic_load(&fs->clamp_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             for (int e = 0; e < 6; e++) ex.odo[e] = ex.poses[e];
-            srukf_step_scalars(fs, ex.odo, 1, ex.a);
+            srukf_step_scalars(fs, ex.odo, 1, ex.a, false);
         }
         if (ex.flag) __hip_atomic_store(ex.flag, ex.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -1,6 +1,7 @@
 // srukf_step.hip — the step-wise API (srukf_predict_motion / srukf_predict_measurement / srukf_update: one frame at a time with the host's association in between,
 // SLAM.cpp:87-112) and its fast path: the staged replay's own frame cut at the association step.  gfx950 only.
 #include "srukf_ctx.h"
+#include <chrono>
 using namespace srukf_impl;
 
 namespace srukf_impl {
@@ -9,9 +10,10 @@ namespace srukf_impl {
 // the checkpoint copy of the frame in flight (its own stream) must be complete before anything on the filter's stream changes S or X, or reads the checkpoint
 void step_ck_join(srukf_ctx* c)
 {
-    if (!c->ck_pending) return;
-    hipStreamWaitEvent(c->stream, c->ck_e2, 0);
-    c->ck_pending = false;
+    if (c->ck_pending) { hipStreamWaitEvent(c->stream, c->ck_e2, 0); c->ck_pending = false; }
+    // ... and the copy an update submitted ahead for the NEXT frame (second buffer pair, ck_e3: it becomes ck_e2 / ck_pending once its frame turns out clean; until
+    // then — a flagged frame that is rewound, a state that is replaced — it is still reading S and X)
+    if (c->ck3_inflight) { hipStreamWaitEvent(c->stream, c->ck_e3, 0); c->ck3_inflight = false; }
 }
 void step_state_replaced(srukf_ctx* c) { step_ck_join(c); c->step_uncommitted = false; c->step_fast = false; c->xr1_pending = false; step_invalidate(c); c->f32_stale = false; c->robot_cached = false; }
 
@@ -35,7 +37,7 @@ void step_state_replaced(srukf_ctx* c) { step_ck_join(c); c->step_uncommitted = 
 
 namespace srukf_impl {
 
-void step_invalidate(srukf_ctx* c) { c->step_chain = false; c->proj_valid = false; c->robot_cached = false; c->view_cached = false; c->ck_valid = false; c->setstep_done = false; c->next_pose_pending = false; c->pre_issued = false; }
+void step_invalidate(srukf_ctx* c) { step_ck_join(c); c->step_chain = false; c->proj_valid = false; c->robot_cached = false; c->view_cached = false; c->ck_valid = false; c->setstep_done = false; c->next_pose_pending = false; c->pre_issued = false; }
 
 }  // namespace srukf_impl
 
@@ -56,16 +58,24 @@ void step_commit_motion(srukf_ctx* c)
 }  // namespace srukf_impl
 
 // Wait for an export of the fast path: spin on the pinned flag word the export kernel writes behind its data (a completion signal through hipStreamSynchronize costs
-// ~10 us more per round trip); after ~2 ms without it — or with the switch off — the stream is synchronised the ordinary way (which also surfaces a faulted launch).
+// ~10 us more per round trip); after 2 ms on the steady clock without it — or with the switch off — the stream is synchronised the ordinary way (which also surfaces a
+// faulted launch).  A spin that succeeds never asks the runtime anything, so every 256th of them queries the stream: a launch that faulted is then reported within 256
+// frames of the one that caused it instead of at some later synchronising call.
 namespace srukf_impl {
 unsigned long long* step_flag(srukf_ctx* c) { return (unsigned long long*)((char*)c->hfs + sizeof(FrameScalars) + sizeof(double) * 32); }
 int step_wait_export(srukf_ctx* c, unsigned long long seq)
 {
     if (c->dbg.step_spin) {
         volatile unsigned long long* f = step_flag(c);
-        for (int spins = 0; spins < 400000; spins++) {
-            if (*f >= seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return SRUKF_OK; }      // (>=: the next frame's pre-issued first launch may already have raised it further)
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        for (unsigned spins = 1;; spins++) {
+            if (*f >= seq) {                                   // (>=: the next frame's pre-issued first launch may already have raised it further)
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                if ((++c->spin_ok & 255) == 0) { const hipError_t q = hipStreamQuery(c->stream); if (q != hipSuccess && q != hipErrorNotReady) HIPCHK(c, q); }
+                return SRUKF_OK;
+            }
             __builtin_ia32_pause();
+            if ((spins & 255) == 0 && std::chrono::steady_clock::now() >= t_end) break;       // (the pause instruction is 40 - 140 cycles depending on the CPU: the bound is the clock's)
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -243,7 +253,7 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
             HIPCHK(c, hipMemcpyAsync(c->ckS2, c->S, sizeof(double) * np * np, hipMemcpyDeviceToDevice, c->ck_stream));
             HIPCHK(c, hipMemcpyAsync(c->ckX2, c->X, sizeof(double) * np, hipMemcpyDeviceToDevice, c->ck_stream));
             HIPCHK(c, hipEventRecord(c->ck_e3, c->ck_stream));
-            early_ck = true;
+            early_ck = true; c->ck3_inflight = true;
         }
         if (c->step_seqF == 2) {                                // this frame's tail projects the pair (cur, next): the next frame's poses are known
             if (!early_set) {                                  // (the tail did not export: a launch of its own)
@@ -278,7 +288,7 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     if (c->proj_valid) { for (int e = 0; e < 3; e++) { c->proj_odo[e] = c->step_odo[3 + e]; c->proj_odo[3 + e] = c->next_odo[3 + e]; } }
     if (early_ck) {                                            // the frame is clean: its end state's copy becomes the next frame's checkpoint
         std::swap(c->ckS, c->ckS2); std::swap(c->ckX, c->ckX2); std::swap(c->ck_e2, c->ck_e3);
-        c->ck_pending = true; c->ck_valid = true;
+        c->ck_pending = true; c->ck_valid = true; c->ck3_inflight = false;
     }
     c->setstep_done = early_set && c->proj_valid;
     if (c->setstep_done) memcpy(c->setstep_odo, c->proj_odo, sizeof c->setstep_odo);

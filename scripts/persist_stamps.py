@@ -1,5 +1,5 @@
 """Per-panel timeline of k_gmw_persist inside the REAL replay at N landmarks (diagnostic build of the library: the script builds
-cv-monoslam_amd/libsrukf_hip_dbg.so with -DSRUKF_GMW_DBG on the GPU box, loads it instead of the product library, replays frames and
+build/variants/libsrukf_hip_dbg.so with -DSRUKF_GMW_DBG (here, or on the GPU box), loads it instead of the product library, replays frames and
 prints the pivot workgroup's time stamps of the last frame).  Ticks are 10 ns (s_memrealtime)."""
 import os, subprocess, sys
 sys.path.insert(0, ".")
@@ -9,7 +9,7 @@ dbgdir = os.path.join(ROOT, "gpurun_out", "dbgobj"); os.makedirs(dbgdir, exist_o
 srcs = ["srukf_api", "srukf_step", "srukf_replay", "srukf_split", "srukf_batch", "srukf_map", "srukf_debug", "srukf_predict", "srukf_factor", "srukf_gmw_persist", "srukf_augment", "srukf_assoc", "srukf_mixed", "srukf_rank"]      # (csrc/Makefile: SRCS)
 flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 -DSRUKF_GMW_DBG -w".split()
 extra = {"srukf_gmw_persist": ["-Os", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}      # (the Makefile's flags for that file: a representative timeline)
-lib = os.path.join(ROOT, "cv-monoslam_amd", "libsrukf_hip_dbg.so")          # built beforehand (hipcc cross-compiles without a GPU: the same flags as below) ...
+lib = os.path.join(ROOT, "build", "variants", "libsrukf_hip_dbg.so")          # built beforehand (hipcc cross-compiles without a GPU: the same flags as below) ...
 if not os.path.exists(lib):                                                    # ... or here
     procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + extra.get(s, []) + ["-c", f"{csrc}/{s}.hip", "-o", f"{dbgdir}/{s}.o"]) for s in srcs]
     assert all(p.wait() == 0 for p in procs)

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "cv-monoslam_amd", "libsrukf_hip_SRUKF_PXY2_DBG_1.so")
+lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "build", "variants", "libsrukf_hip_SRUKF_PXY2_DBG_1.so")
 pkg = ge.load_package()
 synth, srukf = pkg.synth, pkg.srukf
 srukf.load_library(lib)
