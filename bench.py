@@ -465,6 +465,42 @@ def multi_sequence_throughput(torch, synth, srukf, N, B, K, W, local, reps=3, sm
     return out, identical, flagged
 
 
+def theta_clamp_leg(synth, srukf, local, sizes=(8, 200), F=20):
+    """What the reference's theta clamp costs here (SLAM.cpp:2264-2285; the blocked factorisation pivots with max(EPSILON, |c_jj|) and VERIFIES the third candidate
+    theta^2 / beta^2 afterwards: a frame in which it would have won is repeated column by column).  The bench scene uses the reference's commented noise constants
+    (SLAM.cpp:191-194), with which the clamp never fires; this leg runs the SHIPPED a1..a4 = 8 (195-198) at N = 8 — the reference's own operating point — and at the
+    headline's N = 200 for F frames through srukf_run_frames, one frame per call so that every frame's wall time and whether it was repeated are known.  With >= 8
+    matches per frame that filter over-subtracts the shared process noise and diverges: the leg stops at the first non-finite pose."""
+    out = {}
+    for N in sizes:
+        p = synth.default_params()
+        sc = synth.make_scene(N, F, seed=1, p=p)
+        f = srukf.Filter(N, p, device=local)
+        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        t_frame, flagged, done, e0 = [], [], 0, 0
+        for t in range(F):
+            t0 = time.perf_counter()
+            try:
+                tr = f.run_frames(t, 1)
+            except srukf.SrukfError as e:
+                out[f"n{N}_error"] = str(e)[:160]
+                break
+            t_frame.append(time.perf_counter() - t0)
+            e1 = int(f.debug_get("exact_frames"))
+            flagged.append(e1 > e0); e0 = e1
+            done += 1
+            if not np.isfinite(tr).all():
+                break
+        f.close()
+        tf, fl = np.asarray(t_frame), np.asarray(flagged, dtype=bool)
+        out[f"n{N}"] = {"frames": done, "frames_per_s": (done / float(tf.sum())) if done else None, "flagged_frames": int(fl.sum()),
+                        "exact_path_share_of_wall": (float(tf[fl].sum() / tf.sum()) if done else None),
+                        "ms_per_flagged_frame": (float(tf[fl].mean() * 1e3) if fl.any() else None), "ms_per_clean_frame": (float(tf[~fl].mean() * 1e3) if (~fl).any() else None)}
+    out["note"] = ("shipped a1..a4 = 8 (SLAM.cpp:195-198), one srukf_run_frames call per frame (its fixed cost — checkpoint copy, one synchronisation — is in both kinds of "
+                   "frame); a flagged frame = blocked factorisation + rewind + 2 n column launches on the exact path")
+    return out
+
+
 STEP_BENCH = os.path.join(ROOT, "cv-monoslam_amd", "cslam_step_bench.bin")
 
 
@@ -499,7 +535,8 @@ def step_api_leg(synth, sizes=(200, 50), K=200, W=20, timeout=300):
                 for i, (x, y, th) in enumerate(sc["odo"]):
                     fh.write(f"{i + 1} : {0.1 * i:.3f} {float(x)!r} {float(y)!r} {float(th)!r}\n")
             res = {}
-            for name, args in (("capi", ["mode=capi"]), ("capi_hint", ["mode=capi", "hint=1"]), ("facade", ["mode=facade"]), ("assoc", ["mode=assoc", "hint=1"])):
+            for name, args in (("capi", ["mode=capi"]), ("capi_hint", ["mode=capi", "hint=1"]), ("facade", ["mode=facade"]), ("assoc", ["mode=assoc", "hint=1"]),
+                               ("churn", ["mode=facade", "churn=10"])):
                 if N != sizes[0] and name == "assoc":
                     continue
                 try:
@@ -508,16 +545,20 @@ def step_api_leg(synth, sizes=(200, 50), K=200, W=20, timeout=300):
                     d = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr.strip()[-300:]}
                 except Exception as e:                                 # noqa: BLE001 - a report, not a gate
                     d = {"error": f"{type(e).__name__}: {e}"}
-                res[name] = {k: d[k] for k in ("frames_per_s", "us_per_frame", "device_matches", "host_us_per_call", "stats_flag_us_into_first_launch", "error")
-                             if k in d and not (name == "facade" and k in ("host_us_per_call", "stats_flag_us_into_first_launch"))}      # (the facade is timed as a whole)
-                if "pose" in d:
+                res[name] = {k: d[k] for k in ("frames_per_s", "us_per_frame", "device_matches", "host_us_per_call", "stats_flag_us_into_first_launch", "churn", "error")
+                             if k in d and not (name in ("facade", "churn") and k in ("host_us_per_call", "stats_flag_us_into_first_launch"))}      # (the facade is timed as a whole)
+                if "pose" in d and name != "churn":                # (the churn leg is driven by predicted pixels + noise, not by the scene's measurements)
                     res[name]["pose_err_vs_truth_m"] = float(np.abs(np.asarray(d["pose"][:2]) - sc["odo"][W + K, :2]).max())
+                if name == "churn" and "frames_per_s" in res[name] and "frames_per_s" in res.get("facade", {}):
+                    res[name]["fixed_map_facade_over_churn"] = round(res["facade"]["frames_per_s"] / res[name]["frames_per_s"], 2)
             out[f"n{N}"] = res
     out["frames"], out["warmup"] = K, W
     out["note"] = ("wall clock of a C++ host calling srukf_predict_motion / srukf_predict_measurement / srukf_update (+ srukf_get_robot) once per frame with host buffers: "
                    "what binding monoslam::CSLAM gives; the staged replay (`value`) has no host in the loop.  host_us_per_call: where the host's time goes (it waits inside "
                    "predict_measurement for h / Si / visible and inside update for the frame's status); stats_flag_us_into_first_launch: when, inside the frame's first launch, "
-                   "the host gets the statistics")
+                   "the host gets the statistics.  churn: monoslam::CSLAM::SLAM() with the reference's own map policy live (SLAM.cpp:2443-2460 deletions, 552-562 additions): every 10th "
+                   "frame one landmark leaves through updateFeaturesInformation -> deleteOneFeature and one enters through addFeatures -> integrateFeaturesInformation, the frame "
+                   "behind it runs FLAG_4_NEED_REORDER")
     return out
 
 
@@ -547,6 +588,7 @@ def main():
     ap.add_argument("--lib", default=None, help="measurement only: an A/B build of libsrukf_hip.so (scripts/build_variants.sh, scripts/ab_head.sh) instead of the in-tree one")
     ap.add_argument("--repetitions", type=int, default=5, help="the timed block of K frames is run this many times (consecutive frames of the staged sequence); `value` is the median")
     ap.add_argument("--no-step-api", action="store_true", help="skip the step_api leg (drop-in frame rate through the C++ host)")
+    ap.add_argument("--no-theta-clamp", action="store_true", help="skip the theta_clamp leg (the shipped a1..a4 = 8: what the verified-afterwards clamp costs when it fires)")
     ap.add_argument("--no-collectives-check", action="store_true",
                     help="skip the short --force-dist child run whose outcome the default 1-GPU line reports as `collectives_check`")
     args = ap.parse_args()
@@ -776,6 +818,8 @@ def main():
                         "matched_same_algorithm is against those CPUs only"}
             out["pose_rmse_vs_oracle_m"] = float(np.sqrt(np.mean((gt[:, :2] - otraj[:, :2]) ** 2)))
             out["max_abs_dP_robot_vs_oracle"] = float(np.abs(gt[:, 4:] - otraj[:, 4:]).max())
+        if world == 1 and not use_dist and not args.no_theta_clamp:
+            out["theta_clamp"] = theta_clamp_leg(synth, srukf, local)
         if world == 1 and not use_dist and not args.no_step_api:
             out["step_api"] = step_api_leg(synth)
         if world == 1 and not use_dist and not args.no_collectives_check:

@@ -52,7 +52,7 @@ void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*,
 void srukf_launch_gmw_split_alone(hipStream_t, int, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int, const StepExport*);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int, const StepExport*, double);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
@@ -83,11 +83,13 @@ void srukf_launch_warp_patch(hipStream_t, KDims, srukf_params, const double*, co
 void srukf_launch_associate(hipStream_t, KDims, srukf_params, const unsigned char*, const double*, const double*, const int*, const int*,
                             const unsigned char*, double*, int*, double*);
 int srukf_mixed_build_tasks(int np, int ue, short* out_tasks, int* out_tiles, int* ntiles);
+int srukf_mixed_build_tasks_red(int np, int ue, int krows, int rows_lim, short* out_tasks, int* out_tiles, int* ntiles);
+int srukf_mixed_krows(int r);
 size_t srukf_mixed_part_bytes(int ntasks);
 void srukf_launch_cvt_f32(hipStream_t, size_t, const double*, float*);
 void srukf_launch_cvt_robot_cols(hipStream_t, int, int, const double*, float*);
 void srukf_launch_gain_dx(hipStream_t, int, int, const double*, double*, const double*);
-void srukf_launch_syrk32(hipStream_t, int, int, int, const float*, const float*, const void*, int, const void*, int, float*, double*, void*);
+void srukf_launch_syrk32(hipStream_t, int, int, int, const float*, const float*, const void*, int, const void*, int, float*, double*, void*, int);
 int srukf_app_patch_stride(void);
 int srukf_app_tmpl_stride(void);
 }
@@ -132,6 +134,9 @@ struct srukf_ctx {
     float *S32 = nullptr, *X32 = nullptr;
     // SRUKF_STORAGE_F32_MIXED: S^T S - U U^T on the fp32 matrix pipe (srukf_mixed.hip)
     float *U32 = nullptr, *mx_part = nullptr; void *mx_tasks = nullptr, *mx_tiles = nullptr; int mx_ntasks = 0, mx_ntiles = 0;
+    // ... in the rank-aware form (round 6): the kept rows of S in permuted column order as float (the permuted copy's values are the stored floats), K <= r, only the
+    // macro tiles of the pivoted panels; task list / partials of that shape (mixed_red_ensure)
+    float *A32 = nullptr, *mxr_part = nullptr; void *mxr_tasks = nullptr, *mxr_tiles = nullptr; int mxr_ntasks = 0, mxr_ntiles = 0, mxr_krows = 0, mxr_for_r = 0;
     int *perm = nullptr, *iperm = nullptr;
     double* Sdis = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered), one launch per panel
@@ -178,6 +183,9 @@ struct srukf_ctx {
         int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
+        int mixed_rank = 1;                // "mixed_rank": SRUKF_STORAGE_F32_MIXED runs the rank-aware refactorisation (fp32-formed S^T S - U U^T over the kept rows, FP64 factorisation
+                                           // of the kept pivots only); 0: round 2's full-rank form, in which the null pivots divide fp32 noise (the negative study of rounds 2 / 5)
+        int mixed_null_ppm = 1;            // "mixed_null_ppm": ... and its null-direction check allows this many 1e-6 of G_aa on top of 1e-12 (an fp32-formed G cannot resolve 1e-12)
     } dbg;
     bool null_canonical = false;           // every structurally null row of S is exactly sqrt(EPSILON) e_k (update_null_set checks; true behind every rank-aware frame tail)
     bool tail_ok = false;                  // "fused tail" mode is possible: directions 0 and 1 are kept rows (the Si factor names their Z rows: they are projected for every landmark, which
@@ -233,6 +241,7 @@ struct srukf_ctx {
     bool robot_cached = false;             // the 20 doubles behind *hfs hold P4 and the pose of the CURRENT state (fast path: fetched with the frame's status)
     bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
+    int exact_frames = 0;                  // staged frames srukf_run_frames repeated on the exact column path (flagged: theta clamp, a skipped direction that is not null, an abandoned launch): "exact_frames"
     bool async_pending = false;
     std::string err;
     // one captured frame (BATCHED, staged inputs): replayed by srukf_run_frames_async
@@ -345,6 +354,7 @@ void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion = false, bool tab
 void seq_gain_only(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_motion = false, bool table = false, bool fmode = false);
 void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false);
 int update_null_set(srukf_ctx* c);
+int mixed_red_ensure(srukf_ctx* c);
 void drop_graphs(srukf_ctx* c);
 void set_null_canonical(srukf_ctx* c);
 int read_fs(srukf_ctx* c);

@@ -26,15 +26,17 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 struct MxTask { short I, J, chunk, nchunks; };   // macro tile (I <= J) and K chunk; partial slot = task index
 
 // C[k][m] layout: A operand of lane l = As[k + (l >> 5)][m0 + (l & 31)], B likewise; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)
+// krows (a multiple of MX_KS): rows of S32 that hold anything — np for the state itself; for the rank-aware form S32 is the permuted copy of the KEPT rows
+// (r of them, upper triangular in permuted order, zero rows behind): K ends at the kept rows
 __global__ __launch_bounds__(256) void k_syrk32(int np, int ue, const float* __restrict__ S32, const float* __restrict__ U32,
-                                                const MxTask* __restrict__ tasks, float* __restrict__ part)
+                                                const MxTask* __restrict__ tasks, float* __restrict__ part, int krows)
 {
     __shared__ float As[2][MX_KS][MX_LS];
     __shared__ float Bs[2][MX_KS][MX_LS];
     const MxTask tk = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int mb = tk.I * MX_TILE, nb = tk.J * MX_TILE;
-    const int ks = min(mb + MX_TILE, np);                        // S[k][m] = 0 for k > m: rows of S that contribute
+    const int ks = min(mb + MX_TILE, krows);                     // S[k][m] = 0 for k > m: rows of S that contribute
     const int ktot = ks + ue;                                    // concatenated K range: S rows, then U^T rows
     const int kbeg = tk.chunk * MX_KCHUNK, kend = min(ktot, kbeg + MX_KCHUNK);
     const int lr = tid >> 5, lc = (tid & 31) * 4;                // this thread's part of a slab: rows lr + 8 i, columns lc .. lc + 3
@@ -172,13 +174,15 @@ __global__ __launch_bounds__(256) void k_cvt_f32(size_t count, const double* __r
 extern "C" {
 // host-side task list for an np x np matrix with ue rows of U^T: tiles longest-K first, chunks of a tile adjacent.
 // out_tasks: 4 shorts per task; out_tiles: (first task, nchunks) per tile.  Returns the number of tasks; *ntiles gets the tile count.
-int srukf_mixed_build_tasks(int np, int ue, short* out_tasks, int* out_tiles, int* ntiles)
+// krows / rows_lim (rank-aware form): K of the first operand ends at krows, and only the macro tiles that hold rows < rows_lim (the pivoted panels) are formed
+int srukf_mixed_build_tasks_red(int np, int ue, int krows, int rows_lim, short* out_tasks, int* out_tiles, int* ntiles)
 {
     const int T = (np + MX_TILE - 1) / MX_TILE;
     int nt = 0, ntl = 0;
     for (int I = T - 1; I >= 0; I--)                             // large I = long K first
         for (int J = I; J < T; J++) {
-            const int ks = (I + 1) * MX_TILE < np ? (I + 1) * MX_TILE : np;
+            if (I * MX_TILE >= rows_lim) continue;
+            const int ks = (I + 1) * MX_TILE < krows ? (I + 1) * MX_TILE : krows;
             const int nch = (ks + ue + MX_KCHUNK - 1) / MX_KCHUNK;
             if (out_tiles) { out_tiles[2 * ntl] = nt; out_tiles[2 * ntl + 1] = nch; }
             for (int c = 0; c < nch; c++) {
@@ -190,6 +194,8 @@ int srukf_mixed_build_tasks(int np, int ue, short* out_tasks, int* out_tiles, in
     if (ntiles) *ntiles = ntl;
     return nt;
 }
+int srukf_mixed_build_tasks(int np, int ue, short* out_tasks, int* out_tiles, int* ntiles) { return srukf_mixed_build_tasks_red(np, ue, np, np, out_tasks, out_tiles, ntiles); }
+int srukf_mixed_krows(int r) { return (r + MX_KS - 1) / MX_KS * MX_KS; }
 size_t srukf_mixed_part_bytes(int ntasks) { return (size_t)ntasks * MX_TILE * MX_TILE * sizeof(float); }
 void srukf_launch_cvt_f32(hipStream_t st, size_t count, const double* src, float* dst)
 {
@@ -204,9 +210,9 @@ void srukf_launch_cvt_robot_cols(hipStream_t st, int n, int np, const double* S,
     hipLaunchKernelGGL(k_cvt_robot_cols, dim3((n + 255) / 256), dim3(256), 0, st, n, np, S, S32);
 }
 void srukf_launch_syrk32(hipStream_t st, int n, int np, int ue, const float* S32, const float* U32, const void* tasks, int ntasks,
-                         const void* tiles, int ntiles, float* part, double* G, void* fs)
+                         const void* tiles, int ntiles, float* part, double* G, void* fs, int krows)
 {
-    hipLaunchKernelGGL(k_syrk32, dim3(ntasks), dim3(256), 0, st, np, ue, S32, U32, (const MxTask*)tasks, part);
+    hipLaunchKernelGGL(k_syrk32, dim3(ntasks), dim3(256), 0, st, np, ue, S32, U32, (const MxTask*)tasks, part, krows > 0 ? krows : np);
     hipLaunchKernelGGL(k_syrk32_reduce, dim3(ntiles), dim3(256), 0, st, n, np, (const int2*)tiles, (const MxTask*)tasks, part, G, (FrameScalars*)fs);
 }
 }  // extern "C"

@@ -273,13 +273,14 @@ int gate_limit(const srukf_ctx* c) { return c->gmw_shared == 1 ? c->shared_tenan
 void rank_expand(srukf_ctx* c, bool frame_tail, bool table, bool fuse)
 {
     const int n = c->d.n, np = c->d.np;
-    const bool f32s = c->storage == SRUKF_STORAGE_F32;
-    const bool f32fuse = f32s && fuse && table && frame_tail;      // fp32 storage in "fused tail" mode: the launch rounds what it writes (no k_quantize / k_rank_round / k_traj behind it)
+    const bool f32s = c->storage != SRUKF_STORAGE_F64;            // (the mixed mode stores floats as well: the launches behind the tail round, as for fp32 storage without "fused tail" mode)
+    const bool f32fuse = c->storage == SRUKF_STORAGE_F32 && fuse && table && frame_tail;      // fp32 storage in "fused tail" mode: the launch rounds what it writes (no k_quantize / k_rank_round / k_traj behind it)
     const bool f32 = f32s && !f32fuse;
     const bool tt = table && frame_tail && !f32;
     const bool exports = c->step_export.dst && tt && fuse;         // step-wise fast path: this launch is the frame's last and hands status + robot view to the host itself
     srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
-                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 1 : 0, c->d, c->w, c->p, c->Z, c->DZ, f32fuse ? 1 : 0, exports ? &c->step_export : nullptr);
+                             tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 1 : 0, c->d, c->w, c->p, c->Z, c->DZ, f32fuse ? 1 : 0, exports ? &c->step_export : nullptr,
+                             c->storage == SRUKF_STORAGE_F32_MIXED ? 1e-6 * c->dbg.mixed_null_ppm : 0.0);
     c->step_export_attached = exports;
     if (f32) {
         quantize_state(c);
@@ -312,7 +313,7 @@ bool replay_red_fused(const srukf_ctx* c)
 // ... or forms them with k_syrk over the kept rows, still in permuted order (memory tiles, two tiles per worker, one launch per panel: seq_refactor's second branch)
 bool replay_red_perm(const srukf_ctx* c)
 {
-    return c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->shadowA && c->w.wc0 == c->w.wm0 && rank_fused_mode() && c->dbg.table_perm;
+    return c->red_r > 0 && (c->storage != SRUKF_STORAGE_F32_MIXED || (c->dbg.mixed_rank && c->A32)) && c->shadowA && c->w.wc0 == c->w.wm0 && rank_fused_mode() && c->dbg.table_perm;
 }
 
 int replay_motion_mode(const srukf_ctx* c)
@@ -372,7 +373,8 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
     // Measured (frames/s, fused against not fused): N = 200 2 965 / 2 910, N = 100 5 247 / 5 262, N = 50 9 256 / 9 465,
     // N = 300 (two tiles per worker, both to be computed first) 1 544 / 1 663 — so only with one tile per worker and T >= 16.
     // rank-aware form (srukf_rank.hip): permute the null directions to the end, pivot only the leading red_Tp panels
-    const bool reduced = !slow && c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED;
+    // (the mixed-precision downdate too, round 6: the null pivots its fp32-formed G cannot resolve — what made the full-rank form of the mode diverge — are not factored at all)
+    const bool reduced = !slow && c->red_r > 0 && (c->storage != SRUKF_STORAGE_F32_MIXED || (c->dbg.mixed_rank && c->A32));
     // ... and on the replay path directly in permuted order from the shadow copy (no full k_syrk, no permutation pass)
     // (the owners' fold pays with about one tile per worker and T >= 16, as in the full-rank form: frames/s fold / k_syrk over the kept
     //  rows: N = 100 7 360 / 7 610, N = 200 4 360 / 4 300, N = 300 — two tiles per worker — 2 400 / 2 580)
@@ -423,7 +425,15 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
                                srukf_gmw_register_form(c->gplan_red.T, c->gplan_red.Tp, c->gplan_red.ntiles, c->gplan_red.workers);
         {
             ProfScope ps(c, KC_SYRK, rr * rr * rr / 3.0 + rr * rr * (n - rr) + 2.0 * d.mp * (rr * n - rr * rr / 2.0) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * (rr * n + (double)d.mp * n + rp * n));
-            if (own_order) {
+            if (c->storage == SRUKF_STORAGE_F32_MIXED) {
+                // the mixed-precision downdate in the rank-aware form: the kept rows of S in permuted column order (what the stored floats hold: the permuted copy is
+                // rounded with S) and U^T with permuted columns as fp32 operands, K <= r, products on the fp32 matrix pipe, chunk sums in FP64 — only the macro tiles of the
+                // pivoted panels; the state update and the dropped diagonal (FP64, from the same operands) by k_syrk's spare workgroups with an empty tile list
+                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, 0, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table), take_xr1(c));
+                srukf_launch_cvt_f32(c->stream, (size_t)c->mxr_krows * np, c->shadowA, c->A32);
+                srukf_launch_cvt_f32(c->stream, (size_t)d.mp * np, c->Utp, c->U32);
+                srukf_launch_syrk32(c->stream, n, np, d.mp, c->A32, c->U32, c->mxr_tasks, c->mxr_ntasks, c->mxr_tiles, c->mxr_ntiles, c->mxr_part, c->Wf, c->fs, c->mxr_krows);
+            } else if (own_order) {
                 srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
                 srukf_launch_syrk_own(c->stream, n, np, c->shadowA, c->Utp, 0, d.mp, (c->red_r + 15) & ~15, c->Wf, c->fs, c->gplan_red.tiles, c->gplan_red.ntiles, c->red_Tp);
             } else
@@ -451,7 +461,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
         c->dx_pending = false;
         srukf_launch_cvt_f32(c->stream, (size_t)d.mp * np, c->Ut, c->U32);
         srukf_launch_cvt_robot_cols(c->stream, n, np, c->S, c->S32);          // the motion step's columns, computed after the state was rounded
-        srukf_launch_syrk32(c->stream, n, np, d.mp, c->S32, c->U32, c->mx_tasks, c->mx_ntasks, c->mx_tiles, c->mx_ntiles, c->mx_part, c->G, c->fs);
+        srukf_launch_syrk32(c->stream, n, np, d.mp, c->S32, c->U32, c->mx_tasks, c->mx_ntasks, c->mx_tiles, c->mx_ntiles, c->mx_part, c->G, c->fs, np);
     } else {
         ProfScope ps(c, KC_SYRK, syrk_flop * head_frac, syrk_byte * head_frac);
         srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, fused ? c->syrk_head_tiles : c->syrk_tiles,
@@ -741,6 +751,32 @@ int update_null_set(srukf_ctx* c)
         }
     }
     if (was || c->red_r) drop_graphs(c);                          // the captured frames contain one or the other launch sequence
+    return mixed_red_ensure(c);
+}
+
+// SRUKF_STORAGE_F32_MIXED in the rank-aware form: the fp32 copy of the kept rows, the task list of k_syrk32 over the pivoted panels (shape: r, Tp).  Called whenever the
+// null set or the storage mode changes — never inside a capture.
+int mixed_red_ensure(srukf_ctx* c)
+{
+    if (c->storage != SRUKF_STORAGE_F32_MIXED || c->red_r <= 0 || !c->shadowA) return SRUKF_OK;
+    const int np = c->d.np, mp = c->d.mp;
+    if (!c->A32) HIPCHK(c, srukf_dmalloc(&c->A32, sizeof(float) * (size_t)np * np));
+    if (c->mxr_for_r == c->red_r && c->mxr_tasks) return SRUKF_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (void* b : { (void*)c->mxr_part, c->mxr_tasks, c->mxr_tiles }) if (b) srukf_dfree_on(b, c->stream);
+    c->mxr_part = nullptr; c->mxr_tasks = nullptr; c->mxr_tiles = nullptr;
+    c->mxr_krows = std::min(np, srukf_mixed_krows(c->red_r));
+    int ntiles = 0;
+    const int ntasks = srukf_mixed_build_tasks_red(np, mp, c->mxr_krows, 64 * c->red_Tp, nullptr, nullptr, &ntiles);
+    std::vector<short> tk((size_t)4 * ntasks); std::vector<int> tl((size_t)2 * ntiles);
+    srukf_mixed_build_tasks_red(np, mp, c->mxr_krows, 64 * c->red_Tp, tk.data(), tl.data(), &ntiles);
+    HIPCHK(c, srukf_dmalloc(&c->mxr_part, srukf_mixed_part_bytes(ntasks)));
+    HIPCHK(c, srukf_dmalloc(&c->mxr_tasks, sizeof(short) * tk.size()));
+    HIPCHK(c, srukf_dmalloc(&c->mxr_tiles, sizeof(int) * tl.size()));
+    HIPCHK(c, hipMemcpy(c->mxr_tasks, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->mxr_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
+    c->mxr_ntasks = ntasks; c->mxr_ntiles = ntiles; c->mxr_for_r = c->red_r;
+    drop_graphs(c);
     return SRUKF_OK;
 }
 
@@ -846,6 +882,7 @@ void set_null_canonical(srukf_ctx* c)
 static int run_staged_frame_exact(srukf_ctx* c, int frame, double* traj_row)
 {
     const KDims& d = c->d;
+    c->exact_frames++;
     double* tb = traj_row ? traj_row - (size_t)8 * frame : nullptr;
     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, frame, 1);
     hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, tb);

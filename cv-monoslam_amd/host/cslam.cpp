@@ -83,9 +83,13 @@ bool CSLAM::setMap(int N, const double* X, const double* S, const double* px, in
     return true;
 }
 
+namespace { struct Stopwatch { double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                              explicit Stopwatch(double& a) : acc(a) {} ~Stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } }; }
+
 bool CSLAM::integrateFeaturesInformation(int K, const double* kp)
 {
     if (K <= 0) { m_nAddings = 0; return true; }                                                                // SLAM.cpp:820-821
+    Stopwatch sw(m_addTime); m_nAddCalls++;
     if (!ctx_) {                                                                                                // frame 1: robot block only (221-231)
         if (!check(srukf_create(&ctx_, 0, &m_params, device_, nullptr))) return false;
         m_nMapFeatures = 0; mapStore.clear(); relinkMap();
@@ -104,6 +108,7 @@ bool CSLAM::integrateFeaturesInformation(int K, const double* kp)
 bool CSLAM::deleteOneFeature(int id)
 {
     if (!ctx_ || id < 0 || id >= m_nMapFeatures) { lastError = "deleteOneFeature: no such landmark"; return false; }
+    Stopwatch sw(m_deleteTime); m_nDeleteCalls++;
     mirrorsFresh_ = false;
     if (!check(srukf_delete_landmark(ctx_, id))) return false;                                                  // 2643-2668
     mapStore.erase(mapStore.begin() + id); relinkMap();                                                                                // 2670-2705

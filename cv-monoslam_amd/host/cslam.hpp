@@ -168,6 +168,10 @@ public:
     std::string m_recordRobotDir = "RobotPath.txt";
     double MIN_STEP_X = 0.01, MIN_STEP_Y = 0.01, MIN_STEP_THETA = 45;   // SLAM.cpp:45-47
     std::string lastError;
+    // wall time spent inside the map changes (integrateFeaturesInformation / deleteOneFeature: the device call and the host bookkeeping around it) and how many
+    // there were: what a host that watches its frame rate under map churn wants to see (cslam_step_bench churn=P)
+    double m_addTime = 0, m_deleteTime = 0; int m_nAddCalls = 0, m_nDeleteCalls = 0;
+    srukf_ctx* context() const { return ctx_; }          // for srukf_debug_get / srukf_last_error next to the facade (diagnostics: the facade owns the handle)
 
 private:
     bool redirection();

@@ -11,6 +11,13 @@
 //     hint=1 : capi / assoc announce the NEXT frame's odometry with srukf_predict_motion_next before every update (a host that has its odometry
 //              file loaded, as the reference has: loadOdometryData reads it whole, SLAM.cpp:363-496)
 //     set=key:value : srukf_debug_set(ctx, key, value) after the context exists (capi / assoc; measurement switches, e.g. set=step_fuse_export:0)
+//     churn=P (facade): the map changes while the filter runs, through the reference's OWN policy (SLAM.cpp:2443-2460 deletions in updateFeaturesInformation,
+//              552-562 additions through the addFeatures callback): every P frames the host stops matching one landmark and zeroes its match count, so that the
+//              policy's "predicted often, matched rarely" rule (nPredictTimes > 2 nMatchTimes, >= 10 predictions) removes it in that frame's
+//              updateFeaturesInformation -> deleteOneFeature, and sets isAdding, so that the same frame's addFeatures hands one key point to
+//              integrateFeaturesInformation (joint initialisation on the device); the next frame's KalmanUpdate then runs FLAG_4_NEED_REORDER.  N stays where it
+//              was.  Every landmark is "found" at its predicted pixel + 0.5 px of noise (new landmarks have no entry in the scene's z).  Prints frames/s,
+//              the map changes and their wall time per operation, and how many frames ran on the step-wise fast path / on the other one
 // scene.bin: int32 N, int32 F, double a1..a4, double X0[n], double S0[n*n], double z[F][2N]   (the file cslam_replay reads)
 // Prints ONE JSON object.
 #include <chrono>
@@ -29,13 +36,14 @@ int main(int argc, char** argv)
 {
     if (argc < 4) { fprintf(stderr, "usage: %s scene.bin odometry.txt mode=<capi|facade|assoc> [frames=K] [warmup=W] [hint=0|1]\n", argv[0]); return 2; }
     std::string mode = "capi";
-    int K = 200, W = 20, hint = 0;
+    int K = 200, W = 20, hint = 0, churn = 0;
     std::vector<std::pair<std::string, int>> sets;
     for (int a = 3; a < argc; a++) {
         if (!strncmp(argv[a], "mode=", 5)) mode = argv[a] + 5;
         else if (!strncmp(argv[a], "frames=", 7)) K = atoi(argv[a] + 7);
         else if (!strncmp(argv[a], "warmup=", 7)) W = atoi(argv[a] + 7);
         else if (!strncmp(argv[a], "hint=", 5)) hint = atoi(argv[a] + 5);
+        else if (!strncmp(argv[a], "churn=", 6)) churn = atoi(argv[a] + 6);
         else if (!strncmp(argv[a], "set=", 4)) { const char* q = strchr(argv[a] + 4, ':'); if (!q) { fprintf(stderr, "set=key:value\n"); return 2; } sets.emplace_back(std::string((const char*)argv[a] + 4, (size_t)(q - (argv[a] + 4))), atoi(q + 1)); }
     }
     FILE* f = fopen(argv[1], "rb");
@@ -62,12 +70,35 @@ int main(int argc, char** argv)
     double tcall[5] = { 0, 0, 0, 0, 0 };                      // capi / assoc: host time inside predict_motion, predict_measurement, the association, update, get_robot
     long long matches_dev = 0;
     long long flag_ticks = -1;                                       // last frame: start of the frame's first launch -> h / Si / visible flagged to the host (10 ns ticks)
+    char churn_json[400] = "";
     if (mode == "facade") {
         monoslam::CSLAM SLAM;
         SLAM.m_params.a1 = a4[0]; SLAM.m_params.a2 = a4[1]; SLAM.m_params.a3 = a4[2]; SLAM.m_params.a4 = a4[3];
         if (!SLAM.setMap(N, X0.data(), S0.data(), nullptr)) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
         SLAM.MIN_STEP_X = SLAM.MIN_STEP_Y = 0.0;
         if (!SLAM.loadOdometryData(argv[2])) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
+        unsigned long long rs = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&rs]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (double)(rs >> 11) / 9007199254740992.0; };      // xorshift, [0, 1)
+        auto gauss = [&rnd]() { double s = 0; for (int q = 0; q < 12; q++) s += rnd(); return s - 6.0; };
+        int victim_turn = 0;
+        if (churn > 0) {
+            SLAM.dataAssociation = [&](monoslam::CSLAM& s) {
+                const int fr = s.m_frame.counter - 1;
+                const bool change = fr >= 10 && fr % churn == 0;
+                int idx = 0, victim = -1;
+                if (change) { victim = (victim_turn * 7) % s.m_nMapFeatures; victim_turn++; s.isAdding = true; }
+                for (monoslam::PointsMap* mp = s.map; NULL != mp; mp = mp->next, idx++) {
+                    mp->isMatching = mp->isVisible;
+                    mp->matchLocation.x = mp->predictLocation.x + 0.5 * gauss(); mp->matchLocation.y = mp->predictLocation.y + 0.5 * gauss();
+                    if (idx == victim && mp->nPredictTimes >= 10) { mp->isMatching = false; mp->nMatchTimes = 0; }      // the policy's rule 2443: it leaves in this frame
+                }
+            };
+            SLAM.addFeatures = [&](monoslam::CSLAM& s, std::vector<double>& kp) {
+                s.isAdding = false;
+                kp.assign({ 60.0 + 520.0 * rnd(), 60.0 + 360.0 * rnd() });                                  // one key point where the detector "found" a corner
+                return 1;
+            };
+        } else
         SLAM.dataAssociation = [&](monoslam::CSLAM& s) {
             const int fr = s.m_frame.counter - 1;
             for (monoslam::PointsMap* mp = s.map; NULL != mp; mp = mp->next) {
@@ -76,14 +107,27 @@ int main(int argc, char** argv)
             }
         };
         for (int fr = 0; fr < W; fr++) SLAM.SLAM();
+        long long fast0 = 0, slow0 = 0, fast1 = 0, slow1 = 0;
+        srukf_debug_get(SLAM.context(), "step_fast", &fast0); srukf_debug_get(SLAM.context(), "step_slow", &slow0);
+        const double add0 = SLAM.m_addTime, del0 = SLAM.m_deleteTime; const int na0 = SLAM.m_nAddCalls, nd0 = SLAM.m_nDeleteCalls;
         const double t0 = now_s();
         for (int fr = 0; fr < K; fr++) SLAM.SLAM();
         t_timed = now_s() - t0;
+        // (the counters live in the context, and a map change rebuilds the context behind the handle: they restart with it — so the split is read from the facade's
+        //  own bookkeeping where the library cannot give it: frames since the last rebuild)
+        srukf_debug_get(SLAM.context(), "step_fast", &fast1); srukf_debug_get(SLAM.context(), "step_slow", &slow1);
+        if (churn > 0) {
+            const int na = SLAM.m_nAddCalls - na0, nd = SLAM.m_nDeleteCalls - nd0;
+            snprintf(churn_json, sizeof churn_json, "\"churn\": {\"every_frames\": %d, \"additions\": %d, \"deletions\": %d, \"ms_per_addition\": %.3f, \"ms_per_deletion\": %.3f, "
+                     "\"map_change_share_of_wall\": %.3f, \"landmarks_at_end\": %d, \"step_fast_since_last_rebuild\": %lld, \"step_slow_since_last_rebuild\": %lld}, ",
+                     churn, na, nd, na ? (SLAM.m_addTime - add0) / na * 1e3 : 0.0, nd ? (SLAM.m_deleteTime - del0) / nd * 1e3 : 0.0,
+                     (SLAM.m_addTime - add0 + SLAM.m_deleteTime - del0) / t_timed, SLAM.m_nMapFeatures, fast1, slow1);
+        }
         if (!SLAM.lastError.empty()) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
         const int nn = SLAM.m_X_k.rows;
         for (int e = 0; e < 4; e++) pose[e] = SLAM.m_X_k.at(nn - 4 + e, 0);
         P4[0] = SLAM.m_P_k.at(nn - 4, nn - 4); P4[1] = SLAM.m_P_k.at(nn - 4, nn - 3); P4[4] = SLAM.m_P_k.at(nn - 3, nn - 4); P4[5] = SLAM.m_P_k.at(nn - 3, nn - 3);
-        if (SLAM.m_nMapFeatures != N) { fprintf(stderr, "the map changed size (%d landmarks left)\n", SLAM.m_nMapFeatures); return 1; }
+        if (!churn && SLAM.m_nMapFeatures != N) { fprintf(stderr, "the map changed size (%d landmarks left)\n", SLAM.m_nMapFeatures); return 1; }
     } else {
         srukf_params p;
         srukf_default_params(&p);
@@ -150,10 +194,10 @@ int main(int argc, char** argv)
         srukf_debug_get(c, "meas_flag_ticks", &flag_ticks);
         srukf_destroy(c);
     }
-    printf("{\"mode\": \"%s\", \"hint\": %d, \"landmarks\": %d, \"frames\": %d, \"warmup\": %d, \"frames_per_s\": %.2f, \"us_per_frame\": %.2f, "
+    printf("{\"mode\": \"%s\", %s\"hint\": %d, \"landmarks\": %d, \"frames\": %d, \"warmup\": %d, \"frames_per_s\": %.2f, \"us_per_frame\": %.2f, "
            "\"pose\": [%.17g, %.17g, %.17g, %.17g], \"P_robot\": [%.17g, %.17g, %.17g, %.17g], \"device_matches\": %lld, \"stats_flag_us_into_first_launch\": %.2f, \"host_us_per_call\": {\"predict_motion\": %.2f, \"predict_measurement\": %.2f, \"association\": %.2f, \"update\": %.2f, \"get_robot\": %.2f}, "
            "\"filter_driven_by\": \"scene z / matched (host association)\"}\n",
-           mode.c_str(), hint, N, K, W, K / t_timed, t_timed / K * 1e6, pose[0], pose[1], pose[2], pose[3], P4[0], P4[1], P4[4], P4[5], matches_dev, flag_ticks * 0.01,
+           mode.c_str(), churn_json, hint, N, K, W, K / t_timed, t_timed / K * 1e6, pose[0], pose[1], pose[2], pose[3], P4[0], P4[1], P4[4], P4[5], matches_dev, flag_ticks * 0.01,
            tcall[0] / K * 1e6, tcall[1] / K * 1e6, tcall[2] / K * 1e6, tcall[3] / K * 1e6, tcall[4] / K * 1e6);
     return 0;
 }

@@ -115,8 +115,11 @@ def test_oracle_frames_n200(srukf, oracle, synth):
     np.testing.assert_allclose(Sg.T @ Sg, Po, rtol=0, atol=1e-11)
 
 
+ORACLE_JOBS = [("one_frame", dict(N=500, seed=0, storage=st, eps=None, mode=1)) for st in ("f64", "f32")]
+
+
 @pytest.mark.parametrize("storage", ["f64", "f32"])
-def test_oracle_frame_n500(srukf, oracle, synth, storage):
+def test_oracle_frame_n500(srukf, oracle_pool, synth, storage):
     """BASELINE configs[4] (N = 500, n = 3004): one whole batched frame against the oracle (~30 s of CPU).
     fp32 storage: the oracle starts from the same float-rounded state; after the frame the device state is the
     float rounding of its fp64 result, so it is held to one fp32 ulp of the oracle's."""
@@ -129,8 +132,12 @@ def test_oracle_frame_n500(srukf, oracle, synth, storage):
         f.set_storage(srukf.STORAGE_F32)
         X0, S0 = X0.astype(np.float32).astype(np.float64), np.triu(S0).astype(np.float32).astype(np.float64)
     f.set_state(X0, S0)
-    o = oracle.Oracle(N, p); o.set_state(X0, S0)
-    (h, Si, vis), (ho, Sio, viso), (X, P), (Xo, Po) = _step_both(f, o, sc, 0, srukf.UPDATE_BATCHED, srukf)
+    f.predict_motion(sc["odo"][0], sc["odo"][1])
+    h, Si, vis = f.predict_measurement()
+    f.update(sc["z"][0], sc["matched"][0], mode=srukf.UPDATE_BATCHED)
+    X, S_ = f.get_state(); P = S_.T @ S_
+    r = oracle_pool.get("one_frame", N=N, seed=0, storage=storage, eps=None, mode=1)      # the oracle's frame (~30 - 60 s of one core): started with the session, tests/oracle_jobs.py
+    ho, viso, Xo, Po = r["h"], r["vis"], r["Xo"], r["So"].T @ r["So"]
     assert np.array_equal(vis, viso)
     # h = wm0 Z0 + wi sum_c Z_c as the reference accumulates it (SLAM.cpp:1678-1681; wm0 = -1002 at N = 500, 6018 terms,
     # running sum ~3e5) carries ~4e-8 px of rounding in the ORACLE; the device sums deviations from Z0 and is the more

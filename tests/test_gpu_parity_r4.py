@@ -93,8 +93,11 @@ def test_g8_step_api_against_the_oracle_over_40_frames(srukf, golden, synth):
     _hold_to_g8(g, traj, X, S)
 
 
+ORACLE_JOBS = [("batched_filter", dict(b=b, N=200, F=12, Fo=2)) for b in range(8)]
+
+
 @pytest.mark.parametrize("B,wide", [(2, 1), (4, 1), (8, 1), (4, 0)])
-def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle, synth, B, wide):
+def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle_pool, synth, B, wide):
     """srukf_run_frames_batch with B filters at N = 200 (Monte-Carlo runs: one map, own measurement noise).  wide = 1 (default): ONE launch per stage for all
     filters on one stream — k_pxy2_b, k_gain_b, k_syrk_b, k_syrk_own_b, one k_gmw_step64_b per panel, k_rank_expand_b — behind each filter's first frame, which a
     fresh state runs alone.  wide = 0: round 3's form, one stream per filter and one tenant per filter (B persistent launches of 256 / B CUs admitted at a time,
@@ -113,9 +116,8 @@ def test_batched_filters_against_the_oracle_and_against_solo_runs(srukf, oracle,
     for b, sc in enumerate(scs):
         assert fs[b].debug_get("gmw_aborts") == 0 and fs[b].debug_get("clamp_rows") == 0 and fs[b].debug_get("gate_timeouts") == 0
         assert fs[b].debug_get("gmw_shared") == (0 if wide else 1)
-        o = oracle.Oracle(N, p); o.set_state(sc["X0"], sc["S0"])
-        to = o.run_frames(sc["odo"][:Fo + 1], sc["z"][:Fo], sc["matched"][:Fo], oracle.Oracle.BATCHED)
-        Xo, So = o.get_state()
+        r = oracle_pool.get("batched_filter", b=b, N=N, F=F, Fo=Fo)             # (filter b's oracle frames are the same in every parametrisation: tests/oracle_jobs.py)
+        to, Xo, So = r["to"], r["Xo"], r["So"]
         np.testing.assert_allclose(t2[b][:, :4], to[:, :4], rtol=0, atol=1e-9)
         np.testing.assert_allclose(t2[b][:, 4:], to[:, 4:], rtol=0, atol=1e-12)
         np.testing.assert_allclose(mid[b][0], Xo, rtol=0, atol=1e-9)

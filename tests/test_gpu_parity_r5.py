@@ -37,7 +37,7 @@ PLAN_SWEEP = [
 ]
 
 
-def _run_two_frames_against_oracle(srukf, oracle, synth, N, rank_aware=1, storage="f64", F=2, seed=3):
+def _run_two_frames_against_oracle(srukf, oracle_pool, synth, N, rank_aware=1, storage="f64", F=2, seed=3):
     p = synth.scene_params()
     sc = synth.make_scene(N, F, seed=seed, p=p)
     rng = np.random.default_rng(1000 + N)
@@ -54,19 +54,10 @@ def _run_two_frames_against_oracle(srukf, oracle, synth, N, rank_aware=1, storag
     f.set_state(X0, S0); f.stage_sequence(sc["odo"], sc["z"], matched)
     traj = f.run_frames(0, F)
     X, S = f.get_state()
-    o = oracle.Oracle(N, p); o.set_state(X0, S0)
-    n = 6 * N + 4
-    to = np.zeros((F, 8))
-    for t in range(F):
-        tr = o.run_frames(sc["odo"][t:t + 2], sc["z"][t:t + 1], matched[t:t + 1], oracle.Oracle.BATCHED)
-        to[t] = tr[0]
-        if storage == "f32":                                   # the state that lives from frame to frame is float
-            Xo, So = o.get_state()
-            Xo, So = Xo.astype(np.float32).astype(np.float64), np.triu(So).astype(np.float32).astype(np.float64)
-            o.set_state(Xo, So)
-            to[t, :4] = Xo[n - 4:]; to[t, 4:] = (So[:, n - 4:n - 2].T @ So[:, n - 4:n - 2]).ravel()
-    Xo, So = o.get_state()
-    return f, traj, X, S, to, Xo, So
+    # the oracle's half (the same scene, matches and start state; fp32 storage: its state rounded to float after every frame) was started when the session began
+    # and runs in a child process beside the tests: tests/oracle_jobs.py two_frames
+    r = oracle_pool.get("two_frames", N=N, storage=storage, F=F, seed=seed)
+    return f, traj, X, S, r["to"], r["Xo"], r["So"]
 
 
 def _f32_metrics(P, Po, S):
@@ -99,8 +90,8 @@ def _hold(traj, X, S, to, Xo, So, storage):
 
 
 @pytest.mark.parametrize("N,plan", PLAN_SWEEP)
-def test_default_replay_on_both_sides_of_every_plan_threshold(srukf, oracle, synth, N, plan):
-    f, traj, X, S, to, Xo, So = _run_two_frames_against_oracle(srukf, oracle, synth, N)
+def test_default_replay_on_both_sides_of_every_plan_threshold(srukf, oracle_pool, synth, N, plan):
+    f, traj, X, S, to, Xo, So = _run_two_frames_against_oracle(srukf, oracle_pool, synth, N)
     got = {"fuse": f.debug_get("plan_fuse"), "fold": f.debug_get("plan_fold"), "head_fold": f.debug_get("plan_head_fold"), "red_perm": f.debug_get("plan_red_perm"),
            "tpw": f.debug_get("plan_tiles_per_worker"), "split": f.debug_get("split_form"), "persist": f.debug_get("plan_persist"), "motion": f.debug_get("plan_motion")}
     assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("gmw_shared") == 0
@@ -110,13 +101,20 @@ def test_default_replay_on_both_sides_of_every_plan_threshold(srukf, oracle, syn
     _hold(traj, X, S, to, Xo, So, "f64")
 
 
-@pytest.mark.parametrize("N,form", [(100, "full_rank"), (244, "full_rank"), (245, "full_rank"), (300, "full_rank"), (340, "full_rank"), (341, "full_rank"), (400, "full_rank"),
-                                    (100, "f32"), (300, "f32"), (400, "f32")])
-def test_other_forms_at_the_plan_boundaries(srukf, oracle, synth, N, form):
+OTHER_FORMS = [(100, "full_rank"), (244, "full_rank"), (245, "full_rank"), (300, "full_rank"), (340, "full_rank"), (341, "full_rank"), (400, "full_rank"),
+               (100, "f32"), (300, "f32"), (400, "f32")]
+# what the session starts ahead (conftest.pytest_collection_finish), the longest first: the oracle halves of the cases below
+ORACLE_JOBS = sorted([("two_frames", dict(N=N, storage="f64", F=2, seed=3)) for N, _ in PLAN_SWEEP] +
+                     [("two_frames", dict(N=N, storage="f32" if form == "f32" else "f64", F=2, seed=3)) for N, form in OTHER_FORMS] +
+                     [("one_frame", dict(N=500, seed=3, storage="f32", eps=1e-13, mode=1))], key=lambda j: -j[1]["N"])
+
+
+@pytest.mark.parametrize("N,form", OTHER_FORMS)
+def test_other_forms_at_the_plan_boundaries(srukf, oracle_pool, synth, N, form):
     """The same two oracle frames with every pivot factored (srukf_set_rank_aware(0): the full-rank plans — owners' fold up to one tile per worker, memory tiles /
     split form beyond: two register tiles per worker from N = 245, the split form from N = 341 in the sweep) and with fp32 storage of the state (configs[4]'s form: the
     frame tail and the state update round what they write)."""
-    f, traj, X, S, to, Xo, So = _run_two_frames_against_oracle(srukf, oracle, synth, N, rank_aware=0 if form == "full_rank" else 1, storage="f32" if form == "f32" else "f64")
+    f, traj, X, S, to, Xo, So = _run_two_frames_against_oracle(srukf, oracle_pool, synth, N, rank_aware=0 if form == "full_rank" else 1, storage="f32" if form == "f32" else "f64")
     assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("gmw_shared") == 0
     assert f.null_directions() == (0 if form == "full_rank" else 3 * (N - 1))
     if form == "full_rank":
