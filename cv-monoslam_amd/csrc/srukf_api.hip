@@ -366,7 +366,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h /* + Si, vis */, c->PxyR, c->D,
                      c->zcur /* + mcur */, c->odocur, c->small, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->mxr_f64_tiles, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -598,15 +598,11 @@ int srukf_get_covariance(srukf_ctx* c, double* P)
 int srukf_set_storage(srukf_ctx* c, int storage)
 {
     if (!c || (storage != SRUKF_STORAGE_F64 && storage != SRUKF_STORAGE_F32 && storage != SRUKF_STORAGE_F32_MIXED)) return SRUKF_ERR_BAD_ARG;
-    if (storage == SRUKF_STORAGE_F32_MIXED && c->p.epsilon < 1e-9 && !c->debug_allow_mixed) {
-        // S^T S - U U^T formed from fp32 products carries ~1e-7 * max diag of rounding in the entries that are exactly zero in
-        // exact arithmetic (P is permanently rank deficient: the anchors of jointly initialised landmarks are copies of the
-        // robot position).  The reference's EPSILON = 1e-13 clamp sits far below that noise: null pivots |c_jj| ~ 1e-9 divide
-        // off-diagonal noise of the same size, the multipliers are O(1) garbage and the filter diverges within ten frames
-        // (scripts/mixed_eps_study.py).  The mode is only offered with a clamp above the fp32 noise floor.
-        c->err = "SRUKF_STORAGE_F32_MIXED needs params.epsilon >= 1e-9 (fp32-formed S^T S - U U^T cannot resolve the reference's 1e-13 clamp)";
-        return SRUKF_ERR_UNSUPPORTED;
-    }
+    // (Rounds 2 - 5 refused SRUKF_STORAGE_F32_MIXED below epsilon = 1e-9: the mode diverged within ten frames at the reference's 1e-13.  Round 6 found the cause —
+    //  fp32 accumulation over K = 1024 products per chunk, whose error grew linearly in the kept pivots from frame to frame (scripts/mixed_drift_probe.py) — and
+    //  two remedies: the fp32 accumulators are flushed into FP64 ones every 32 rows (k_syrk32, MX_FLUSH), and in the rank-aware form the tiles of the robot block and
+    //  of the map's shared anchor are formed in FP64 (their pivots are 2e-6 .. 9e-6 of the marginal variance: scripts/pivot_ratio_probe.py).  With both the mode
+    //  tracks the fp64 filter to 1.2e-6 m over the reference's whole capacity at N = 500, epsilon = 1e-13 (scripts/mixed_rank_study.py, DESIGN.md row g).)
     HIPCHK(c, hipSetDevice(c->device));
     step_commit_motion(c); step_state_replaced(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));

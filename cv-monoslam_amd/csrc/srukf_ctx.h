@@ -89,7 +89,7 @@ size_t srukf_mixed_part_bytes(int ntasks);
 void srukf_launch_cvt_f32(hipStream_t, size_t, const double*, float*);
 void srukf_launch_cvt_robot_cols(hipStream_t, int, int, const double*, float*);
 void srukf_launch_gain_dx(hipStream_t, int, int, const double*, double*, const double*);
-void srukf_launch_syrk32(hipStream_t, int, int, int, const float*, const float*, const void*, int, const void*, int, float*, double*, void*, int);
+void srukf_launch_syrk32(hipStream_t, int, int, int, const float*, const float*, const void*, int, const void*, int, double*, double*, void*, int);
 int srukf_app_patch_stride(void);
 int srukf_app_tmpl_stride(void);
 }
@@ -133,10 +133,16 @@ struct srukf_ctx {
     int storage = SRUKF_STORAGE_F64;       // SRUKF_STORAGE_F32 / _F32_MIXED: X32 / S32 hold the inter-frame state
     float *S32 = nullptr, *X32 = nullptr;
     // SRUKF_STORAGE_F32_MIXED: S^T S - U U^T on the fp32 matrix pipe (srukf_mixed.hip)
-    float *U32 = nullptr, *mx_part = nullptr; void *mx_tasks = nullptr, *mx_tiles = nullptr; int mx_ntasks = 0, mx_ntiles = 0;
+    float *U32 = nullptr; double* mx_part = nullptr; void *mx_tasks = nullptr, *mx_tiles = nullptr; int mx_ntasks = 0, mx_ntiles = 0;
     // ... in the rank-aware form (round 6): the kept rows of S in permuted column order as float (the permuted copy's values are the stored floats), K <= r, only the
     // macro tiles of the pivoted panels; task list / partials of that shape (mixed_red_ensure)
-    float *A32 = nullptr, *mxr_part = nullptr; void *mxr_tasks = nullptr, *mxr_tiles = nullptr; int mxr_ntasks = 0, mxr_ntiles = 0, mxr_krows = 0, mxr_for_r = 0;
+    float* A32 = nullptr; double* mxr_part = nullptr; void *mxr_tasks = nullptr, *mxr_tiles = nullptr; int mxr_ntasks = 0, mxr_ntiles = 0, mxr_krows = 0, mxr_for_r = 0;
+    // ... and which 32 x 32 tiles of it are formed in FP64 after all (k_syrk over this list, behind the fp32 launch): the tile rows / columns that hold the robot block
+    // and the map's shared anchor (permuted positions r-4 .. r-1 and 0 .. 2).  The robot's pivots are its variance GIVEN the map — 2e-6 .. 9e-6 of its marginal variance
+    // in the benchmark scene, the z coordinate exactly null (scripts/pivot_ratio_probe.py) — and the regression that produces them has weight ~1 on the anchor the
+    // robot position was copied into: an fp32-formed entry there (relative error ~1e-7 .. 1e-6) is as large as the pivot itself.  Every other kept pivot is >= 0.1 of
+    // its marginal variance
+    int* mxr_f64_tiles = nullptr; int mxr_n_f64_tiles = 0;
     int *perm = nullptr, *iperm = nullptr;
     double* Sdis = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered), one launch per panel
@@ -186,6 +192,7 @@ struct srukf_ctx {
         int mixed_rank = 1;                // "mixed_rank": SRUKF_STORAGE_F32_MIXED runs the rank-aware refactorisation (fp32-formed S^T S - U U^T over the kept rows, FP64 factorisation
                                            // of the kept pivots only); 0: round 2's full-rank form, in which the null pivots divide fp32 noise (the negative study of rounds 2 / 5)
         int mixed_null_ppm = 1;            // "mixed_null_ppm": ... and its null-direction check allows this many 1e-6 of G_aa on top of 1e-12 (an fp32-formed G cannot resolve 1e-12)
+        int mixed_f64_robot = 1;           // "mixed_f64_robot": ... with the tiles of the robot block and of the shared anchor in FP64 (mxr_f64_tiles); 0: every kept tile from the fp32 pipe (study)
     } dbg;
     bool null_canonical = false;           // every structurally null row of S is exactly sqrt(EPSILON) e_k (update_null_set checks; true behind every rank-aware frame tail)
     bool tail_ok = false;                  // "fused tail" mode is possible: directions 0 and 1 are kept rows (the Si factor names their Z rows: they are projected for every landmark, which
@@ -260,6 +267,10 @@ struct srukf_ctx {
     (ctx)->err = b_; return SRUKF_ERR_HIP; } } while (0)
 
 namespace srukf_impl {
+
+// fp32 storage of the state with everything that goes with it in "fused tail" mode (the tail and the state update round what they write).  The mixed-precision downdate in
+// its rank-aware form (round 6) IS that mode with one difference: where the staged frame forms S^T S - U U^T over the kept rows (seq_refactor, red_perm branch)
+inline bool storage_f32_like(const srukf_ctx* c) { return c->storage == SRUKF_STORAGE_F32 || (c->storage == SRUKF_STORAGE_F32_MIXED && c->dbg.mixed_rank && c->A32); }
 
 extern const char* const kclass_name[KC_COUNT];
 extern thread_local std::string g_create_error;

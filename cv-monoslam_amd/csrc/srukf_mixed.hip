@@ -20,7 +20,16 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 
 #define MX_TILE 128
 #define MX_KS 32                       // rows per slab
-#define MX_KCHUNK 1024                 // fp32 accumulation length (error ~1e-7 sum|ab|, cdna_hip_programming.md "FP32-input MFMA")
+#ifndef MX_KCHUNK
+#define MX_KCHUNK 1024                 // K range of one task (a multiple of MX_KS * MX_FLUSH)
+#endif
+// fp32 accumulation length in slabs of MX_KS rows: after every MX_FLUSH slabs the fp32 accumulators are added to FP64 ones held beside them in registers and cleared.
+// Measured with the accumulation length as the K chunk (round 6, N = 500, the hybrid form: scripts/mixed_drift_probe.py): the kept pivots of the filter drift away
+// from the fp64 filter's LINEARLY in the frame count, in proportion to that length — 1024 rows: 3 % after 240 frames, then a flagged frame and divergence; 256: the same
+// at frame 637; 128: 1 % after 800 frames.  An fp32 sum of K products carries ~ sqrt(K) eps32 of sum |a b|, and it does so in every entry of P in every frame.
+#ifndef MX_FLUSH
+#define MX_FLUSH 1
+#endif
 #define MX_LS (MX_TILE + 32)           // LDS row stride in floats: the two 32-lane halves of a fragment read (rows k, k + 1) land on opposite bank halves
 
 struct MxTask { short I, J, chunk, nchunks; };   // macro tile (I <= J) and K chunk; partial slot = task index
@@ -29,7 +38,7 @@ struct MxTask { short I, J, chunk, nchunks; };   // macro tile (I <= J) and K ch
 // krows (a multiple of MX_KS): rows of S32 that hold anything — np for the state itself; for the rank-aware form S32 is the permuted copy of the KEPT rows
 // (r of them, upper triangular in permuted order, zero rows behind): K ends at the kept rows
 __global__ __launch_bounds__(256) void k_syrk32(int np, int ue, const float* __restrict__ S32, const float* __restrict__ U32,
-                                                const MxTask* __restrict__ tasks, float* __restrict__ part, int krows)
+                                                const MxTask* __restrict__ tasks, double* __restrict__ part, int krows)
 {
     __shared__ float As[2][MX_KS][MX_LS];
     __shared__ float Bs[2][MX_KS][MX_LS];
@@ -41,12 +50,13 @@ __global__ __launch_bounds__(256) void k_syrk32(int np, int ue, const float* __r
     const int kbeg = tk.chunk * MX_KCHUNK, kend = min(ktot, kbeg + MX_KCHUNK);
     const int lr = tid >> 5, lc = (tid & 31) * 4;                // this thread's part of a slab: rows lr + 8 i, columns lc .. lc + 3
     f16v acc[2][2];
+    double acc64[2][2][16];                                      // what the fp32 accumulators have been flushed into (MX_FLUSH)
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int t = 0; t < 16; t++) acc[a][b][t] = 0.f;
+            for (int t = 0; t < 16; t++) { acc[a][b][t] = 0.f; acc64[a][b][t] = 0.0; }
     const int wm = 64 * (wv >> 1), wn = 64 * (wv & 1);
     const bool active = (mb + wm < np) && (nb + wn < np) && (nb + wn + 64 > mb + wm);   // quadrant inside the matrix and not strictly below the diagonal
     f4v ra[4], rb[4];
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(256) void k_syrk32(int np, int ue, const float* __r
 #pragma unroll
         for (int i = 0; i < 4; i++) { *(f4v*)&As[buf][lr + 8 * i][lc] = ra[i]; *(f4v*)&Bs[buf][lr + 8 * i][lc] = rb[i]; }
     };
-    int buf = 0;
+    int buf = 0, nslab = 0;
     if (kbeg < kend) { fetch(kbeg); stash(0); }
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += MX_KS) {
@@ -94,12 +104,21 @@ __global__ __launch_bounds__(256) void k_syrk32(int np, int ue, const float* __r
                 a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
             }
         }
+        if (active && (++nslab == MX_FLUSH || !more)) {
+            nslab = 0;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 16; t++) { acc64[a][b][t] += (double)acc[a][b][t]; acc[a][b][t] = 0.f; }
+        }
         if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-    // partial tile of this chunk: part[task][128][128] floats
-    float* out = part + (size_t)blockIdx.x * MX_TILE * MX_TILE;
+    // partial tile of this chunk: part[task][128][128] doubles
+    double* out = part + (size_t)blockIdx.x * MX_TILE * MX_TILE;
     const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -108,13 +127,13 @@ __global__ __launch_bounds__(256) void k_syrk32(int np, int ue, const float* __r
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const int r = wm + 32 * a + (t & 3) + 8 * (t >> 2) + 4 * h, c = wn + 32 * b + l31;
-                out[r * MX_TILE + c] = acc[a][b][t];
+                out[r * MX_TILE + c] = acc64[a][b][t];
             }
 }
 
 // one workgroup per macro tile: G = sum over the tile's chunks (FP64, chunk order), gamma = max diag, xi = max(0, max offdiag)
 __global__ __launch_bounds__(256) void k_syrk32_reduce(int n, int np, const int2* __restrict__ tiles /* (first task, nchunks) per tile */,
-                                                       const MxTask* __restrict__ tasks, const float* __restrict__ part,
+                                                       const MxTask* __restrict__ tasks, const double* __restrict__ part,
                                                        double* __restrict__ G, FrameScalars* __restrict__ fs)
 {
     const int2 tl = tiles[blockIdx.x];
@@ -126,8 +145,8 @@ __global__ __launch_bounds__(256) void k_syrk32_reduce(int n, int np, const int2
         if (mb + r >= np || nb + c >= np) continue;
         double s[4] = { 0.0, 0.0, 0.0, 0.0 };
         for (int q = 0; q < tl.y; q++) {
-            const f4v v = *(const f4v*)(part + ((size_t)(tl.x + q) * MX_TILE + r) * MX_TILE + c);
-            s[0] += (double)v[0]; s[1] += (double)v[1]; s[2] += (double)v[2]; s[3] += (double)v[3];
+            const d4 v = *(const d4*)(part + ((size_t)(tl.x + q) * MX_TILE + r) * MX_TILE + c);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
         const int gr = mb + r;
 #pragma unroll
@@ -196,7 +215,7 @@ int srukf_mixed_build_tasks_red(int np, int ue, int krows, int rows_lim, short* 
 }
 int srukf_mixed_build_tasks(int np, int ue, short* out_tasks, int* out_tiles, int* ntiles) { return srukf_mixed_build_tasks_red(np, ue, np, np, out_tasks, out_tiles, ntiles); }
 int srukf_mixed_krows(int r) { return (r + MX_KS - 1) / MX_KS * MX_KS; }
-size_t srukf_mixed_part_bytes(int ntasks) { return (size_t)ntasks * MX_TILE * MX_TILE * sizeof(float); }
+size_t srukf_mixed_part_bytes(int ntasks) { return (size_t)ntasks * MX_TILE * MX_TILE * sizeof(double); }
 void srukf_launch_cvt_f32(hipStream_t st, size_t count, const double* src, float* dst)
 {
     hipLaunchKernelGGL(k_cvt_f32, dim3((unsigned)((count / 4 + 255) / 256 + 1)), dim3(256), 0, st, count, src, dst);
@@ -210,7 +229,7 @@ void srukf_launch_cvt_robot_cols(hipStream_t st, int n, int np, const double* S,
     hipLaunchKernelGGL(k_cvt_robot_cols, dim3((n + 255) / 256), dim3(256), 0, st, n, np, S, S32);
 }
 void srukf_launch_syrk32(hipStream_t st, int n, int np, int ue, const float* S32, const float* U32, const void* tasks, int ntasks,
-                         const void* tiles, int ntiles, float* part, double* G, void* fs, int krows)
+                         const void* tiles, int ntiles, double* part, double* G, void* fs, int krows)
 {
     hipLaunchKernelGGL(k_syrk32, dim3(ntasks), dim3(256), 0, st, np, ue, S32, U32, (const MxTask*)tasks, part, krows > 0 ? krows : np);
     hipLaunchKernelGGL(k_syrk32_reduce, dim3(ntiles), dim3(256), 0, st, n, np, (const int2*)tiles, (const MxTask*)tasks, part, G, (FrameScalars*)fs);

@@ -274,7 +274,7 @@ void rank_expand(srukf_ctx* c, bool frame_tail, bool table, bool fuse)
 {
     const int n = c->d.n, np = c->d.np;
     const bool f32s = c->storage != SRUKF_STORAGE_F64;            // (the mixed mode stores floats as well: the launches behind the tail round, as for fp32 storage without "fused tail" mode)
-    const bool f32fuse = c->storage == SRUKF_STORAGE_F32 && fuse && table && frame_tail;      // fp32 storage in "fused tail" mode: the launch rounds what it writes (no k_quantize / k_rank_round / k_traj behind it)
+    const bool f32fuse = storage_f32_like(c) && fuse && table && frame_tail;      // fp32 storage in "fused tail" mode: the launch rounds what it writes (no k_quantize / k_rank_round / k_traj behind it)
     const bool f32 = f32s && !f32fuse;
     const bool tt = table && frame_tail && !f32;
     const bool exports = c->step_export.dst && tt && fuse;         // step-wise fast path: this launch is the frame's last and hands status + robot view to the host itself
@@ -320,7 +320,7 @@ int replay_motion_mode(const srukf_ctx* c)
 {
     // fp32 storage: only as "fused tail" mode (k_rank_expand<2> and the state update round what they write; "table" mode alone has no such form)
     const bool st_ok = c->storage == SRUKF_STORAGE_F64 ||
-                       (c->storage == SRUKF_STORAGE_F32 && c->dbg.f32_fuse && c->dbg.tail_fuse && c->dbg.pxy2 && c->dbg.nullskip && c->nskip && c->tail_ok &&
+                       (storage_f32_like(c) && c->dbg.f32_fuse && c->dbg.tail_fuse && c->dbg.pxy2 && c->dbg.nullskip && c->nskip && c->tail_ok &&
                         (size_t)c->d.np * sizeof(double) <= 48 * 1024);
     // (null_canonical: "table" mode and everything on top of it read the structurally null rows of S as sqrt(EPSILON) e_k without looking)
     if (c->dbg.fused_motion == 2 && !((replay_red_fused(c) || replay_red_perm(c)) && st_ok && c->null_canonical)) return 1;
@@ -391,7 +391,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
         if (!head_fold) {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
             ProfScope ps(c, KC_SYRK, head_flop, head_byte);
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -402,7 +402,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
             if (head_fold) {
                 ha.tiles = (const int2*)c->syrk_head_tiles; ha.ntiles = c->n_syrk_head_tiles; ha.ncrit = c->n_syrk_head_crit;
                 ha.dxp = c->dx_pending ? c->dxp : nullptr; ha.X = c->X; ha.xr1 = take_xr1(c); ha.ndx = c->dx_pending ? (n + 255) / 256 : 0;
-                ha.ra = rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
+                ha.ra = rank_args(c, table, false, fuse && storage_f32_like(c)); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
                 ha.nhelp = ha.ntiles + ha.ndx + ha.ngd;             // one helper workgroup per job, behind the pivot and the workers in dispatch order
                 c->dx_pending = false;
             }
@@ -429,15 +429,18 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
                 // the mixed-precision downdate in the rank-aware form: the kept rows of S in permuted column order (what the stored floats hold: the permuted copy is
                 // rounded with S) and U^T with permuted columns as fp32 operands, K <= r, products on the fp32 matrix pipe, chunk sums in FP64 — only the macro tiles of the
                 // pivoted panels; the state update and the dropped diagonal (FP64, from the same operands) by k_syrk's spare workgroups with an empty tile list
-                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, 0, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table), take_xr1(c));
                 srukf_launch_cvt_f32(c->stream, (size_t)c->mxr_krows * np, c->shadowA, c->A32);
                 srukf_launch_cvt_f32(c->stream, (size_t)d.mp * np, c->Utp, c->U32);
                 srukf_launch_syrk32(c->stream, n, np, d.mp, c->A32, c->U32, c->mxr_tasks, c->mxr_ntasks, c->mxr_tiles, c->mxr_ntiles, c->mxr_part, c->Wf, c->fs, c->mxr_krows);
+                // ... and BEHIND it, in FP64 from the FP64 operands, the few tiles whose pivots an fp32-formed product cannot resolve (the robot block, the shared anchor:
+                // mxr_f64_tiles) — they overwrite what the fp32 launch left there
+                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->mxr_f64_tiles, c->dbg.mixed_f64_robot ? c->mxr_n_f64_tiles : 0,
+                                  c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
             } else if (own_order) {
-                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
+                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
                 srukf_launch_syrk_own(c->stream, n, np, c->shadowA, c->Utp, 0, d.mp, (c->red_r + 15) & ~15, c->Wf, c->fs, c->gplan_red.tiles, c->gplan_red.ntiles, c->red_Tp);
             } else
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && c->storage == SRUKF_STORAGE_F32), take_xr1(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -454,8 +457,10 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
     const double nn = n;
     const double syrk_flop = nn * nn * nn / 3.0 + nn * nn * (ue - ub), syrk_byte = 8.0 * (nn * nn + (double)(ue - ub) * nn);
     const double head_frac = fused ? fmin(1.0, 2.0 * srukf_gmw_head_rows() / nn) : 1.0;      // share of the tiles k_syrk still computes (rows / n, upper triangle)
-    if (c->storage == SRUKF_STORAGE_F32_MIXED && ub == 0 && ue == d.mp) {
-        // mixed precision: the fp32 state S32 and U^T rounded once, products on the fp32 matrix pipe, chunk sums in FP64
+    if (c->storage == SRUKF_STORAGE_F32_MIXED && ub == 0 && ue == d.mp && !(c->dbg.mixed_rank && c->A32)) {
+        // mixed precision, round 2's full-rank form (study: "mixed_rank" 0): the fp32 state S32 and U^T rounded once, products on the fp32 matrix pipe, chunk sums in FP64.
+        // (In the rank-aware form of the mode only the staged replay's branch above forms the product in fp32; whatever comes through here — the step-wise calls, a
+        //  flagged frame's repeat on the exact path — forms it in FP64 from the FP64 working copies of the stored floats: the exact path must not divide fp32 noise.)
         ProfScope ps(c, KC_SYRK, syrk_flop, 4.0 * (nn * nn + (double)(ue - ub) * nn) + 8.0 * nn * nn / 2);
         if (c->dx_pending) srukf_launch_gain_dx(c->stream, n, np, c->dxp, c->X, take_xr1(c));
         c->dx_pending = false;
@@ -630,7 +635,7 @@ void seq_gain_only(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fus
     ProfScope ps(c, KC_GAIN, 8.0 * d.n * 2 * d.N, 8.0 * 2.0 * d.n * 2 * d.N);
     srukf_launch_gain(c->stream, d, c->w, c->Ut, c->PxyR, c->Si, c->vis, c->h, c->z_seq, z_dev, c->m_seq, m_dev, c->fs, c->dxp, c->X, c->Z, rank_args(c),
                       fused_motion ? c->Cmat : nullptr, c->S, table ? c->P1 : nullptr, c->pxy2_split_b0, c->DZ,
-                      (fmode && c->storage == SRUKF_STORAGE_F32) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon),   // (the null rows of S as they are stored)
+                      (fmode && storage_f32_like(c)) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon),   // (the null rows of S as they are stored)
                       c->sigR, fmode ? 1 : 0, c->next_pose_pending ? c->next_odo + 3 : nullptr, c->odo_step);
     c->next_pose_pending = false;
     c->dx_pending = true;                             // applied by the next k_syrk launch (seq_refactor)
@@ -763,8 +768,8 @@ int mixed_red_ensure(srukf_ctx* c)
     if (!c->A32) HIPCHK(c, srukf_dmalloc(&c->A32, sizeof(float) * (size_t)np * np));
     if (c->mxr_for_r == c->red_r && c->mxr_tasks) return SRUKF_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (void* b : { (void*)c->mxr_part, c->mxr_tasks, c->mxr_tiles }) if (b) srukf_dfree_on(b, c->stream);
-    c->mxr_part = nullptr; c->mxr_tasks = nullptr; c->mxr_tiles = nullptr;
+    for (void* b : { (void*)c->mxr_part, c->mxr_tasks, c->mxr_tiles, (void*)c->mxr_f64_tiles }) if (b) srukf_dfree_on(b, c->stream);
+    c->mxr_part = nullptr; c->mxr_tasks = nullptr; c->mxr_tiles = nullptr; c->mxr_f64_tiles = nullptr;
     c->mxr_krows = std::min(np, srukf_mixed_krows(c->red_r));
     int ntiles = 0;
     const int ntasks = srukf_mixed_build_tasks_red(np, mp, c->mxr_krows, 64 * c->red_Tp, nullptr, nullptr, &ntiles);
@@ -776,6 +781,18 @@ int mixed_red_ensure(srukf_ctx* c)
     HIPCHK(c, hipMemcpy(c->mxr_tasks, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->mxr_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
     c->mxr_ntasks = ntasks; c->mxr_ntiles = ntiles; c->mxr_for_r = c->red_r;
+    {
+        // the FP64 tiles (32 x 32, permuted order, upper triangle, rows of the pivoted panels): tile row / column 0 (the shared anchor: permuted positions 0 .. 2) and the
+        // one or two tile rows / columns of the robot block (r-4 .. r-1)
+        const int T32 = np / 32, rows32 = 2 * c->red_Tp, q0 = 0, q1 = (c->red_r - 4) / 32, q2 = (c->red_r - 1) / 32;
+        std::vector<int> tl;
+        for (int I = 0; I < rows32 && I < T32; I++)
+            for (int J = I; J < T32; J++)
+                if (I == q0 || I == q1 || I == q2 || J == q1 || J == q2) { tl.push_back(I); tl.push_back(J); }
+        HIPCHK(c, srukf_dmalloc(&c->mxr_f64_tiles, sizeof(int) * (tl.size() + 2)));
+        HIPCHK(c, hipMemcpy(c->mxr_f64_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
+        c->mxr_n_f64_tiles = (int)tl.size() / 2;
+    }
     drop_graphs(c);
     return SRUKF_OK;
 }
@@ -900,7 +917,7 @@ static int run_staged_frame_exact(srukf_ctx* c, int frame, double* traj_row)
         for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
         quantize_state(c);
         rc = update_null_set(c); if (rc) return rc;      // the null set is re-derived from the exact factor (see srukf_update)
-    } else if (c->storage != SRUKF_STORAGE_F32_MIXED) set_null_canonical(c);
+    } else if (c->storage != SRUKF_STORAGE_F32_MIXED || storage_f32_like(c)) set_null_canonical(c);
     srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -1012,7 +1029,7 @@ int srukf_run_frames_async(srukf_ctx* c, int first, int count, int mode, double*
         for (int f = 0; f < count; f++) replay_one_frame(c);
     }
     // fp32 storage in "fused tail" mode: S and X are rounded as they are written; the float copies (srukf_get_state_f32) once per run
-    if (c->storage == SRUKF_STORAGE_F32 && replay_fuse_mode(c)) quantize_state(c);
+    if (storage_f32_like(c) && replay_fuse_mode(c)) quantize_state(c);
     c->async_pending = true;
     c->phase = 0;
     HIPCHK(c, hipGetLastError());

@@ -298,7 +298,7 @@ static int step_update_fast(srukf_ctx* c, const double* z, const int* matched, i
     c->robot_cached = true;
     c->view_cached = view;
     if (view && ++c->view_unused >= 3) c->view_auto = false;   // (nobody reads them)
-    c->f32_stale = c->storage == SRUKF_STORAGE_F32;
+    c->f32_stale = storage_f32_like(c);
     c->step_fast_frames++;
     HIPCHK(c, hipGetLastError());
     return SRUKF_OK;
@@ -371,7 +371,7 @@ static int step_update_slow(srukf_ctx* c, const double* z, const int* matched, i
     if (reorder == SRUKF_NEED_REORDER || exact_ran) { const int rc = update_null_set(c); if (rc) return rc; }
     else {
         shadow_rebuild(c);
-        if (c->storage != SRUKF_STORAGE_F32_MIXED) set_null_canonical(c);     // the rank-aware tail (k_rank_expand) has written sqrt(EPSILON) e_k into every skipped row
+        if (c->storage != SRUKF_STORAGE_F32_MIXED || storage_f32_like(c)) set_null_canonical(c);     // the rank-aware tail (k_rank_expand) has written sqrt(EPSILON) e_k into every skipped row
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());

@@ -80,9 +80,10 @@ typedef enum srukf_reorder { SRUKF_NEED_REORDER = 0, SRUKF_NEEDNOT_REORDER = 1 }
  * (SLAM.cpp:2118-2120, 2149), is formed on the fp32 matrix pipe from the fp32 state and U^T rounded once, in K chunks of
  * <= 1024 summed in FP64; pivots, diagonal blocks and trailing updates of the modified Cholesky stay FP64.  BATCHED
  * updates only use it (a SEQUENTIAL / single-column refactor keeps the FP64 contraction).  srukf_set_storage refuses it
- * (SRUKF_ERR_UNSUPPORTED) unless params.epsilon >= 1e-9: P is permanently rank deficient and the reference's clamp
- * EPSILON = 1e-13 lies below the rounding an fp32-formed S^T S - U U^T leaves in its null space (the tolerance study in
- * diverges at 1e-13, within 1.3e-6 m of the fp64 / 1e-13 run at 1e-8). */
+ * Round 6: offered at every epsilon, the reference's 1e-13 included (rounds 2 - 5 refused it below 1e-9).  Its fp32 accumulators are flushed into FP64 every 32
+ * rows of K, and in the rank-aware form (the default wherever a null set exists) only the kept pivots are factored and the tiles of the robot block and of the
+ * map's shared anchor are formed in FP64: within 1.2e-6 m of the fp64 filter over 3 000 frames at N = 500 (fp32 storage with FP64 arithmetic: 6.8e-7;
+ * DESIGN.md, row g).  On MI355X the FP32 matrix peak is 2 x the FP64 one and the mode's extra passes use that up: it is NOT faster than SRUKF_STORAGE_F32. */
 typedef enum srukf_storage { SRUKF_STORAGE_F64 = 0, SRUKF_STORAGE_F32 = 1, SRUKF_STORAGE_F32_MIXED = 2 } srukf_storage;
 
 typedef struct srukf_ctx srukf_ctx;   /* opaque; owns all device buffers + pinned staging */
@@ -276,8 +277,7 @@ int  srukf_profile_reset(srukf_ctx* ctx);
  * bounded waits and the fallback to per-panel launches). */
 int  srukf_debug_poke_state(srukf_ctx* ctx, int row, int col, double value);
 int  srukf_debug_starve_workers(srukf_ctx* ctx, int on);      /* on = 2: only the split form's pair is starved (the tier it falls back to runs undisturbed) */
-/* Study hook, not for hosts: lets srukf_set_storage accept SRUKF_STORAGE_F32_MIXED below its epsilon floor (where the filter
- * diverges; scripts/mixed_eps_study.py documents exactly that). */
+/* Kept for ABI compatibility (rounds 2 - 5: let srukf_set_storage accept SRUKF_STORAGE_F32_MIXED below its then epsilon floor): no effect since round 6. */
 int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
 
 /* Measurement / test switches, not for hosts (every one defaults to the product path; captured graphs are dropped).

@@ -24,7 +24,7 @@ marks = [m for m in (1, 10, 30, 100, 300, 1000, 1500, 2000, 2500, 3000) if m <= 
 BLK = 50
 
 
-def run(storage, mixed_rank=1, null_ppm=1, slow_limit_s=20.0):
+def run(storage, mixed_rank=1, f64_robot=1, slow_limit_s=20.0):
     p = synth.scene_params()
     sc = synth.make_scene(N, F, seed=0, p=p)
     f = srukf.Filter(N, p)
@@ -34,7 +34,7 @@ def run(storage, mixed_rank=1, null_ppm=1, slow_limit_s=20.0):
         f.set_storage(storage)
     f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
     if storage == srukf.STORAGE_F32_MIXED:
-        f.debug_set("mixed_rank", mixed_rank); f.debug_set("mixed_null_ppm", null_ppm)
+        f.debug_set("mixed_rank", mixed_rank); f.debug_set("mixed_f64_robot", f64_robot)
     rows, minpiv, stopped, t_run = [], {}, None, 0.0
     r = int(f.debug_get("plan_kept"))
     for a in range(0, F, BLK):
@@ -76,8 +76,8 @@ t64, truth, i64 = run(srukf.STORAGE_F64)
 out = {"workload": f"N = {N}, benchmark sequence (seed 0), EPSILON = 1e-13 (the reference's), {F} frames through srukf_run_frames in blocks of {BLK}", "frames": marks,
        "f64": {"pose_err_vs_truth_m": [float(np.abs(t64[m - 1, :2] - truth[m - 1, :2]).max()) for m in marks], "info": i64}}
 for name, st, kw in (("f32_storage", srukf.STORAGE_F32, {}),
-                     ("f32_mixed_rank_aware", srukf.STORAGE_F32_MIXED, {"mixed_rank": 1, "null_ppm": 1}),
-                     ("f32_mixed_rank_aware_null_check_1e-12", srukf.STORAGE_F32_MIXED, {"mixed_rank": 1, "null_ppm": 0}),
+                     ("f32_mixed_rank_aware_robot_and_anchor_tiles_f64", srukf.STORAGE_F32_MIXED, {"mixed_rank": 1, "f64_robot": 1}),
+                     ("f32_mixed_rank_aware_every_tile_f32", srukf.STORAGE_F32_MIXED, {"mixed_rank": 1, "f64_robot": 0}),
                      ("f32_mixed_full_rank", srukf.STORAGE_F32_MIXED, {"mixed_rank": 0})):
     t, _, info = run(st, **kw)
     out[name] = curve(t, t64, truth)

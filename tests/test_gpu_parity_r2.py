@@ -186,17 +186,11 @@ def test_replay_recovers_from_theta_clamp_frame(srukf, oracle, synth):
 
 @pytest.mark.parametrize("N", [20, 50, 200])
 def test_mixed_precision_downdate(srukf, oracle, synth, N):
-    """SRUKF_STORAGE_F32_MIXED (BASELINE configs[4]): fp32 state, S^T S - U U^T on the fp32 matrix pipe in K chunks summed in
-    FP64, pivots and trailing updates FP64.  Refused with the reference's EPSILON = 1e-13 (the fp32-formed covariance cannot
-    resolve that clamp: it diverges, scripts/mixed_eps_study.py); with the clamp at 1e-8 one frame from the float-rounded
-    state matches the oracle's fp64 frame to what single-precision products imply, and the trajectory stays within 1e-6 m of
-    the fp64 run with the same clamp."""
+    """SRUKF_STORAGE_F32_MIXED (BASELINE configs[4]): fp32 state, S^T S - U U^T on the fp32 matrix pipe (fp32 accumulators flushed into FP64 every 32 rows),
+    pivots and trailing updates FP64 — at the reference's EPSILON = 1e-13 (refused until round 6: the mode diverged there; DESIGN.md row g).  N = 20: no null set is
+    taken (n < 128), the product is formed in state order; N = 50 / 200: the rank-aware form — kept rows only, robot / shared-anchor tiles in FP64.  One frame from the
+    float-rounded state matches the oracle's fp64 frame to what single-precision products imply, and the trajectory stays within 1e-6 m of the fp64 run."""
     p = synth.scene_params()
-    g = srukf.Filter(N, p)
-    with pytest.raises(srukf.SrukfError) as e:
-        g.set_storage(srukf.STORAGE_F32_MIXED)
-    assert e.value.rc == -6
-    p["epsilon"] = 1e-8
     F = 12 if N < 200 else 6
     sc = synth.make_scene(N, F, seed=3, p=p)
     X0 = sc["X0"].astype(np.float32).astype(np.float64); S0 = np.triu(sc["S0"]).astype(np.float32).astype(np.float64)
@@ -210,9 +204,14 @@ def test_mixed_precision_downdate(srukf, oracle, synth, N):
     eps32 = float(np.finfo(np.float32).eps)
     np.testing.assert_allclose(X, Xo, rtol=eps32, atol=1e-9)
     P, Po = S.T @ S, So.T @ So
-    sd = np.sqrt(np.diag(Po))
-    rel = np.abs(P - Po) / (np.outer(sd, sd) + 1e-30)
-    assert rel.max() < 4e-6, rel.max()                            # measured 5e-7: fp32 products of the stored factors + the clamp level
+    # entries of P in units of what single-precision products of the stored factors imply, eps32 (|S|^T |S|)_ij, where that scale is above 1e-10; absolutely below it
+    # (the structurally null directions: an fp32-formed product leaves ~1e-7 of the neighbouring variances there, the reference's clamp 1e-13)
+    B = eps32 * (np.abs(So).T @ np.abs(So))
+    d, big = np.abs(P - Po), B > 1e-10
+    ratio, small = float((d[big] / B[big]).max()), float(d[~big].max()) if (~big).any() else 0.0
+    print(f"mixed downdate N = {N}, one frame: max |dP| / (eps32 |S|^T|S|) = {ratio:.2f}, max |dP| below that scale = {small:.2e}")
+    # (measured, round 6: ratio 0.76 - 0.85; below the scale 2e-11 in the rank-aware form and 5.6e-7 at N = 20, where every pivot is factored and the null ones divide fp32 noise)
+    assert ratio <= 16.0 and small <= (2e-9 if N > 20 else 4e-6), (ratio, small)
     tr = {}
     for st in (srukf.STORAGE_F64, srukf.STORAGE_F32_MIXED):
         g = srukf.Filter(N, p); g.set_storage(st); g.set_state(sc["X0"], sc["S0"]); g.stage_sequence(sc["odo"], sc["z"], sc["matched"])
