@@ -744,39 +744,59 @@ __global__ __launch_bounds__(256) void k_gmw_check(int n, int ld, const double* 
 }
 
 // ---- column-by-column path: evaluates every pivot exactly as the reference does -----------------
-// k_gmw_col_a(j): W[j][i] = G[j][i] - sum_{k<j} (W[k][j]/D[k]) * W[k][i]  for i >= j; theta_j.
-// W is stored in Wf (full n x n, upper).  grid over i.
-__global__ __launch_bounds__(256) void k_gmw_col_a(int ld, int j, const double* __restrict__ G, double* __restrict__ Wf,
-                                                   const double* __restrict__ D, unsigned long long* __restrict__ theta_bits)
+// k_gmw_col(j), one launch per pivot j = 0 .. n (left-looking, SLAM.cpp:2220-2296):
+//   1. row j - 1 is complete (the previous launch): D_{j-1} = max(EPSILON, |C_{j-1,j-1}|, theta_{j-1}^2 / beta^2) — every workgroup evaluates it for itself, the first
+//      one records it — and S row j - 1 = sqrt(D) (W / D) goes out;
+//   2. the multipliers m_k = W[k][j] / D[k], k < j, ONCE per workgroup into LDS;
+//   3. W[j][i] = G[j][i] - sum_{k<j} m_k W[k][i] for i >= j (same terms in the same order as the reference's recurrence), theta_j = max_{i>j} |W[j][i]|.
+// The launch with j = n only finishes row n - 1.  W is stored in Wf (full n x n, upper).  grid over i.
+// (Until round 6 every thread of every column divided W[k][j] / D[k] itself inside the k loop — j dependent fp64 divisions in front of j dependent loads — and a second
+//  launch per column wrote the S row: 126 ms per flagged frame at N = 200, 2 408 launches; bench.py "theta_clamp".)
+__global__ __launch_bounds__(256) void k_gmw_col(int n, int ld, int j, double eps, const double* __restrict__ G, double* __restrict__ Wf, double* __restrict__ D,
+                                                 unsigned long long* __restrict__ theta_bits, FrameScalars* __restrict__ fs, double* __restrict__ Sout)
 {
+    extern __shared__ double mk[];                              // j multipliers
     const int i = j + blockIdx.x * 256 + threadIdx.x;
+    double dprev = 0.0;
+    if (j > 0) {
+        const double gamma = __longlong_as_double((long long)fs->gmax_bits);
+        const double xi = __longlong_as_double((long long)fs->ximax_bits);
+        const double nu = fmax(1.0, sqrt((double)n * n - 1.0));
+        const double beta2 = fmax(fmax(gamma, xi / nu), 1e-15);
+        const double th = __longlong_as_double((long long)theta_bits[j - 1]);
+        const double cjj = fabs(Wf[(size_t)(j - 1) * ld + (j - 1)]);
+        const double t2 = th * th / beta2;
+        dprev = fmax(fmax(eps, cjj), t2);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            D[j - 1] = dprev;
+            if (t2 > fmax(eps, cjj)) atomicAdd(&fs->clamp_rows, 1);
+            if (j - 1 < n) Sout[(size_t)(j - 1) * ld + (j - 1)] = sqrt(dprev);
+        }
+        if (i < n && j - 1 < n) Sout[(size_t)(j - 1) * ld + i] = sqrt(dprev) * (Wf[(size_t)(j - 1) * ld + i] / dprev);
+    }
+    if (j >= n) return;
+    for (int k = threadIdx.x; k < j; k += 256) mk[k] = Wf[(size_t)k * ld + j] / (k == j - 1 ? dprev : D[k]);
+    __syncthreads();
     double v = 0.0;
     if (i < ld) {
         double acc = 0.0;
-        for (int k = 0; k < j; k++) acc += (Wf[(size_t)k * ld + j] / D[k]) * Wf[(size_t)k * ld + i];
+        const double* col = Wf + i;
+        // (32 rows requested before the first product: the loop is a chain of dependent additions over independent loads — one row per trip was a memory round trip per row)
+        int k = 0;
+        for (; k + 32 <= j; k += 32) {
+            double wv[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) wv[u] = col[(size_t)(k + u) * ld];
+#pragma unroll
+            for (int u = 0; u < 32; u++) acc += mk[k + u] * wv[u];
+        }
+        for (; k < j; k++) acc += mk[k] * col[(size_t)k * ld];
         v = G[(size_t)j * ld + i] - acc;
         Wf[(size_t)j * ld + i] = v;
     }
     double mx = (i < ld && i > j) ? fabs(v) : 0.0;
     mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(&theta_bits[j], (unsigned long long)__double_as_longlong(mx));
-}
-// k_gmw_col_b(j): D_j = max(EPSILON, |C_jj|, theta_j^2/beta^2); S row j.
-__global__ __launch_bounds__(256) void k_gmw_col_b(int n, int ld, int j, double eps, const double* __restrict__ Wf, double* __restrict__ D,
-                                                   const unsigned long long* __restrict__ theta_bits, FrameScalars* __restrict__ fs,
-                                                   double* __restrict__ Sout)
-{
-    const double gamma = __longlong_as_double((long long)fs->gmax_bits);
-    const double xi = __longlong_as_double((long long)fs->ximax_bits);
-    const double nu = fmax(1.0, sqrt((double)n * n - 1.0));
-    const double beta2 = fmax(fmax(gamma, xi / nu), 1e-15);
-    const double th = __longlong_as_double((long long)theta_bits[j]);
-    const double cjj = fabs(Wf[(size_t)j * ld + j]);
-    const double t2 = th * th / beta2;
-    const double dj = fmax(fmax(eps, cjj), t2);
-    const int i = j + blockIdx.x * 256 + threadIdx.x;
-    if (i == j) { D[j] = dj; if (t2 > fmax(eps, cjj)) atomicAdd(&fs->clamp_rows, 1); }
-    if (i < n && j < n) Sout[(size_t)j * ld + i] = (i == j) ? sqrt(dj) : sqrt(dj) * (Wf[(size_t)j * ld + i] / dj);
 }
 
 // k_gmw_stats: gamma / xi of an arbitrary symmetric G (stand-alone GMW entry point)
@@ -915,9 +935,9 @@ void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, cons
 void srukf_launch_gmw_col(hipStream_t st, int n, int ld, int j, double eps, const double* G, double* Wf, double* D,
                           unsigned long long* theta_bits, FrameScalars* fs, double* Sout)
 {
-    const int blocks = (ld - j + 255) / 256;
-    hipLaunchKernelGGL(k_gmw_col_a, dim3(blocks), dim3(256), 0, st, ld, j, G, Wf, D, theta_bits);
-    hipLaunchKernelGGL(k_gmw_col_b, dim3(blocks), dim3(256), 0, st, n, ld, j, eps, Wf, D, theta_bits, fs, Sout);
+    // (callers loop j = 0 .. n - 1; the launch behind the last pivot finishes its row)
+    hipLaunchKernelGGL(k_gmw_col, dim3((ld - j + 255) / 256), dim3(256), sizeof(double) * (size_t)(j > 0 ? j : 1), st, n, ld, j, eps, G, Wf, D, theta_bits, fs, Sout);
+    if (j == n - 1) hipLaunchKernelGGL(k_gmw_col, dim3((ld - n + 255) / 256 > 0 ? (ld - n + 255) / 256 : 1), dim3(256), sizeof(double), st, n, ld, n, eps, G, Wf, D, theta_bits, fs, Sout);
 }
 void srukf_launch_gmw_stats(hipStream_t st, int n, int ld, const double* G, FrameScalars* fs)
 {
