@@ -351,6 +351,8 @@ int srukf_destroy(srukf_ctx* c)
 {
     if (!c) return SRUKF_OK;
     hipSetDevice(c->device);
+    for (srukf_ctx* r : c->retired) srukf_destroy(r);            // (they launch on this handle's stream: before it goes)
+    c->retired.clear();
     batch_plan_forget(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     // the side streams too, BEFORE any buffer goes back to the pool: the step-wise fast path returns as soon as the tail raises its pinned flag and has by then queued
@@ -384,6 +386,60 @@ int srukf_destroy(srukf_ctx* c)
     delete c;
     return SRUKF_OK;
 }
+
+}  // extern "C"
+
+namespace srukf_impl {
+
+// A context the handle outgrew at a map change, kept for the next time the map has that size.  Everything of it that depends on the STATE is rebuilt by whoever revives
+// it (srukf_reset here; the caller's factorisation, srukf_set_storage and update_null_set afterwards); what depends only on N, the device and the parameters — buffers,
+// plans, tile tables, pinned areas, side streams — is what it is kept for.
+void ctx_retire(srukf_ctx* handle, srukf_ctx* old)
+{
+    drop_graphs(old);
+    old->own_stream = false;
+    handle->retired.push_back(old);
+    while (handle->retired.size() > 8) { srukf_destroy(handle->retired.front()); handle->retired.erase(handle->retired.begin()); }
+}
+
+static int ctx_revive(srukf_ctx* r)
+{
+    if (r->ck_stream) HIPCHK(r, hipStreamSynchronize(r->ck_stream));
+    if (r->side) HIPCHK(r, hipStreamSynchronize(r->side));
+    r->ck_pending = false; r->ck3_inflight = false; r->ck_valid = false;
+    if (r->odo_seq) { srukf_dfree_on(r->odo_seq, r->stream); srukf_dfree_on(r->z_seq, r->stream); srukf_dfree_on(r->m_seq, r->stream); r->odo_seq = nullptr; r->z_seq = nullptr; r->m_seq = nullptr; }
+    r->seqF = 0;
+    r->storage = SRUKF_STORAGE_F64;                              // (as a fresh context: the caller sets the handle's mode; S32 / X32 / A32 stay allocated)
+    r->K_new = 0; r->dx_pending = false; r->xr1_pending = false;
+    r->null_canonical = false; r->tail_ok = false;
+    r->clamp_frame_host = r->clamp_row_host = -1;
+    r->next_odo_valid = false; r->fs_seq_step = false; r->last_update_sequential = false;
+    r->step_export_attached = false; r->step_export = StepExport{}; r->mirror_next = false; r->meas_seq = 0;
+    r->view_auto = false; r->view_unused = 0; r->view_hits = 0;
+    r->step_fast_frames = r->step_slow_frames = 0; r->exact_frames = 0;
+    r->profiling = false; r->pev.clear();
+    r->err.clear();
+    HIPCHK(r, hipMemsetAsync(r->fs, 0, sizeof(FrameScalars), r->stream));
+    return srukf_reset(r);                                       // step-path flags, X / S as srukf_create leaves them, frame scalars, null set off, graphs dropped
+}
+
+int ctx_obtain(srukf_ctx* handle, srukf_ctx** out, int N)
+{
+    for (size_t q = 0; q < handle->retired.size(); q++) {
+        srukf_ctx* r = handle->retired[q];
+        if (r->d.N != N || r->device != handle->device || r->stream != handle->stream || memcmp(&r->p, &handle->p, sizeof(srukf_params)) != 0) continue;
+        handle->retired.erase(handle->retired.begin() + (long)q);
+        if (ctx_revive(r) == SRUKF_OK) { *out = r; return SRUKF_OK; }
+        srukf_destroy(r);
+        break;
+    }
+    // (nothing to revive: a new context.  The retired one keeps its side stream for its next life; the new one finds its own — split_ensure)
+    return srukf_create(out, N, &handle->p, handle->device, handle->stream);
+}
+
+}  // namespace srukf_impl
+
+extern "C" {
 
 int srukf_reset(srukf_ctx* c)
 {

@@ -250,6 +250,11 @@ struct srukf_ctx {
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
     int exact_frames = 0;                  // staged frames srukf_run_frames repeated on the exact column path (flagged: theta clamp, a skipped direction that is not null, an abandoned launch): "exact_frames"
     bool async_pending = false;
+    // Map changes rebuild the context behind the handle (srukf_add_landmarks / srukf_delete_landmark: adopt_context).  A rebuilt context used to be destroyed and the
+    // next one created from nothing — ~0.3 ms of allocations, plans and tile tables, 0.5 - 2.4 ms of frees (pinned host memory among them) per map change at N = 200,
+    // where the reference's map changes every few frames (SLAM.cpp:552-562, 2443-2460) and N only moves by +- 1.  The handle keeps the last few contexts it outgrew
+    // (shape, device, stream and parameters identical when N comes back) and revives one instead of creating it: ctx_obtain / ctx_retire (srukf_api.hip)
+    std::vector<srukf_ctx*> retired;
     std::string err;
     // one captured frame (BATCHED, staged inputs): replayed by srukf_run_frames_async
     hipGraph_t graph = nullptr, graph8 = nullptr;          // one frame / SRUKF_GRAPH_FRAMES frames
@@ -312,6 +317,8 @@ void host_weights(int Na, const srukf_params& p, KWeights& w);
 std::vector<int> build_tile_table(int n_own, int n_other, bool upper, bool own_is_row, int k_index /* 0: K grows with tile.x, 1: with tile.y */);
 void prof_collect(srukf_ctx* c);
 void adopt_context(srukf_ctx* c, srukf_ctx* c2);
+int ctx_obtain(srukf_ctx* handle, srukf_ctx** out, int N);     // a context for N landmarks with the handle's device / stream / parameters: a retired one revived, or srukf_create
+void ctx_retire(srukf_ctx* handle, srukf_ctx* old);
 
 struct ProfScope {
     srukf_ctx* c; int kc; hipEvent_t a = nullptr, b = nullptr;

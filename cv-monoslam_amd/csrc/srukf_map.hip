@@ -2,7 +2,23 @@
 // and data association (wrapPatch + dataAssociation, 1803-2009).  A map change rebuilds the context behind the handle (adopt_context).
 
 #include "srukf_ctx.h"
+#include <chrono>
 using namespace srukf_impl;
+
+// SRUKF_MAP_TIMING=1 in the environment: wall time of the phases of a map change on stderr (measurement: where do the milliseconds of srukf_add_landmarks /
+// srukf_delete_landmark go — the device work or the context that is rebuilt around it?)
+namespace {
+struct MapTimer {
+    bool on; const char* what; std::chrono::steady_clock::time_point t0, tl; std::string line;
+    explicit MapTimer(const char* w) : on(getenv("SRUKF_MAP_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()), tl(t0) {}
+    void mark(const char* label) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        char b[64]; snprintf(b, sizeof b, " %s %.0f", label, std::chrono::duration<double, std::micro>(t - tl).count()); line += b; tl = t;
+    }
+    ~MapTimer() { if (on) fprintf(stderr, "[map timing] %s: total %.0f us:%s\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), line.c_str()); }
+};
+}
 
 static int ensure_appearance(srukf_ctx* c)
 {
@@ -43,7 +59,9 @@ namespace srukf_impl {
 void adopt_context(srukf_ctx* c, srukf_ctx* c2)
 {
     const bool own = c->own_stream;
+    std::vector<srukf_ctx*> kept = std::move(c->retired);       // (the handle's list of retired contexts stays with the handle)
     std::swap(*c, *c2);
+    c->retired = std::move(kept); c2->retired.clear();
     c->own_stream = own; c2->own_stream = false;
     c->profiling = c2->profiling; c->use_graph = c2->use_graph;
     // per-context switches the caller set on the handle survive the rebuild (before srukf_set_storage / update_null_set run on it)
@@ -52,7 +70,7 @@ void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     memcpy(c->prof_ms, c2->prof_ms, sizeof c->prof_ms); memcpy(c->prof_n, c2->prof_n, sizeof c->prof_n);
     memcpy(c->prof_flops, c2->prof_flops, sizeof c->prof_flops); memcpy(c->prof_bytes, c2->prof_bytes, sizeof c->prof_bytes);
     c2->profiling = false; c2->pev.clear();
-    srukf_destroy(c2);
+    ctx_retire(c, c2);                                           // (not destroyed: revived when the map has this size again — ctx_obtain)
     c->phase = 0;
     if (shared != c->gmw_shared) set_shared(c, shared, tenants);
 }
@@ -138,14 +156,16 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
 {
     if (!c || K < 1 || !uv) return SRUKF_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    MapTimer mt("add_landmarks");
     step_commit_motion(c); step_invalidate(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    mt.mark("sync");
     const int dim = c->d.n, ld = c->d.np;
     const int Na = dim + 3 * K, L = 2 * Na + 1, dimn = dim + 6 * K;                          // 827-828
     srukf_ctx* c2 = nullptr;
-    side_stream_lend(c);
-    int rc = srukf_create(&c2, c->d.N + K, &c->p, c->device, c->stream);
+    int rc = ctx_obtain(c, &c2, c->d.N + K);
     if (rc) { c->err = std::string("add_landmarks: ") + g_create_error; return rc; }
+    mt.mark("create");
     const int ldn = c2->d.np, rows_p = round_up(2 * Na, 16);
     KWeights wa; host_weights(Na, c->p, wa);                                                 // 867
     std::vector<int> perm(dimn);
@@ -186,6 +206,7 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     cleanup();
+    mt.mark("numeric");
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("add_landmarks: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
     if (c->app_patch) {                                      // the old landmarks keep their appearance records
         rc = ensure_appearance(c2);
@@ -194,9 +215,13 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
         hipStreamSynchronize(c->stream);
     }
     const int storage = c->storage;
+    mt.mark("appearance");
     adopt_context(c, c2);
+    mt.mark("adopt+destroy");
     rc = srukf_set_storage(c, storage); if (rc) return rc;
+    mt.mark("set_storage");
     rc = update_null_set(c); if (rc) return rc;
+    mt.mark("null_set");
     return srukf_set_new_landmarks(c, K);
 }
 
@@ -210,12 +235,14 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     const int N = c->d.N, n = c->d.n, np = c->d.np;
     if (id < 0 || id >= N) { c->err = "delete_landmark: no such landmark"; return SRUKF_ERR_BAD_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    MapTimer mt("delete_landmark");
     step_commit_motion(c); step_invalidate(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    mt.mark("sync");
     srukf_ctx* c2 = nullptr;
-    side_stream_lend(c);
-    int rc = srukf_create(&c2, N - 1, &c->p, c->device, c->stream);
+    int rc = ctx_obtain(c, &c2, N - 1);
     if (rc) { c->err = std::string("delete_landmark: ") + g_create_error; return rc; }
+    mt.mark("create");
     const int nn = n - 6, ldn = c2->d.np;
     std::vector<int> map(nn);
     for (int a = 0; a < nn; a++) map[a] = a < 6 * id ? a : a + 6;
@@ -239,6 +266,7 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     srukf_dfree(d_map);
+    mt.mark("numeric");
     if (e != hipSuccess) { srukf_destroy(c2); c->err = std::string("delete_landmark: ") + hipGetErrorString(e); return SRUKF_ERR_HIP; }
     // m_nFilters-- when one of the landmarks added last is the one that goes (SLAM.cpp:2468-2492)
     const int k_new = c->K_new > 0 ? (id >= N - c->K_new ? c->K_new - 1 : c->K_new) : 0;
@@ -249,9 +277,13 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
         hipStreamSynchronize(c->stream);
     }
     const int storage = c->storage;
+    mt.mark("appearance");
     adopt_context(c, c2);
+    mt.mark("adopt+destroy");
     rc = srukf_set_storage(c, storage); if (rc) return rc;
+    mt.mark("set_storage");
     rc = update_null_set(c); if (rc) return rc;
+    mt.mark("null_set");
     return srukf_set_new_landmarks(c, k_new);
 }
 

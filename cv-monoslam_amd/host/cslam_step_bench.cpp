@@ -70,7 +70,7 @@ int main(int argc, char** argv)
     double tcall[5] = { 0, 0, 0, 0, 0 };                      // capi / assoc: host time inside predict_motion, predict_measurement, the association, update, get_robot
     long long matches_dev = 0;
     long long flag_ticks = -1;                                       // last frame: start of the frame's first launch -> h / Si / visible flagged to the host (10 ns ticks)
-    char churn_json[400] = "";
+    char churn_json[900] = "";
     if (mode == "facade") {
         monoslam::CSLAM SLAM;
         SLAM.m_params.a1 = a4[0]; SLAM.m_params.a2 = a4[1]; SLAM.m_params.a3 = a4[2]; SLAM.m_params.a4 = a4[3];
@@ -86,7 +86,12 @@ int main(int argc, char** argv)
                 const int fr = s.m_frame.counter - 1;
                 const bool change = fr >= 10 && fr % churn == 0;
                 int idx = 0, victim = -1;
-                if (change) { victim = (victim_turn * 7) % s.m_nMapFeatures; victim_turn++; s.isAdding = true; }
+                if (change) {
+                    // the next landmark (from a rotating start) that has been predicted often enough for the rule to remove it in THIS frame
+                    const int start = (victim_turn * 7) % s.m_nMapFeatures; victim_turn++;
+                    for (int q = 0; q < s.m_nMapFeatures && victim < 0; q++) { const int k = (start + q) % s.m_nMapFeatures; if (s.map[k].nPredictTimes >= 10) victim = k; }
+                    s.isAdding = true;
+                }
                 for (monoslam::PointsMap* mp = s.map; NULL != mp; mp = mp->next, idx++) {
                     mp->isMatching = mp->isVisible;
                     mp->matchLocation.x = mp->predictLocation.x + 0.5 * gauss(); mp->matchLocation.y = mp->predictLocation.y + 0.5 * gauss();
@@ -111,7 +116,13 @@ int main(int argc, char** argv)
         srukf_debug_get(SLAM.context(), "step_fast", &fast0); srukf_debug_get(SLAM.context(), "step_slow", &slow0);
         const double add0 = SLAM.m_addTime, del0 = SLAM.m_deleteTime; const int na0 = SLAM.m_nAddCalls, nd0 = SLAM.m_nDeleteCalls;
         const double t0 = now_s();
-        for (int fr = 0; fr < K; fr++) SLAM.SLAM();
+        double by_phase[4] = { 0, 0, 0, 0 }; int n_phase[4] = { 0, 0, 0, 0 };      // churn: frames by distance from the last map change (0: the frame that changes the map, 1: the NEED_REORDER frame, 2, 3+)
+        for (int fr = 0; fr < K; fr++) {
+            const int counter = SLAM.m_frame.counter - 1;
+            const double f0 = now_s();
+            SLAM.SLAM();
+            if (churn > 0) { const int ph = counter >= 10 ? (counter % churn < 3 ? counter % churn : 3) : 3; by_phase[ph] += now_s() - f0; n_phase[ph]++; }
+        }
         t_timed = now_s() - t0;
         // (the counters live in the context, and a map change rebuilds the context behind the handle: they restart with it — so the split is read from the facade's
         //  own bookkeeping where the library cannot give it: frames since the last rebuild)
@@ -119,9 +130,12 @@ int main(int argc, char** argv)
         if (churn > 0) {
             const int na = SLAM.m_nAddCalls - na0, nd = SLAM.m_nDeleteCalls - nd0;
             snprintf(churn_json, sizeof churn_json, "\"churn\": {\"every_frames\": %d, \"additions\": %d, \"deletions\": %d, \"ms_per_addition\": %.3f, \"ms_per_deletion\": %.3f, "
-                     "\"map_change_share_of_wall\": %.3f, \"landmarks_at_end\": %d, \"step_fast_since_last_rebuild\": %lld, \"step_slow_since_last_rebuild\": %lld}, ",
+                     "\"map_change_share_of_wall\": %.3f, \"landmarks_at_end\": %d, \"step_fast_since_last_rebuild\": %lld, \"step_slow_since_last_rebuild\": %lld, "
+                     "\"us_per_frame_by_distance_from_the_change\": {\"0_changes_the_map\": %.1f, \"1_need_reorder\": %.1f, \"2\": %.1f, \"3_and_later\": %.1f}}, ",
                      churn, na, nd, na ? (SLAM.m_addTime - add0) / na * 1e3 : 0.0, nd ? (SLAM.m_deleteTime - del0) / nd * 1e3 : 0.0,
-                     (SLAM.m_addTime - add0 + SLAM.m_deleteTime - del0) / t_timed, SLAM.m_nMapFeatures, fast1, slow1);
+                     (SLAM.m_addTime - add0 + SLAM.m_deleteTime - del0) / t_timed, SLAM.m_nMapFeatures, fast1, slow1,
+                     n_phase[0] ? by_phase[0] / n_phase[0] * 1e6 : 0.0, n_phase[1] ? by_phase[1] / n_phase[1] * 1e6 : 0.0, n_phase[2] ? by_phase[2] / n_phase[2] * 1e6 : 0.0,
+                     n_phase[3] ? by_phase[3] / n_phase[3] * 1e6 : 0.0);
         }
         if (!SLAM.lastError.empty()) { fprintf(stderr, "%s\n", SLAM.lastError.c_str()); return 1; }
         const int nn = SLAM.m_X_k.rows;
