@@ -85,6 +85,8 @@ void srukf_launch_associate(hipStream_t, KDims, srukf_params, const unsigned cha
 int srukf_mixed_build_tasks(int np, int ue, short* out_tasks, int* out_tiles, int* ntiles);
 int srukf_mixed_build_tasks_red(int np, int ue, int krows, int rows_lim, short* out_tasks, int* out_tiles, int* ntiles);
 int srukf_mixed_krows(int r);
+void srukf_launch_split_bf3(hipStream_t, int, int, int, int, const double*, void*, size_t);
+void srukf_launch_syrk_bf3(hipStream_t, int, int, int, int, int, const void*, size_t, const void*, int, const void*, int, double*, double*, void*);
 size_t srukf_mixed_part_bytes(int ntasks);
 void srukf_launch_cvt_f32(hipStream_t, size_t, const double*, float*);
 void srukf_launch_cvt_robot_cols(hipStream_t, int, int, const double*, float*);
@@ -143,6 +145,8 @@ struct srukf_ctx {
     // robot position was copied into: an fp32-formed entry there (relative error ~1e-7 .. 1e-6) is as large as the pivot itself.  Every other kept pivot is >= 0.1 of
     // its marginal variance
     int* mxr_f64_tiles = nullptr; int mxr_n_f64_tiles = 0;
+    // ... and the operands of the bf16-piece form of the product (k_split_bf3 / k_syrk_bf3): X^T = [kept rows of S | U^T]^T as three planes of bf16, [np columns][mxr_ktot]
+    unsigned short* mxr_xt = nullptr; size_t mxr_xt_stride = 0; int mxr_ktot = 0;
     int *perm = nullptr, *iperm = nullptr;
     double* Sdis = nullptr;
     void* pan[2] = { nullptr, nullptr };   // GMW panel hand-off buffers (double-buffered), one launch per panel
@@ -192,6 +196,11 @@ struct srukf_ctx {
         int mixed_rank = 1;                // "mixed_rank": SRUKF_STORAGE_F32_MIXED runs the rank-aware refactorisation (fp32-formed S^T S - U U^T over the kept rows, FP64 factorisation
                                            // of the kept pivots only); 0: round 2's full-rank form, in which the null pivots divide fp32 noise (the negative study of rounds 2 / 5)
         int mixed_null_ppm = 1;            // "mixed_null_ppm": ... and its null-direction check allows this many 1e-6 of G_aa on top of 1e-12 (an fp32-formed G cannot resolve 1e-12)
+        int mixed_bf16 = 0;                // "mixed_bf16": 1: the fp32 products from three bf16 pieces per operand on the bf16 matrix pipe (k_syrk_bf3) instead of the fp32 pipe
+                                           // (k_syrk32).  Built and measured in round 6 (N = 500): 168 us + 2 x 19 us of splitting against 187 us + 2 x 9 us of conversion —
+                                           // no gain: at one workgroup per CU (the FP64 accumulators beside the fp32 ones: 256 + 65 registers) every 32-row slab waits for its
+                                           // operands (~1 us of load latency against 0.64 us of matrix work), so neither form is bound by its matrix pipe; and its error is
+                                           // 1.6 x the fp32 pipe's (12.5 against 7.7 eps32 units over fixture g9).  Kept behind the switch, held to the same fixture
         int mixed_f64_robot = 1;           // "mixed_f64_robot": ... with the tiles of the robot block and of the shared anchor in FP64 (mxr_f64_tiles); 0: every kept tile from the fp32 pipe (study)
     } dbg;
     bool null_canonical = false;           // every structurally null row of S is exactly sqrt(EPSILON) e_k (update_null_set checks; true behind every rank-aware frame tail)

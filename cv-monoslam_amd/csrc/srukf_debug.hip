@@ -118,6 +118,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
     else if (!strcmp(key, "mixed_rank")) c->dbg.mixed_rank = value ? 1 : 0;
     else if (!strcmp(key, "mixed_f64_robot")) c->dbg.mixed_f64_robot = value ? 1 : 0;
+    else if (!strcmp(key, "mixed_bf16")) c->dbg.mixed_bf16 = value ? 1 : 0;
     else if (!strcmp(key, "mixed_null_ppm")) c->dbg.mixed_null_ppm = value < 0 ? 0 : value;
     else if (!strcmp(key, "step_fast")) c->dbg.step_fast = value ? 1 : 0;
     else if (!strcmp(key, "step_spin")) c->dbg.step_spin = value ? 1 : 0;

@@ -131,6 +131,134 @@ __global__ __launch_bounds__(256) void k_syrk32(int np, int ue, const float* __r
             }
 }
 
+// ---- the same product from bf16 pieces (round 6) ----------------------------------------------------------------------------------------------------------------
+// On MI355X the FP32 matrix peak is 2 x the FP64 one and 1/16 of the bf16 one.  A float splits EXACTLY into three bf16 pieces of eight significant bits each
+// (x = h + m + l: h = x truncated to its upper 16 bits, m = (x - h) truncated, l = the rest), and a product of two floats is then six bf16 products up to 2^-24 of itself
+// (h h', h m', m h', m m', h l', l h'; the three dropped ones are below 2^-24): six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block of multiply-adds at 32 cycles each
+// against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 — 2.7 x the fp32 pipe's rate, 5.3 x the FP64 one's —, accumulated in fp32 and flushed into FP64 registers every
+// 32 rows like k_syrk32.  Operands: X^T as three planes of bf16, [column][K] with K contiguous (the A rows first, the U^T rows behind them at krows): a lane's MFMA
+// fragment — eight consecutive k of one column — is one 16-byte load from global memory and one ds_read_b128 from the LDS image, which is a plain copy of it.
+// k_split_bf3: rows [0, rows) of a K-major fp64 matrix -> rounded to float (one rounding: the stored state is float already, U^T is rounded as for k_syrk32), split,
+// transposed into the planes at K offset koff.  grid (ld / 64, rows / 32), 256 threads.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef unsigned short us8v __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_split_bf3(int rows, int ld, int ktot, int koff, const double* __restrict__ src, unsigned short* __restrict__ planes, size_t plane_stride)
+{
+    __shared__ float t[32][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 32, tid = threadIdx.x;
+    {
+        const int r = tid >> 3, c8 = (tid & 7) * 8;
+        const double* q = src + (size_t)(r0 + r) * ld + c0 + c8;
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[r][c8 + u] = (r0 + r < rows) ? (float)q[u] : 0.f;
+    }
+    __syncthreads();
+    const int col = tid & 63, kg = tid >> 6;
+    us8v h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float x = t[kg * 8 + j][col];
+        const unsigned xb = __float_as_uint(x) & 0xffff0000u;
+        const float r1 = x - __uint_as_float(xb);                 // exact
+        const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mb);                // exact, at most eight significant bits
+        h[j] = (unsigned short)(xb >> 16); m[j] = (unsigned short)(mb >> 16); l[j] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+    unsigned short* o = planes + (size_t)(c0 + col) * ktot + koff + r0 + kg * 8;
+    *(us8v*)o = h; *(us8v*)(o + plane_stride) = m; *(us8v*)(o + 2 * plane_stride) = l;
+}
+
+#define BF3_LROW 40                    // LDS row of one column: 32 k (64 bytes) + 16 bytes of padding (ushorts): 16 lanes' ds_read_b128 cover the 64 banks once
+__global__ __launch_bounds__(256) void k_syrk_bf3(int np, int ktot, int krows, int ue, const unsigned short* __restrict__ planes, size_t plane_stride,
+                                                  const MxTask* __restrict__ tasks, double* __restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short sA[3][MX_TILE][BF3_LROW];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[3][MX_TILE][BF3_LROW];
+    const MxTask tk = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int mb = tk.I * MX_TILE, nb = tk.J * MX_TILE;
+    const int ks = min(mb + MX_TILE, krows);
+    const int klen = ks + ue;
+    const int kbeg = tk.chunk * MX_KCHUNK, kend = min(klen, kbeg + MX_KCHUNK);
+    f16v acc[2][2];
+    double acc64[2][2][16];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 16; t++) { acc[a][b][t] = 0.f; acc64[a][b][t] = 0.0; }
+    const int wm = 64 * (wv >> 1), wn = 64 * (wv & 1);
+    const bool active = (mb + wm < np) && (nb + wn < np) && (nb + wn + 64 > mb + wm);
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    u4v ra[6], rb[6];
+    auto fetch = [&](int k0) {
+        const bool inS = k0 < ks;
+        const int kk = inS ? k0 : krows + (k0 - ks);            // position in the concatenated K of the planes
+        const unsigned flip = inS ? 0u : 0x80008000u;           // - U U^T: the row operand's pieces change sign
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int q = tid + 256 * i, p = q >> 9, rem = q & 511, col = rem >> 2, pt = rem & 3;
+            const unsigned short* base = planes + (size_t)p * plane_stride + kk + pt * 8;
+            ra[i] = (mb + col < np) ? *(const u4v*)(base + (size_t)(mb + col) * ktot) : (u4v){0u, 0u, 0u, 0u};
+            rb[i] = (nb + col < np) ? *(const u4v*)(base + (size_t)(nb + col) * ktot) : (u4v){0u, 0u, 0u, 0u};
+            ra[i] ^= (u4v){flip, flip, flip, flip};
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int q = tid + 256 * i, p = q >> 9, rem = q & 511, col = rem >> 2, pt = rem & 3;
+            *(u4v*)&sA[p][col][pt * 8] = ra[i]; *(u4v*)&sB[p][col][pt * 8] = rb[i];
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    const int l31 = lane & 31, h = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += MX_KS) {
+        __syncthreads();                                        // the previous slab's fragments have been read
+        stash();
+        __syncthreads();
+        if (k0 + MX_KS < kend) fetch(k0 + MX_KS);               // next slab in flight under this one's products
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                bf8v fa[2][3], fb[2][3];
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) {
+                        fa[a][p] = *(const bf8v*)&sA[p][wm + 32 * a + l31][16 * st + 8 * h];
+                        fb[a][p] = *(const bf8v*)&sB[p][wn + 32 * a + l31][16 * st + 8 * h];
+                    }
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const int pa = (c == 2 || c == 3) ? 1 : (c == 5 ? 2 : 0), pb = (c == 1 || c == 3) ? 1 : (c == 4 ? 2 : 0);      // (h h) (h m) (m h) (m m) (h l) (l h)
+#pragma unroll
+                    for (int a = 0; a < 2; a++)
+#pragma unroll
+                        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][pa], fb[b][pb], acc[a][b], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 16; t++) { acc64[a][b][t] += (double)acc[a][b][t]; acc[a][b][t] = 0.f; }
+        }
+    }
+    double* out = part + (size_t)blockIdx.x * MX_TILE * MX_TILE;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int r = wm + 32 * a + (t & 3) + 8 * (t >> 2) + 4 * h, c = wn + 32 * b + l31;
+                out[r * MX_TILE + c] = acc64[a][b][t];
+            }
+}
+
 // one workgroup per macro tile: G = sum over the tile's chunks (FP64, chunk order), gamma = max diag, xi = max(0, max offdiag)
 __global__ __launch_bounds__(256) void k_syrk32_reduce(int n, int np, const int2* __restrict__ tiles /* (first task, nchunks) per tile */,
                                                        const MxTask* __restrict__ tasks, const double* __restrict__ part,
@@ -232,6 +360,17 @@ void srukf_launch_syrk32(hipStream_t st, int n, int np, int ue, const float* S32
                          const void* tiles, int ntiles, double* part, double* G, void* fs, int krows)
 {
     hipLaunchKernelGGL(k_syrk32, dim3(ntasks), dim3(256), 0, st, np, ue, S32, U32, (const MxTask*)tasks, part, krows > 0 ? krows : np);
+    hipLaunchKernelGGL(k_syrk32_reduce, dim3(ntiles), dim3(256), 0, st, n, np, (const int2*)tiles, (const MxTask*)tasks, part, G, (FrameScalars*)fs);
+}
+// the bf16-piece form: operands as X^T planes (k_split_bf3), products by k_syrk_bf3, the same reduction
+void srukf_launch_split_bf3(hipStream_t st, int rows, int ld, int ktot, int koff, const double* src, void* planes, size_t plane_stride)
+{
+    hipLaunchKernelGGL(k_split_bf3, dim3(ld / 64, (rows + 31) / 32), dim3(256), 0, st, rows, ld, ktot, koff, src, (unsigned short*)planes, plane_stride);
+}
+void srukf_launch_syrk_bf3(hipStream_t st, int n, int np, int ue, int krows, int ktot, const void* planes, size_t plane_stride, const void* tasks, int ntasks,
+                           const void* tiles, int ntiles, double* part, double* G, void* fs)
+{
+    hipLaunchKernelGGL(k_syrk_bf3, dim3(ntasks), dim3(256), 0, st, np, ktot, krows, ue, (const unsigned short*)planes, plane_stride, (const MxTask*)tasks, part);
     hipLaunchKernelGGL(k_syrk32_reduce, dim3(ntiles), dim3(256), 0, st, n, np, (const int2*)tiles, (const MxTask*)tasks, part, G, (FrameScalars*)fs);
 }
 }  // extern "C"

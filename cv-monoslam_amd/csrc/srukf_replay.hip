@@ -429,9 +429,17 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
                 // the mixed-precision downdate in the rank-aware form: the kept rows of S in permuted column order (what the stored floats hold: the permuted copy is
                 // rounded with S) and U^T with permuted columns as fp32 operands, K <= r, products on the fp32 matrix pipe, chunk sums in FP64 — only the macro tiles of the
                 // pivoted panels; the state update and the dropped diagonal (FP64, from the same operands) by k_syrk's spare workgroups with an empty tile list
-                srukf_launch_cvt_f32(c->stream, (size_t)c->mxr_krows * np, c->shadowA, c->A32);
-                srukf_launch_cvt_f32(c->stream, (size_t)d.mp * np, c->Utp, c->U32);
-                srukf_launch_syrk32(c->stream, n, np, d.mp, c->A32, c->U32, c->mxr_tasks, c->mxr_ntasks, c->mxr_tiles, c->mxr_ntiles, c->mxr_part, c->Wf, c->fs, c->mxr_krows);
+                if (c->dbg.mixed_bf16 && c->mxr_xt) {
+                    // operands as three bf16 pieces each, transposed (K contiguous per column): the products on the bf16 matrix pipe, six per fp32 product
+                    srukf_launch_split_bf3(c->stream, c->mxr_krows, np, c->mxr_ktot, 0, c->shadowA, c->mxr_xt, c->mxr_xt_stride);
+                    srukf_launch_split_bf3(c->stream, d.mp, np, c->mxr_ktot, c->mxr_krows, c->Utp, c->mxr_xt, c->mxr_xt_stride);
+                    srukf_launch_syrk_bf3(c->stream, n, np, d.mp, c->mxr_krows, c->mxr_ktot, c->mxr_xt, c->mxr_xt_stride, c->mxr_tasks, c->mxr_ntasks, c->mxr_tiles, c->mxr_ntiles,
+                                          c->mxr_part, c->Wf, c->fs);
+                } else {
+                    srukf_launch_cvt_f32(c->stream, (size_t)c->mxr_krows * np, c->shadowA, c->A32);
+                    srukf_launch_cvt_f32(c->stream, (size_t)d.mp * np, c->Utp, c->U32);
+                    srukf_launch_syrk32(c->stream, n, np, d.mp, c->A32, c->U32, c->mxr_tasks, c->mxr_ntasks, c->mxr_tiles, c->mxr_ntiles, c->mxr_part, c->Wf, c->fs, c->mxr_krows);
+                }
                 // ... and BEHIND it, in FP64 from the FP64 operands, the few tiles whose pivots an fp32-formed product cannot resolve (the robot block, the shared anchor:
                 // mxr_f64_tiles) — they overwrite what the fp32 launch left there
                 srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->mxr_f64_tiles, c->dbg.mixed_f64_robot ? c->mxr_n_f64_tiles : 0,
@@ -768,8 +776,8 @@ int mixed_red_ensure(srukf_ctx* c)
     if (!c->A32) HIPCHK(c, srukf_dmalloc(&c->A32, sizeof(float) * (size_t)np * np));
     if (c->mxr_for_r == c->red_r && c->mxr_tasks) return SRUKF_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (void* b : { (void*)c->mxr_part, c->mxr_tasks, c->mxr_tiles, (void*)c->mxr_f64_tiles }) if (b) srukf_dfree_on(b, c->stream);
-    c->mxr_part = nullptr; c->mxr_tasks = nullptr; c->mxr_tiles = nullptr; c->mxr_f64_tiles = nullptr;
+    for (void* b : { (void*)c->mxr_part, c->mxr_tasks, c->mxr_tiles, (void*)c->mxr_f64_tiles, (void*)c->mxr_xt }) if (b) srukf_dfree_on(b, c->stream);
+    c->mxr_part = nullptr; c->mxr_tasks = nullptr; c->mxr_tiles = nullptr; c->mxr_f64_tiles = nullptr; c->mxr_xt = nullptr;
     c->mxr_krows = std::min(np, srukf_mixed_krows(c->red_r));
     int ntiles = 0;
     const int ntasks = srukf_mixed_build_tasks_red(np, mp, c->mxr_krows, 64 * c->red_Tp, nullptr, nullptr, &ntiles);
@@ -781,6 +789,9 @@ int mixed_red_ensure(srukf_ctx* c)
     HIPCHK(c, hipMemcpy(c->mxr_tasks, tk.data(), sizeof(short) * tk.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->mxr_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
     c->mxr_ntasks = ntasks; c->mxr_ntiles = ntiles; c->mxr_for_r = c->red_r;
+    c->mxr_ktot = c->mxr_krows + mp; c->mxr_xt_stride = (size_t)np * c->mxr_ktot;
+    HIPCHK(c, srukf_dmalloc(&c->mxr_xt, sizeof(unsigned short) * 3 * c->mxr_xt_stride));
+    HIPCHK(c, hipMemsetAsync(c->mxr_xt, 0, sizeof(unsigned short) * 3 * c->mxr_xt_stride, c->stream));
     {
         // the FP64 tiles (32 x 32, permuted order, upper triangle, rows of the pivoted panels): tile row / column 0 (the shared anchor: permuted positions 0 .. 2) and the
         // one or two tile rows / columns of the robot block (r-4 .. r-1)

@@ -222,7 +222,7 @@ def test_g10_n800_against_oracle_frames(srukf, golden, synth, variant):
     g7_check(g, Xh, S.T @ S, 1e-9, 1e-11 * F)
 
 
-@pytest.mark.parametrize("form", ["rank_aware", "every_tile_f32", "full_rank"])
+@pytest.mark.parametrize("form", ["rank_aware", "rank_aware_bf16_pieces", "every_tile_f32", "full_rank"])
 def test_mixed_precision_downdate_n500(srukf, golden, synth, form):
     """Row g (BASELINE configs[4]: "500 landmarks fp32 SRUKF with mixed-precision sqrt(S) downdate, tolerance study") at the config's own size and at the reference's
     EPSILON = 1e-13: SRUKF_STORAGE_F32_MIXED — S^T S - U U^T over the kept rows on the fp32 matrix pipe, fp32 accumulators flushed into FP64 every 32 rows, FP64
@@ -235,6 +235,8 @@ def test_mixed_precision_downdate_n500(srukf, golden, synth, form):
     assert p["epsilon"] == 1e-13
     f = srukf.Filter(N, p); f.set_storage(srukf.STORAGE_F32_MIXED)                 # accepted at 1e-13 since round 6
     f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], matched)
+    if form == "rank_aware_bf16_pieces":                        # the same products from three bf16 pieces per operand on the bf16 matrix pipe (k_split_bf3 / k_syrk_bf3)
+        f.debug_set("mixed_bf16", 1)
     if form == "every_tile_f32":
         f.debug_set("mixed_f64_robot", 0)
     if form == "full_rank":
@@ -262,7 +264,7 @@ def test_mixed_precision_downdate_n500(srukf, golden, synth, form):
           f"max |dpose| = {dpose:.3e} m; max rel |dX| = {dX:.2e}")
     # measured (round 6), eight frames: rank_aware 7.7 / 4.1e-11 / pose 0 / 7.6e-7 (fp32 storage with FP64 arithmetic: 0.78 / 2.8e-11); every_tile_f32 1 946 / 3.5e-8 /
     # 8.2e-8 m / 3.9e-5; full_rank 3 204 / 5.5e-8 / 5.6e-8 m / 6.3e-5 — the robot block's pivots are 2e-6 .. 9e-6 of its marginal variance, which an fp32 product cannot hold
-    if form == "rank_aware":
+    if form.startswith("rank_aware"):                            # (bf16 pieces: 12.5 / 1.4e-10 / pose 0 / 5.2e-7)
         assert dpose <= 1e-8 and ratio <= 32.0 and small <= 4e-10 and dX <= 8e-6, (dpose, ratio, small, dX)
     else:
         assert dpose <= 1e-6 and ratio <= 2e4 and small <= 5e-7 and dX <= 1e-3, (dpose, ratio, small, dX)
