@@ -368,7 +368,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h /* + Si, vis */, c->PxyR, c->D,
                      c->zcur /* + mcur */, c->odocur, c->small, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->mxr_f64_tiles, c->mxr_xt, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->fold_sync, c->dxk, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->mxr_f64_tiles, c->mxr_xt, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);
@@ -410,7 +410,8 @@ static int ctx_revive(srukf_ctx* r)
     if (r->odo_seq) { srukf_dfree_on(r->odo_seq, r->stream); srukf_dfree_on(r->z_seq, r->stream); srukf_dfree_on(r->m_seq, r->stream); r->odo_seq = nullptr; r->z_seq = nullptr; r->m_seq = nullptr; }
     r->seqF = 0;
     r->storage = SRUKF_STORAGE_F64;                              // (as a fresh context: the caller sets the handle's mode; S32 / X32 / A32 stay allocated)
-    r->K_new = 0; r->dx_pending = false; r->xr1_pending = false;
+    r->K_new = 0; r->dx_pending = false; r->dx_lm = false; r->xr1_pending = false;
+    if (r->fold_sync) HIPCHK(r, hipMemsetAsync(r->fold_sync, 0, sizeof(unsigned int) * (size_t)srukf_fold_words(r->d.mp / 64, r->d.np / 64), r->stream));
     r->null_canonical = false; r->tail_ok = false;
     r->clamp_frame_host = r->clamp_row_host = -1;
     r->next_odo_valid = false; r->fs_seq_step = false; r->last_update_sequential = false;

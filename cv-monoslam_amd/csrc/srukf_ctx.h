@@ -37,7 +37,7 @@ void srukf_launch_traj(hipStream_t, KDims, const double*, const double*, FrameSc
 void srukf_launch_block_cov(hipStream_t, KDims, const double*, int, int, double*, const double*);
 void srukf_launch_project_points(hipStream_t, srukf_params, int, const double*, const double*, const double*, const double*, double*);
 void srukf_launch_pxy(hipStream_t, KDims, const double*, const double*, double*, const void*, int, KWeights, MeasArgs);
-void srukf_launch_pxy2(hipStream_t, KDims, const double*, const double*, double*, double*, const void*, int, int, KWeights, MeasArgs);
+void srukf_launch_pxy2(hipStream_t, KDims, const double*, const double*, double*, double*, const void*, int, int, KWeights, MeasArgs, GainFold);
 int srukf_pxy2_build_tiles(int mp, int np, int kr, int* out);
 int srukf_pxy2_split_groups(void);
 void srukf_launch_syrk(hipStream_t, KDims, const double*, const double*, int, int, double*, FrameScalars*, const void*, int, const double*, double*, RankArgs, const double*);
@@ -52,7 +52,7 @@ void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*,
 void srukf_launch_gmw_split_alone(hipStream_t, int, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
-void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int, const StepExport*, double);
+void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*, const double*, const int*, const int*, const double*, void*, const double*, int, double*, double*, double*, double, int, KDims, KWeights, srukf_params, double*, double*, int, const StepExport*, double, unsigned int*, int);
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
@@ -124,6 +124,10 @@ struct srukf_ctx {
     int *vis = nullptr, *mcur = nullptr;
     unsigned long long* theta = nullptr;
     bool dx_pending = false;               // k_gain left slice partials of dX that the next k_syrk must add to X
+    bool dx_lm = false;                    // ... as per-landmark shares in dxk (the gain fold of k_pxy2) instead of k_gain's slice partials in dxp
+    // gain fold (round 6: k_gain's work inside k_pxy2 in the staged replay's "fused tail" mode): its sync words (zero between frames), the per-landmark shares of the
+    // state update (N x np), how many tile workgroups read the robot columns of the permuted copy
+    unsigned int* fold_sync = nullptr; double* dxk = nullptr; int fold_robot_tiles = 0;
     bool xr1_pending = false;              // replay path: the robot mean after the motion step waits in fs->Xr1 for the same launch
     // NEED_REORDER (frames that follow a landmark addition): K_new = m_nFilters, permutation between the normal and the
     // disordered layout (getPermutationMatrix, SLAM.cpp:1303-1334), disordered factor
@@ -193,6 +197,7 @@ struct srukf_ctx {
         int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
+        int gain_fold = 0;                 // "gain_fold": the staged replay's "fused tail" frames form U^T and the state update in the tile epilogue of k_pxy2 (three launches per frame); 0: k_gain
         int mixed_rank = 1;                // "mixed_rank": SRUKF_STORAGE_F32_MIXED runs the rank-aware refactorisation (fp32-formed S^T S - U U^T over the kept rows, FP64 factorisation
                                            // of the kept pivots only); 0: round 2's full-rank form, in which the null pivots divide fp32 noise (the negative study of rounds 2 / 5)
         int mixed_null_ppm = 1;            // "mixed_null_ppm": ... and its null-direction check allows this many 1e-6 of G_aa on top of 1e-12 (an fp32-formed G cannot resolve 1e-12)
@@ -257,6 +262,7 @@ struct srukf_ctx {
     bool robot_cached = false;             // the 20 doubles behind *hfs hold P4 and the pose of the CURRENT state (fast path: fetched with the frame's status)
     bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
+    int fold_seqs = 0;                     // frame sequences enqueued (or captured) with the gain fold: "fold_seqs" (tests: the switch took effect)
     int exact_frames = 0;                  // staged frames srukf_run_frames repeated on the exact column path (flagged: theta clamp, a skipped direction that is not null, an abandoned launch): "exact_frames"
     bool async_pending = false;
     // Map changes rebuild the context behind the handle (srukf_add_landmarks / srukf_delete_landmark: adopt_context).  A rebuilt context used to be destroyed and the
@@ -377,7 +383,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
 void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
 void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow);
 int refactor_reorder(srukf_ctx* c, int ub, int ue);
-void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false);
+void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false, bool fold = false);
 void seq_gain_only(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_motion = false, bool table = false, bool fmode = false);
 void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false);
 int update_null_set(srukf_ctx* c);

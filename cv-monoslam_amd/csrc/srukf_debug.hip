@@ -46,6 +46,7 @@ static bool debug_buffer(srukf_ctx* c, const char* key, double** ptr, long long*
     else if (!strcmp(key, "Gbak")) { src = c->Gbak; n = (long long)d.np * d.np; }
     else if (!strcmp(key, "G")) { src = c->G; n = (long long)d.np * d.np; }
     else if (!strcmp(key, "D")) { src = c->D; n = d.np; }
+    else if (!strcmp(key, "fold_dbg")) { src = c->fold_sync ? (double*)(c->fold_sync + ((srukf_fold_words(d.mp / 64, d.np / 64) + 1) & ~1)) : nullptr; n = c->fold_sync ? FOLD_DBG_STAMPS : 0; }      // -DSRUKF_FOLD_DBG: time stamps of the gain fold
     else if (!strcmp(key, "gsW")) { src = c->gsW; n = c->gsW ? (long long)c->gs_panels * 64 * d.np : 0; }
     else if (!strcmp(key, "gsL")) { src = c->gsL; n = c->gsL ? (long long)c->gs_panels * 64 * d.np : 0; }
     else if (!strcmp(key, "pans")) { src = (double*)gp.pans; n = gp.pans ? (long long)srukf_gmw_panel_bytes() * gp.T / 8 : 0; }
@@ -116,6 +117,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "table_perm")) c->dbg.table_perm = value ? 1 : 0;
     else if (!strcmp(key, "f32_fuse")) c->dbg.f32_fuse = value ? 1 : 0;
     else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
+    else if (!strcmp(key, "gain_fold")) c->dbg.gain_fold = value ? 1 : 0;
     else if (!strcmp(key, "mixed_rank")) c->dbg.mixed_rank = value ? 1 : 0;
     else if (!strcmp(key, "mixed_f64_robot")) c->dbg.mixed_f64_robot = value ? 1 : 0;
     else if (!strcmp(key, "mixed_bf16")) c->dbg.mixed_bf16 = value ? 1 : 0;
@@ -184,6 +186,7 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     else if (!strcmp(key, "step_fast")) *value = c->step_fast_frames;          // frames the step-wise API ran on the staged replay's launch sequence / on its own
     else if (!strcmp(key, "step_slow")) *value = c->step_slow_frames;
     else if (!strcmp(key, "exact_frames")) *value = c->exact_frames;
+    else if (!strcmp(key, "fold_seqs")) *value = c->fold_seqs;
     else if (!strncmp(key, "pxy2_stamp", 10) && key[10] >= '1' && key[10] <= '7') { const unsigned long long* t = (const unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N); *value = (long long)(t[key[10] - '0'] - t[0]); }   // diagnostic build (-DSRUKF_PXY2_DBG): 2 motion end, 4..7 sampled tiles' ends
     else if (!strcmp(key, "meas_flag_ticks")) { const unsigned long long* t = (const unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N); *value = (long long)(t[1] - t[0]); }   // last fast-path k_pxy2: first workgroup's start -> statistics flag, 10 ns ticks
     else if (!strcmp(key, "view_hits")) *value = c->view_hits;                     // srukf_get_frame_view calls served from the view an update exported with its status

@@ -243,11 +243,22 @@ __device__ __forceinline__ void srukf_project_sigma(const srukf_params& p, doubl
 // xr1 (replay path, may be null): the robot mean after the motion step, which k_project_motion left beside X because the
 // projection threads of its launch were still reading the mean before it
 // f32: fp32 storage, "fused tail" mode: the new state is rounded to float here (what k_quantize does after the refactorisation in the other modes)
-__device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job, const double* xr1 = nullptr, int f32 = 0)
+// lmN > 0: dxp holds per-landmark shares dxk[k][row] (the gain fold of k_pxy2) instead of slice partials: summed here in exactly the order k_gain and the loop above take —
+// per slice of ceil(N / 32) landmarks four interleaved sub-slices, (s0 + s1) + (s2 + s3), then the slices in order — so that both forms give the same bits
+__device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* __restrict__ dxp, double* __restrict__ X, int job, const double* xr1 = nullptr, int f32 = 0, int lmN = 0)
 {
     const int r = job * 256 + threadIdx.x;
     if (r >= n) return;
     double acc = 0.0;
+    if (lmN > 0) {
+        const int per = (lmN + GAIN_SLICES - 1) / GAIN_SLICES;
+        for (int u = 0; u < GAIN_SLICES; u++) {
+            const int kb = u * per, cnt = min(lmN, kb + per) - kb;
+            double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int q = 0; q < cnt; q++) s[q & 3] += dxp[(size_t)(kb + q) * np + r];
+            acc += (s[0] + s[1]) + (s[2] + s[3]);
+        }
+    } else
 #pragma unroll
     for (int u = 0; u < GAIN_SLICES; u++) acc += dxp[(size_t)u * np + r];
     const double x = (xr1 && r >= n - 4) ? xr1[r - (n - 4)] : X[r];
@@ -255,6 +266,80 @@ __device__ __forceinline__ void srukf_gain_dx_job(int n, int np, const double* _
     if (f32) v = (double)(float)v;
     X[r] = v;
 }
+
+// ---- the arithmetic of KalmanUpdate's gains (SLAM.cpp:2070-2080), one function per formula ----------------------------------------------------------------------
+// k_gain forms U = Pxy Si^-1 and the state update; since round 6 the staged replay forms them in the tile epilogue of k_pxy2 instead (GainFold, srukf_factor.hip).  Both
+// must give the same bits (the step-wise API, which keeps k_gain, equals the staged replay bit for bit): every multiply-add is written out, the compiler's own
+// contraction is off, and both kernels call these.
+struct GainLm { double i00, i01, i10, i11, y0, y1; int on; };      // Si^-1 (OpenCV's closed-form 2 x 2 inverse), y = Si^-T (z - h), matched && visible
+__device__ __forceinline__ GainLm srukf_gain_lm(double s00, double s01, double s10, double s11, double z0, double z1, double h0, double h1, int on)
+{
+#pragma clang fp contract(off)
+    GainLm g;
+    double det = fma(s00, s11, -(s01 * s10));
+    g.i00 = 0.0; g.i01 = 0.0; g.i10 = 0.0; g.i11 = 0.0;
+    if (det != 0.0) { det = 1.0 / det; g.i00 = s11 * det; g.i01 = -s01 * det; g.i10 = -s10 * det; g.i11 = s00 * det; }
+    const double v0 = z0 - h0, v1 = z1 - h1;
+    g.y0 = fma(g.i10, v1, g.i00 * v0); g.y1 = fma(g.i11, v1, g.i01 * v0);
+    g.on = on;
+    return g;
+}
+// raw product of one measurement row and one state row -> Pxy entry: the two K halves of k_pxy2, the sqrt(EPSILON) DZ term of a structurally null row, the wi gamma scale
+__device__ __forceinline__ double srukf_gain_pxy(double q0, double q1, bool split, double dz, bool nullrow, double sqeps, double sc)
+{
+#pragma clang fp contract(off)
+    double q = q0;
+    if (split) q = q + q1;
+    if (nullrow) q = fma(sqeps, dz, q);
+    return sc * q;
+}
+// robot rows in "fused tail" mode: the statistics left the sums around the centre point's robot part; re-centred on the mean and on h
+__device__ __forceinline__ double srukf_gain_recentre(double p, double dxs, double s4, double hz, double rse)
+{
+#pragma clang fp contract(off)
+    return fma(-hz, rse, fma(-dxs, s4, p));
+}
+// U = Pxy Si^-1 for one state row (the landmark's two measurement rows), and the row's share of K (z - h)
+__device__ __forceinline__ void srukf_gain_apply(const GainLm& g, double p0, double p1, double& u0, double& u1, double& c)
+{
+#pragma clang fp contract(off)
+    u0 = fma(p1, g.i10, p0 * g.i00);
+    u1 = fma(p1, g.i11, p0 * g.i01);
+    c = fma(u1, g.y1, u0 * g.y0);
+}
+
+// "Gain fold" (round 6; the staged replay in "fused tail" mode): k_gain's work rides on k_pxy2.  A 64 x 64 tile of the cross covariances holds 32 whole landmarks x 64
+// state rows, and what U = Pxy Si^-1 needs besides the tile — Si, h, visible of those 32 landmarks — is exactly one landmark group of the statistics jobs of the same
+// launch: the workgroup that finishes a tile (the second of the two when its K range is cut) waits for that group's final pass and writes U^T for the tile itself; the
+// state update's per-landmark shares go to dxk[k][state row] and the job that applies the update sums them in k_gain's order (srukf_gain_dx_job); the motion workgroup
+// commits the motion step's columns once the tiles that read them are through.  One launch (7.7 us + a gap of the 182-us frame at N = 200) less.
+// sync (uints, zero between frames: the frame tail clears them): see FOLD_* below.
+struct GainFold {
+    unsigned int* sync;                                        // null: no fold (k_gain follows)
+    double* Utp; double* dxk;
+    const double* z_seq; const int* m_seq;
+    const double* DZp; const int* perm; const int* iperm; int r; int split_b0; double sqeps; double sc;
+    double* S; double* A;                                      // the motion step's columns are committed here (what k_gain did with Cm)
+    int nmt, nbt, bt_r0, bt_r1, robot_tiles;                   // tiles per column block, column blocks, the block(s) of the robot columns and how many tile workgroups read them
+};
+// Layout: the pair counters first (four words apart), then the flags that many workgroups POLL, each 4 KB from the next: ~130 waiting tile workgroups polling seven
+// words in neighbouring cache lines queued at one memory channel, and the statistics' final passes — chains of dependent device-scope round trips — queued behind
+// them (their flags moved from 17 to 23 us: scripts/fold_stamps.py)
+#define FOLD_FLAG_STRIDE 1024
+#define FOLD_PAIR(mt, bt, nbt) (4 * ((mt) * (nbt) + (bt)))
+__host__ __device__ inline int srukf_fold_flag_base(int nmt, int nbt) { return (4 * nmt * nbt + FOLD_FLAG_STRIDE - 1) / FOLD_FLAG_STRIDE * FOLD_FLAG_STRIDE; }
+#define FOLD_MOTION(nmt, nbt) (srukf_fold_flag_base(nmt, nbt))                                  // 1: the motion reduction's results are visible; 2: the run is frozen behind a flagged frame
+#define FOLD_ROBOT(nmt, nbt) (srukf_fold_flag_base(nmt, nbt) + FOLD_FLAG_STRIDE)                // tile workgroups of the robot columns' block(s) that are through
+#define FOLD_STAT(g, nmt, nbt) (srukf_fold_flag_base(nmt, nbt) + FOLD_FLAG_STRIDE * (2 + (g)))  // 1: landmark group g's h / Si / visible / PxyR are visible
+__host__ __device__ inline int srukf_fold_words(int nmt, int nbt) { return srukf_fold_flag_base(nmt, nbt) + FOLD_FLAG_STRIDE * (2 + SRUKF_STAT_GROUPS); }
+// diagnostic builds (-DSRUKF_FOLD_DBG): 8192 time stamps (s_memrealtime, 10 ns ticks) behind the sync words, which the frame tail does not clear (srukf_debug_copy "fold_dbg")
+#define FOLD_DBG_STAMPS 8192
+#ifdef SRUKF_FOLD_DBG
+#define FOLD_TS(gf, slot) do { if ((gf).sync && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    ((unsigned long long*)((gf).sync + ((srukf_fold_words((gf).nmt, (gf).nbt) + 1) & ~1)))[slot] = t_; } } while (0)
+#else
+#define FOLD_TS(gf, slot) do { } while (0)
+#endif
 
 // measurement-statistics work attached to a k_pxy launch (replay path): Z == null -> none
 // "Table" mode of the rank-aware replay: a structurally null row of S (sqrt(EPSILON) e_i, nothing in the robot columns) moves ONE landmark

@@ -19,7 +19,8 @@
 // A statistics job that rides on a contraction launch has stored its partial sums: the LAST of the MEAS_SLICES jobs of a landmark
 // group (device-scope counter per group) runs that group's final pass with its whole workgroup.  (One last workgroup for all
 // landmarks, 208 dependent loads per thread, was an 8 us tail on the launch's critical path.)
-__device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w, const MeasArgs& ms, int bx, double* shm)
+// fold_flag (may be null): the gain fold of k_pxy2 — the group's h / Si / visible / PxyR are made visible device-wide and the word is raised behind them
+__device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w, const MeasArgs& ms, int bx, double* shm, unsigned int* fold_flag = nullptr)
 {
     __shared__ int last;
     // what the final pass will want from memory besides the partial sums — rows 0, 1, 2 of Z at the group's columns — is requested by EVERY job before it counts itself:
@@ -46,8 +47,12 @@ __device__ __forceinline__ void meas_job_done(const KDims& d, const KWeights& w,
     if (!last) return;
     PXY2_TS(5);
     MeasOut mo;
-    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode, &pre, &mo);      // (always handed over: a conditional pointer keeps the struct in scratch)
+    meas_final_group(d, w, ms.sigR, ms.Z, ms.part, ms.h, ms.Si, ms.vis, ms.PxyR, bx, shm, ms.fmode, &pre, &mo, fold_flag ? 1 : 0);      // (always handed over: a conditional pointer keeps the struct in scratch)
     PXY2_TS(3);
+    if (fold_flag && threadIdx.x < 64) {                       // (the 32 lanes that stored the group's results — write-through — are in wave 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(fold_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (!ms.hmirror) return;
     // step-wise API: the 32 lanes that stored this group's h / Si / visible (one wave) repeat them into the host's pinned buffer; the group that completes the count raises
     // the flag.  A wave's fence covers all its lanes' stores, and every group fences at system scope BEFORE it counts.
@@ -135,8 +140,103 @@ __global__ __launch_bounds__(256) void k_pxy(KDims d, const double* __restrict__
 // scripts/mb/mb_mfma_f64.hip; the four-wave form of this kernel took 20.6 us for its 8.5 us of MFMA).  Waves w and w + 4 share a
 // 32 x 32 sub-tile and take k-steps 0-1 / 2-3 of every group; the upper four hand their accumulators over through LDS at the end.
 // (the body takes the workgroup's index explicitly: k_pxy2 passes blockIdx.x, the batched launch k_pxy2_b the index within its filter's share of the grid)
+// bounded wait of the gain fold (a whole wave polls under a wave-uniform condition): the word becomes non-zero / reaches `want`
+__device__ __forceinline__ unsigned fold_wait(const unsigned int* p, unsigned want)
+{
+    unsigned v = 0;
+    for (int spins = 0; spins < (1 << 15); spins++) {
+        v = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= want) break;
+        __builtin_amdgcn_s_sleep(12);                          // (~0.3 us between polls: one poll per 27 ns from each of ~130 waiting workgroups slowed what they were waiting for)
+    }
+    return v;
+}
+// The gain of one finished tile (mt, bt), by the workgroup that finished it, from the tile's values IN ITS REGISTERS (v: this workgroup's K half, or the whole range;
+// other: the other half, read back by the caller): U^T for 32 landmarks x 64 permuted columns (the block's robot columns from the statistics' robot rows), the landmarks'
+// shares of the state update.  Waves 0 .. 3 of the tile's workgroup; a lane holds 16 (measurement row, column) elements: row m0 + mo + 16 a + lk + 4 t, column
+// b0 + bo + 16 b + lr — the two rows of a landmark sit in lanes l and l ^ 16.  sm: >= 32 * 8 doubles + 32 ints of LDS.
+// (First form, measured with time stamps (scripts/fold_stamps.py): every pair's products written through and read back by the job — the reads' traffic reached the
+//  memory side exactly when the statistics' final passes, chains of dependent round trips, ran: their flags moved from 17 to 19 - 21 us and the launch got longer.)
+__device__ __forceinline__ void pxy2_gain_job(const KDims& d, const MeasArgs& ms, const GainFold& gf, const d4 (&v)[2][2], const d4 (&other)[2][2], const bool split, const int half,
+                                              const int mt, const int bt, const int mo, const int bo, double* sm)
+{
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4, N = d.N, np = d.np, mp = d.mp, n = d.n;
+    double (*glm)[8] = (double (*)[8])sm;
+    int* gon = (int*)(sm + 32 * 8);
+    __shared__ unsigned fold_state[2];
+    const bool robot_blk = bt == gf.bt_r0 || bt == gf.bt_r1;
+    // what does not depend on the statistics is requested BEFORE the wait for them: the columns' state rows, this frame's measurements, a null row's DZ term
+    int rpc[2], rc[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) { rpc[b] = 64 * bt + bo + 16 * b + lr; rc[b] = gf.perm[rpc[b]]; }
+    const int frame = ms.fs->frame;
+    double zk0 = 0.0, zk1 = 0.0; int mk = 0;
+    if (tid < 32 && 32 * mt + tid < N) {
+        const int k = 32 * mt + tid;
+        const double* z = gf.z_seq + (size_t)frame * 2 * N;
+        zk0 = z[2 * k]; zk1 = z[2 * k + 1]; mk = gf.m_seq[(size_t)frame * N + k];
+    }
+    if (tid < 64) {                                            // wave 0 polls
+        const unsigned st = fold_wait(gf.sync + FOLD_STAT(mt, gf.nmt, gf.nbt), 1u);
+        const unsigned mq = robot_blk ? fold_wait(gf.sync + FOLD_MOTION(gf.nmt, gf.nbt), 1u) : 1u;
+        if (tid == 0) { fold_state[0] = st; fold_state[1] = mq; }
+    }
+    __syncthreads();
+    if (fold_state[0] == 0 || fold_state[1] != 1) {            // a wait expired (flag the frame) or the run is frozen behind a flagged frame (nothing to compute from)
+        if (tid == 0 && (fold_state[0] == 0 || fold_state[1] == 0)) { atomicAdd(&ms.fs->clamp_rows, 1); atomicMin(&ms.fs->clamp_first, 0); }
+        return;
+    }
+    if (tid < 64) FOLD_TS(gf, 512 + 4 * (mt * gf.nbt + bt) + 2);                                    // [2]: the waits are over
+    if (tid < 32) {
+        const int k = 32 * mt + tid;
+        GainLm g = { 0, 0, 0, 0, 0, 0, 0 };
+        if (k < N) {
+            const int on = (mk != 0) && (__hip_atomic_load(&ms.vis[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+            g = srukf_gain_lm(ld_dev(&ms.Si[4 * k]), ld_dev(&ms.Si[4 * k + 1]), ld_dev(&ms.Si[4 * k + 2]), ld_dev(&ms.Si[4 * k + 3]), zk0, zk1,
+                              ld_dev(&ms.h[2 * k]), ld_dev(&ms.h[2 * k + 1]), on ? 1 : 0);
+        }
+        glm[tid][0] = g.i00; glm[tid][1] = g.i01; glm[tid][2] = g.i10; glm[tid][3] = g.i11; glm[tid][4] = g.y0; glm[tid][5] = g.y1;
+        gon[tid] = g.on;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int rp = rpc[b], r = rc[b];
+        const int e = rp - (gf.r - 4);                         // 0 .. 3: a robot column
+        const bool robot = e >= 0 && e < 4 && r < n;
+        double dxs = 0.0, rse = 0.0;
+        if (robot) { dxs = ld_dev(&ms.fs->Xr1[e]) - ms.sigR[e]; rse = ld_dev(&ms.sigR[(size_t)d.L * 8 + e]); }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int ml = mo + 16 * a + lk + 4 * t, m = 64 * mt + ml, kl = ml >> 1, k = 32 * mt + kl;       // measurement row (local / global), landmark (local / global)
+                // this lane's row of Pxy
+                double pown;
+                if (robot) pown = (k < N) ? srukf_gain_recentre(ld_dev(&ms.PxyR[(size_t)e * mp + m]), dxs, ld_dev(&ms.PxyR[(size_t)4 * mp + m]), ld_dev(&ms.h[m]) - ms.Z[m], rse) : 0.0;
+                else {
+                    const bool nullrow = rp >= gf.r && r < n && k == r / 6;
+                    const double h0v = half == 0 ? v[a][b][t] : other[a][b][t], h1v = half == 0 ? other[a][b][t] : v[a][b][t];
+                    pown = srukf_gain_pxy(h0v, h1v, split, nullrow ? gf.DZp[(size_t)rp * mp + m] : 0.0, nullrow, gf.sqeps, gf.sc);
+                }
+                const double ppar = __shfl_xor(pown, 16);      // the landmark's other row (rows 2 k, 2 k + 1: lanes l, l ^ 16)
+                const bool odd = (ml & 1) != 0;
+                double u0 = 0.0, u1 = 0.0, cq = 0.0;
+                if (k < N && gon[kl] && r < n) {
+                    const GainLm g = { glm[kl][0], glm[kl][1], glm[kl][2], glm[kl][3], glm[kl][4], glm[kl][5], 1 };
+                    srukf_gain_apply(g, odd ? ppar : pown, odd ? pown : ppar, u0, u1, cq);
+                }
+                if (k < N) {
+                    gf.Utp[(size_t)m * np + rp] = odd ? u1 : u0;
+                    if (!odd && r < n) gf.dxk[(size_t)k * np + r] = cq;
+                }
+            }
+    }
+}
+
+template <bool FOLD>
 __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
-                                          const int4* __restrict__ tiles, int ntiles, int kr, const KWeights& w, const MeasArgs& ms, const int bid)
+                                          const int4* __restrict__ tiles, int ntiles, int kr, const KWeights& w, const MeasArgs& ms, const int bid, const GainFold& gf)
 {
     __shared__ double shm[2 * 2 * 16 * PXY2_LS];               // [buf][A|B][k][PXY2_LS]; >= MEAS_SM_DOUBLES (statistics scratch), >= 4 x 64 x 17 (hand-over)
     static_assert(2 * 2 * 16 * PXY2_LS >= MEAS_SM_DOUBLES && 2 * 2 * 16 * PXY2_LS >= 4 * 64 * 17, "scratch");
@@ -147,7 +247,61 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
         if (ms.hstamp && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[0] = t_; }
         if (threadIdx.x >= 256) return;
         const RankArgs ra0 = {};
+        if (FOLD && threadIdx.x == 0) { ms.fs->gmax_bits = 0ull; ms.fs->ximax_bits = 0ull; }      // (what k_gain's first workgroup does for the refactorisation that follows)
+        if (threadIdx.x < 64) FOLD_TS(gf, 0);
         motion_reduce_body<256, false>(d, w, const_cast<double*>(ms.X), nullptr, const_cast<double*>(ms.sigR), ms.Cm, ms.fs, ra0, shm);
+        if (threadIdx.x < 64) FOLD_TS(gf, 1);
+        if (FOLD) {
+            // gain fold: the reduction's results (Cm, fs->Xr1, the rs row of the table) become visible to the tile workgroups' gain jobs, then — once every tile that
+            // reads the robot columns of the permuted copy is through — the motion step's columns are committed (k_gain's first duty)
+            __syncthreads();
+            if (threadIdx.x < 4) {                             // (all that other workgroups read of the reduction: the mean and the rs row; write-through, no fence)
+                st_dev(&ms.fs->Xr1[threadIdx.x], ms.fs->Xr1[threadIdx.x]);
+                double* rs = const_cast<double*>(ms.sigR) + (size_t)d.L * 8 + threadIdx.x;
+                st_dev(rs, *rs);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // the commit's operands are requested now, its stores wait for the tiles that still read the robot columns
+            double4 cv[5]; int ca[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int r = threadIdx.x + 256 * i;
+                cv[i] = make_double4(0, 0, 0, 0); ca[i] = 0;
+                if (r < d.n) { cv[i] = *reinterpret_cast<const double4*>(ms.Cm + (size_t)r * 4); ca[i] = (r < d.n - 4) ? gf.iperm[r] : gf.r - 4 + (r - (d.n - 4)); }
+            }
+            __syncthreads();
+            __shared__ unsigned mo_state;
+            if (threadIdx.x < 64) {
+                const int fz = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ms.fs->frozen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (threadIdx.x == 0) __hip_atomic_store(gf.sync + FOLD_MOTION(gf.nmt, gf.nbt), fz ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                FOLD_TS(gf, 2);
+                const unsigned got = fz ? 0u : fold_wait(gf.sync + FOLD_ROBOT(gf.nmt, gf.nbt), (unsigned)gf.robot_tiles);
+                FOLD_TS(gf, 3);
+                if (threadIdx.x == 0) mo_state = fz ? 2u : (got >= (unsigned)gf.robot_tiles ? 1u : 0u);
+            }
+            __syncthreads();
+            if (mo_state == 0 && threadIdx.x == 0) { atomicAdd(&ms.fs->clamp_rows, 1); atomicMin(&ms.fs->clamp_first, 0); }
+            if (mo_state == 1) {
+                const int n = d.n, ld = d.np;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int r = threadIdx.x + 256 * i;
+                    if (r >= n) continue;
+                    const double4 v = cv[i];
+                    *reinterpret_cast<double2*>(gf.S + (size_t)r * ld + (n - 4)) = make_double2(v.x, v.y);
+                    *reinterpret_cast<double2*>(gf.S + (size_t)r * ld + (n - 2)) = make_double2(v.z, v.w);
+                    if (ca[i] < gf.r) { double* o = gf.A + (size_t)ca[i] * ld + (gf.r - 4); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+                }
+                for (int r = threadIdx.x + 256 * 5; r < n; r += 256) {          // (n > 1280: the rows beyond the prefetched ones)
+                    const double4 v = *reinterpret_cast<const double4*>(ms.Cm + (size_t)r * 4);
+                    *reinterpret_cast<double2*>(gf.S + (size_t)r * ld + (n - 4)) = make_double2(v.x, v.y);
+                    *reinterpret_cast<double2*>(gf.S + (size_t)r * ld + (n - 2)) = make_double2(v.z, v.w);
+                    const int arow = (r < n - 4) ? gf.iperm[r] : gf.r - 4 + (r - (n - 4));
+                    if (arow < gf.r) { double* o = gf.A + (size_t)arow * ld + (gf.r - 4); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+                }
+            }
+            if (threadIdx.x < 64) FOLD_TS(gf, 4);
+        }
 #ifdef SRUKF_PXY2_DBG
         if (ms.hstamp && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ms.hstamp[2] = t_; }
 #endif
@@ -165,7 +319,11 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
 #endif
         const int job = bid - stat0;               // the statistics jobs are written for 256 threads: the upper half of the workgroup leaves (no barrier waits for it: s_barrier counts the waves still alive)
         meas_partial_job<true>(d, w, ms.xrob, ms.sigR, ms.Z, ms.part, job % ms.gx, job / ms.gx, shm, ms.ns);
-        meas_job_done(d, w, ms, job % ms.gx, shm);
+        if (threadIdx.x < 64 && job / ms.gx == 0) FOLD_TS(gf, 16 + 4 * (job % ms.gx));
+        meas_job_done(d, w, ms, job % ms.gx, shm, FOLD ? gf.sync + FOLD_STAT(job % ms.gx, gf.nmt, gf.nbt) : nullptr);
+#ifdef SRUKF_FOLD_DBG
+        if (FOLD && threadIdx.x < 64 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gf.sync + FOLD_STAT(job % ms.gx, gf.nmt, gf.nbt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) FOLD_TS(gf, 17 + 4 * (job % ms.gx));
+#endif
         return;
     }
     if (bid - tile0 >= ntiles) return;                         // (padding of the batched grid)
@@ -233,13 +391,54 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
     __syncthreads();
     if (wv >= 4) return;
     double* P = (tl.w == 2 && tl.z == 1) ? P1 : P0;
+    d4 vfin[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                P[(size_t)(m0 + mo + 16 * a + lk + 4 * t) * d.np + b0 + bo + 16 * b + lr] = acc[a][b][t] + ho[wv][lane][(a * 2 + b) * 4 + t];
+            for (int t = 0; t < 4; t++) vfin[a][b][t] = acc[a][b][t] + ho[wv][lane][(a * 2 + b) * 4 + t];
+    if (!FOLD || tl.w == 2) {
+        // (gain fold: only a K half is written — through, for the workgroup that finishes the pair; a tile whose K range is not cut never leaves the registers)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    double* pp = &P[(size_t)(m0 + mo + 16 * a + lk + 4 * t) * d.np + b0 + bo + 16 * b + lr];
+                    if (FOLD) st_dev(pp, vfin[a][b][t]); else *pp = vfin[a][b][t];
+                }
+    }
+    if (FOLD) {
+        // gain fold: count the tile (and, for the block(s) of the robot columns, tell the motion workgroup that one reader fewer is left); the workgroup that completes the
+        // pair of K halves writes U^T for the tile
+        __shared__ int fold_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // (waves 4 .. 7 have left: the barrier counts the waves still alive)
+        if (tid == 0) {
+            if (tl.y == gf.bt_r0 || tl.y == gf.bt_r1) __hip_atomic_fetch_add(gf.sync + FOLD_ROBOT(gf.nmt, gf.nbt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned old = __hip_atomic_fetch_add(gf.sync + FOLD_PAIR(tl.x, tl.y, gf.nbt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fold_last = (int)old == tl.w - 1;
+        }
+        __syncthreads();
+        if (tid < 64) FOLD_TS(gf, 512 + 4 * (tl.x * gf.nbt + tl.y) + (fold_last ? 1 : 0));       // [0]: the first half's end (or nothing), [1]: the pair complete
+        if (fold_last) {
+            d4 oth[2][2];
+            zero_acc(oth);
+            if (tl.w == 2) {                                   // the other half, as the workgroup that finished first wrote it
+                const double* Po = (tl.z == 1) ? P0 : P1;
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++) oth[a][b][t] = ld_dev(&Po[(size_t)(m0 + mo + 16 * a + lk + 4 * t) * d.np + b0 + bo + 16 * b + lr]);
+            }
+            pxy2_gain_job(d, ms, gf, vfin, oth, tl.w == 2, tl.w == 2 ? tl.z : 0, tl.x, tl.y, mo, bo, shm);
+            if (tid < 64) FOLD_TS(gf, 512 + 4 * (tl.x * gf.nbt + tl.y) + 3);
+        }
+    }
 #ifdef SRUKF_PXY2_DBG
     if (ms.hstamp && threadIdx.x == 0) {
         const int ti = bid - tile0;
@@ -253,7 +452,13 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pxy2(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
                                               const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
 {
-    pxy2_body(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x);
+    pxy2_body<false>(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x, GainFold{});
+}
+// the same with the gain fold compiled in (the "gain_fold" switch, off by default: DESIGN.md 10 — the fold's code in the plain kernel cost it 4 us, so it is a kernel of its own)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pxy2_fold(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
+                                              const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms, GainFold gf)
+{
+    pxy2_body<true>(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x, gf);
 }
 // Batched form (srukf_run_frames_batch, B filters of one shape in ONE launch per stage): filter f owns workgroups [f per, (f + 1) per) — per is a multiple of 8, so
 // the XCD-aware tile list keeps its meaning — and takes its pointers from tab[f] (device memory: one scalar load round trip at the head of the launch).
@@ -261,7 +466,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 {
     const int f = (int)blockIdx.x / per, bid = (int)blockIdx.x - f * per;
     const Pxy2Args a = tab[f];
-    pxy2_body(d, a.DZp, a.A, a.P0, a.P1, tiles, ntiles, kr, w, a.ms, bid);
+    pxy2_body<false>(d, a.DZp, a.A, a.P0, a.P1, tiles, ntiles, kr, w, a.ms, bid, GainFold{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,7 +488,7 @@ __device__ __forceinline__ void syrk_body(const KDims& d, const double* __restri
     if (bid >= ntiles + ndx) { srukf_rank_gdiag_job(d.n, d.np, ue, ra, &fs->gmax_bits, bid - ntiles - ndx); return; }
     if (bid >= ntiles) {
         if (ra.prep_next && bid == ntiles && threadIdx.x == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
-        srukf_gain_dx_job(d.n, d.np, dxp, X, bid - ntiles, xr1, ra.f32round);
+        srukf_gain_dx_job(d.n, d.np, dxp, X, bid - ntiles, xr1, ra.f32round, ra.dxN);
         return;
     }
     __shared__ double red[3][64][17];
@@ -822,10 +1027,12 @@ void srukf_launch_pxy(hipStream_t st, KDims d, const double* DZ, const double* S
     const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
     hipLaunchKernelGGL(k_pxy, dim3(ntiles + extra), dim3(256), 0, st, d, DZ, S, Ut, (const int2*)tiles, ntiles, w, ms);
 }
-void srukf_launch_pxy2(hipStream_t st, KDims d, const double* DZp, const double* A, double* P0, double* P1, const void* tiles, int ntiles, int kr, KWeights w, MeasArgs ms)
+void srukf_launch_pxy2(hipStream_t st, KDims d, const double* DZp, const double* A, double* P0, double* P1, const void* tiles, int ntiles, int kr, KWeights w, MeasArgs ms, GainFold gf)
 {
     const int extra = ms.Z ? MEAS_SLICES * ms.gx : 0;
-    hipLaunchKernelGGL(k_pxy2, dim3(ntiles + extra + (ms.fmode ? 1 : 0)), dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms);
+    const dim3 grid(ntiles + extra + (ms.fmode ? 1 : 0));
+    if (gf.sync) hipLaunchKernelGGL(k_pxy2_fold, grid, dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms, gf);
+    else hipLaunchKernelGGL(k_pxy2, grid, dim3(512), 0, st, d, DZp, A, P0, P1, (const int4*)tiles, ntiles, kr, w, ms);
 }
 // host-side tile list of k_pxy2 (4 ints per workgroup: mt, bt, half, halves; mt < 0: empty slot).  K ranges of at least PXY2_SPLIT
 // groups are cut in two.  XCD-aware: workgroup w runs on XCD w % 8 (round-robin dispatch; the statistics jobs in front of the

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void k_gmw_persist(int n, int ld, int T, int T
         } else if (job < ha.ntiles + ha.ndx) {
             const int dj = job - ha.ntiles;
             if (ha.ra.prep_next && dj == 0 && tid == 255) fs->ctl_next_valid = srukf_prepare_control(fs, fs->frame + 1) ? 1 : 0;
-            srukf_gain_dx_job(n, ld, ha.dxp, ha.X, dj, ha.xr1, ha.ra.f32round);
+            srukf_gain_dx_job(n, ld, ha.dxp, ha.X, dj, ha.xr1, ha.ra.f32round, ha.ra.dxN);
         } else if (job < nhead) srukf_rank_gdiag_job(n, ld, u1, ha.ra, &fs->gmax_bits, job - ha.ntiles - ha.ndx);
         if ((int)blockIdx.x == nmain) GMW_TS(sy, 131, 1);
         if ((int)blockIdx.x == (int)gridDim.x - 1) GMW_TS(sy, 131, 2);

@@ -141,7 +141,7 @@ struct MeasOut { double h[2]; double si[4]; int vis; };
 __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                 const double* __restrict__ Z, const double (&t)[MEAS_NS],
                                                 double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                double* __restrict__ PxyR, int k, int defer = 0, const MeasPre* pre = nullptr, MeasOut* out = nullptr);
+                                                double* __restrict__ PxyR, int k, int defer = 0, const MeasPre* pre = nullptr, MeasOut* out = nullptr, int devst = 0);
 // landmark k: reduce the slices, finish h, Si, visible, PxyR
 template <bool COHERENT>
 __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w, const double* __restrict__ X, const double* __restrict__ sigR,
@@ -165,7 +165,7 @@ __device__ __forceinline__ void meas_final_one(const KDims& d, const KWeights& w
 __device__ __forceinline__ void meas_final_group(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                  const double* __restrict__ Z, const double* __restrict__ part,
                                                  double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                 double* __restrict__ PxyR, int bx, double* smem, int defer = 0, const MeasPre* pre = nullptr, MeasOut* out = nullptr)
+                                                 double* __restrict__ PxyR, int bx, double* smem, int defer = 0, const MeasPre* pre = nullptr, MeasOut* out = nullptr, int devst = 0)
 {
     double (*sm)[32][MEAS_NS] = (double (*)[32][MEAS_NS])smem;
     const int lx = threadIdx.x & 31, pr = threadIdx.x >> 5;
@@ -193,15 +193,18 @@ __device__ __forceinline__ void meas_final_group(const KDims& d, const KWeights&
             for (int u = 0; u < 8; u++) acc += sm[u][lx][q];
             t[q] = acc;
         }
-        meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k, defer, pre, out);
+        meas_final_tail(d, w, sigR, Z, t, h, Si, vis, PxyR, k, defer, pre, out, devst);
     }
 }
 __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& w, const double* __restrict__ sigR,
                                                 const double* __restrict__ Z, const double (&t)[MEAS_NS],
                                                 double* __restrict__ h, double* __restrict__ Si, int* __restrict__ vis,
-                                                double* __restrict__ PxyR, int k, int defer, const MeasPre* pre, MeasOut* out)
+                                                double* __restrict__ PxyR, int k, int defer, const MeasPre* pre, MeasOut* out, int devst)
 {
 #pragma clang fp contract(off)
+    // devst (the gain fold of k_pxy2): the results are read by other workgroups of the SAME launch — write-through stores (a release fence instead would write the whole
+    // L2 back: 2 us on the launch's longest chain)
+    auto stv = [&](double* q, double v) { if (devst) st_dev(q, v); else *q = v; };
     // (every fused multiply-add written out, contraction off: this function is compiled into three kernels — k_meas_final, k_pxy, k_pxy2 — and which of two
     //  products the compiler fuses depends on the code around an inlined call; the step-wise API and the replay must give the same bits)
     const int mp = d.mp;
@@ -211,16 +214,16 @@ __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& 
     const double hx = fma(wsum, z0.x, w.wi * t[0]), hy = fma(wsum, z0.y, w.wi * t[1]);
     // robot rows of Pxy: sum_c w_c (r_c - xr)(Z_c - h) = sum_c w_c (r_c - xr)(Z_c - Z0) - (h - Z0) * sum_c w_c (r_c - xr)
     const bool v = (hx != 0.0) && (hy != 0.0);
-    h[2 * k] = hx; h[2 * k + 1] = hy;
-    vis[k] = v ? 1 : 0;
+    stv(&h[2 * k], hx); stv(&h[2 * k + 1], hy);
+    if (devst) __hip_atomic_store(&vis[k], v ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else vis[k] = v ? 1 : 0;
     if (defer) {
         // "fused tail" mode: the motion reduction of this frame runs in the same launch, so neither the mean xr nor rs exist yet.  The sums were
         // taken around the centre point's robot part r_0 instead of xr; with sum_c w_c (Z_c - Z_0) = wi t[0..1] (the centre's own term is zero)
         //     sum_c w_c (r_c - xr)(Z_c - Z_0) = sum_c w_c (r_c - r_0)(Z_c - Z_0) - (xr - r_0) wi t[0..1]
         // and k_gain applies that and the (h - Z_0) rs term: raw sums here, wi t[0..1] in row 4
 #pragma unroll
-        for (int e = 0; e < 4; e++) { PxyR[(size_t)e * mp + 2 * k] = t[5 + e]; PxyR[(size_t)e * mp + 2 * k + 1] = t[9 + e]; }
-        PxyR[(size_t)4 * mp + 2 * k] = w.wi * t[0]; PxyR[(size_t)4 * mp + 2 * k + 1] = w.wi * t[1];
+        for (int e = 0; e < 4; e++) { stv(&PxyR[(size_t)e * mp + 2 * k], t[5 + e]); stv(&PxyR[(size_t)e * mp + 2 * k + 1], t[9 + e]); }
+        stv(&PxyR[(size_t)4 * mp + 2 * k], w.wi * t[0]); stv(&PxyR[(size_t)4 * mp + 2 * k + 1], w.wi * t[1]);
     } else {
         double rs[4];
 #pragma unroll
@@ -254,7 +257,7 @@ __device__ __forceinline__ void meas_final_tail(const KDims& d, const KWeights& 
     const double rest2 = fma(-bp1, bp1, nrm2);
     double R11 = bp1;
     if (rest2 > 0.0) R11 = -(bp1 >= 0.0 ? 1.0 : -1.0) * sqrt(nrm2);
-    Si[4 * k + 0] = v ? R00 : 0.0; Si[4 * k + 1] = v ? R01 : 0.0; Si[4 * k + 2] = 0.0; Si[4 * k + 3] = v ? R11 : 0.0;
+    stv(&Si[4 * k + 0], v ? R00 : 0.0); stv(&Si[4 * k + 1], v ? R01 : 0.0); stv(&Si[4 * k + 2], 0.0); stv(&Si[4 * k + 3], v ? R11 : 0.0);
     if (out) { out->h[0] = hx; out->h[1] = hy; out->si[0] = v ? R00 : 0.0; out->si[1] = v ? R01 : 0.0; out->si[2] = 0.0; out->si[3] = v ? R11 : 0.0; out->vis = v ? 1 : 0; }
 }
 

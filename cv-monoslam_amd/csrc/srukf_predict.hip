@@ -476,13 +476,9 @@ __device__ __forceinline__ void gain_body(const KDims& d, const KWeights& w,
         if ((int)threadIdx.x < cnt) {
             const int k = k0 + threadIdx.x;
             const bool on = (mt[k] != 0) && (vis[k] != 0);
-            const double s00 = Si[4 * k], s01 = Si[4 * k + 1], s10 = Si[4 * k + 2], s11 = Si[4 * k + 3];
-            double det = s00 * s11 - s01 * s10;
-            double i00 = 0, i01 = 0, i10 = 0, i11 = 0;
-            if (det != 0.0) { det = 1.0 / det; i00 = s11 * det; i01 = -s01 * det; i10 = -s10 * det; i11 = s00 * det; }
-            const double v0 = z[2 * k] - h[2 * k], v1 = z[2 * k + 1] - h[2 * k + 1];
-            lk[threadIdx.x][0] = i00; lk[threadIdx.x][1] = i01; lk[threadIdx.x][2] = i10; lk[threadIdx.x][3] = i11;
-            lk[threadIdx.x][4] = i00 * v0 + i10 * v1; lk[threadIdx.x][5] = i01 * v0 + i11 * v1;
+            const GainLm g = srukf_gain_lm(Si[4 * k], Si[4 * k + 1], Si[4 * k + 2], Si[4 * k + 3], z[2 * k], z[2 * k + 1], h[2 * k], h[2 * k + 1], on ? 1 : 0);
+            lk[threadIdx.x][0] = g.i00; lk[threadIdx.x][1] = g.i01; lk[threadIdx.x][2] = g.i10; lk[threadIdx.x][3] = g.i11;
+            lk[threadIdx.x][4] = g.y0; lk[threadIdx.x][5] = g.y1;
             lon[threadIdx.x] = on ? 1 : 0;
         }
         __syncthreads();
@@ -494,11 +490,10 @@ __device__ __forceinline__ void gain_body(const KDims& d, const KWeights& w,
                 if (r < n - 4 && P1) {
                     // "table" mode: the raw product arrives in permuted columns (k_pxy2): first K half in Utp, second in P1 where the
                     // range was cut; a structurally null row of S contributes sqrt(EPSILON) DZ[r] to its own column only
-                    double q0 = ra.Utp[(size_t)(2 * k) * ld + rp], q1 = ra.Utp[(size_t)(2 * k + 1) * ld + rp];
-                    if (rp >= split_b0) { q0 += P1[(size_t)(2 * k) * ld + rp]; q1 += P1[(size_t)(2 * k + 1) * ld + rp]; }
+                    const bool split = rp >= split_b0, nullrow = rp >= ra.r && k == r / 6;
                     // (its DZ row is zero outside its own landmark r / 6 — exactly, see NullSkip — and may not even be written there)
-                    if (rp >= ra.r && k == r / 6) { q0 += sqeps * DZp[(size_t)rp * mp + 2 * k]; q1 += sqeps * DZp[(size_t)rp * mp + 2 * k + 1]; }
-                    p0 = sc * q0; p1 = sc * q1;
+                    p0 = srukf_gain_pxy(ra.Utp[(size_t)(2 * k) * ld + rp], split ? P1[(size_t)(2 * k) * ld + rp] : 0.0, split, nullrow ? DZp[(size_t)rp * mp + 2 * k] : 0.0, nullrow, sqeps, sc);
+                    p1 = srukf_gain_pxy(ra.Utp[(size_t)(2 * k + 1) * ld + rp], split ? P1[(size_t)(2 * k + 1) * ld + rp] : 0.0, split, nullrow ? DZp[(size_t)rp * mp + 2 * k + 1] : 0.0, nullrow, sqeps, sc);
                 } else if (r < n - 4) {
                     p0 = sc * Ut[(size_t)(2 * k) * ld + r];
                     p1 = sc * Ut[(size_t)(2 * k + 1) * ld + r];
@@ -510,13 +505,14 @@ __device__ __forceinline__ void gain_body(const KDims& d, const KWeights& w,
                         // "fused tail" mode: the statistics left the sums around the centre point's robot part r_0 (srukf_meas.h, meas_final_tail); the frame's
                         // motion reduction has run since: re-centre on the mean xr and on h
                         const double dxs = fs->Xr1[e] - sigR[e], rse = sigR[(size_t)d.L * 8 + e];
-                        p0 = p0 - dxs * PxyR[(size_t)4 * mp + 2 * k] - (h[2 * k] - Z0[2 * k]) * rse;
-                        p1 = p1 - dxs * PxyR[(size_t)4 * mp + 2 * k + 1] - (h[2 * k + 1] - Z0[2 * k + 1]) * rse;
+                        p0 = srukf_gain_recentre(p0, dxs, PxyR[(size_t)4 * mp + 2 * k], h[2 * k] - Z0[2 * k], rse);
+                        p1 = srukf_gain_recentre(p1, dxs, PxyR[(size_t)4 * mp + 2 * k + 1], h[2 * k + 1] - Z0[2 * k + 1], rse);
                     }
                 }
-                u0 = p0 * lk[q][0] + p1 * lk[q][2];
-                u1 = p0 * lk[q][1] + p1 * lk[q][3];
-                dx += u0 * lk[q][4] + u1 * lk[q][5];
+                const GainLm g = { lk[q][0], lk[q][1], lk[q][2], lk[q][3], lk[q][4], lk[q][5], 1 };
+                double cq;
+                srukf_gain_apply(g, p0, p1, u0, u1, cq);
+                dx += cq;
             }
             if (!P1) {                                         // ("table" mode consumes U^T in permuted columns only)
                 Ut[(size_t)(2 * k) * ld + r] = u0;

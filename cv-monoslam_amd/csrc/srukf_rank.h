@@ -16,6 +16,7 @@ struct RankArgs {
                            // the rounding points of k_quantize, without its launch)
     int prep_next;         // "table" mode of the replay: the k_syrk launch also prepares the NEXT frame's control in fs->ctl (this frame's motion
                            // step has consumed it; the tail that needs it must not read the frame counter it advances itself)
+    int dxN;               // > 0: the pending state update arrives as per-landmark shares dxk[k][row] of dxN landmarks (the gain fold of k_pxy2) instead of slice partials
 };
 
 // per-filter arguments of the batched launches that carry RankArgs / MeasArgs (srukf_run_frames_batch; tables in device memory)

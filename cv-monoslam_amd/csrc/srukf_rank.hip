@@ -72,7 +72,8 @@ __device__ __forceinline__ void rank_expand_body(int n, int ld, int r, double ep
                                                  FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
                                                  double* __restrict__ A, double* __restrict__ sigR, double gamma,
                                                  const KDims& d, const KWeights& w,
-                                                 const srukf_params& p, double* __restrict__ Z, double* __restrict__ DZ, int f32, const int bid, const StepExport& ex, const double null_rel = 0.0)
+                                                 const srukf_params& p, double* __restrict__ Z, double* __restrict__ DZ, int f32, const int bid, const StepExport& ex, const double null_rel = 0.0,
+                                                 unsigned int* __restrict__ fold_sync = nullptr, const int fold_words = 0)
 {
     constexpr bool PROJ = MODE == 2;
     // f32 (fp32 storage, "fused tail" mode): every value this launch writes into S / the permuted copy — and reads back for the table, the projection and
@@ -131,6 +132,12 @@ __device__ __forceinline__ void rank_expand_body(int n, int ld, int r, double ep
         }
     }
     if (j == n) {
+        // (the gain fold of k_pxy2 counts in these words; they are zero between frames: cleared here, in the launch that follows the frame's k_pxy2 and precedes the next one's)
+        if (fold_sync) {                                       // (fold_words: the pair counters, contiguous; the polled flags stand FOLD_FLAG_STRIDE apart behind them)
+            const int base = (fold_words + FOLD_FLAG_STRIDE - 1) / FOLD_FLAG_STRIDE * FOLD_FLAG_STRIDE;
+            for (int q = threadIdx.x; q < fold_words; q += 256) fold_sync[q] = 0u;
+            if (threadIdx.x < 2 + SRUKF_STAT_GROUPS) fold_sync[base + FOLD_FLAG_STRIDE * threadIdx.x] = 0u;
+        }
         if (table && threadIdx.x < (PROJ ? 1 : 11)) {
             const double zero4[4] = { 0, 0, 0, 0 };
             if (threadIdx.x == 0) {
@@ -332,12 +339,13 @@ __global__ __launch_bounds__(256) void k_rank_expand(int n, int ld, int r, doubl
                                                      FrameScalars* __restrict__ fs, const double* __restrict__ X, int do_traj, double* __restrict__ S,
                                                      double* __restrict__ A, double* __restrict__ sigR, double gamma,
                                                      KDims d, KWeights w,
-                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32, StepExport ex, double null_rel)
+                                                     srukf_params p, double* __restrict__ Z, double* __restrict__ DZ, int f32, StepExport ex, double null_rel,
+                                                     unsigned int* __restrict__ fold_sync, int fold_words)
 {
     // dispatch order: the frame tail, the null checks and the noise rows (the longest chains of round trips: a column walk over every kept row) first, then the rows
     const int extra = (int)gridDim.x - n;
     const int bid = (int)blockIdx.x < extra ? n + (int)blockIdx.x : (int)blockIdx.x - extra;
-    rank_expand_body<MODE>(n, ld, r, eps, Sp, D, perm, iperm, gdiag, fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, bid, ex, null_rel);
+    rank_expand_body<MODE>(n, ld, r, eps, Sp, D, perm, iperm, gdiag, fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, bid, ex, null_rel, fold_sync, fold_words);
     if (!ex.dst) return;
     // step-wise API: this is the frame's last launch.  A workgroup's updates of *fs are device-scope atomics (the clamp counters) or device-scope stores (the frame
     // tail's), complete once its s_waitcnt returns.  The last workgroup through copies *fs and the view to the host with loads that bypass its own L2.
@@ -407,14 +415,15 @@ void srukf_launch_rank_diag(hipStream_t st, int n, int ld, const double* G, cons
 }
 void srukf_launch_rank_expand(hipStream_t st, int n, int ld, int r, double eps, const double* Sp, const double* D, const int* perm, const int* iperm,
                               const double* gdiag, void* fs, const double* X, int do_traj, double* S, double* A, double* sigR, double gamma,
-                              int fuse, KDims d, KWeights w, srukf_params p, double* Z, double* DZ, int f32, const StepExport* exp, double null_rel)
+                              int fuse, KDims d, KWeights w, srukf_params p, double* Z, double* DZ, int f32, const StepExport* exp, double null_rel,
+                              unsigned int* fold_sync, int fold_words)
 {
     const StepExport ex = (exp && fuse) ? *exp : StepExport{};
     // fuse: "fused tail" mode (projection of the next frame: five more workgroups, the row in LDS)
     const int nchk = (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
     const dim3 grid(n + 1 + nchk + (fuse ? 5 : 0));
-    if (fuse) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, ex, null_rel);
-    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, 0, StepExport{}, null_rel);
+    if (fuse) hipLaunchKernelGGL(k_rank_expand<2>, grid, dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, f32, ex, null_rel, fold_sync, fold_words);
+    else hipLaunchKernelGGL(k_rank_expand<0>, grid, dim3(256), 0, st, n, ld, r, eps, Sp, D, perm, iperm, gdiag, (FrameScalars*)fs, X, do_traj, S, A, sigR, gamma, d, w, p, Z, DZ, 0, StepExport{}, null_rel, fold_sync, fold_words);
 }
 void srukf_launch_rank_expand_b(hipStream_t st, int n, int ld, int r, double eps, const void* tab, int B, double gamma, KDims d, KWeights w, srukf_params p)
 {

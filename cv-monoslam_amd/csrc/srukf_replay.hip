@@ -176,10 +176,14 @@ void quantize_state(srukf_ctx* c)
 }
 
 // rank-aware replay form: what k_motion / k_gain / k_syrk carry along (all null when the shadow copy does not exist)
+// the pending state update as the launch that applies it takes it: k_gain's slice partials, or the per-landmark shares the gain fold of k_pxy2 left (RankArgs::dxN)
+static const double* dx_src(const srukf_ctx* c) { return c->dx_pending ? (c->dx_lm ? c->dxk : c->dxp) : nullptr; }
+
 RankArgs rank_args(const srukf_ctx* c, bool prep_next, bool dzperm, bool f32round)
 {
     RankArgs ra = {};
     ra.prep_next = prep_next ? 1 : 0; ra.dzperm = dzperm ? 1 : 0; ra.f32round = f32round ? 1 : 0;
+    ra.dxN = (c->dx_pending && c->dx_lm) ? c->d.N : 0;
     if (c->red_r > 0 && c->shadowA) { ra.A = c->shadowA; ra.Utp = c->Utp; ra.gdiag = c->gdiag; ra.iperm = c->red_iperm; ra.perm = c->red_perm; ra.r = c->red_r; }
     return ra;
 }
@@ -280,7 +284,8 @@ void rank_expand(srukf_ctx* c, bool frame_tail, bool table, bool fuse)
     const bool exports = c->step_export.dst && tt && fuse;         // step-wise fast path: this launch is the frame's last and hands status + robot view to the host itself
     srukf_launch_rank_expand(c->stream, n, np, c->red_r, c->p.epsilon, c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, (frame_tail && !f32) ? 1 : 0, c->S, c->shadowA,
                              tt ? c->sigR : nullptr, c->w.gamma, (tt && fuse) ? 1 : 0, c->d, c->w, c->p, c->Z, c->DZ, f32fuse ? 1 : 0, exports ? &c->step_export : nullptr,
-                             c->storage == SRUKF_STORAGE_F32_MIXED ? 1e-6 * c->dbg.mixed_null_ppm : 0.0);
+                             c->storage == SRUKF_STORAGE_F32_MIXED ? 1e-6 * c->dbg.mixed_null_ppm : 0.0,
+                             (tt && fuse) ? c->fold_sync : nullptr, c->fold_sync ? 4 * (c->d.mp / 64) * (c->d.np / 64) : 0);
     c->step_export_attached = exports;
     if (f32) {
         quantize_state(c);
@@ -391,7 +396,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
         if (!head_fold) {
             // head rows of Gp: K = hr rows of the shadow copy (upper triangular) + the 2N measurement rows; + the dropped diagonal
             ProfScope ps(c, KC_SYRK, head_flop, head_byte);
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, dx_src(c), c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -401,7 +406,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
             HeadArgs ha = {};
             if (head_fold) {
                 ha.tiles = (const int2*)c->syrk_head_tiles; ha.ntiles = c->n_syrk_head_tiles; ha.ncrit = c->n_syrk_head_crit;
-                ha.dxp = c->dx_pending ? c->dxp : nullptr; ha.X = c->X; ha.xr1 = take_xr1(c); ha.ndx = c->dx_pending ? (n + 255) / 256 : 0;
+                ha.dxp = dx_src(c); ha.X = c->X; ha.xr1 = take_xr1(c); ha.ndx = c->dx_pending ? (n + 255) / 256 : 0;
                 ha.ra = rank_args(c, table, false, fuse && storage_f32_like(c)); ha.ngd = (n - c->red_r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS;
                 ha.nhelp = ha.ntiles + ha.ndx + ha.ngd;             // one helper workgroup per job, behind the pivot and the workers in dispatch order
                 c->dx_pending = false;
@@ -443,12 +448,12 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
                 // ... and BEHIND it, in FP64 from the FP64 operands, the few tiles whose pivots an fp32-formed product cannot resolve (the robot block, the shared anchor:
                 // mxr_f64_tiles) — they overwrite what the fp32 launch left there
                 srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->mxr_f64_tiles, c->dbg.mixed_f64_robot ? c->mxr_n_f64_tiles : 0,
-                                  c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
+                                  dx_src(c), c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
             } else if (own_order) {
-                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
+                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, dx_src(c), c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
                 srukf_launch_syrk_own(c->stream, n, np, c->shadowA, c->Utp, 0, d.mp, (c->red_r + 15) & ~15, c->Wf, c->fs, c->gplan_red.tiles, c->gplan_red.ntiles, c->red_Tp);
             } else
-            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
+            srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, dx_src(c), c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
             c->dx_pending = false;
         }
         {
@@ -478,7 +483,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
     } else {
         ProfScope ps(c, KC_SYRK, syrk_flop * head_frac, syrk_byte * head_frac);
         srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, fused ? c->syrk_head_tiles : c->syrk_tiles,
-                          fused ? c->n_syrk_head_tiles : c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{}, take_xr1(c));
+                          fused ? c->n_syrk_head_tiles : c->n_syrk_tiles, dx_src(c), c->X, RankArgs{}, take_xr1(c));
         c->dx_pending = false;
     }
     if (keep_backup) hipMemcpyAsync(c->Gbak, c->G, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
@@ -590,7 +595,7 @@ int refactor_reorder(srukf_ctx* c, int ub, int ue)
     const size_t bytes = sizeof(double) * (size_t)np * np;
     if (!c->Sdis) { if (srukf_dmalloc((void**)&c->Sdis, bytes) != hipSuccess) { c->err = "out of device memory (NEED_REORDER buffer)"; return SRUKF_ERR_NOMEM; } }
     hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 1);
-    srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, c->dx_pending ? c->dxp : nullptr, c->X, RankArgs{}, take_xr1(c));
+    srukf_launch_syrk(c->stream, d, c->S, c->Ut, ub, ue, c->G, c->fs, c->syrk_tiles, c->n_syrk_tiles, dx_src(c), c->X, RankArgs{}, take_xr1(c));
     c->dx_pending = false;
     for (int stage = 0; stage < 2; stage++) {
         double* out = stage == 0 ? c->Sdis : c->S;
@@ -616,7 +621,7 @@ int refactor_reorder(srukf_ctx* c, int ub, int ue)
 // fused_motion: the frame's motion step ran inside k_project_motion: the statistics take the robot mean from fs->Xr1, k_gain commits Cmat
 // table: "table" mode of the replay — the product on the permuted operands (k_pxy2), k_gain takes it from there
 // first half: the cross covariances (and, riding on the launch, the measurement statistics h / Si / visible; in "fused tail" mode the frame's motion reduction)
-void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion, bool table, bool preamble, bool fmode)
+void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion, bool table, bool preamble, bool fmode, bool fold)
 {
     const KDims& d = c->d;
     const double nn = d.n;
@@ -632,7 +637,16 @@ void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion, bool table, bool
         ms.hseq = c->meas_seq;
         ms.hstamp = (unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N);       // (the spare words behind h | Si | visible)
     }
-    if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms);
+    GainFold gf = {};
+    if (fold && table && fmode) {
+        gf.sync = c->fold_sync; gf.Utp = c->Utp; gf.dxk = c->dxk; gf.z_seq = c->z_seq; gf.m_seq = c->m_seq;
+        gf.DZp = c->DZ; gf.perm = c->red_perm; gf.iperm = c->red_iperm; gf.r = c->red_r; gf.split_b0 = c->pxy2_split_b0;
+        gf.sqeps = storage_f32_like(c) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon);      // (the null rows of S as they are stored: what seq_gain_only hands k_gain)
+        gf.sc = c->w.wi * c->w.gamma;
+        gf.S = c->S; gf.A = c->shadowA;
+        gf.nmt = d.mp / 64; gf.nbt = d.np / 64; gf.bt_r0 = (c->red_r - 4) / 64; gf.bt_r1 = (c->red_r - 1) / 64; gf.robot_tiles = c->fold_robot_tiles;
+    }
+    if (table) srukf_launch_pxy2(c->stream, d, c->DZ, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->n_pxy2_tiles, (c->red_r + 15) & ~15, c->w, ms, gf);
     else srukf_launch_pxy(c->stream, d, c->DZ, c->S, c->Ut, c->pxy_tiles, c->n_pxy_tiles, c->w, ms);
 }
 
@@ -646,13 +660,17 @@ void seq_gain_only(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fus
                       (fmode && storage_f32_like(c)) ? (double)(float)sqrt(c->p.epsilon) : sqrt(c->p.epsilon),   // (the null rows of S as they are stored)
                       c->sigR, fmode ? 1 : 0, c->next_pose_pending ? c->next_odo + 3 : nullptr, c->odo_step);
     c->next_pose_pending = false;
-    c->dx_pending = true;                             // applied by the next k_syrk launch (seq_refactor)
+    c->dx_pending = true; c->dx_lm = false;           // applied by the next k_syrk launch (seq_refactor)
 }
 
 void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_stats, bool fused_motion, bool table, bool preamble, bool fmode)
 {
-    seq_pxy(c, fused_stats, fused_motion, table, preamble, fmode);
-    seq_gain_only(c, z_dev, m_dev, fused_motion, table, fmode);
+    // gain fold: the staged replay's "fused tail" frames (staged measurements, nothing for the host in between) form U^T and the state update inside k_pxy2
+    const bool fold = c->dbg.gain_fold && fmode && table && fused_stats && fused_motion && !z_dev && !m_dev && !c->mirror_next && !c->next_pose_pending &&
+                      c->fold_sync && c->dxk && c->w.wc0 == c->w.wm0 && c->z_seq && c->m_seq;
+    seq_pxy(c, fused_stats, fused_motion, table, preamble, fmode, fold);
+    if (fold) { c->dx_pending = true; c->dx_lm = true; c->fold_seqs++; }
+    else seq_gain_only(c, z_dev, m_dev, fused_motion, table, fmode);
 }
 
 }  // namespace srukf_impl
@@ -728,6 +746,11 @@ int update_null_set(srukf_ctx* c)
                 HIPCHK(c, hipMemsetAsync(c->Utp, 0, sizeof(double) * (size_t)c->d.mp * np, c->stream));
                 HIPCHK(c, srukf_dmalloc(&c->P1, sizeof(double) * (size_t)c->d.mp * np));
                 HIPCHK(c, hipMemsetAsync(c->P1, 0, sizeof(double) * (size_t)c->d.mp * np, c->stream));
+                // gain fold of k_pxy2: sync words (zero between frames) and the per-landmark shares of the state update
+                const size_t fw = sizeof(unsigned int) * (size_t)(srukf_fold_words(c->d.mp / 64, np / 64) + 2) + sizeof(unsigned long long) * FOLD_DBG_STAMPS;
+                HIPCHK(c, srukf_dmalloc(&c->fold_sync, fw)); HIPCHK(c, hipMemsetAsync(c->fold_sync, 0, fw, c->stream));
+                HIPCHK(c, srukf_dmalloc(&c->dxk, sizeof(double) * (size_t)(c->d.N > 0 ? c->d.N : 1) * np));
+                HIPCHK(c, hipMemsetAsync(c->dxk, 0, sizeof(double) * (size_t)(c->d.N > 0 ? c->d.N : 1) * np, c->stream));
             }
             {
                 // k_pxy2 ("table" mode): 64 x 64 tiles of the permuted product, K ends at the kept rows, long K ranges in two halves
@@ -737,6 +760,8 @@ int update_null_set(srukf_ctx* c)
                 srukf_pxy2_build_tiles(c->d.mp, np, kr, tl.data());
                 if (c->pxy2_tiles) srukf_dfree_on(c->pxy2_tiles, c->stream);
                 c->pxy2_tiles = nullptr; c->n_pxy2_tiles = nt;
+                c->fold_robot_tiles = 0;                          // tile workgroups that read the robot columns (permuted positions r-4 .. r-1) of the permuted copy: gain fold
+                for (int q = 0; q < nt; q++) if (tl[4 * q] >= 0 && (tl[4 * q + 1] == (r - 4) / 64 || tl[4 * q + 1] == (r - 1) / 64)) c->fold_robot_tiles++;
                 HIPCHK(c, srukf_dmalloc(&c->pxy2_tiles, sizeof(int) * tl.size()));
                 HIPCHK(c, hipMemcpy(c->pxy2_tiles, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice));
                 {

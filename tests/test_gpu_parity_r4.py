@@ -49,7 +49,7 @@ def test_g8_default_replay_against_the_oracle_over_40_frames(srukf, golden, synt
     _hold_to_g8(g, traj, X, S)
 
 
-SWITCHES = [("fused_motion", 0, False), ("fused_motion", 1, False), ("pxy2", 0, False), ("nullskip", 0, False), ("head_fold", 0, False),
+SWITCHES = [("fused_motion", 0, False), ("fused_motion", 1, False), ("pxy2", 0, False), ("nullskip", 0, False), ("head_fold", 0, False), ("gain_fold", 1, False),
             ("gmw_persist", 0, True), ("gmw_fused", 0, True), ("rank_fused", 0, True), ("rank_fold", 0, True), ("rank_aware", 0, True)]
 
 
@@ -59,7 +59,8 @@ def test_g8_every_measurement_switch_against_the_oracle(srukf, golden, synth, ke
     "use_graph" are the `table` and `eager` variants above), flipped away from the default, against the same 40 oracle frames: the alternatives are held to the
     ORACLE, not only to the default path.  fused_motion 0 / 1: k_motion + k_project / k_project_motion instead of "table" mode; pxy2 0: k_pxy; nullskip 0: every
     direction projected for every landmark; head_fold 0: k_syrk launch in front of the persistent launch; gmw_persist 0: one launch per 64-row panel; gmw_fused /
-    rank_fused / rank_fold 0: the owners never form their tiles (k_syrk does, then the permutation pass / the kept rows only); rank_aware 0: every pivot factored."""
+    rank_fused / rank_fold 0: the owners never form their tiles (k_syrk does, then the permutation pass / the kept rows only); rank_aware 0: every pivot factored;
+    gain_fold 1: k_gain's work in the tile epilogue of k_pxy2_fold (three launches per frame; round 6's experiment, off by default because it is slower)."""
     g, N, F, p, sc, matched = _g8_scene(golden, synth)
     if process_wide:
         srukf.debug_set_global(key, value)
@@ -71,6 +72,7 @@ def test_g8_every_measurement_switch_against_the_oracle(srukf, golden, synth, ke
         assert f.null_directions() == (0 if key == "rank_aware" else 3 * (N - 1))
         traj = f.run_frames(0, F)
         assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0
+        assert (f.debug_get("fold_seqs") > 0) == (key == "gain_fold")
         X, S = f.get_state()
         f.close()
     finally:
