@@ -368,7 +368,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h /* + Si, vis */, c->PxyR, c->D,
                      c->zcur /* + mcur */, c->odocur, c->small, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->fold_sync, c->dxk, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->mxr_f64_tiles, c->mxr_xt, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->red_head0_tiles, c->split_fold_list, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->fold_sync, c->dxk, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->mxr_f64_tiles, c->mxr_xt, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);

@@ -49,6 +49,9 @@ int srukf_gmw_persist_workers(int T, int Tp, int max_workers);
 void srukf_launch_gmw_persist(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int);
 void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, int, void*, const double*, const double*, int, int, int, int, int, const HeadArgs*);
 void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*, int);
+void srukf_launch_gmw_split_fold(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*, const double*, const double*, int);
+int srukf_gmw_build_fold_list(int T, int Tp, short* out);
+int srukf_gmw_fold_head_tile(int tr, int tc);
 void srukf_launch_gmw_split_alone(hipStream_t, int, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
@@ -170,6 +173,9 @@ struct srukf_ctx {
                                            // graph sharing a hardware queue): the context keeps to the memory-tile instance of k_gmw_persist (read_fs; srukf_debug_get "split_off")
     double* P1 = nullptr; int* pxy2_tiles = nullptr; int n_pxy2_tiles = 0, pxy2_split_b0 = 0;   // "table" mode: k_pxy2's second K half, its tile list
     int* nskip = nullptr; int ns_full = 0, ns_null = 0, ns_rows = 0;   // NullSkip lists (srukf_device.h): [dirs | nulls | rows] in one buffer
+    int* red_head0_tiles = nullptr; int n_red_head0_tiles = 0; // split fold: the k_syrk tiles that stay with the launch in front (block row 0, tile (1, 1)) ...
+    void* split_fold_list = nullptr; int n_split_fold = 0;     // ... and the grid of k_gmw_tiles_fold (forming jobs + tile workgroups, row by row: srukf_gmw_build_fold_list)
+    double red_head0_flop = 0.0;                               // flop of the tiles in red_head0_tiles (the rest of k_syrk's count moves to the persistent launch's line of the profile)
     int* red_syrk_tiles = nullptr; int n_red_syrk_tiles = 0;   // k_syrk tiles of the kept rows (rows < 64 red_Tp) in permuted order: replay form without the owners' fold
     double red_fac_flop = 0, red_own_flop = 0;         // algorithmic flop of the rank-aware persistent launch: factorisation / owners' tiles of S^T S - U U^T
     GmwPlan gplan_red;                                 // tile list / sync block of the persistent launch with red_Tp pivoted panels
@@ -197,6 +203,7 @@ struct srukf_ctx {
         int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
+        int split_fold = 1;                // "split_fold": the split form's tile launch forms the tiles of S^T S - U U^T itself (k_gmw_tiles_fold), k_syrk in front keeps block row 0; 0: k_syrk forms everything first
         int gain_fold = 0;                 // "gain_fold": the staged replay's "fused tail" frames form U^T and the state update in the tile epilogue of k_pxy2 (three launches per frame); 0: k_gain
         int mixed_rank = 1;                // "mixed_rank": SRUKF_STORAGE_F32_MIXED runs the rank-aware refactorisation (fp32-formed S^T S - U U^T over the kept rows, FP64 factorisation
                                            // of the kept pivots only); 0: round 2's full-rank form, in which the null pivots divide fp32 noise (the negative study of rounds 2 / 5)
@@ -262,6 +269,7 @@ struct srukf_ctx {
     bool robot_cached = false;             // the 20 doubles behind *hfs hold P4 and the pose of the CURRENT state (fast path: fetched with the frame's status)
     bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
+    int split_fold_seqs = 0;               // split-form pairs enqueued (or captured) with the split fold: "split_fold_seqs"
     int fold_seqs = 0;                     // frame sequences enqueued (or captured) with the gain fold: "fold_seqs" (tests: the switch took effect)
     int exact_frames = 0;                  // staged frames srukf_run_frames repeated on the exact column path (flagged: theta clamp, a skipped direction that is not null, an abandoned launch): "exact_frames"
     bool async_pending = false;
@@ -380,7 +388,8 @@ int gmw_fused_mode();
 int rank_fused_mode();
 int rank_fold_mode();
 void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, bool need_reset, bool frame_tail, bool table = false, bool fuse = false);
-void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false);
+void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced = false, bool fold = false);
+bool split_fold_ok(const srukf_ctx* c);
 void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow);
 int refactor_reorder(srukf_ctx* c, int ub, int ue);
 void seq_pxy(srukf_ctx* c, bool fused_stats, bool fused_motion = false, bool table = false, bool preamble = false, bool fmode = false, bool fold = false);

@@ -118,6 +118,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "f32_fuse")) c->dbg.f32_fuse = value ? 1 : 0;
     else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
     else if (!strcmp(key, "gain_fold")) c->dbg.gain_fold = value ? 1 : 0;
+    else if (!strcmp(key, "split_fold")) c->dbg.split_fold = value < 0 ? 0 : value > 2 ? 2 : value;      // (2: measurements — the fold's launch behind a k_syrk that has formed everything)
     else if (!strcmp(key, "mixed_rank")) c->dbg.mixed_rank = value ? 1 : 0;
     else if (!strcmp(key, "mixed_f64_robot")) c->dbg.mixed_f64_robot = value ? 1 : 0;
     else if (!strcmp(key, "mixed_bf16")) c->dbg.mixed_bf16 = value ? 1 : 0;
@@ -187,6 +188,7 @@ int srukf_debug_get(srukf_ctx* c, const char* key, long long* value)
     else if (!strcmp(key, "step_slow")) *value = c->step_slow_frames;
     else if (!strcmp(key, "exact_frames")) *value = c->exact_frames;
     else if (!strcmp(key, "fold_seqs")) *value = c->fold_seqs;
+    else if (!strcmp(key, "split_fold_seqs")) *value = c->split_fold_seqs;
     else if (!strncmp(key, "pxy2_stamp", 10) && key[10] >= '1' && key[10] <= '7') { const unsigned long long* t = (const unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N); *value = (long long)(t[key[10] - '0'] - t[0]); }   // diagnostic build (-DSRUKF_PXY2_DBG): 2 motion end, 4..7 sampled tiles' ends
     else if (!strcmp(key, "meas_flag_ticks")) { const unsigned long long* t = (const unsigned long long*)(c->hmeas + c->d.mp + 5 * (size_t)c->d.N); *value = (long long)(t[1] - t[0]); }   // last fast-path k_pxy2: first workgroup's start -> statistics flag, 10 ns ticks
     else if (!strcmp(key, "view_hits")) *value = c->view_hits;                     // srukf_get_frame_view calls served from the view an update exported with its status

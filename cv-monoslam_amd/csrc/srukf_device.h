@@ -431,6 +431,8 @@ __device__ __forceinline__ unsigned long long* gmw_sync_ver(GmwSync* sy) { retur
 #define GMW_VER_STRIDE 16
 #define GMW_VIDX(I, J, T) (((size_t)(I) * (T) + (J)) * GMW_VER_STRIDE)
 __device__ __forceinline__ unsigned long long* gmw_sync_slabver(GmwSync* sy, int T) { return (unsigned long long*)(sy + 1) + (size_t)T * T * GMW_VER_STRIDE; }
+// ... followed by unsigned long long formver[T*T] (split fold): (epoch << SHIFT) + the 32 x 32 quarters of tile (I, J) that the forming jobs of the tile launch have stored
+__device__ __forceinline__ unsigned long long* gmw_sync_formver(GmwSync* sy, int T) { return (unsigned long long*)(sy + 1) + (size_t)2 * T * T * GMW_VER_STRIDE; }
 
 #ifdef SRUKF_GMW_DBG
 #define GMW_DBG(sy, slot, val) do { if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0 && (sy)->dbg) __hip_atomic_store(&(sy)->dbg[blockIdx.x * 8 + (slot)], (unsigned long long)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)

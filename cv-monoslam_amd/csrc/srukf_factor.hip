@@ -236,8 +236,9 @@ __device__ __forceinline__ void pxy2_gain_job(const KDims& d, const MeasArgs& ms
 
 template <bool FOLD>
 __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
-                                          const int4* __restrict__ tiles, int ntiles, int kr, const KWeights& w, const MeasArgs& ms, const int bid, const GainFold& gf)
+                                          const int4* __restrict__ tiles, int ntiles, int kr, const KWeights& w, const MeasArgs& ms, const int bid, const GainFold& gf_in)
 {
+    const GainFold& gf = gf_in;                                // (the motion workgroup and the statistics jobs; the tiles' epilogue reads its own copy late)
     __shared__ double shm[2 * 2 * 16 * PXY2_LS];               // [buf][A|B][k][PXY2_LS]; >= MEAS_SM_DOUBLES (statistics scratch), >= 4 x 64 x 17 (hand-over)
     static_assert(2 * 2 * 16 * PXY2_LS >= MEAS_SM_DOUBLES && 2 * 2 * 16 * PXY2_LS >= 4 * 64 * 17, "scratch");
     const int nstat = ms.Z ? MEAS_SLICES * ms.gx : 0;         // statistics jobs first: they start with the launch, the tiles fill in behind
@@ -411,6 +412,11 @@ __device__ __forceinline__ void pxy2_body(const KDims& d, const double* __restri
                 }
     }
     if (FOLD) {
+        // (the fold's arguments are read from the kernel's argument segment HERE: held in scalar registers across the contraction they spilled — 31 SGPRs into vector lanes,
+        //  and 104 VGPRs behind them)
+        const GainFold* gq = &gf_in;
+        asm volatile("" : "+s"(gq) :: "memory");
+        const GainFold gf = *gq;
         // gain fold: count the tile (and, for the block(s) of the robot columns, tell the motion workgroup that one reader fewer is left); the workgroup that completes the
         // pair of K halves writes U^T for the tile
         __shared__ int fold_last;
@@ -455,7 +461,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     pxy2_body<false>(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x, GainFold{});
 }
 // the same with the gain fold compiled in (the "gain_fold" switch, off by default: DESIGN.md 10 — the fold's code in the plain kernel cost it 4 us, so it is a kernel of its own)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pxy2_fold(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
+#ifndef FOLD_WAVES
+#define FOLD_WAVES 4
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FOLD_WAVES, 4))) void k_pxy2_fold(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
                                               const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms, GainFold gf)
 {
     pxy2_body<true>(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x, gf);

@@ -2,6 +2,12 @@
 // persistent launch: a resident pivot workgroup and worker workgroups that own the trailing tiles.  gfx950 only.
 // The per-panel form, the theta-clamp check and the exact column path are in srukf_factor.hip.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <vector>
 #include "srukf_device.h"
 #include "srukf_tiles.h"
 #include "srukf_gmw_cols.h"
@@ -921,6 +927,198 @@ void k_gmw_tiles_persist(int ld, int T, double* __restrict__ G, GmwSync* __restr
         }
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Split FOLD (round 6; rank-aware replay of the split form, N >= 267): the tile launch also FORMS the tiles.  Until here a k_syrk launch over the kept rows
+// (N = 500: 212 us at 56 TFLOP/s, the machine full) stood in front of the pair, and the pair then ran 24 panels of 13.6 us with the matrix pipes 57 % idle: a
+// throughput launch in front of a latency chain, one after the other.  Here k_syrk keeps block row 0 and tile (1, 1) (what the pivot and the slab workgroups read
+// unversioned) and the tile launch's grid is, per block row I = 1, 2, ..: the row's FORMING JOBS (one 32 x 32 tile of S^T S - U U^T each: k_syrk's workgroup, its
+// K split over the four waves, its summation order — bit for bit what the launch in front stored), then the row's tile workgroups, which wait for their three or
+// four quarters (formver) before they load the tile.  Dispatch is in grid order, so a row is formed ~9 us after the one before it while the chain needs one per
+// 13.6 us; a forming job waits for nothing, a tile workgroup only for jobs in front of it in the grid and for the resident pivot / slab launch: whatever part of
+// the grid is resident, it makes progress.  Jobs of one pair of columns sit on one XCD (list position % 8), so its L2 serves their operand slab once.
+// entry: I, J, nsteps as GmwTile for a tile workgroup; nsteps = -1: forming job for the 32 x 32 tile (I, J) (32-row units); nsteps = -2: padding.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gmw_form_job(int n, int ld, int krows, const double* __restrict__ A, const double* __restrict__ Ut, int mp, int tr, int tc,
+                                             double* __restrict__ G, FrameScalars* __restrict__ fs, double (*red)[64][17], int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    const int m0 = tr * 32, n0 = tc * 32;
+    d4 acc[2][2];
+    zero_acc(acc);
+    const int ke = min(m0 + 32, krows);
+    const int ngs = ke >> 4, ngu = mp >> 4, ng = ngs + ngu;
+    const int g0 = (ng * wv) >> 2, g1 = (ng * (wv + 1)) >> 2;
+#if defined(SF_EXP) && SF_EXP == 4
+    const int lds = 0;                                         // (measurement build: every k-step reads the operands' first rows — the arithmetic without its memory traffic)
+#else
+    const int lds = ld;
+#endif
+    if (g0 < ngs) tile32_tn<false>(acc, A, lds, A, lds, m0, n0, g0 << 4, min(g1, ngs) << 4, lane);
+    if (g1 > ngs) tile32_tn<true>(acc, Ut, lds, Ut, lds, m0, n0, (max(g0, ngs) - ngs) << 4, (g1 - ngs) << 4, lane);
+    splitk_reduce(acc, red, wv, lane);
+    if (wv != 0) return;
+    const int lr = lane & 15, lk = lane >> 4;
+    double gmax = 0.0, xmax = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
+                const double v = acc[a][b][t];
+#if defined(SF_EXP) && SF_EXP >= 3
+                if (fs->frame == -12345)                       // (measurement build: the arithmetic and its operand traffic without the result)
+#endif
+                st_dev(&G[(size_t)r * ld + c], v);             // read by a tile workgroup of this launch, on whatever XCD
+                if (r < n && c < n) { if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v); }
+            }
+    gmax = wave_max(gmax); xmax = wave_max(xmax);
+    if (lane == 0) {
+        if (gmax > 0.0) atomicMax(&fs->gmax_bits, (unsigned long long)__double_as_longlong(gmax));
+        if (xmax > 0.0) atomicMax(&fs->ximax_bits, (unsigned long long)__double_as_longlong(xmax));
+    }
+}
+// A tile workgroup of the split fold: tile (I, J) in registers from its first update to its last (k_gmw_tiles_persist), behind the wait for its formed quarters.
+__device__ __forceinline__ void gmw_fold_tile_wg(int ld, int T, int I, int J, int ns, double* __restrict__ G, GmwSync* __restrict__ sy, unsigned long long ebase,
+                                                 const double* __restrict__ Wslab, const double* __restrict__ Lslab, int* okp)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const bool wv0 = __builtin_amdgcn_readfirstlane(wv) == 0;
+    unsigned long long* ver = gmw_sync_ver(sy);
+    const unsigned long long* slabver = gmw_sync_slabver(sy, T);
+    unsigned long long* formver = gmw_sync_formver(sy, T);
+    int& ok = *okp;
+    {
+        // ---- tile workgroup: k_gmw_tiles_persist behind the wait for its quarters ----
+        // (its waves share their SIMDs with forming jobs, which keep the matrix pipe busy: the update steps of the rows the pivot waits for go first)
+        __builtin_amdgcn_s_setprio(3);
+        const int m0 = 64 * I + 32 * (wv >> 1), c0 = 64 * J + 32 * (wv & 1);
+        const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
+        if (wv0) {
+            // (the row's jobs stand right in front of it in the grid: 10 - 20 us away; ~800 of these workgroups are resident at N = 500, so they ask about once a microsecond)
+            const unsigned long long want = ebase + (I == J ? 3 : 4);
+            const unsigned long long* w = &formver[GMW_VIDX(I, J, T)];
+            int got = 0;
+            for (int spins = 0; spins < GMW_XWG_LIMIT && !got; spins++) {
+                if (gmw_uniform64(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= want) got = 1;
+                else {
+                    if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+                    if (I <= 2) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
+                }
+            }
+            ok = got;
+        }
+        __syncthreads();
+        bool good = ok != 0;
+        __syncthreads();                                       // ok is rewritten by the first poll below
+        d4 acc[2][2];
+        zero_acc(acc);
+        if (good && live) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[a][b][t] = ld_dev(&G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr]);
+        }
+        for (int k = 0; k < ns && good; k++) {
+            if (wv0) {
+                const unsigned long long want = ebase + 1;
+                unsigned long long a = 0, b = 0;
+                for (int spins = 0; spins < GMW_XWG_LIMIT; spins++) {
+                    a = gmw_uniform64(__hip_atomic_load(&slabver[GMW_VIDX(k, I, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    b = gmw_uniform64(__hip_atomic_load(&slabver[GMW_VIDX(k, J, T)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (a >= want && b >= want) break;
+                    if ((spins & 31) == 31 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+                    if (I - k <= 2) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
+                }
+                ok = (a >= want && b >= want) ? 1 : 0;
+            }
+            __syncthreads();
+            good = ok != 0;
+            if (good && live) {
+                const double* __restrict__ Lb = Lslab + (size_t)k * 64 * ld + m0 + lr;
+                const double* __restrict__ Wb = Wslab + (size_t)k * 64 * ld + c0 + lr;
+                // all 64 operand values of the step requested at once: under the forming jobs' traffic a round trip is several microseconds, and four of them
+                // one behind the other (k_gmw_tiles_persist's loop) were most of a panel's slack — same MFMA order
+                double a0[16], a1[16], b0[16], b1[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const size_t ro = (size_t)(4 * u + lk) * ld;
+                    a0[u] = Lb[ro]; a1[u] = Lb[ro + 16]; b0[u] = Wb[ro]; b1[u] = Wb[ro + 16];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[u], b0[u], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[u], b1[u], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[u], b0[u], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[u], b1[u], acc[1][1], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        if (good) {
+            if (live) {
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++) st_dev(&G[(size_t)(m0 + 16 * a + lk + 4 * t) * ld + c0 + 16 * b + lr], acc[a][b][t]);
+            }
+            gmw_publish(&ver[GMW_VIDX(I, J, T)], ebase + ns, wv0);
+        } else if (wv0) gmw_abandon(sy, 6);
+        }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void k_gmw_tiles_fold(int n, int ld, int T, double* __restrict__ G, GmwSync* __restrict__ sy, const GmwTile* __restrict__ list, FrameScalars* __restrict__ fs,
+                      const double* __restrict__ Wslab, const double* __restrict__ Lslab, unsigned int total_exits,
+                      const double* __restrict__ A, const double* __restrict__ Ut, int mp, int krows)
+{
+    __shared__ int ok;
+    __shared__ double red[3][64][17];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const unsigned long long tq = ((const unsigned long long*)list)[blockIdx.x];
+    int frozen_now = fs->frozen;
+    unsigned long long epoch_now = sy->epoch;
+    if (frozen_now) return;
+    const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
+    const int I = (int)(short)(tq & 0xffff), J = (int)(short)((tq >> 16) & 0xffff), ns = (int)(short)((tq >> 32) & 0xffff);
+    const bool wv0 = __builtin_amdgcn_readfirstlane(wv) == 0;
+    unsigned long long* ver = gmw_sync_ver(sy);
+    const unsigned long long* slabver = gmw_sync_slabver(sy, T);
+    unsigned long long* formver = gmw_sync_formver(sy, T);
+    if (ns == -1) {
+        // ---- forming job: the 32 x 32 tile (I, J) of 32-row units ----
+#if !defined(SF_EXP) || SF_EXP != 1
+        gmw_form_job(n, ld, krows, A, Ut, mp, I, J, G, fs, red, tid);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // wave 0's stores have landed
+        if (tid == 0) {
+            // count the quarter in its 64 x 64 tile's word: values of older launches are replaced (the words never need clearing), the quarters of this one add up
+            unsigned long long* w = &formver[GMW_VIDX(I >> 1, J >> 1, T)];
+            unsigned long long cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                const unsigned long long nxt = (cur >= ebase ? cur : ebase) + 1;
+                if (__hip_atomic_compare_exchange_strong(w, &cur, nxt, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            }
+        }
+    } else if (ns >= 0) {
+        gmw_fold_tile_wg(ld, T, I, J, ns, G, sy, ebase, Wslab, Lslab, &ok);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(&sy->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == total_exits - 1) {
+            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicAdd(&fs->clamp_rows, 1); atomicMin(&fs->clamp_first, 0); atomicAdd(&fs->gmw_aborts, 1); }
+            __hip_atomic_store(&sy->abort, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->resident, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sy->epoch, (ebase >> GMW_EPOCH_SHIFT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 // In front of k_gmw_tiles_persist on its stream: lets it start only when every workgroup of the pivot / slab launch is resident (their CUs are then taken; the
 // tile workgroups get the others).  One wave; gives up after ~50 ms and abandons the launch pair (the frame is flagged).
 __global__ void k_gmw_split_gate(GmwSync* __restrict__ sy, const FrameScalars* __restrict__ fs, unsigned int want)
@@ -934,7 +1132,7 @@ __global__ void k_gmw_split_gate(GmwSync* __restrict__ sy, const FrameScalars* _
 }
 
 extern "C" {
-int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + 2 * sizeof(unsigned long long) * (size_t)T * T * GMW_VER_STRIDE); }
+int srukf_gmw_sync_bytes(int T) { return (int)(sizeof(GmwSync) + 3 * sizeof(unsigned long long) * (size_t)T * T * GMW_VER_STRIDE); }
 // host-side tile list of the persistent launch: every tile (I, J), 1 <= I <= J < T, with the number of panel updates
 // its owner applies (I off the diagonal; I - 1 on it: the pivot applies the last one itself), ordered by the step at
 // which it is finished, so that worker w and worker w + workers hold tiles that retire at different times.
@@ -1039,6 +1237,69 @@ void srukf_launch_gmw_split_alone(hipStream_t st, int which, int n, int ld, doub
     const int nreal = ntiles - ((Tp < T) ? T - Tp : 0);
     if (which == 0) hipLaunchKernelGGL(k_gmw_pivslab_persist, dim3(T), dim3(256), 0, st, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps, (GmwSync*)sync, (FrameScalars*)fs, krows, Wslab, Lslab, (unsigned)T);
     else if (nreal > 0) hipLaunchKernelGGL(k_gmw_tiles_persist, dim3(nreal), dim3(256), 0, st, ld, T, G, (GmwSync*)sync, (const GmwTile*)tiles, (FrameScalars*)fs, Wslab, Lslab, (unsigned)nreal);
+}
+// Split fold: the grid of k_gmw_tiles_fold (4 shorts per entry; out may be null; returns the number of entries) for T block columns, Tp pivoted panels.  Per block row
+// I >= 1 with tile workgroups: the row's forming jobs — every 32 x 32 tile (tr, tc), tr in {2 I, 2 I + 1}, tc >= tr, that srukf_gmw_fold_head_tile() does not give to the
+// k_syrk launch in front — with the jobs of one column pair tc / 2 on one XCD (entry index % 8), then the row's tile workgroups as srukf_gmw_build_tiles lists them
+// (without the pass-on row); every segment padded to a multiple of 8 entries (nsteps = -2).
+int srukf_gmw_fold_head_tile(int tr, int tc) { return (tr < 2 || (tr < 4 && tc < 4)) ? 1 : 0; }      // block row 0 and tile (1, 1): read unversioned by the pivot and the slab workgroups
+int srukf_gmw_build_fold_list(int T, int Tp, short* out)
+{
+    if (Tp <= 0 || Tp > T) Tp = T;
+    const int nt = srukf_gmw_build_tiles(T, Tp, nullptr);
+    std::vector<short> tk((size_t)4 * (nt > 0 ? nt : 1));
+    srukf_gmw_build_tiles(T, Tp, tk.data());
+    const int nreal = nt - ((Tp < T) ? T - Tp : 0);
+    const int Ilast = (Tp < T) ? Tp - 1 : T - 1;
+    int cnt = 0;
+    auto emit = [&](int a, int b, int c) { if (out) { out[4 * cnt] = (short)a; out[4 * cnt + 1] = (short)b; out[4 * cnt + 2] = (short)c; out[4 * cnt + 3] = 0; } cnt++; };
+    auto pad8 = [&]() { while (cnt % 8) emit(0, 0, -2); };
+    // Where a row's tile workgroups stand.  A tile workgroup holds its registers from its dispatch to its row's last update, working or waiting: with every row's
+    // workgroups right behind the row's jobs, the rows that were formed ahead of the chain (forming: ~9 us per row, the chain: 13.6) filled the machine with
+    // waiting workgroups — 805 of 836 places at N = 500 — and the forming jobs behind them got what was left: the pair took chain + forming (measured: 510 us
+    // against 327 + 212 one after the other).  The slabs of every panel stay in Wslab / Lslab, so a tile workgroup may arrive late and catch up: row I stands
+    // behind the jobs of row place(I) = max(I, lead_a I - lead_b) — about three panels (+ its catch-up time) before the chain needs it.
+    double lead_a = 1.38, lead_b = 4.6;
+    if (const char* e = getenv("SRUKF_FOLD_LEAD")) sscanf(e, "%lf,%lf", &lead_a, &lead_b);       // (measurements)
+    auto place = [&](int I) { const int f = (int)floor(lead_a * I - lead_b); return std::min(Ilast, std::max(I, f)); };
+    // Segments of `rows` block rows (the first `single` rows one by one: the chain waits for them): within a segment the jobs of one column pair stand together on
+    // their XCD, row after row, so the pair's operand slab crosses the fabric once per segment instead of once per row.
+    int rows = 2, single = 2;
+    if (const char* e = getenv("SRUKF_FOLD_ROWS")) sscanf(e, "%d,%d", &rows, &single);            // (measurements)
+    if (rows < 1) rows = 1;
+    for (int F0 = 1; F0 <= Ilast;) {
+        const int F1 = std::min(Ilast, F0 <= single ? F0 : F0 + rows - 1);
+        std::vector<std::pair<short, short>> q[8];
+        for (int Jc = F0; Jc < T; Jc++)
+            for (int F = F0; F <= F1 && F <= Jc; F++)
+                for (int tc = 2 * Jc; tc <= 2 * Jc + 1; tc++)
+                    for (int tr = 2 * F; tr <= 2 * F + 1 && tr <= tc; tr++)
+                        if (!srukf_gmw_fold_head_tile(tr, tc)) q[Jc % 8].push_back({ (short)tr, (short)tc });
+        size_t longest = 0;
+        for (int x = 0; x < 8; x++) longest = std::max(longest, q[x].size());
+        for (size_t r = 0; r < longest; r++)
+            for (int x = 0; x < 8; x++) { if (r < q[x].size()) emit(q[x][r].first, q[x][r].second, -1); else emit(0, 0, -2); }
+        for (int I = 1; I <= Ilast; I++) {
+            const int pl = place(I);
+            if (pl < F0 || pl > F1) continue;
+            for (int t = 0; t < nreal; t++) if (tk[4 * t] == I) emit(tk[4 * t], tk[4 * t + 1], tk[4 * t + 2]);
+        }
+        pad8();
+        F0 = F1 + 1;
+    }
+    return cnt;
+}
+// the pair of the split form with the fold: A / Ut (mp rows) / krows = the operands k_syrk would have read (the permuted copy of the kept rows, U^T with permuted columns)
+void srukf_launch_gmw_split_fold(hipStream_t stA, hipStream_t stB, int n, int ld, double eps, double* G, void* pans, double* D, double* Sout, void* sync,
+                                 const void* list, int nlist, void* fs, int Tp, int krows, double* Wslab, double* Lslab, const double* A, const double* Ut, int mp)
+{
+    const int T = ld / 64;
+    if (Tp <= 0 || Tp > T) Tp = T;
+    if (krows <= 0 || krows > ld) krows = ld;
+    const unsigned int total = (unsigned)(T + nlist);
+    hipLaunchKernelGGL(k_gmw_pivslab_persist, dim3(T), dim3(256), 0, stA, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps, (GmwSync*)sync, (FrameScalars*)fs, krows, Wslab, Lslab, total);
+    hipLaunchKernelGGL(k_gmw_split_gate, dim3(1), dim3(64), 0, stB, (GmwSync*)sync, (const FrameScalars*)fs, (unsigned)T);
+    if (nlist > 0) hipLaunchKernelGGL(k_gmw_tiles_fold, dim3(nlist), dim3(256), 0, stB, n, ld, T, G, (GmwSync*)sync, (const GmwTile*)list, (FrameScalars*)fs, Wslab, Lslab, total, A, Ut, mp, krows);
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }

@@ -428,8 +428,10 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
         // its tiles from Gp.  (The memory-tile form and the launches per panel keep the split-K k_syrk over the kept rows: nothing to be identical to.)
         const bool own_order = c->gmw_shared == 1 && gmw_use_persist(c) && c->gplan_red.workers > 0 && c->gplan_red.T >= 16 && !c->debug_starve && gmw_fused_mode() && rank_fold_mode() &&
                                srukf_gmw_register_form(c->gplan_red.T, c->gplan_red.Tp, c->gplan_red.ntiles, c->gplan_red.workers);
+        const bool sfold = !own_order && split_fold_ok(c);
+        const double syrk_flop_all = rr * rr * rr / 3.0 + rr * rr * (n - rr) + 2.0 * d.mp * (rr * n - rr * rr / 2.0) + 2.0 * (n - rr) * (rr + d.mp);
         {
-            ProfScope ps(c, KC_SYRK, rr * rr * rr / 3.0 + rr * rr * (n - rr) + 2.0 * d.mp * (rr * n - rr * rr / 2.0) + 2.0 * (n - rr) * (rr + d.mp), 8.0 * (rr * n + (double)d.mp * n + rp * n));
+            ProfScope ps(c, KC_SYRK, sfold ? c->red_head0_flop + 2.0 * (n - rr) * (rr + d.mp) : syrk_flop_all, 8.0 * (rr * n + (double)d.mp * n + rp * n));
             if (c->storage == SRUKF_STORAGE_F32_MIXED) {
                 // the mixed-precision downdate in the rank-aware form: the kept rows of S in permuted column order (what the stored floats hold: the permuted copy is
                 // rounded with S) and U^T with permuted columns as fp32 operands, K <= r, products on the fp32 matrix pipe, chunk sums in FP64 — only the macro tiles of the
@@ -452,13 +454,16 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
             } else if (own_order) {
                 srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->syrk_head_tiles, c->n_syrk_head_tiles, dx_src(c), c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
                 srukf_launch_syrk_own(c->stream, n, np, c->shadowA, c->Utp, 0, d.mp, (c->red_r + 15) & ~15, c->Wf, c->fs, c->gplan_red.tiles, c->gplan_red.ntiles, c->red_Tp);
-            } else
+            } else if (sfold && c->dbg.split_fold != 2)
+                // split fold: block row 0 and tile (1, 1) here (+ the state update and the dropped diagonal, as always); the tile launch of the pair forms the rest
+                srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_head0_tiles, c->n_red_head0_tiles, dx_src(c), c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
+            else
             srukf_launch_syrk(c->stream, d, c->shadowA, c->Utp, 0, d.mp, c->Wf, c->fs, c->red_syrk_tiles, c->n_red_syrk_tiles, dx_src(c), c->X, rank_args(c, table, false, fuse && storage_f32_like(c)), take_xr1(c));
             c->dx_pending = false;
         }
         {
-            ProfScope ps(c, gmw_use_persist(c) && gmw_plan_persists(c, c->gplan_red) ? KC_GMW_PERSIST : KC_GMW_TRAIL, c->red_fac_flop, 8.0 * 2.0 * rp * n);
-            launch_gmw_fast(c, c->Wf, c->G, true);
+            ProfScope ps(c, gmw_use_persist(c) && gmw_plan_persists(c, c->gplan_red) ? KC_GMW_PERSIST : KC_GMW_TRAIL, c->red_fac_flop + (sfold ? syrk_flop_all - c->red_head0_flop : 0.0), 8.0 * 2.0 * rp * n);
+            launch_gmw_fast(c, c->Wf, c->G, true, sfold);
         }
         ProfScope ps(c, KC_RANK_EXPAND, 0, 8.0 * 2.5 * (double)n * n);
         rank_expand(c, frame_tail, table, fuse);
@@ -539,7 +544,14 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
 
 // Blocked fast path (or, slow, the exact column path) on an arbitrary matrix buffer: Gbuf (upper triangle,
 // destroyed) -> upper-triangular factor rows in Sout (whose lower triangle must already be zero).
-void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced)
+// split fold (srukf_gmw_persist.hip, k_gmw_tiles_fold): the rank-aware replay's k_syrk over the kept rows becomes jobs of the split form's tile launch
+bool split_fold_ok(const srukf_ctx* c)
+{
+    return c->dbg.split_fold && c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->split_fold_list && c->n_split_fold > 0 && c->red_head0_tiles && !c->debug_starve &&
+           !c->dbg.split_record && gmw_use_persist(c) && gmw_plan_persists(c, c->gplan_red) && split_form(c, c->gplan_red, true);
+}
+
+void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced, bool fold)
 {
     const int np = c->d.np, n = c->d.n;
     const GmwPlan& gp = reduced ? c->gplan_red : c->gplan;
@@ -553,6 +565,11 @@ void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced)
             if (c->dbg.split_record) hipMemcpyAsync(c->Gbak, Gbuf, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToDevice, c->stream);
             hipEventRecord(c->ev_fork, c->stream);
             hipStreamWaitEvent(c->side, c->ev_fork, 0);
+            if (fold && reduced) c->split_fold_seqs++;
+            if (fold && reduced)
+                srukf_launch_gmw_split_fold(c->stream, c->side, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, c->split_fold_list, c->n_split_fold, c->fs, Tp, (c->red_r + 15) & ~15,
+                                            c->gsW, c->gsL, c->shadowA, c->Utp, c->d.mp);
+            else
             srukf_launch_gmw_split(c->stream, c->side, n, np, c->p.epsilon, Gbuf, gp.pans, c->D, Sout, gp.sync, gp.tiles, gp.ntiles, c->fs, Tp, reduced ? ((c->red_r + 15) & ~15) : 0, c->gsW, c->gsL, c->debug_starve ? 1 : 0);
             hipEventRecord(c->ev_join, c->side);
             hipStreamWaitEvent(c->stream, c->ev_join, 0);
@@ -740,6 +757,25 @@ int update_null_set(srukf_ctx* c)
                 c->red_syrk_tiles = nullptr; c->n_red_syrk_tiles = (int)tr.size() / 2;
                 HIPCHK(c, srukf_dmalloc(&c->red_syrk_tiles, sizeof(int) * tr.size()));
                 HIPCHK(c, hipMemcpy(c->red_syrk_tiles, tr.data(), sizeof(int) * tr.size(), hipMemcpyHostToDevice));
+                // split fold: what of that list stays with k_syrk, and the grid of the tile launch that forms the rest (srukf_gmw_persist.hip)
+                std::vector<int> th;
+                c->red_head0_flop = 0.0;
+                const int kr16 = (r + 15) & ~15;
+                for (size_t q = 0; q + 1 < tr.size(); q += 2) if (srukf_gmw_fold_head_tile(tr[q], tr[q + 1])) {
+                    th.push_back(tr[q]); th.push_back(tr[q + 1]);
+                    c->red_head0_flop += 2.0 * 32.0 * 32.0 * (std::min(32 * tr[q] + 32, kr16) + c->d.mp);
+                }
+                if (c->red_head0_tiles) srukf_dfree_on(c->red_head0_tiles, c->stream);
+                if (c->split_fold_list) srukf_dfree_on(c->split_fold_list, c->stream);
+                c->red_head0_tiles = nullptr; c->split_fold_list = nullptr;
+                c->n_red_head0_tiles = (int)th.size() / 2;
+                HIPCHK(c, srukf_dmalloc(&c->red_head0_tiles, sizeof(int) * std::max<size_t>(th.size(), 2)));
+                HIPCHK(c, hipMemcpy(c->red_head0_tiles, th.data(), sizeof(int) * th.size(), hipMemcpyHostToDevice));
+                c->n_split_fold = srukf_gmw_build_fold_list(T, Tp, nullptr);
+                std::vector<short> fl((size_t)4 * std::max(c->n_split_fold, 1));
+                srukf_gmw_build_fold_list(T, Tp, fl.data());
+                HIPCHK(c, srukf_dmalloc(&c->split_fold_list, sizeof(short) * fl.size()));
+                HIPCHK(c, hipMemcpy(c->split_fold_list, fl.data(), sizeof(short) * fl.size(), hipMemcpyHostToDevice));
             }
             if (!c->shadowA) {
                 HIPCHK(c, srukf_dmalloc(&c->shadowA, sizeof(double) * (size_t)np * np)); HIPCHK(c, srukf_dmalloc(&c->Utp, sizeof(double) * (size_t)c->d.mp * np));

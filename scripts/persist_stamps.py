@@ -24,6 +24,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 p = synth.scene_params(); F = 60
 sc = synth.make_scene(N, F, seed=0, p=p)
 f = srukf.Filter(N, p)
+for kv in sys.argv[3:]:                                # key=value pairs for srukf_debug_set (e.g. split_fold=0)
+    f.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
 f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
 f.run_frames(0, 20)
 f.debug_gmw_stamps()                                   # arm

@@ -189,6 +189,31 @@ def test_split_form_of_the_persistent_factorisation(srukf, synth, N, storage, ra
     assert np.abs(res[0][0][-1, :2] - sc["odo"][F, :2]).max() < 5e-3      # and it tracks
 
 
+@pytest.mark.parametrize("N,storage", [(400, "f64"), (500, "f32")])
+def test_split_fold_forms_the_same_tiles_as_k_syrk(srukf, synth, N, storage):
+    """Round 6: in the rank-aware replay of the split form the tile launch forms the tiles of S^T S - U U^T itself (k_gmw_tiles_fold: forming jobs in k_syrk's summation
+    order, row by row in front of the row's tile workgroups) while the pivot chain is already running; srukf_debug_set "split_fold" 0 is the k_syrk launch over the kept
+    rows in front of the pair.  Same state and trajectory bit for bit, nothing abandoned, and the switch took effect ("split_fold_seqs")."""
+    p = synth.scene_params()
+    F = 12
+    sc = synth.make_scene(N, F, seed=23, p=p)
+    res = []
+    for fold in (1, 0):
+        f = srukf.Filter(N, p)
+        if storage == "f32": f.set_storage(srukf.STORAGE_F32)
+        f.debug_set("split_fold", fold)
+        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+        tr = [f.run_frames(0, 3), f.run_frames(3, F - 3)]
+        if not f.debug_get("split_form"):
+            f.close(); pytest.skip("this plan does not run the split form here")
+        assert (f.debug_get("split_fold_seqs") > 0) == (fold == 1)
+        assert f.debug_get("gmw_aborts") == 0 and f.debug_get("clamp_rows") == 0 and f.debug_get("exact_frames") == 0
+        X, S = f.get_state()
+        res.append((np.vstack(tr), X, S))
+        f.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
 def test_split_form_without_its_tile_launch_falls_back(srukf, synth):
     """The split form whose tile launch never arrives (srukf_debug_starve_workers: as if somebody else held the GPU) must not hang: the bounded waits of the pivot and of
     the slab workgroups expire, the frame is flagged and repeated on the exact path, the filter goes on with one launch per panel — and ends where an undisturbed filter ends
