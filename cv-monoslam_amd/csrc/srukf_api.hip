@@ -399,7 +399,11 @@ void ctx_retire(srukf_ctx* handle, srukf_ctx* old)
     drop_graphs(old);
     old->own_stream = false;
     handle->retired.push_back(old);
-    while (handle->retired.size() > 8) { srukf_destroy(handle->retired.front()); handle->retired.erase(handle->retired.begin()); }
+    // How many: a map that breathes by +- 1 around a size revisits ~16 sizes (bench.py's churn leg: 200 -> 185 landmarks), and destroying the context that falls out of
+    // the list is the expensive part of a miss (2.6 of 3.6 ms at N = 200: ~60 device frees).  Up to 32 contexts or ~16 GB of them (a context is ~14 matrices of np^2 doubles).
+    const double ctx_bytes = 14.0 * 8.0 * (double)old->d.np * old->d.np;
+    const size_t keep = (size_t)std::min(32.0, std::max(4.0, 16e9 / ctx_bytes));
+    while (handle->retired.size() > keep) { srukf_destroy(handle->retired.front()); handle->retired.erase(handle->retired.begin()); }
 }
 
 static int ctx_revive(srukf_ctx* r)

@@ -547,8 +547,13 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
 // split fold (srukf_gmw_persist.hip, k_gmw_tiles_fold): the rank-aware replay's k_syrk over the kept rows becomes jobs of the split form's tile launch
 bool split_fold_ok(const srukf_ctx* c)
 {
-    return c->dbg.split_fold && c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->split_fold_list && c->n_split_fold > 0 && c->red_head0_tiles && !c->debug_starve &&
-           !c->dbg.split_record && gmw_use_persist(c) && gmw_plan_persists(c, c->gplan_red) && split_form(c, c->gplan_red, true);
+    // Only while every tile workgroup of the plan can be resident beside the pivot / slab launch (four per CU): they hold their places from dispatch to their row's
+    // last update, and beyond that the forming jobs queue behind waiting workgroups — frames/s with / without the fold: N = 400 2 150 / 1 960, 500 1 385 / 1 350,
+    // 600 (1 190 tile workgroups for 796 places) 855 / 893, 800 393 / 459.
+    const GmwPlan& gp = c->gplan_red;
+    const bool fits = gp.nreal <= 4 * (gp.cus - gp.T);
+    return c->dbg.split_fold && (fits || c->dbg.split_fold == 2) && c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->split_fold_list && c->n_split_fold > 0 && c->red_head0_tiles &&
+           !c->debug_starve && !c->dbg.split_record && gmw_use_persist(c) && gmw_plan_persists(c, gp) && split_form(c, gp, true);
 }
 
 void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced, bool fold)
