@@ -51,7 +51,8 @@ void srukf_launch_gmw_persist_head(hipStream_t, int, int, double, double*, void*
 void srukf_launch_gmw_split(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*, int);
 void srukf_launch_gmw_split_fold(hipStream_t, hipStream_t, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*, const double*, const double*, int);
 int srukf_gmw_build_fold_list(int T, int Tp, short* out);
-int srukf_gmw_fold_head_tile(int tr, int tc);
+int srukf_gmw_fold_head_tile(int tr, int tc, int head_rows);
+int srukf_gmw_fold_head_rows(int Tp);
 void srukf_launch_gmw_split_alone(hipStream_t, int, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);

@@ -981,7 +981,7 @@ __device__ __forceinline__ void gmw_form_job(int n, int ld, int krows, const dou
 }
 // A tile workgroup of the split fold: tile (I, J) in registers from its first update to its last (k_gmw_tiles_persist), behind the wait for its formed quarters.
 __device__ __forceinline__ void gmw_fold_tile_wg(int ld, int T, int I, int J, int ns, double* __restrict__ G, GmwSync* __restrict__ sy, unsigned long long ebase,
-                                                 const double* __restrict__ Wslab, const double* __restrict__ Lslab, int* okp)
+                                                 const double* __restrict__ Wslab, const double* __restrict__ Lslab, int* okp, int head_rows)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const bool wv0 = __builtin_amdgcn_readfirstlane(wv) == 0;
@@ -997,9 +997,11 @@ __device__ __forceinline__ void gmw_fold_tile_wg(int ld, int T, int I, int J, in
         const bool live = (m0 < ld) && (c0 < ld) && (c0 + 32 > m0);
         if (wv0) {
             // (the row's jobs stand right in front of it in the grid: 10 - 20 us away; ~800 of these workgroups are resident at N = 500, so they ask about once a microsecond)
-            const unsigned long long want = ebase + (I == J ? 3 : 4);
+            // (quarters the grid's jobs form: none for the block rows the launch in front has formed)
+            const int nq = (I < head_rows || (I == 1 && J == 1)) ? 0 : (I == J ? 3 : 4);
+            const unsigned long long want = ebase + nq;
             const unsigned long long* w = &formver[GMW_VIDX(I, J, T)];
-            int got = 0;
+            int got = nq == 0 ? 1 : 0;
             for (int spins = 0; spins < GMW_XWG_LIMIT && !got; spins++) {
                 if (gmw_uniform64(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= want) got = 1;
                 else {
@@ -1074,7 +1076,7 @@ __device__ __forceinline__ void gmw_fold_tile_wg(int ld, int T, int I, int J, in
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k_gmw_tiles_fold(int n, int ld, int T, double* __restrict__ G, GmwSync* __restrict__ sy, const GmwTile* __restrict__ list, FrameScalars* __restrict__ fs,
                       const double* __restrict__ Wslab, const double* __restrict__ Lslab, unsigned int total_exits,
-                      const double* __restrict__ A, const double* __restrict__ Ut, int mp, int krows)
+                      const double* __restrict__ A, const double* __restrict__ Ut, int mp, int krows, int head_rows)
 {
     __shared__ int ok;
     __shared__ double red[3][64][17];
@@ -1105,7 +1107,7 @@ void k_gmw_tiles_fold(int n, int ld, int T, double* __restrict__ G, GmwSync* __r
             }
         }
     } else if (ns >= 0) {
-        gmw_fold_tile_wg(ld, T, I, J, ns, G, sy, ebase, Wslab, Lslab, &ok);
+        gmw_fold_tile_wg(ld, T, I, J, ns, G, sy, ebase, Wslab, Lslab, &ok, head_rows);
     }
     __syncthreads();
     if (tid == 0) {
@@ -1242,7 +1244,17 @@ void srukf_launch_gmw_split_alone(hipStream_t st, int which, int n, int ld, doub
 // I >= 1 with tile workgroups: the row's forming jobs — every 32 x 32 tile (tr, tc), tr in {2 I, 2 I + 1}, tc >= tr, that srukf_gmw_fold_head_tile() does not give to the
 // k_syrk launch in front — with the jobs of one column pair tc / 2 on one XCD (entry index % 8), then the row's tile workgroups as srukf_gmw_build_tiles lists them
 // (without the pass-on row); every segment padded to a multiple of 8 entries (nsteps = -2).
-int srukf_gmw_fold_head_tile(int tr, int tc) { return (tr < 2 || (tr < 4 && tc < 4)) ? 1 : 0; }      // block row 0 and tile (1, 1): read unversioned by the pivot and the slab workgroups
+// How many block rows the launch in front forms: row 0 and tile (1, 1) at least — read unversioned by the pivot and the slab workgroups.  More than that because
+// forming inside the pair is worth less than forming in front of it (the jobs share SIMDs and places with the tile workgroups: §10 of DESIGN.md) and the more so the
+// fuller the machine is with tile workgroups: frames/s by head rows — N = 400 (Tp = 19): 1 2 168, 4 2 188, 8 2 130, 12 2 058 (all in front: 1 958); N = 450 (Tp = 22): 1 1 682,
+// 4 1 702, 8 1 712, 10 1 720, 14 1 686 (1 587); N = 500 (Tp = 24, fp32 storage): 1 1 370, 4 1 394, 10 1 426, 12 1 433, 14 1 450, 16 1 440, 18 1 420 (1 342).  2 (Tp - 17) fits the three.
+int srukf_gmw_fold_head_rows(int Tp)
+{
+    int v = 2 * (Tp - 17);
+    if (const char* e = getenv("SRUKF_FOLD_HEAD")) v = atoi(e);                      // (measurements)
+    return std::max(1, std::min(v, Tp - 4));
+}
+int srukf_gmw_fold_head_tile(int tr, int tc, int head_rows) { return (tr < 2 * head_rows || (tr < 4 && tc < 4)) ? 1 : 0; }
 int srukf_gmw_build_fold_list(int T, int Tp, short* out)
 {
     if (Tp <= 0 || Tp > T) Tp = T;
@@ -1251,6 +1263,7 @@ int srukf_gmw_build_fold_list(int T, int Tp, short* out)
     srukf_gmw_build_tiles(T, Tp, tk.data());
     const int nreal = nt - ((Tp < T) ? T - Tp : 0);
     const int Ilast = (Tp < T) ? Tp - 1 : T - 1;
+    const int head_rows = srukf_gmw_fold_head_rows(Tp);
     int cnt = 0;
     auto emit = [&](int a, int b, int c) { if (out) { out[4 * cnt] = (short)a; out[4 * cnt + 1] = (short)b; out[4 * cnt + 2] = (short)c; out[4 * cnt + 3] = 0; } cnt++; };
     auto pad8 = [&]() { while (cnt % 8) emit(0, 0, -2); };
@@ -1274,7 +1287,7 @@ int srukf_gmw_build_fold_list(int T, int Tp, short* out)
             for (int F = F0; F <= F1 && F <= Jc; F++)
                 for (int tc = 2 * Jc; tc <= 2 * Jc + 1; tc++)
                     for (int tr = 2 * F; tr <= 2 * F + 1 && tr <= tc; tr++)
-                        if (!srukf_gmw_fold_head_tile(tr, tc)) q[Jc % 8].push_back({ (short)tr, (short)tc });
+                        if (!srukf_gmw_fold_head_tile(tr, tc, head_rows)) q[Jc % 8].push_back({ (short)tr, (short)tc });
         size_t longest = 0;
         for (int x = 0; x < 8; x++) longest = std::max(longest, q[x].size());
         for (size_t r = 0; r < longest; r++)
@@ -1299,7 +1312,7 @@ void srukf_launch_gmw_split_fold(hipStream_t stA, hipStream_t stB, int n, int ld
     const unsigned int total = (unsigned)(T + nlist);
     hipLaunchKernelGGL(k_gmw_pivslab_persist, dim3(T), dim3(256), 0, stA, n, ld, T, Tp, G, (GmwPanel64*)pans, Sout, D, eps, (GmwSync*)sync, (FrameScalars*)fs, krows, Wslab, Lslab, total);
     hipLaunchKernelGGL(k_gmw_split_gate, dim3(1), dim3(64), 0, stB, (GmwSync*)sync, (const FrameScalars*)fs, (unsigned)T);
-    if (nlist > 0) hipLaunchKernelGGL(k_gmw_tiles_fold, dim3(nlist), dim3(256), 0, stB, n, ld, T, G, (GmwSync*)sync, (const GmwTile*)list, (FrameScalars*)fs, Wslab, Lslab, total, A, Ut, mp, krows);
+    if (nlist > 0) hipLaunchKernelGGL(k_gmw_tiles_fold, dim3(nlist), dim3(256), 0, stB, n, ld, T, G, (GmwSync*)sync, (const GmwTile*)list, (FrameScalars*)fs, Wslab, Lslab, total, A, Ut, mp, krows, srukf_gmw_fold_head_rows(Tp));
 }
 int srukf_gmw_head_rows(void) { return 64 * GMW_HEAD_ROWS; }
 int srukf_gmw_head_extra_diag(void) { return GMW_HEAD_EXTRA_DIAG; }

@@ -551,7 +551,7 @@ bool split_fold_ok(const srukf_ctx* c)
     // last update, and beyond that the forming jobs queue behind waiting workgroups — frames/s with / without the fold: N = 400 2 150 / 1 960, 500 1 385 / 1 350,
     // 600 (1 190 tile workgroups for 796 places) 855 / 893, 800 393 / 459.
     const GmwPlan& gp = c->gplan_red;
-    const bool fits = gp.nreal <= 4 * (gp.cus - gp.T);
+    const bool fits = gp.nreal <= 4 * (gp.cus - gp.T) || getenv("SRUKF_FOLD_FORCE") != nullptr;      // (the variable: measurements)
     return c->dbg.split_fold && (fits || c->dbg.split_fold == 2) && c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->split_fold_list && c->n_split_fold > 0 && c->red_head0_tiles &&
            !c->debug_starve && !c->dbg.split_record && gmw_use_persist(c) && gmw_plan_persists(c, gp) && split_form(c, gp, true);
 }
@@ -766,7 +766,8 @@ int update_null_set(srukf_ctx* c)
                 std::vector<int> th;
                 c->red_head0_flop = 0.0;
                 const int kr16 = (r + 15) & ~15;
-                for (size_t q = 0; q + 1 < tr.size(); q += 2) if (srukf_gmw_fold_head_tile(tr[q], tr[q + 1])) {
+                const int fold_head = srukf_gmw_fold_head_rows(Tp);
+                for (size_t q = 0; q + 1 < tr.size(); q += 2) if (srukf_gmw_fold_head_tile(tr[q], tr[q + 1], fold_head)) {
                     th.push_back(tr[q]); th.push_back(tr[q + 1]);
                     c->red_head0_flop += 2.0 * 32.0 * 32.0 * (std::min(32 * tr[q] + 32, kr16) + c->d.mp);
                 }

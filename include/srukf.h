@@ -79,7 +79,7 @@ typedef enum srukf_reorder { SRUKF_NEED_REORDER = 0, SRUKF_NEEDNOT_REORDER = 1 }
 /* F32_MIXED adds the mixed-precision downdate of that config: the covariance that is re-factorised, S^T S - U U^T
  * (SLAM.cpp:2118-2120, 2149), is formed on the fp32 matrix pipe from the fp32 state and U^T rounded once, in K chunks of
  * <= 1024 summed in FP64; pivots, diagonal blocks and trailing updates of the modified Cholesky stay FP64.  BATCHED
- * updates only use it (a SEQUENTIAL / single-column refactor keeps the FP64 contraction).  srukf_set_storage refuses it
+ * updates only use it (a SEQUENTIAL / single-column refactor keeps the FP64 contraction).
  * Round 6: offered at every epsilon, the reference's 1e-13 included (rounds 2 - 5 refused it below 1e-9).  Its fp32 accumulators are flushed into FP64 every 32
  * rows of K, and in the rank-aware form (the default wherever a null set exists) only the kept pivots are factored and the tiles of the robot block and of the
  * map's shared anchor are formed in FP64: within 1.2e-6 m of the fp64 filter over 3 000 frames at N = 500 (fp32 storage with FP64 arithmetic: 6.8e-7;

@@ -21,6 +21,7 @@ X, S = f.get_state()
 out = {"workload": f"N = {N}, fp32 storage, {F} frames of the benchmark sequence through srukf_run_frames in blocks of 250 (graph replay), split form of the factorisation",
        "frames_per_s_per_block": [round(r, 1) for r in rates], "frames_per_s_median": float(np.median(rates)), "max_pose_err_vs_truth_m_per_block": errs,
        "split_form_at_the_end": int(f.debug_get("split_form")), "fell_back_to_per_panel_launches": int(f.debug_get("gmw_shared") == 2), "blocks_with_abandoned_launches": flagged,
-       "state_finite": bool(np.isfinite(X).all() and np.isfinite(S).all()), "null_directions": f.null_directions()}
+       "state_finite": bool(np.isfinite(X).all() and np.isfinite(S).all()), "null_directions": f.null_directions(),
+       "split_fold_sequences_enqueued": int(f.debug_get("split_fold_seqs")), "exact_frames": int(f.debug_get("exact_frames"))}
 json.dump(out, open(f"gpurun_out/{tag}.json", "w"), indent=1)
 print(json.dumps(out))

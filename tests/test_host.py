@@ -137,6 +137,48 @@ def test_pxy2_tile_list_covers_every_tile_once(pkg):
                     assert xcd.setdefault((bt, h), slot % 8) == slot % 8
 
 
+def test_split_fold_grid_forms_every_tile_before_its_owner_waits_for_it(pkg):
+    """Grid of k_gmw_tiles_fold (srukf_gmw_build_fold_list, round 6): for every plan shape — every 32 x 32 tile of the pivoted block rows >= 1 is formed exactly once, by a job of
+    the grid or by the k_syrk launch in front (srukf_gmw_fold_head_tile); every tile workgroup of the split form's list appears exactly once and BEHIND all the jobs that form its
+    quarters (dispatch is in grid order: what it waits for is never behind it); segments are multiples of 8 entries and the jobs of one column pair sit on one XCD per segment."""
+    lib = pkg.srukf.load_library()
+    build, tiles = lib.srukf_gmw_build_fold_list, lib.srukf_gmw_build_tiles
+    build.argtypes = [C.c_int, C.c_int, C.c_void_p]; tiles.argtypes = [C.c_int, C.c_int, C.c_void_p]; head_t = lib.srukf_gmw_fold_head_tile; head_t.argtypes = [C.c_int, C.c_int, C.c_int]
+    rows = lib.srukf_gmw_fold_head_rows; rows.argtypes = [C.c_int]
+    for T, Tp in [(19, 10), (38, 19), (47, 24), (47, 47), (57, 29), (76, 38), (8, 3), (5, 5)]:
+        hr = rows(Tp)
+        assert 1 <= hr <= max(1, Tp - 4)
+        head = lambda tr, tc: head_t(tr, tc, hr)
+        cnt = build(T, Tp, None)
+        out = np.zeros(4 * max(cnt, 1), dtype=np.int16)
+        assert build(T, Tp, out.ctypes.data) == cnt and cnt % 8 == 0
+        ent = out.reshape(-1, 4)[:cnt]
+        nt = tiles(T, Tp, None)
+        tk = np.zeros(4 * max(nt, 1), dtype=np.int16); tiles(T, Tp, tk.ctypes.data)
+        nreal = nt - (T - Tp if Tp < T else 0)
+        want_tiles = {(int(a), int(b)): int(c) for a, b, c, _ in tk.reshape(-1, 4)[:nreal]}
+        Ilast = Tp - 1 if Tp < T else T - 1
+        want_jobs = {(tr, tc) for I in range(1, Ilast + 1) for tr in (2 * I, 2 * I + 1) for tc in range(tr, 2 * T) if not head(tr, tc)}
+        jobs, owners = {}, {}
+        for pos, (a, b, c, _) in enumerate(ent):
+            if c == -1:
+                assert (int(a), int(b)) not in jobs
+                jobs[(int(a), int(b))] = pos
+            elif c >= 0:
+                assert (int(a), int(b)) not in owners and want_tiles.get((int(a), int(b))) == int(c)
+                owners[(int(a), int(b))] = pos
+            else:
+                assert c == -2
+        assert set(jobs) == want_jobs and set(owners) == set(want_tiles), (T, Tp)
+        for (I, J), pos in owners.items():
+            for tr in (2 * I, 2 * I + 1):
+                for tc in (2 * J, 2 * J + 1):
+                    if tc >= tr and not head(tr, tc):
+                        assert jobs[(tr, tc)] < pos, (T, Tp, I, J)
+        # block row 0 and tile (1, 1) stay with k_syrk: what the pivot and the slab workgroups read without a version
+        assert all(head(tr, tc) for tr in (0, 1) for tc in range(tr, 2 * T)) and head(2, 2) and head(2, 3) and head(3, 3) and (hr > 1 or not head(2, 4))
+
+
 @pytest.mark.parametrize("exe", ["cslam_replay.bin", "cslam_step_bench.bin", "cslam_replay_multi.bin"])
 def test_cpp_hosts_are_built_and_print_their_usage(exe):
     """The C++ hosts of cv-monoslam_amd/host (the reference's language) link against the in-tree libraries and start without a GPU: no arguments -> usage, exit code 2."""
