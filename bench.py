@@ -495,9 +495,11 @@ def theta_clamp_leg(synth, srukf, local, sizes=(8, 200), F=20):
         tf, fl = np.asarray(t_frame), np.asarray(flagged, dtype=bool)
         out[f"n{N}"] = {"frames": done, "frames_per_s": (done / float(tf.sum())) if done else None, "flagged_frames": int(fl.sum()),
                         "exact_path_share_of_wall": (float(tf[fl].sum() / tf.sum()) if done else None),
-                        "ms_per_flagged_frame": (float(tf[fl].mean() * 1e3) if fl.any() else None), "ms_per_clean_frame": (float(tf[~fl].mean() * 1e3) if (~fl).any() else None)}
+                        "ms_per_flagged_frame": (float(tf[fl].mean() * 1e3) if fl.any() else None), "ms_of_each_flagged_frame": [round(float(v) * 1e3, 2) for v in tf[fl]],
+                        "ms_per_clean_frame": (float(tf[~fl].mean() * 1e3) if (~fl).any() else None)}
     out["note"] = ("shipped a1..a4 = 8 (SLAM.cpp:195-198), one srukf_run_frames call per frame (its fixed cost — checkpoint copy, one synchronisation — is in both kinds of "
-                   "frame); a flagged frame = blocked factorisation + rewind + 2 n column launches on the exact path")
+                   "frame); a flagged frame = blocked factorisation + rewind + the exact path (right-looking, 8 pivots per launch at N = 200: n / 8 launches; the first flagged "
+                   "frame of a process also loads that kernel)")
     return out
 
 

@@ -53,6 +53,7 @@ void srukf_launch_gmw_split_fold(hipStream_t, hipStream_t, int, int, double, dou
 int srukf_gmw_build_fold_list(int T, int Tp, short* out);
 int srukf_gmw_fold_head_tile(int tr, int tc, int head_rows);
 int srukf_gmw_fold_head_rows(int Tp);
+void srukf_gmw_fold_head_override(int v);
 void srukf_launch_gmw_split_alone(hipStream_t, int, int, int, double, double*, void*, double*, double*, void*, const void*, int, void*, int, int, double*, double*);
 void srukf_launch_row_energy(hipStream_t, int, int, const double*, double*);
 void srukf_launch_rank_diag(hipStream_t, int, int, const double*, const int*, double*);
@@ -76,6 +77,9 @@ int srukf_gmw_head_rows(void);
 int srukf_gmw_head_extra_diag(void);
 void srukf_launch_gmw_check(hipStream_t, int, int, const double*, const double*, FrameScalars*, const double*, int, double*);
 void srukf_launch_gmw_col(hipStream_t, int, int, int, double, const double*, double*, double*, unsigned long long*, FrameScalars*, double*);
+void srukf_set_exact_right_looking(int on);
+void srukf_warm_exact_path(hipStream_t st, FrameScalars* fs);
+int srukf_get_exact_right_looking(void);
 void srukf_launch_gmw_stats(hipStream_t, int, int, const double*, FrameScalars*);
 void srukf_launch_landmarks_cartesian(hipStream_t, KDims, const double*, const double*, double*, double*);
 void srukf_launch_aug_map(hipStream_t, srukf_params, int, int, int, int, double, const double*, const double*, const double*, double*);
@@ -306,6 +310,7 @@ extern thread_local std::string g_create_error;
 // srukf_debug_set switches (process-wide; srukf_debug.hip)
 extern std::atomic<int> g_dbg_gmw_persist, g_dbg_gmw_fused, g_dbg_rank_fused, g_dbg_rank_fold, g_dbg_rank_aware, g_dbg_graphs, g_dbg_mem_split, g_dbg_shared_tenants;
 extern std::atomic<int> g_dbg_batch_wide, g_dbg_batch_groups, g_dbg_batch_split, g_dbg_head_fold_free;
+extern std::atomic<int> g_dbg_timing, g_dbg_fold_head, g_dbg_fold_force;      // process-wide measurement switches (srukf_debug_set(0, "timing" / "fold_head" / "fold_force", v)): the library reads no environment variable
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -399,6 +404,7 @@ void seq_gain(srukf_ctx* c, const double* z_dev, const int* m_dev, bool fused_st
 int update_null_set(srukf_ctx* c);
 int mixed_red_ensure(srukf_ctx* c);
 void drop_graphs(srukf_ctx* c);
+void exact_path(srukf_ctx* c, const double* Gbuf, double* Sout);      // the exact column path for Gbuf -> Sout (D, theta, clamp count as side effects)
 void set_null_canonical(srukf_ctx* c);
 int read_fs(srukf_ctx* c);
 int read_fs_host(srukf_ctx* c);

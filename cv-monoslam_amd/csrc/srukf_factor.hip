@@ -1148,9 +1148,107 @@ void srukf_launch_gmw_check(hipStream_t st, int n, int ld, const double* D, cons
 {
     hipLaunchKernelGGL(k_gmw_check, dim3(n + (do_traj ? 1 : 0)), dim3(256), 0, st, n, ld, D, S, fs, X, do_traj, Scopy);
 }
+// The exact path, right-looking and blocked (round 6; SLAM.cpp:2246-2262 is written right-looking: C[r][c] -= C[j][r] C[j][c] / D_j for every r, c behind pivot j).
+// k_gmw_col above forms row j from ALL rows above it with (ld - j) / 256 <= 5 workgroups — j dependent memory round trips per thread, 37 us per pivot at n = 1 204 with
+// the machine empty, 45 ms per flagged frame.  Here one launch takes B pivots j0 .. j0 + B - 1: EVERY workgroup loads those B rows (columns j0 .. n) into LDS and factors the
+// B x (n - j0) panel itself — theta_j = the largest |C[j][c]|, c > j, over the whole row as the reference takes it, D_j = max(EPSILON, |C_jj|, theta_j^2 / beta^2), the
+// pivot applied to the panel rows behind it — redundantly, so nobody waits for anybody; then it applies the B pivots, in order, to its 32 x 256 tile of the trailing triangle.
+// Same operations on every element in the same order as one pivot per launch (B = 1 is that form: bit-identical); n / B launches and 1 / B of the trailing traffic.
+#define GMW_RL_ROWS 32
+#define GMW_RL_BMAX 8
+__global__ __launch_bounds__(256) void k_gmw_rl(int n, int ld, int j0, int B, double eps, double* __restrict__ C, double* __restrict__ D,
+                                                FrameScalars* __restrict__ fs, double* __restrict__ Sout)
+{
+    extern __shared__ double P[];                              // B rows of W = n - j0 doubles
+    __shared__ double red[4], Dsh[GMW_RL_BMAX], mrow[GMW_RL_BMAX][GMW_RL_ROWS];
+    const int tid = threadIdx.x, W = n - j0, Bn = min(B, W);
+    const int c = j0 + Bn + blockIdx.x * 256 + tid, r0 = j0 + Bn + blockIdx.y * GMW_RL_ROWS;
+    if (j0 + Bn + (int)blockIdx.x * 256 + 255 < r0) return;    // the whole tile lies under the diagonal
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    const double gamma = __longlong_as_double((long long)fs->gmax_bits);
+    const double xi = __longlong_as_double((long long)fs->ximax_bits);
+    const double nu = fmax(1.0, sqrt((double)n * n - 1.0));
+    const double beta2 = fmax(fmax(gamma, xi / nu), 1e-15);
+    for (int b = 0; b < Bn; b++)
+        for (int q = tid; q < W; q += 256) P[b * W + q] = C[(size_t)(j0 + b) * ld + j0 + q];
+    __syncthreads();
+    for (int b = 0; b < Bn; b++) {
+        double mx = 0.0;
+        for (int q = b + 1 + tid; q < W; q += 256) mx = fmax(mx, fabs(P[b * W + q]));
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        const double th = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        const double cjj = fabs(P[b * W + b]);
+        const double t2 = th * th / beta2;
+        const double Db = fmax(fmax(eps, cjj), t2);           // SLAM.cpp:2279-2285
+        if (tid == 0) {
+            Dsh[b] = Db;
+            if (first) { D[j0 + b] = Db; if (t2 > fmax(eps, cjj)) atomicAdd(&fs->clamp_rows, 1); }
+        }
+        for (int b2 = b + 1; b2 < Bn; b2++) {
+            const double m = P[b * W + b2] / Db;
+            for (int q = b2 + tid; q < W; q += 256) P[b2 * W + q] = P[b2 * W + q] - m * P[b * W + q];
+        }
+        __syncthreads();
+    }
+    if (first) {
+        for (int b = 0; b < Bn; b++) {
+            const double Db = Dsh[b], sq = sqrt(Db);
+            for (int q = b + tid; q < W; q += 256) Sout[(size_t)(j0 + b) * ld + j0 + q] = (q == b) ? sq : sq * (P[b * W + q] / Db);
+        }
+    }
+    if (tid < GMW_RL_ROWS) {
+        const int r = r0 + tid;
+        for (int b = 0; b < Bn; b++) mrow[b][tid] = (r < n) ? P[b * W + (r - j0)] / Dsh[b] : 0.0;
+    }
+    double cv[GMW_RL_BMAX];
+#pragma unroll
+    for (int b = 0; b < GMW_RL_BMAX; b++) cv[b] = (b < Bn && c < n) ? P[b * W + (c - j0)] : 0.0;
+    __syncthreads();
+    if (c >= n) return;
+    for (int rr = 0; rr < GMW_RL_ROWS; rr++) {
+        const int r = r0 + rr;
+        if (r < n && c >= r) {
+            double v = C[(size_t)r * ld + c];
+#pragma unroll
+            for (int b = 0; b < GMW_RL_BMAX; b++) if (b < Bn) v = v - mrow[b][rr] * cv[b];
+            C[(size_t)r * ld + c] = v;
+        }
+    }
+}
+static bool g_exact_right_looking = true;
+static int g_exact_rl_block = 0;                              // 0: as many pivots per launch as fit                     // srukf_debug_set(0, "exact_rl", 0): k_gmw_col (the left-looking form, one row per launch)
+void srukf_set_exact_right_looking(int on) { g_exact_right_looking = on != 0; g_exact_rl_block = on > 1 ? std::min(on - 1, GMW_RL_BMAX) : 0; }
+int srukf_get_exact_right_looking(void) { return g_exact_right_looking ? 1 : 0; }
+// The first launch of a kernel with more than 64 KB of dynamic LDS costs ~75 ms once per process (measured: the first flagged frame at N = 200 took 82 ms, the others 6.5).
+// srukf_create pays it: an empty launch (n = 0: every thread leaves at once) with the largest panel the exact path asks for.
+void srukf_warm_exact_path(hipStream_t st, FrameScalars* fs)
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    (void)hipFuncSetAttribute((const void*)k_gmw_rl, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(k_gmw_rl, dim3(1, 1), dim3(256), 144 * 1024, st, 0, 0, 0, 1, 0.0, (double*)nullptr, (double*)nullptr, fs, (double*)nullptr);
+}
 void srukf_launch_gmw_col(hipStream_t st, int n, int ld, int j, double eps, const double* G, double* Wf, double* D,
                           unsigned long long* theta_bits, FrameScalars* fs, double* Sout)
 {
+    if (g_exact_right_looking) {
+        // (callers loop j = 0 .. n - 1: the first call submits the whole sequence on a working copy of G, the others nothing)
+        if (j != 0) return;
+        hipMemcpyAsync(Wf, G, sizeof(double) * (size_t)ld * ld, hipMemcpyDeviceToDevice, st);
+        // B pivots per launch: as many rows of n doubles as fit in ~144 KB of LDS, at most 8 (srukf_debug_set(0, "exact_rl", 1 + B) forces B: tests)
+        int B = g_exact_rl_block > 0 ? g_exact_rl_block : (int)std::min<size_t>(GMW_RL_BMAX, (144 * 1024) / (sizeof(double) * (size_t)n));
+        if (B < 1) B = 1;
+        srukf_warm_exact_path(st, fs);                         // (sets the kernel's LDS limit; normally done by srukf_create)
+        for (int q = 0; q < n; q += B) {
+            const int Bn = std::min(B, n - q), rem = n - q - Bn;
+            hipLaunchKernelGGL(k_gmw_rl, dim3(rem > 0 ? (rem + 255) / 256 : 1, rem > 0 ? (rem + GMW_RL_ROWS - 1) / GMW_RL_ROWS : 1), dim3(256), sizeof(double) * (size_t)Bn * (n - q), st,
+                               n, ld, q, B, eps, Wf, D, fs, Sout);
+        }
+        return;
+    }
     // (callers loop j = 0 .. n - 1; the launch behind the last pivot finishes its row)
     hipLaunchKernelGGL(k_gmw_col, dim3((ld - j + 255) / 256), dim3(256), sizeof(double) * (size_t)(j > 0 ? j : 1), st, n, ld, j, eps, G, Wf, D, theta_bits, fs, Sout);
     if (j == n - 1) hipLaunchKernelGGL(k_gmw_col, dim3((ld - n + 255) / 256 > 0 ? (ld - n + 255) / 256 : 1), dim3(256), sizeof(double), st, n, ld, n, eps, G, Wf, D, theta_bits, fs, Sout);

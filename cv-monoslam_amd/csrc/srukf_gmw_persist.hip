@@ -1248,10 +1248,12 @@ void srukf_launch_gmw_split_alone(hipStream_t st, int which, int n, int ld, doub
 // forming inside the pair is worth less than forming in front of it (the jobs share SIMDs and places with the tile workgroups: §10 of DESIGN.md) and the more so the
 // fuller the machine is with tile workgroups: frames/s by head rows — N = 400 (Tp = 19): 1 2 168, 4 2 188, 8 2 130, 12 2 058 (all in front: 1 958); N = 450 (Tp = 22): 1 1 682,
 // 4 1 702, 8 1 712, 10 1 720, 14 1 686 (1 587); N = 500 (Tp = 24, fp32 storage): 1 1 370, 4 1 394, 10 1 426, 12 1 433, 14 1 450, 16 1 440, 18 1 420 (1 342).  2 (Tp - 17) fits the three.
+static int g_fold_head_override = 0;
+void srukf_gmw_fold_head_override(int v) { g_fold_head_override = v; }
 int srukf_gmw_fold_head_rows(int Tp)
 {
     int v = 2 * (Tp - 17);
-    if (const char* e = getenv("SRUKF_FOLD_HEAD")) v = atoi(e);                      // (measurements)
+    if (g_fold_head_override > 0) v = g_fold_head_override;                          // (measurements: srukf_debug_set(0, "fold_head", v))
     return std::max(1, std::min(v, Tp - 4));
 }
 int srukf_gmw_fold_head_tile(int tr, int tc, int head_rows) { return (tr < 2 * head_rows || (tr < 4 && tc < 4)) ? 1 : 0; }
@@ -1272,14 +1274,11 @@ int srukf_gmw_build_fold_list(int T, int Tp, short* out)
     // waiting workgroups — 805 of 836 places at N = 500 — and the forming jobs behind them got what was left: the pair took chain + forming (measured: 510 us
     // against 327 + 212 one after the other).  The slabs of every panel stay in Wslab / Lslab, so a tile workgroup may arrive late and catch up: row I stands
     // behind the jobs of row place(I) = max(I, lead_a I - lead_b) — about three panels (+ its catch-up time) before the chain needs it.
-    double lead_a = 1.38, lead_b = 4.6;
-    if (const char* e = getenv("SRUKF_FOLD_LEAD")) sscanf(e, "%lf,%lf", &lead_a, &lead_b);       // (measurements)
+    const double lead_a = 1.38, lead_b = 4.6;
     auto place = [&](int I) { const int f = (int)floor(lead_a * I - lead_b); return std::min(Ilast, std::max(I, f)); };
     // Segments of `rows` block rows (the first `single` rows one by one: the chain waits for them): within a segment the jobs of one column pair stand together on
     // their XCD, row after row, so the pair's operand slab crosses the fabric once per segment instead of once per row.
-    int rows = 2, single = 2;
-    if (const char* e = getenv("SRUKF_FOLD_ROWS")) sscanf(e, "%d,%d", &rows, &single);            // (measurements)
-    if (rows < 1) rows = 1;
+    const int rows = 2, single = 2;
     for (int F0 = 1; F0 <= Ilast;) {
         const int F1 = std::min(Ilast, F0 <= single ? F0 : F0 + rows - 1);
         std::vector<std::pair<short, short>> q[8];

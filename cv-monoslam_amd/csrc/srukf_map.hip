@@ -5,12 +5,12 @@
 #include <chrono>
 using namespace srukf_impl;
 
-// SRUKF_MAP_TIMING=1 in the environment: wall time of the phases of a map change on stderr (measurement: where do the milliseconds of srukf_add_landmarks /
+// srukf_debug_set(0, "timing", 1): wall time of the phases of a map change on stderr (measurement: where do the milliseconds of srukf_add_landmarks /
 // srukf_delete_landmark go — the device work or the context that is rebuilt around it?)
 namespace {
 struct MapTimer {
     bool on; const char* what; std::chrono::steady_clock::time_point t0, tl; std::string line;
-    explicit MapTimer(const char* w) : on(getenv("SRUKF_MAP_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()), tl(t0) {}
+    explicit MapTimer(const char* w) : on(g_dbg_timing.load() != 0), what(w), t0(std::chrono::steady_clock::now()), tl(t0) {}
     void mark(const char* label) {
         if (!on) return;
         const auto t = std::chrono::steady_clock::now();

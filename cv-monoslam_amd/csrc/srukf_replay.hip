@@ -534,8 +534,7 @@ void seq_refactor(srukf_ctx* c, int ub, int ue, bool slow, bool keep_backup, boo
         srukf_launch_gmw_check(c->stream, n, np, c->D, fused ? c->Wf : c->S, c->fs, c->X, frame_tail ? 1 : 0, fused ? c->S : nullptr);
     } else {
         ProfScope ps(c, KC_GMW_COL, (double)n * n * n / 3.0, 8.0 * (double)n * n * n / 3.0);
-        for (int j = 0; j < n; j++)
-            srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+        exact_path(c, c->G, c->S);
         quantize_state(c);
         if (frame_tail) srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     }
@@ -551,7 +550,7 @@ bool split_fold_ok(const srukf_ctx* c)
     // last update, and beyond that the forming jobs queue behind waiting workgroups — frames/s with / without the fold: N = 400 2 150 / 1 960, 500 1 385 / 1 350,
     // 600 (1 190 tile workgroups for 796 places) 855 / 893, 800 393 / 459.
     const GmwPlan& gp = c->gplan_red;
-    const bool fits = gp.nreal <= 4 * (gp.cus - gp.T) || getenv("SRUKF_FOLD_FORCE") != nullptr;      // (the variable: measurements)
+    const bool fits = gp.nreal <= 4 * (gp.cus - gp.T) || g_dbg_fold_force.load() != 0;      // ("fold_force": measurements)
     return c->dbg.split_fold && (fits || c->dbg.split_fold == 2) && c->red_r > 0 && c->storage != SRUKF_STORAGE_F32_MIXED && c->split_fold_list && c->n_split_fold > 0 && c->red_head0_tiles &&
            !c->debug_starve && !c->dbg.split_record && gmw_use_persist(c) && gmw_plan_persists(c, gp) && split_form(c, gp, true);
 }
@@ -591,6 +590,15 @@ void launch_gmw_fast(srukf_ctx* c, double* Gbuf, double* Sout, bool reduced, boo
         srukf_launch_gmw_step64(c->stream, n, np, j0, c->p.epsilon, Gbuf, c->pan[pb ^ 1], c->pan[pb], c->D, Sout, c->fs);
 }
 
+// The exact path: n + 1 launches behind one call (srukf_launch_gmw_col submits the right-looking sequence on its first call).  Launch-bound: 13.6 ms per flagged frame at
+// N = 200 for ~5 ms of kernels.  As ONE captured graph per context it measured worse where it counts (38.8 ms per flagged frame over bench.py's 20-frame leg with three flagged
+// frames: instantiating 1 205 nodes costs more than the two replays save), so the launches stay eager.
+void exact_path(srukf_ctx* c, const double* Gbuf, double* Sout)
+{
+    const int np = c->d.np, n = c->d.n;
+    for (int j = 0; j < n; j++) srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, Gbuf, c->Wf, c->D, c->theta, c->fs, Sout);
+}
+
 void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow)
 {
     const int np = c->d.np, n = c->d.n;
@@ -599,7 +607,7 @@ void run_gmw(srukf_ctx* c, double* Gbuf, double* Sout, bool slow)
         srukf_launch_gmw_check(c->stream, n, np, c->D, Sout, c->fs, c->X, 0, nullptr);
     } else {
         hipLaunchKernelGGL(k_refactor_reset, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->theta, c->fs, 0);
-        for (int j = 0; j < n; j++) srukf_launch_gmw_col(c->stream, n, np, j, c->p.epsilon, Gbuf, c->Wf, c->D, c->theta, c->fs, Sout);
+        exact_path(c, Gbuf, Sout);
     }
 }
 
@@ -978,23 +986,32 @@ static int run_staged_frame_exact(srukf_ctx* c, int frame, double* traj_row)
 {
     const KDims& d = c->d;
     c->exact_frames++;
+    const bool timing = g_dbg_timing.load() != 0;              // (srukf_debug_set(0, "timing", 1): where a flagged frame's milliseconds go, on stderr)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    auto lap = [&](const char* what) { if (timing) { hipStreamSynchronize(c->stream); auto t1 = now(); fprintf(stderr, "[exact frame] %s %.0f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count()); t0 = t1; } };
     double* tb = traj_row ? traj_row - (size_t)8 * frame : nullptr;
     hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, frame, 1);
     hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, tb);
     seq_predict_motion(c, nullptr);
     seq_predict_measurement(c, true);
+    lap("predict");
     seq_gain(c, nullptr, nullptr, true);
+    lap("gain");
     seq_refactor(c, 0, d.mp, false, true, false, false);
     int rc = read_fs(c); if (rc) return rc;
+    lap("blocked refactor");
     if (c->hfs->clamp_rows > 0) {
         hipLaunchKernelGGL(k_set_frame, dim3(1), dim3(1), 0, c->stream, c->fs, frame, 1);
         hipLaunchKernelGGL(k_set_traj, dim3(1), dim3(1), 0, c->stream, c->fs, tb);
         hipLaunchKernelGGL(k_refactor_reset, dim3((d.np + 255) / 256), dim3(256), 0, c->stream, d.np, c->theta, c->fs, 0);
         HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
         ProfScope ps(c, KC_GMW_COL, 0, 0);
-        for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+        exact_path(c, c->G, c->S);
         quantize_state(c);
+        lap("exact path");
         rc = update_null_set(c); if (rc) return rc;      // the null set is re-derived from the exact factor (see srukf_update)
+        lap("null set");
     } else if (c->storage != SRUKF_STORAGE_F32_MIXED || storage_f32_like(c)) set_null_canonical(c);
     srukf_launch_traj(c->stream, d, c->X, c->S, c->fs, nullptr, 1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1138,14 +1155,19 @@ int srukf_run_frames(srukf_ctx* c, int first, int count, int mode, double* traj_
         else { if (c->null_canonical != ck_canon) { c->null_canonical = ck_canon; drop_graphs(c); } quantize_state(c); shadow_rebuild(c); }
     };
     int rc = SRUKF_OK, done = 0;
+    const bool timing = g_dbg_timing.load() != 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (timing) { hipStreamSynchronize(c->stream); auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[run_frames] %s %.0f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count()); t0 = t1; } };
     while (done < count) {
         checkpoint(true);
         rc = srukf_run_frames_async(c, first + done, count - done, mode, dt + (size_t)8 * done);
         if (rc == SRUKF_OK) rc = srukf_synchronize(c);
         if (rc != SRUKF_ERR_CLAMP_PENDING) break;
+        lap("flagged attempt");
         const int fc = c->clamp_frame_host;                               // absolute index of the first flagged frame
         if (fc < first + done || fc >= first + count) { c->err = "run_frames: flagged frame outside the block"; rc = SRUKF_ERR_HIP; break; }
         checkpoint(false);
+        lap("rewind");
         const int good = fc - (first + done);
         if (good > 0) {
             rc = srukf_run_frames_async(c, first + done, good, mode, dt + (size_t)8 * done);

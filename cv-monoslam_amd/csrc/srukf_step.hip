@@ -339,7 +339,7 @@ static int step_update_slow(srukf_ctx* c, const double* z, const int* matched, i
             launch_refactor_reset(c->stream, d.np, c->theta, c->fs, 0);
             HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
             ProfScope ps(c, KC_GMW_COL, 0, 0);
-            for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+            exact_path(c, c->G, c->S);
             quantize_state(c);
         }
     } else {
@@ -358,7 +358,7 @@ static int step_update_slow(srukf_ctx* c, const double* z, const int* matched, i
                     launch_set_frame(c->stream, c->fs, 0, 1);
                     launch_refactor_reset(c->stream, d.np, c->theta, c->fs, 0);
                     HIPCHK(c, hipMemcpyAsync(c->G, c->Gbak, sizeof(double) * (size_t)d.np * d.np, hipMemcpyDeviceToDevice, c->stream));
-                    for (int j = 0; j < d.n; j++) srukf_launch_gmw_col(c->stream, d.n, d.np, j, c->p.epsilon, c->G, c->Wf, c->D, c->theta, c->fs, c->S);
+                    exact_path(c, c->G, c->S);
                     quantize_state(c);
                     launch_set_frame(c->stream, c->fs, 0, 1);
                 }

@@ -46,6 +46,7 @@ int main(int argc, char** argv)
         else if (!strncmp(argv[a], "churn=", 6)) churn = atoi(argv[a] + 6);
         else if (!strncmp(argv[a], "set=", 4)) { const char* q = strchr(argv[a] + 4, ':'); if (!q) { fprintf(stderr, "set=key:value\n"); return 2; } sets.emplace_back(std::string((const char*)argv[a] + 4, (size_t)(q - (argv[a] + 4))), atoi(q + 1)); }
     }
+    for (auto& kv : sets) (void)srukf_debug_set(nullptr, kv.first.c_str(), kv.second);      // process-wide keys (e.g. set=timing:1) apply in every mode; per-filter keys: mode=capi, below
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     int N = 0, F = 0; double a4[4];

@@ -1,5 +1,5 @@
 #!/bin/bash
-# where do the milliseconds of a map change go?  cslam_step_bench mode=facade churn=10 with SRUKF_MAP_TIMING=1 (phases of srukf_add_landmarks / srukf_delete_landmark on stderr)
+# where do the milliseconds of a map change go?  cslam_step_bench mode=facade churn=10 with set=timing:1 (srukf_debug_set(0, "timing", 1): phases of srukf_add_landmarks / srukf_delete_landmark on stderr)
 #   bash scripts/churn_probe.sh [N] [frames]
 N=${1:-200}; K=${2:-60}
 python - <<PY
@@ -17,5 +17,5 @@ with open("gpurun_out/churn_odo.txt", "w") as fh:
     for i, (x, y, th) in enumerate(sc["odo"]):
         fh.write(f"{i + 1} : {0.1 * i:.3f} {float(x)!r} {float(y)!r} {float(th)!r}\n")
 PY
-SRUKF_MAP_TIMING=1 cv-monoslam_amd/cslam_step_bench.bin gpurun_out/churn_scene.bin gpurun_out/churn_odo.txt mode=facade churn=10 frames=$K warmup=20 2> gpurun_out/churn_timing.txt | cut -c1-1200
+cv-monoslam_amd/cslam_step_bench.bin gpurun_out/churn_scene.bin gpurun_out/churn_odo.txt mode=facade churn=10 frames=$K warmup=20 set=timing:1 2> gpurun_out/churn_timing.txt | cut -c1-1200
 grep "map timing" gpurun_out/churn_timing.txt | tail -8

@@ -14,6 +14,9 @@ pkg = ge.load_package()
 synth, srukf = pkg.synth, pkg.srukf
 if os.environ.get('LIB'):
     srukf.load_library(os.path.join(ROOT, os.environ['LIB']))      # an A/B build (scripts/build_variants.sh)
+for k_, v_ in (("fold_head", os.environ.get("FOLD_HEAD")), ("fold_force", os.environ.get("FOLD_FORCE"))):
+    if v_:
+        srukf.debug_set_global(k_, int(v_))      # measurements: head rows of the split fold / the fold where it does not fit
 for arg in (sys.argv[1:] or ["400", "500:f32"]):
     N = int(arg.split(":")[0]); storage = arg.split(":")[1] if ":" in arg else "f64"
     F = int(os.environ.get('FRAMES', 24))
