@@ -1,10 +1,12 @@
+"""The exact path's forms on ONE matrix with active theta clamps (tiny diagonal entries under O(1) off-diagonals), through srukf_gmw_host with force_slow: left-looking k_gmw_col
+(exact_rl 0), right-looking one pivot per launch (exact_rl 2), right-looking 8 pivots per launch (default) — clamp counts, D, P = S^T S against each other (against the oracle:
+tests/test_gpu_parity_r4.py::test_exact_path_forms_under_active_theta_clamps).   python scripts/exact_gmw_check.py"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 pkg = ge.load_package(); srukf = pkg.srukf
-from oracle import oracle as O
 rng = np.random.default_rng(5)
 for n in (40, 300, 1204):
     A = rng.standard_normal((n + 10, n)); G = A.T @ A
@@ -21,7 +23,3 @@ for n in (40, 300, 1204):
     print(n, "hits", {k_: v[2] for k_, v in out.items()}, "rl1==rlb", np.array_equal(out["rl1"][0], out["rlb"][0]),
           "max|D ll-rlb|/D %.2e" % (np.abs(out["ll"][1] - out["rlb"][1]) / np.abs(out["ll"][1])).max(),
           "max|P ll-rlb| %.2e (scale %.2e)" % (np.abs(P["ll"] - P["rlb"]).max(), np.abs(P["ll"]).max()))
-    if n <= 300:
-        ro = O.gmw(G)
-        So = ro[0]
-        print("   oracle: max|P o-ll| %.2e, max|P o-rlb| %.2e, rest %s" % (np.abs(So.T @ So - P["ll"]).max(), np.abs(So.T @ So - P["rlb"]).max(), [type(x).__name__ if hasattr(x, "shape") else x for x in ro[1:]]))

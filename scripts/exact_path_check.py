@@ -13,8 +13,7 @@ import __graft_entry__ as ge  # noqa: E402
 pkg = ge.load_package()
 synth, srukf = pkg.synth, pkg.srukf
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-p = synth.scene_params()
-p.update(a1=8.0, a2=8.0, a3=8.0, a4=8.0)
+p = synth.default_params()                             # the shipped a1 .. a4 = 8: bench.py's theta_clamp scene (the filter it describes diverges after ~10 frames at N = 200: DESIGN.md)
 sc = synth.make_scene(N, 12, seed=1, p=p)
 res = {}
 for name, v in (("left_looking", 0), ("right_looking_b1", 2), ("right_looking_blocked", 1)):
@@ -29,6 +28,5 @@ for name, v in (("left_looking", 0), ("right_looking_b1", 2), ("right_looking_bl
 srukf.debug_set_global("exact_rl", 1)
 a, b, c = res["left_looking"], res["right_looking_b1"], res["right_looking_blocked"]
 print("blocked == one pivot per launch bit for bit:", all(np.array_equal(x, y) for x, y in zip(b, c)))
-print("left-looking vs blocked: max |dX| %.2e, max |dP| %.2e" % (np.abs(a[0] - c[0]).max(), np.abs(a[1].T @ a[1] - c[1].T @ c[1]).max()))
 for t in range(12):
     print(f"frame {t}: pose left-looking - blocked {np.abs(a[2][t, :4] - c[2][t, :4]).max():.2e}; error vs truth left-looking {np.abs(a[2][t, :2] - sc['odo'][t + 1, :2]).max():.2e}, blocked {np.abs(c[2][t, :2] - sc['odo'][t + 1, :2]).max():.2e}")

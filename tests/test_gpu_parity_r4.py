@@ -266,3 +266,31 @@ def test_batched_filters_at_n400_against_the_split_form_run_alone(srukf, synth):
         g.close()
     for f in fs:
         f.close()
+
+
+@pytest.mark.parametrize("n", [40, 300])
+def test_exact_path_forms_under_active_theta_clamps(srukf, oracle, n):
+    """The exact path (what a flagged frame is repeated on) in its three forms — left-looking k_gmw_col (srukf_debug_set "exact_rl" 0), right-looking with one pivot per launch
+    (2) and with 8 pivots per launch (default, round 6) — on a matrix whose tiny diagonal entries under O(1) off-diagonals make the reference's theta clamp
+    (SLAM.cpp:2279-2285) win at dozens of pivots: the same clamp count as the oracle's modifiedCholeskyDecomposition, P = S^T S within 1e-13 of the matrix' scale, and the two
+    right-looking forms bit for bit (same operations on every element in the same order)."""
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n + 10, n)); G = A.T @ A
+    k = n // 3
+    for kk in (k, k + 7, 2 * k):
+        G[kk, kk] = 1e-7
+    G[:, n - 5:] *= 1e-4; G[n - 5:, :] *= 1e-4
+    So, Do, _, ce, ct = oracle.gmw(G)
+    assert ct > 10                                                       # the theta clamp is active at many pivots
+    Po, out = So.T @ So, {}
+    try:
+        for name, v in (("left", 0), ("right_1", 2), ("right_8", 1)):
+            srukf.debug_set_global("exact_rl", v)
+            out[name] = srukf.gmw(G, force_slow=True)
+    finally:
+        srukf.debug_set_global("exact_rl", 1)
+    scale = np.abs(Po).max()
+    for name, (S, D, hit) in out.items():
+        assert hit == ct, (name, hit, ct)
+        assert np.abs(S.T @ S - Po).max() <= 1e-13 * scale and np.abs(D - Do).max() <= 1e-12 * np.abs(Do).max(), name
+    assert np.array_equal(out["right_1"][0], out["right_8"][0]) and np.array_equal(out["right_1"][1], out["right_8"][1])
