@@ -23,7 +23,7 @@ struct BatchPlan {
 // batches for filters on several devices (round-4 advisor finding: streams created once on whichever device came first).
 // The groups' streams: created together, once per device, so that they sit on different hardware queues whatever the filters' own streams map to (streams that share a
 // queue serialise: with the groups on their first filters' streams, 4 + 4 filters ran slower than 4 alone).  They go when the device's last plan goes.
-struct BatchDev { BatchPlan* plans[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr }; hipStream_t streams[SRUKF_BATCH_GROUPS_MAX] = { nullptr, nullptr, nullptr, nullptr }; };
+struct BatchDev { BatchPlan* plans[SRUKF_BATCH_GROUPS_MAX] = {}; hipStream_t streams[SRUKF_BATCH_GROUPS_MAX] = {}; };
 static thread_local std::map<int, BatchDev> g_batch_dev;
 static hipStream_t batch_stream(int device, int grp)
 {

@@ -107,7 +107,10 @@ int srukf_app_tmpl_stride(void);
 #define SRUKF_GRAPH_FRAMES 8
 #define SRUKF_MAX_TENANTS 4                                    // 4 x (1 pivot + 63 workers with two register tiles each) fill 256 CUs at N = 200
 #define SRUKF_NULL_ENERGY 1e-12
-#define SRUKF_BATCH_GROUPS_MAX 4                              // groups of filters srukf_run_frames_batch runs side by side, each on a stream of its own
+#ifndef SRUKF_BATCH_GROUPS_MAX
+#define SRUKF_BATCH_GROUPS_MAX 4
+#endif
+//                                                          // groups of filters srukf_run_frames_batch runs side by side, each on a stream of its own
 
 enum KClass { KC_MOTION = 0, KC_PROJECT, KC_STATS, KC_PXY, KC_GAIN, KC_SYRK, KC_GMW_TRAIL, KC_GMW_PERSIST, KC_GMW_CHECK,
               KC_GMW_COL, KC_RANK_EXPAND, KC_PROJECT_MOTION, KC_PROJECT_TABLE, KC_PXY2, KC_MISC, KC_COUNT };

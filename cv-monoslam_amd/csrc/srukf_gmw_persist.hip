@@ -448,6 +448,9 @@ struct GmwTile { short I, J, nsteps, pad; };
 // GMW_HEAD_EXTRA_DIAG = 2: the 2 x 2 block of tiles behind the head rows, (2,2), (2,3), (3,3) — the third panel's iteration still waited ~2 us for (3,3).
 #define GMW_HEAD_EXTRA_DIAG 2
 __device__ __forceinline__ bool gmw_owner_computes(int I, int J) { return I >= GMW_HEAD_ROWS && !(I < GMW_HEAD_ROWS + GMW_HEAD_EXTRA_DIAG && J < GMW_HEAD_ROWS + GMW_HEAD_EXTRA_DIAG); }
+// DEEP: four rotating fragment buffers (a wave that has its SIMD to itself: the owners of the persistent launch); otherwise the double-buffered loop of k_syrk (128
+// registers less: four waves per SIMD hide the latency instead — the batched launch, where a SIMD is shared).  Same products in the same order either way.
+template <bool DEEP = true>
 __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1,
                                                int I, int J, d4 (&acc)[2][2], FrameScalars* __restrict__ fs, int tid, int krows)
 {
@@ -455,8 +458,13 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
     const int m0 = 64 * I + 32 * (wv >> 1), c0 = 64 * J + 32 * (wv & 1);
     zero_acc(acc);
     if (m0 >= d.ld || c0 >= d.ld || c0 + 32 <= m0) return;
-    tile32_tn_deep<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, krows), lane);     // S0[k][r] = 0 for k > r and for k >= krows
-    tile32_tn_deep<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
+    if constexpr (DEEP) {
+        tile32_tn_deep<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, krows), lane);     // S0[k][r] = 0 for k > r and for k >= krows
+        tile32_tn_deep<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
+    } else {
+        tile32_tn<false>(acc, S0, d.ld, S0, d.ld, m0, c0, 0, min(m0 + 32, krows), lane);
+        tile32_tn<true>(acc, Ut0, d.ld, Ut0, d.ld, m0, c0, u0, u1, lane);
+    }
     double gmax = 0.0, xmax = 0.0;                             // gamma / xi of the GMW bound, as in k_syrk
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -479,6 +487,7 @@ __device__ __forceinline__ void gmw_owner_syrk(const KDimsLite d, const double* 
 // result of the launch whose owners fold.  Used where a worker owns two register tiles (filters that share the GPU with three or four tenants: forming both tiles
 // before the first step would hold up the pivot chain), so that a filter's results do not depend on how many filters run beside it.
 // One workgroup per tile of the persistent launch's list, longest K first; tiles the head launch covers leave at once.
+template <bool DEEP>
 __device__ __forceinline__ void syrk_own_body(int n, int ld, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows,
                                               double* __restrict__ G, FrameScalars* __restrict__ fs, const GmwTile* __restrict__ tiles, int nreal, const int bid)
 {
@@ -487,7 +496,7 @@ __device__ __forceinline__ void syrk_own_body(int n, int ld, const double* __res
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
     d4 acc[2][2];
     const KDimsLite dl = { n, ld };
-    gmw_owner_syrk(dl, S0, Ut0, u0, u1, t.I, t.J, acc, fs, tid, krows);
+    gmw_owner_syrk<DEEP>(dl, S0, Ut0, u0, u1, t.I, t.J, acc, fs, tid, krows);
     const int m0 = 64 * t.I + 32 * (wv >> 1), c0 = 64 * t.J + 32 * (wv & 1);
     if (m0 >= ld || c0 >= ld || c0 + 32 <= m0) return;         // (what gmw_tile_update's `live` loads)
 #pragma unroll
@@ -500,14 +509,17 @@ __device__ __forceinline__ void syrk_own_body(int n, int ld, const double* __res
 __global__ __launch_bounds__(256) void k_syrk_own(int n, int ld, const double* __restrict__ S0, const double* __restrict__ Ut0, int u0, int u1, int krows,
                                                   double* __restrict__ G, FrameScalars* __restrict__ fs, const GmwTile* __restrict__ tiles, int nreal)
 {
-    syrk_own_body(n, ld, S0, Ut0, u0, u1, krows, G, fs, tiles, nreal, (int)blockIdx.x);
+    syrk_own_body<true>(n, ld, S0, Ut0, u0, u1, krows, G, fs, tiles, nreal, (int)blockIdx.x);
 }
 // batched form: workgroup index = tile B + f (the B filters' longest tiles first)
-__global__ __launch_bounds__(256) void k_syrk_own_b(int n, int ld, const SyrkOwnArgs* __restrict__ tab, int B, int u0, int u1, int krows, const GmwTile* __restrict__ tiles, int nreal)
+#ifndef SYRK_OWN_B_DEEP
+#define SYRK_OWN_B_DEEP false
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_syrk_own_b(int n, int ld, const SyrkOwnArgs* __restrict__ tab, int B, int u0, int u1, int krows, const GmwTile* __restrict__ tiles, int nreal)
 {
     const int f = (int)blockIdx.x % B, bid = (int)blockIdx.x / B;
     const SyrkOwnArgs a = tab[f];
-    syrk_own_body(n, ld, a.S0, a.Ut0, u0, u1, krows, a.G, a.fs, tiles, nreal, bid);
+    syrk_own_body<SYRK_OWN_B_DEEP>(n, ld, a.S0, a.Ut0, u0, u1, krows, a.G, a.fs, tiles, nreal, bid);
 }
 
 // Admission of persistent launches when several filters share the GPU (srukf_set_exclusive(ctx, 0)): every such launch keeps to
