@@ -461,10 +461,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     pxy2_body<false>(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x, GainFold{});
 }
 // the same with the gain fold compiled in (the "gain_fold" switch, off by default: DESIGN.md 10 — the fold's code in the plain kernel cost it 4 us, so it is a kernel of its own)
-#ifndef FOLD_WAVES
-#define FOLD_WAVES 4
-#endif
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(FOLD_WAVES, 4))) void k_pxy2_fold(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pxy2_fold(KDims d, const double* __restrict__ DZp, const double* __restrict__ A, double* __restrict__ P0, double* __restrict__ P1,
                                               const int4* __restrict__ tiles, int ntiles, int kr, KWeights w, MeasArgs ms, GainFold gf)
 {
     pxy2_body<true>(d, DZp, A, P0, P1, tiles, ntiles, kr, w, ms, (int)blockIdx.x, gf);

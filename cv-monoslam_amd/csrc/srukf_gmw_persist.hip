@@ -512,14 +512,11 @@ __global__ __launch_bounds__(256) void k_syrk_own(int n, int ld, const double* _
     syrk_own_body<true>(n, ld, S0, Ut0, u0, u1, krows, G, fs, tiles, nreal, (int)blockIdx.x);
 }
 // batched form: workgroup index = tile B + f (the B filters' longest tiles first)
-#ifndef SYRK_OWN_B_DEEP
-#define SYRK_OWN_B_DEEP false
-#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_syrk_own_b(int n, int ld, const SyrkOwnArgs* __restrict__ tab, int B, int u0, int u1, int krows, const GmwTile* __restrict__ tiles, int nreal)
 {
     const int f = (int)blockIdx.x % B, bid = (int)blockIdx.x / B;
     const SyrkOwnArgs a = tab[f];
-    syrk_own_body<SYRK_OWN_B_DEEP>(n, ld, a.S0, a.Ut0, u0, u1, krows, a.G, a.fs, tiles, nreal, bid);
+    syrk_own_body<false>(n, ld, a.S0, a.Ut0, u0, u1, krows, a.G, a.fs, tiles, nreal, bid);
 }
 
 // Admission of persistent launches when several filters share the GPU (srukf_set_exclusive(ctx, 0)): every such launch keeps to
@@ -960,13 +957,8 @@ __device__ __forceinline__ void gmw_form_job(int n, int ld, int krows, const dou
     const int ke = min(m0 + 32, krows);
     const int ngs = ke >> 4, ngu = mp >> 4, ng = ngs + ngu;
     const int g0 = (ng * wv) >> 2, g1 = (ng * (wv + 1)) >> 2;
-#if defined(SF_EXP) && SF_EXP == 4
-    const int lds = 0;                                         // (measurement build: every k-step reads the operands' first rows — the arithmetic without its memory traffic)
-#else
-    const int lds = ld;
-#endif
-    if (g0 < ngs) tile32_tn<false>(acc, A, lds, A, lds, m0, n0, g0 << 4, min(g1, ngs) << 4, lane);
-    if (g1 > ngs) tile32_tn<true>(acc, Ut, lds, Ut, lds, m0, n0, (max(g0, ngs) - ngs) << 4, (g1 - ngs) << 4, lane);
+    if (g0 < ngs) tile32_tn<false>(acc, A, ld, A, ld, m0, n0, g0 << 4, min(g1, ngs) << 4, lane);
+    if (g1 > ngs) tile32_tn<true>(acc, Ut, ld, Ut, ld, m0, n0, (max(g0, ngs) - ngs) << 4, (g1 - ngs) << 4, lane);
     splitk_reduce(acc, red, wv, lane);
     if (wv != 0) return;
     const int lr = lane & 15, lk = lane >> 4;
@@ -979,9 +971,6 @@ __device__ __forceinline__ void gmw_form_job(int n, int ld, int krows, const dou
             for (int t = 0; t < 4; t++) {
                 const int r = m0 + 16 * a + lk + 4 * t, c = n0 + 16 * b + lr;
                 const double v = acc[a][b][t];
-#if defined(SF_EXP) && SF_EXP >= 3
-                if (fs->frame == -12345)                       // (measurement build: the arithmetic and its operand traffic without the result)
-#endif
                 st_dev(&G[(size_t)r * ld + c], v);             // read by a tile workgroup of this launch, on whatever XCD
                 if (r < n && c < n) { if (r == c) gmax = fmax(gmax, v); else xmax = fmax(xmax, v); }
             }
@@ -1092,22 +1081,17 @@ void k_gmw_tiles_fold(int n, int ld, int T, double* __restrict__ G, GmwSync* __r
 {
     __shared__ int ok;
     __shared__ double red[3][64][17];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int tid = threadIdx.x;
     const unsigned long long tq = ((const unsigned long long*)list)[blockIdx.x];
     int frozen_now = fs->frozen;
     unsigned long long epoch_now = sy->epoch;
     if (frozen_now) return;
     const unsigned long long ebase = epoch_now << GMW_EPOCH_SHIFT;
     const int I = (int)(short)(tq & 0xffff), J = (int)(short)((tq >> 16) & 0xffff), ns = (int)(short)((tq >> 32) & 0xffff);
-    const bool wv0 = __builtin_amdgcn_readfirstlane(wv) == 0;
-    unsigned long long* ver = gmw_sync_ver(sy);
-    const unsigned long long* slabver = gmw_sync_slabver(sy, T);
     unsigned long long* formver = gmw_sync_formver(sy, T);
     if (ns == -1) {
         // ---- forming job: the 32 x 32 tile (I, J) of 32-row units ----
-#if !defined(SF_EXP) || SF_EXP != 1
         gmw_form_job(n, ld, krows, A, Ut, mp, I, J, G, fs, red, tid);
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // wave 0's stores have landed
         if (tid == 0) {
             // count the quarter in its 64 x 64 tile's word: values of older launches are replaced (the words never need clearing), the quarters of this one add up
