@@ -354,6 +354,7 @@ int srukf_destroy(srukf_ctx* c)
     hipSetDevice(c->device);
     for (srukf_ctx* r : c->retired) srukf_destroy(r);            // (they launch on this handle's stream: before it goes)
     c->retired.clear();
+    if (c->spare_stage) { hipHostFree(c->spare_stage); c->spare_stage = nullptr; c->spare_stage_bytes = 0; }
     batch_plan_forget(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     // the side streams too, BEFORE any buffer goes back to the pool: the step-wise fast path returns as soon as the tail raises its pinned flag and has by then queued
@@ -399,6 +400,15 @@ void ctx_retire(srukf_ctx* handle, srukf_ctx* old)
 {
     drop_graphs(old);
     old->own_stream = false;
+    // its pinned staging area goes to the handle: the next context this handle creates or revives takes it (srukf_create's hipHostMalloc of np^2 doubles was 2.5 of the
+    // 3.5 ms a map change to a size not seen before cost)
+    if (old->hstage) {
+        if (!handle->spare_stage || handle->spare_stage_bytes < old->hstage_bytes) {
+            if (handle->spare_stage) hipHostFree(handle->spare_stage);
+            handle->spare_stage = old->hstage; handle->spare_stage_bytes = old->hstage_bytes;
+        } else hipHostFree(old->hstage);
+        old->hstage = nullptr; old->hstage_bytes = 0;
+    }
     handle->retired.push_back(old);
     // How many: a map that breathes by +- 1 around a size revisits ~16 sizes (bench.py's churn leg: 200 -> 185 landmarks), and destroying the context that falls out of
     // the list is the expensive part of a miss (2.6 of 3.6 ms at N = 200: ~60 device frees).  Up to 32 contexts or ~16 GB of them (a context is ~14 matrices of np^2 doubles).
@@ -435,11 +445,18 @@ int ctx_obtain(srukf_ctx* handle, srukf_ctx** out, int N)
         srukf_ctx* r = handle->retired[q];
         if (r->d.N != N || r->device != handle->device || r->stream != handle->stream || memcmp(&r->p, &handle->p, sizeof(srukf_params)) != 0) continue;
         handle->retired.erase(handle->retired.begin() + (long)q);
+        if (!r->hstage) {                                       // (retired contexts keep no staging area: ctx_retire)
+            const size_t need = sizeof(double) * ((size_t)r->d.np * r->d.np + 4096);
+            if (handle->spare_stage && handle->spare_stage_bytes >= need) { r->hstage = handle->spare_stage; r->hstage_bytes = handle->spare_stage_bytes; handle->spare_stage = nullptr; handle->spare_stage_bytes = 0; }
+            else if (hipHostMalloc((void**)&r->hstage, need) == hipSuccess) r->hstage_bytes = need;
+            else { r->hstage = nullptr; srukf_destroy(r); break; }
+        }
         if (ctx_revive(r) == SRUKF_OK) { *out = r; return SRUKF_OK; }
         srukf_destroy(r);
         break;
     }
     // (nothing to revive: a new context.  The retired one keeps its side stream for its next life; the new one finds its own — split_ensure)
+    if (handle->spare_stage && !g_spare_stage) { g_spare_stage = handle->spare_stage; g_spare_stage_bytes = handle->spare_stage_bytes; handle->spare_stage = nullptr; handle->spare_stage_bytes = 0; }
     return srukf_create(out, N, &handle->p, handle->device, handle->stream);
 }
 

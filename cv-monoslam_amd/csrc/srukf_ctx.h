@@ -277,6 +277,7 @@ struct srukf_ctx {
     bool robot_cached = false;             // the 20 doubles behind *hfs hold P4 and the pose of the CURRENT state (fast path: fetched with the frame's status)
     bool f32_stale = false;                // fp32 storage: X32 / S32 (srukf_get_state_f32) are behind the rounded fp64 working copies (refreshed on demand)
     int step_fast_frames = 0, step_slow_frames = 0;   // srukf_debug_get "step_fast" / "step_slow"
+    double* spare_stage = nullptr; size_t spare_stage_bytes = 0;   // pinned staging of the context retired last (a handle's retired contexts keep none: pinning 11.8 MB costs ~2.5 ms)
     int split_fold_seqs = 0;               // split-form pairs enqueued (or captured) with the split fold: "split_fold_seqs"
     int fold_seqs = 0;                     // frame sequences enqueued (or captured) with the gain fold: "fold_seqs" (tests: the switch took effect)
     int exact_frames = 0;                  // staged frames srukf_run_frames repeated on the exact column path (flagged: theta clamp, a skipped direction that is not null, an abandoned launch): "exact_frames"

@@ -62,6 +62,7 @@ void adopt_context(srukf_ctx* c, srukf_ctx* c2)
     std::vector<srukf_ctx*> kept = std::move(c->retired);       // (the handle's list of retired contexts stays with the handle)
     std::swap(*c, *c2);
     c->retired = std::move(kept); c2->retired.clear();
+    c->spare_stage = c2->spare_stage; c->spare_stage_bytes = c2->spare_stage_bytes; c2->spare_stage = nullptr; c2->spare_stage_bytes = 0;      // (the handle's spare staging area too)
     c->own_stream = own; c2->own_stream = false;
     c->profiling = c2->profiling; c->use_graph = c2->use_graph;
     // per-context switches the caller set on the handle survive the rebuild (before srukf_set_storage / update_null_set run on it)
