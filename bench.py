@@ -483,34 +483,49 @@ def theta_clamp_leg(synth, srukf, local, sizes=(8, 200), F=20):
     headline's N = 200 for F frames through srukf_run_frames, one frame per call so that every frame's wall time and whether it was repeated are known.  With >= 8
     matches per frame that filter over-subtracts the shared process noise and diverges: the leg stops at the first non-finite pose."""
     out = {}
+    R = 3                                                           # repetitions (fresh filter each): the rate printed is their median, like the headline's
     for N in sizes:
         p = synth.default_params()
         sc = synth.make_scene(N, F, seed=1, p=p)
-        f = srukf.Filter(N, p, device=local)
-        f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
-        t_frame, flagged, done, e0 = [], [], 0, 0
-        for t in range(F):
-            t0 = time.perf_counter()
-            try:
-                tr = f.run_frames(t, 1)
-            except srukf.SrukfError as e:
-                out[f"n{N}_error"] = str(e)[:160]
-                break
-            t_frame.append(time.perf_counter() - t0)
-            e1 = int(f.debug_get("exact_frames"))
-            flagged.append(e1 > e0); e0 = e1
-            done += 1
-            if not np.isfinite(tr).all():
-                break
-        f.close()
-        tf, fl = np.asarray(t_frame), np.asarray(flagged, dtype=bool)
-        out[f"n{N}"] = {"frames": done, "frames_per_s": (done / float(tf.sum())) if done else None, "flagged_frames": int(fl.sum()),
-                        "exact_path_share_of_wall": (float(tf[fl].sum() / tf.sum()) if done else None),
-                        "ms_per_flagged_frame": (float(tf[fl].mean() * 1e3) if fl.any() else None), "ms_of_each_flagged_frame": [round(float(v) * 1e3, 2) for v in tf[fl]],
-                        "ms_per_clean_frame": (float(tf[~fl].mean() * 1e3) if (~fl).any() else None)}
+        if os.environ.get("BENCH_TIMING"):                          # measurements: phases of the flagged frames on stderr
+            srukf.debug_set_global("timing", 1)
+        reps = []
+        for rep in range(R):
+            f = srukf.Filter(N, p, device=local)
+            f.set_state(sc["X0"], sc["S0"]); f.stage_sequence(sc["odo"], sc["z"], sc["matched"])
+            t_frame, flagged, done, e0, err = [], [], 0, 0, None
+            for t in range(F):
+                t0 = time.perf_counter()
+                try:
+                    tr = f.run_frames(t, 1)
+                except srukf.SrukfError as e:
+                    err = str(e)[:160]
+                    break
+                t_frame.append(time.perf_counter() - t0)
+                e1 = int(f.debug_get("exact_frames"))
+                flagged.append(e1 > e0); e0 = e1
+                done += 1
+                if not np.isfinite(tr).all():
+                    break
+            f.close()
+            tf, fl = np.asarray(t_frame), np.asarray(flagged, dtype=bool)
+            reps.append({"frames": done, "frames_per_s": (done / float(tf.sum())) if done else None, "flagged_frames": int(fl.sum()),
+                         "exact_path_share_of_wall": (float(tf[fl].sum() / tf.sum()) if done else None),
+                         "ms_per_flagged_frame": (float(tf[fl].mean() * 1e3) if fl.any() else None), "ms_of_each_flagged_frame": [round(float(v) * 1e3, 2) for v in tf[fl]],
+                         "ms_per_clean_frame": (float(tf[~fl].mean() * 1e3) if (~fl).any() else None), "error": err})
+        ok = sorted((r for r in reps if r["frames_per_s"]), key=lambda r: r["frames_per_s"])
+        if ok:
+            out[f"n{N}"] = dict(ok[len(ok) // 2])                   # the median repetition, whole
+            out[f"n{N}"].pop("error")
+            out[f"n{N}"]["frames_per_s_repetitions"] = [round(r["frames_per_s"], 1) for r in reps if r["frames_per_s"]]
+        for r in reps:
+            if r["error"]:
+                out[f"n{N}_error"] = r["error"]
     out["note"] = ("shipped a1..a4 = 8 (SLAM.cpp:195-198), one srukf_run_frames call per frame (its fixed cost — checkpoint copy, one synchronisation — is in both kinds of "
                    "frame); a flagged frame = blocked factorisation + rewind + the exact path (right-looking, 8 pivots per launch at N = 200: n / 8 launches; the first flagged "
-                   "frame of a process also loads that kernel)")
+                   "frame of a process also loads that kernel).  Three repetitions with a fresh filter each, the median one printed whole: a 20-frame leg whose flagged frames are "
+                   "151 eager launches each is at the mercy of one host or driver stall (70 - 85 ms events, about one per leg in a full run on the pool's boxes, none in a run of "
+                   "this leg alone)")
     return out
 
 
@@ -791,6 +806,10 @@ def main():
         if world == 1 and not args.no_configs4:
             out["configs4"] = configs4_leg(torch, synth, srukf, local)
             c4_traj, c4_frames = out["configs4"].pop("_traj"), out["configs4"].pop("_frames")
+        # (before the CPU legs: they run OpenMP teams on every CPU the cgroup grants, and a launch-heavy frame — the exact path is 151 launches — that starts while
+        #  the quota is being paid back stalls for tens of milliseconds: measured as one 70 - 80 ms flagged frame among 6.5-ms ones when this leg ran behind them)
+        if world == 1 and not use_dist and not args.no_theta_clamp:
+            out["theta_clamp"] = theta_clamp_leg(synth, srukf, local)
         if world == 1 and not args.no_cpu_baseline:
             cb, otraj = cpu_baseline(synth, sc, N, args.cpu_frames)
             # the whole run (every frame the device computed: measurement leg, warm-up, timed block) against the CPU port's trajectory of the same scene
@@ -831,8 +850,6 @@ def main():
                         "matched_same_algorithm is against those CPUs only"}
             out["pose_rmse_vs_oracle_m"] = float(np.sqrt(np.mean((gt[:, :2] - otraj[:, :2]) ** 2)))
             out["max_abs_dP_robot_vs_oracle"] = float(np.abs(gt[:, 4:] - otraj[:, 4:]).max())
-        if world == 1 and not use_dist and not args.no_theta_clamp:
-            out["theta_clamp"] = theta_clamp_leg(synth, srukf, local)
         if world == 1 and not use_dist and not args.no_step_api:
             out["step_api"] = step_api_leg(synth)
         if world == 1 and not use_dist and not args.no_collectives_check:

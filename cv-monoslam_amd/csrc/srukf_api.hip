@@ -343,7 +343,7 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
                                                                                           // hstage is every accessor's staging area, and an accessor may run between predict_motion and predict_measurement)
     int rc = srukf_reset(c);
     if (rc) { g_create_error = c->err; srukf_destroy(c); return rc; }
-    srukf_warm_exact_path(c->stream, c->fs);                     // (once per process: the exact path's first large-LDS launch, ~75 ms, not inside somebody's flagged frame)
+    srukf_warm_exact_path(c->stream, c->fs);                     // (the exact path's first large-LDS launch on a stream costs ~75 ms: here, not inside somebody's flagged frame)
     *out = c;
     return SRUKF_OK;
 }

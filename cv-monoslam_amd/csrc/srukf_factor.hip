@@ -1218,15 +1218,14 @@ static bool g_exact_right_looking = true;
 static int g_exact_rl_block = 0;                              // 0: as many pivots per launch as fit                     // srukf_debug_set(0, "exact_rl", 0): k_gmw_col (the left-looking form, one row per launch)
 void srukf_set_exact_right_looking(int on) { g_exact_right_looking = on != 0; g_exact_rl_block = on > 1 ? std::min(on - 1, GMW_RL_BMAX) : 0; }
 int srukf_get_exact_right_looking(void) { return g_exact_right_looking ? 1 : 0; }
-// The first launch of a kernel with more than 64 KB of dynamic LDS costs ~75 ms once per process (measured: the first flagged frame at N = 200 took 82 ms, the others 6.5).
+// The first launch of a kernel with more than 64 KB of dynamic LDS costs ~75 ms once per stream (measured: the first flagged frame at N = 200 took 82 ms, the others 6.5).
 // srukf_create pays it: an empty launch (n = 0: every thread leaves at once) with the largest panel the exact path asks for.
 void srukf_warm_exact_path(hipStream_t st, FrameScalars* fs)
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    (void)hipFuncSetAttribute((const void*)k_gmw_rl, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipLaunchKernelGGL(k_gmw_rl, dim3(1, 1), dim3(256), 144 * 1024, st, 0, 0, 0, 1, 0.0, (double*)nullptr, (double*)nullptr, fs, (double*)nullptr);
+    // (per stream, not per process: the cost comes back on a stream — hardware queue — that has not run such a launch yet; on one that has, the empty launch is ~10 us)
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gmw_rl, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_gmw_rl, dim3(8, 64), dim3(256), 144 * 1024, st, 0, 0, 0, 1, 0.0, (double*)nullptr, (double*)nullptr, fs, (double*)nullptr);      // (every CU: 512 workgroups that leave at once)
 }
 void srukf_launch_gmw_col(hipStream_t st, int n, int ld, int j, double eps, const double* G, double* Wf, double* D,
                           unsigned long long* theta_bits, FrameScalars* fs, double* Sout)
@@ -1238,7 +1237,7 @@ void srukf_launch_gmw_col(hipStream_t st, int n, int ld, int j, double eps, cons
         // B pivots per launch: as many rows of n doubles as fit in ~144 KB of LDS, at most 8 (srukf_debug_set(0, "exact_rl", 1 + B) forces B: tests)
         int B = g_exact_rl_block > 0 ? g_exact_rl_block : (int)std::min<size_t>(GMW_RL_BMAX, (144 * 1024) / (sizeof(double) * (size_t)n));
         if (B < 1) B = 1;
-        srukf_warm_exact_path(st, fs);                         // (sets the kernel's LDS limit; normally done by srukf_create)
+        { static bool attr2 = false; if (!attr2) { (void)hipFuncSetAttribute((const void*)k_gmw_rl, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr2 = true; } }
         for (int q = 0; q < n; q += B) {
             const int Bn = std::min(B, n - q), rem = n - q - Bn;
             hipLaunchKernelGGL(k_gmw_rl, dim3(rem > 0 ? (rem + 255) / 256 : 1, rem > 0 ? (rem + GMW_RL_ROWS - 1) / GMW_RL_ROWS : 1), dim3(256), sizeof(double) * (size_t)Bn * (n - q), st,
