@@ -288,14 +288,20 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  *   "batch_wide" (0: srukf_run_frames_batch never takes the batched launches), "batch_groups" (1..4: groups the batched filters are cut into),
  *   "batch_split" (0: one launch per panel in the batched replay instead of slabs + plain trailing updates),
  *   "mem_split" (0: sizes beyond two register tiles per worker — N >= 400 — keep the memory-tile instance of k_gmw_persist instead of the split form
- *   k_gmw_pivslab_persist + k_gmw_tiles_persist; 2: the split form also where a worker would own two register tiles).
+ *   k_gmw_pivslab_persist + k_gmw_tiles_persist; 2: the split form also where a worker would own two register tiles),
+ *   round 6: "exact_rl" (0: the left-looking exact path k_gmw_col, one row per launch; 1: right-looking, as many pivots per launch as fit — default; 1 + B: B pivots per
+ *   launch), "fold_head" (block rows the k_syrk launch in front of the split fold forms; 0: the rule 2 (Tp - 17)), "fold_force" (the split fold also where the tile workgroups
+ *   do not all fit beside the pivot / slab launch), "timing" (1: phases of map changes and of flagged frames on stderr).
  * Per-context keys: "use_graph" (0: eager launches), "fused_motion" (0: k_motion + k_project as two launches, 1: k_project_motion, 2: "table"
  *   mode), "pxy2" (0: k_pxy instead of k_pxy2), "nullskip", "head_fold" (0: k_syrk launch in front of the persistent launch), "tail_fuse"
  *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse", "step_fast" (0: the step-wise API keeps to its own launch sequences instead of the
  *   staged replay's cut at the association step), "step_fuse_export" (0: the fast path's results leave through export launches of their own instead of from the
  *   launches that form them), "step_early" (what srukf_update submits of the NEXT frame behind its own tail: 0 nothing, 1 checkpoint copy + frame scalars, 2 (default)
  *   also the announced frame's first launch), "step_spin" (0: wait with hipStreamSynchronize instead of spinning on the pinned flag word), "view_auto" (0: the display
- *   view is never exported with an update's status), "split_record".  See srukf_ctx.h (srukf_ctx::DbgSwitches). */
+ *   view is never exported with an update's status), "split_record"; round 6: "gain_fold" (1: k_gain's work in the tile epilogue of k_pxy2_fold — three launches per frame,
+ *   slower: off), "split_fold" (0: k_syrk over all kept rows in front of the split form's pair instead of forming jobs inside its tile launch), "mixed_rank" (0: round 2's
+ *   full-rank form of SRUKF_STORAGE_F32_MIXED), "mixed_f64_robot" (0: every tile of the mixed downdate on the fp32 pipe), "mixed_bf16" (1: its fp32 products from three bf16
+ *   pieces), "mixed_null_ppm".  See srukf_ctx.h (srukf_ctx::DbgSwitches). */
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
 /* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared", "split_form", "split_off",
  * "step_fast" / "step_slow": frames the step-wise API ran on the fast / the other path, "view_hits": srukf_get_frame_view calls served from an exported view,
