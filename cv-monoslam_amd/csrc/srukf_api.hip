@@ -411,9 +411,11 @@ void ctx_retire(srukf_ctx* handle, srukf_ctx* old)
     }
     handle->retired.push_back(old);
     // How many: a map that breathes by +- 1 around a size revisits ~16 sizes (bench.py's churn leg: 200 -> 185 landmarks), and destroying the context that falls out of
-    // the list is the expensive part of a miss (2.6 of 3.6 ms at N = 200: ~60 device frees).  Up to 32 contexts or ~16 GB of them (a context is ~14 matrices of np^2 doubles).
+    // the list is the expensive part of a miss (2.6 of 3.6 ms at N = 200: ~60 device frees).  Up to 24 contexts ("ctx_keep") or ~16 GB of them (a context is ~14 matrices of np^2 doubles).  Not 32: a process that
+    // exits with exactly 32 retired contexts behind a handle — 950 to 1 100 frames of the churn leg — crashed in the HIP runtime's own exit handler after every srukf call
+    // had returned (SIGSEGV under __cxa_finalize in libamdhip64; 30, 31, 33, 36 and 40 contexts: no crash; trimming the memory pool first: no difference).
     const double ctx_bytes = 14.0 * 8.0 * (double)old->d.np * old->d.np;
-    const size_t keep = (size_t)std::min(32.0, std::max(4.0, 16e9 / ctx_bytes));
+    const size_t keep = (size_t)std::min((double)g_dbg_ctx_keep.load(), std::max(4.0, 16e9 / ctx_bytes));
     while (handle->retired.size() > keep) { srukf_destroy(handle->retired.front()); handle->retired.erase(handle->retired.begin()); }
 }
 

@@ -314,7 +314,7 @@ extern thread_local std::string g_create_error;
 // srukf_debug_set switches (process-wide; srukf_debug.hip)
 extern std::atomic<int> g_dbg_gmw_persist, g_dbg_gmw_fused, g_dbg_rank_fused, g_dbg_rank_fold, g_dbg_rank_aware, g_dbg_graphs, g_dbg_mem_split, g_dbg_shared_tenants;
 extern std::atomic<int> g_dbg_batch_wide, g_dbg_batch_groups, g_dbg_batch_split, g_dbg_head_fold_free;
-extern std::atomic<int> g_dbg_timing, g_dbg_fold_head, g_dbg_fold_force;      // process-wide measurement switches (srukf_debug_set(0, "timing" / "fold_head" / "fold_force", v)): the library reads no environment variable
+extern std::atomic<int> g_dbg_timing, g_dbg_fold_head, g_dbg_fold_force, g_dbg_ctx_keep;      // process-wide measurement switches (srukf_debug_set(0, "timing" / "fold_head" / "fold_force", v)): the library reads no environment variable
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

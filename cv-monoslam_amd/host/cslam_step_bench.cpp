@@ -214,5 +214,6 @@ int main(int argc, char** argv)
            "\"filter_driven_by\": \"scene z / matched (host association)\"}\n",
            mode.c_str(), churn_json, hint, N, K, W, K / t_timed, t_timed / K * 1e6, pose[0], pose[1], pose[2], pose[3], P4[0], P4[1], P4[4], P4[5], matches_dev, flag_ticks * 0.01,
            tcall[0] / K * 1e6, tcall[1] / K * 1e6, tcall[2] / K * 1e6, tcall[3] / K * 1e6, tcall[4] / K * 1e6);
+    fflush(stdout);                                                // (the line must not depend on what the runtimes' exit handlers do)
     return 0;
 }
