@@ -427,7 +427,7 @@ def configs4_leg(torch, synth, srukf, local, N=500, K=40, W=6, PF=6):
            "roofline": roof, "launch_plan": fb, "null_directions_skipped": f.null_directions(), "pose_err_vs_truth_m": err,
            "kernels_us_per_frame": {k: round(v["ms"] / PF * 1e3, 1) for k, v in prof.items() if v["launches"]},
            "note": ("the mixed-precision sqrt(S) downdate of configs[4] (SRUKF_STORAGE_F32_MIXED) holds the reference's epsilon = 1e-13 over 3 000 frames on the rank-aware form "
-                    "(pose within 1.2e-6 m of the fp64 filter) and is NOT faster than this leg's fp32 storage with FP64 arithmetic: DESIGN.md section 8, profiles/r06_mixed_rank_n500.json")}
+                    "(pose within ~1e-6 m of the fp64 filter: 7.3e-7 / 1.2e-6 in two runs of the study) and is NOT faster than this leg's fp32 storage with FP64 arithmetic: DESIGN.md section 8, profiles/r06_mixed_rank_n500.json")}
     f.close()
     out["_traj"] = traj.cpu().numpy()                              # (popped by the caller: the whole-run comparison with the CPU port)
     out["_frames"] = Ftot

@@ -82,7 +82,7 @@ typedef enum srukf_reorder { SRUKF_NEED_REORDER = 0, SRUKF_NEEDNOT_REORDER = 1 }
  * updates only use it (a SEQUENTIAL / single-column refactor keeps the FP64 contraction).
  * Round 6: offered at every epsilon, the reference's 1e-13 included (rounds 2 - 5 refused it below 1e-9).  Its fp32 accumulators are flushed into FP64 every 32
  * rows of K, and in the rank-aware form (the default wherever a null set exists) only the kept pivots are factored and the tiles of the robot block and of the
- * map's shared anchor are formed in FP64: within 1.2e-6 m of the fp64 filter over 3 000 frames at N = 500 (fp32 storage with FP64 arithmetic: 6.8e-7;
+ * map's shared anchor are formed in FP64: within ~1e-6 m of the fp64 filter over 3 000 frames at N = 500 (7.3e-7 / 1.2e-6 in two runs) (fp32 storage with FP64 arithmetic: 6.8e-7;
  * DESIGN.md, row g).  On MI355X the FP32 matrix peak is 2 x the FP64 one and the mode's extra passes use that up: it is NOT faster than SRUKF_STORAGE_F32. */
 typedef enum srukf_storage { SRUKF_STORAGE_F64 = 0, SRUKF_STORAGE_F32 = 1, SRUKF_STORAGE_F32_MIXED = 2 } srukf_storage;
 
