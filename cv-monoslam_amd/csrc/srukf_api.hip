@@ -321,6 +321,23 @@ int srukf_create(srukf_ctx** out, int N, const srukf_params* p, int device, void
         for (size_t q = 0; q + 1 < th.size(); q += 2) if (th[q] * 32 < 128 && th[q + 1] * 32 < 128) c->n_syrk_head_crit++;
         c->n_syrk_head_tiles = (int)th.size() / 2;
         ALLOC(c->syrk_head_tiles, th.size() ? th.size() : 2);
+        {
+            // the batched launch (k_syrk_b: B filters x these tiles, no pivot waiting for the first ones) is bound by its operand traffic — 35 MB per filter for 10 MB of
+            // operands: in the table's order an XCD owns tile ROWS, so the four tile rows of the head fetch every column slab (S and U^T, K x 32 doubles) four times over
+            // four L2s.  Here the tiles of one pair of tile columns go to one XCD (list position % 8): a slab crosses the fabric once.
+            std::vector<int> qx[8], tb;
+            for (size_t q = 0; q + 1 < th.size(); q += 2) { const int x = (th[q + 1] / 2) % 8; qx[x].push_back(th[q]); qx[x].push_back(th[q + 1]); }
+            size_t longest = 0;
+            for (int x = 0; x < 8; x++) longest = std::max(longest, qx[x].size() / 2);
+            for (size_t rnd = 0; rnd < longest; rnd++)
+                for (int x = 0; x < 8; x++) { tb.push_back(2 * rnd + 1 < qx[x].size() ? qx[x][2 * rnd] : -1); tb.push_back(2 * rnd + 1 < qx[x].size() ? qx[x][2 * rnd + 1] : -1); }
+            c->n_syrk_head_tiles_b = (int)tb.size() / 2;
+            ALLOC(c->syrk_head_tiles_b, tb.size() ? tb.size() : 2);
+            if (!tb.empty() && hipMemcpyAsync(c->syrk_head_tiles_b, tb.data(), sizeof(int) * tb.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                g_create_error = "tile table upload failed"; srukf_destroy(c); return SRUKF_ERR_HIP;
+            }
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { g_create_error = "tile table upload failed"; srukf_destroy(c); return SRUKF_ERR_HIP; }      // (tb is a local)
+        }
         if (!th.empty() && hipMemcpyAsync(c->syrk_head_tiles, th.data(), sizeof(int) * th.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
             g_create_error = "tile table upload failed"; srukf_destroy(c); return SRUKF_ERR_HIP;
         }
@@ -370,7 +387,7 @@ int srukf_destroy(srukf_ctx* c)
     if (c->graphN) hipGraphDestroy(c->graphN);
     void* bufs[] = { c->X, c->S, c->G, c->Gbak, c->Wf, c->sigR, c->Cmat, c->Z, c->DZ, c->Ut, c->h /* + Si, vis */, c->PxyR, c->D,
                      c->zcur /* + mcur */, c->odocur, c->small, c->theta, c->fs, c->odo_seq, c->z_seq, c->m_seq, c->pan[0], c->pan[1], c->mpart, c->dxp, c->syrk_tiles, c->pxy_tiles, c->syrk_head_tiles,
-                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->red_head0_tiles, c->split_fold_list, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->fold_sync, c->dxk, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->mxr_f64_tiles, c->mxr_xt, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
+                     c->perm, c->iperm, c->Sdis, c->ckS, c->ckX, c->ckS2, c->ckX2, c->odo_step, c->export_cnt, c->red_perm, c->red_iperm, c->gdiag, c->red_syrk_tiles, c->syrk_head_tiles_b, c->red_head0_tiles, c->split_fold_list, c->shadowA, c->Utp, c->P1, c->pxy2_tiles, c->nskip, c->slabW, c->slabL, c->gsW, c->gsL, c->S32, c->X32, c->U32, c->mx_part, c->mx_tasks, c->mx_tiles, c->fold_sync, c->dxk, c->A32, c->mxr_part, c->mxr_tasks, c->mxr_tiles, c->mxr_f64_tiles, c->mxr_xt, c->app_patch, c->app_tmpl, c->d_image, c->appR, c->appT, c->appPx, c->corr, c->has_app };
     for (void* b : bufs) if (b) srukf_dfree_on(b, c->stream);
     gmw_plan_destroy(c->gplan, c->stream);
     gmw_plan_destroy(c->gplan_red, c->stream);

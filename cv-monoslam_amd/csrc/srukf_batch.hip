@@ -111,7 +111,8 @@ static void batch_frame(const BatchPlan* bp, hipStream_t st)
     const int n = d.n, np = d.np, r = c->red_r, Tp = c->red_Tp, B = bp->B, kr = (r + 15) & ~15;
     srukf_launch_pxy2_b(st, d, bp->t_pxy2, B, c->pxy2_tiles, c->n_pxy2_tiles, kr, c->w, (d.N + 31) / 32);
     srukf_launch_gain_b(st, d, c->w, bp->t_gain, B, c->pxy2_split_b0, sqrt(c->p.epsilon));
-    srukf_launch_syrk_b(st, d, bp->t_syrk, B, c->syrk_head_tiles, c->n_syrk_head_tiles, std::min(np, kr), (n + 255) / 256, (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS);
+    srukf_launch_syrk_b(st, d, bp->t_syrk, B, g_dbg_batch_xcd.load() ? c->syrk_head_tiles_b : c->syrk_head_tiles, g_dbg_batch_xcd.load() ? c->n_syrk_head_tiles_b : c->n_syrk_head_tiles, std::min(np, kr), (n + 255) / 256,
+                        (n - r + SRUKF_RANK_COLS - 1) / SRUKF_RANK_COLS);
     srukf_launch_syrk_own_b(st, n, np, bp->t_own, B, 0, d.mp, kr, c->gplan_red.tiles, c->gplan_red.ntiles, Tp);
     int pb = 0;
     for (int j0 = -64; j0 + 64 < np && j0 + 64 <= 64 * Tp; j0 += 64, pb ^= 1) {

@@ -232,6 +232,7 @@ struct srukf_ctx {
     int *syrk_tiles = nullptr, *pxy_tiles = nullptr;   // (by, bx) per workgroup, XCD-aware order
     int *syrk_head_tiles = nullptr;                    // k_syrk tiles of the first srukf_gmw_head_rows() rows only (fused refactor)
     int n_syrk_tiles = 0, n_pxy_tiles = 0, n_syrk_head_tiles = 0, n_syrk_head_crit = 0;
+    int* syrk_head_tiles_b = nullptr; int n_syrk_head_tiles_b = 0;      // the same tiles in the batched launch's order (k_syrk_b): one pair of tile columns per XCD, empty slots (-1) where a share is shorter
     FrameScalars* fs = nullptr;
     // staged sequence
     int seqF = 0;
@@ -314,7 +315,7 @@ extern thread_local std::string g_create_error;
 // srukf_debug_set switches (process-wide; srukf_debug.hip)
 extern std::atomic<int> g_dbg_gmw_persist, g_dbg_gmw_fused, g_dbg_rank_fused, g_dbg_rank_fold, g_dbg_rank_aware, g_dbg_graphs, g_dbg_mem_split, g_dbg_shared_tenants;
 extern std::atomic<int> g_dbg_batch_wide, g_dbg_batch_groups, g_dbg_batch_split, g_dbg_head_fold_free;
-extern std::atomic<int> g_dbg_timing, g_dbg_fold_head, g_dbg_fold_force, g_dbg_ctx_keep;      // process-wide measurement switches (srukf_debug_set(0, "timing" / "fold_head" / "fold_force", v)): the library reads no environment variable
+extern std::atomic<int> g_dbg_timing, g_dbg_fold_head, g_dbg_fold_force, g_dbg_ctx_keep, g_dbg_batch_xcd;      // process-wide measurement switches (srukf_debug_set(0, "timing" / "fold_head" / "fold_force", v)): the library reads no environment variable
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
