@@ -122,8 +122,15 @@ static void batch_frame(const BatchPlan* bp, hipStream_t st)
         }
         // split form: A = critical-path workgroups + the panel's slabs (and S rows) once per column block, B = the trailing tiles of the kept rows as plain K = 64
         // updates.  The last pivoted panel has no tiles to update (the pass-on row's values are never used: its S rows come from the slab workgroups).
-        srukf_launch_gmw_pivslab_b(st, n, np, j0, c->p.epsilon, bp->t_step, B, pb);
-        if (j0 >= 0 && Tp - j0 / 64 - 1 >= 1) srukf_launch_gmw_trail_b(st, np, j0, bp->t_step, B, Tp - j0 / 64 - 1);
+        // K = 128 (round 6): panels in pairs (a, b = a + 64).  Step a's trailing update only touches what step b's pivots and slabs read (block row 0, tile (1, 1): "thin");
+        // step b's pass applies panel a's slabs and then panel b's to everything else — one pass over G instead of two, the products per element in the same order
+        // (bit-identical).  A pair needs step b to have trailing tiles; the slabs of a pair live in the two halves of slabW / slabL.
+        const int rows = Tp - j0 / 64 - 1, pair = j0 >= 0 ? (j0 / 64) & 1 : 0;
+        const bool k128 = g_dbg_batch_k128.load() != 0;
+        const bool first_of_pair = k128 && j0 >= 0 && pair == 0 && rows - 1 >= 1 && j0 + 128 < np && j0 + 128 <= 64 * Tp;
+        const bool second_of_pair = k128 && j0 >= 64 && pair == 1 && rows >= 1;
+        srukf_launch_gmw_pivslab_b(st, n, np, j0, c->p.epsilon, bp->t_step, B, pb, second_of_pair ? 1 : 0);
+        if (j0 >= 0 && rows >= 1) srukf_launch_gmw_trail_b(st, np, j0, bp->t_step, B, rows, second_of_pair ? 1 : 0, first_of_pair ? 1 : second_of_pair ? 2 : 0);
     }
     srukf_launch_rank_expand_b(st, n, np, r, c->p.epsilon, bp->t_exp, B, c->w.gamma, d, c->w, c->p);
 }
@@ -170,8 +177,8 @@ static int batch_run(srukf_ctx* const* cs, int B, int first, int count, double* 
         a3[b] = SyrkArgs{ c->shadowA, c->Utp, c->Wf, c->fs, c->dxp, c->X, rank_args(c, true), (const double*)((const char*)c->fs + offsetof(FrameScalars, Xr1)) };
         a4[b] = SyrkOwnArgs{ c->shadowA, c->Utp, c->Wf, c->fs };
         if (!c->slabW) {
-            HIPCHK(c, srukf_dmalloc(&c->slabW, sizeof(double) * 64 * (size_t)d.np)); HIPCHK(c, srukf_dmalloc(&c->slabL, sizeof(double) * 64 * (size_t)d.np));
-            HIPCHK(c, hipMemset(c->slabW, 0, sizeof(double) * 64 * (size_t)d.np)); HIPCHK(c, hipMemset(c->slabL, 0, sizeof(double) * 64 * (size_t)d.np));
+            HIPCHK(c, srukf_dmalloc(&c->slabW, sizeof(double) * 2 * 64 * (size_t)d.np)); HIPCHK(c, srukf_dmalloc(&c->slabL, sizeof(double) * 2 * 64 * (size_t)d.np));
+            HIPCHK(c, hipMemset(c->slabW, 0, sizeof(double) * 2 * 64 * (size_t)d.np)); HIPCHK(c, hipMemset(c->slabL, 0, sizeof(double) * 2 * 64 * (size_t)d.np));
         }
         a5[b] = Step64Args{ c->Wf, c->G, c->D, { c->pan[0], c->pan[1] }, c->slabW, c->slabL };
         a6[b] = ExpandArgs{ c->G, c->D, c->red_perm, c->red_iperm, c->gdiag, c->fs, c->X, c->S, c->shadowA, c->sigR, c->Z, c->DZ };

@@ -70,8 +70,8 @@ void srukf_launch_gain_b(hipStream_t, KDims, KWeights, const void*, int, int, do
 void srukf_launch_syrk_b(hipStream_t, KDims, const void*, int, const void*, int, int, int, int);
 void srukf_launch_syrk_own_b(hipStream_t, int, int, const void*, int, int, int, int, const void*, int, int);
 void srukf_launch_gmw_step64_b(hipStream_t, int, int, int, double, const void*, int, int, int);
-void srukf_launch_gmw_pivslab_b(hipStream_t, int, int, int, double, const void*, int, int);
-void srukf_launch_gmw_trail_b(hipStream_t, int, int, const void*, int, int);
+void srukf_launch_gmw_pivslab_b(hipStream_t, int, int, int, double, const void*, int, int, int);
+void srukf_launch_gmw_trail_b(hipStream_t, int, int, const void*, int, int, int, int);
 void srukf_launch_rank_expand_b(hipStream_t, int, int, int, double, const void*, int, double, KDims, KWeights, srukf_params);
 int srukf_gmw_head_rows(void);
 int srukf_gmw_head_extra_diag(void);
@@ -172,7 +172,7 @@ struct srukf_ctx {
     int *red_perm = nullptr, *red_iperm = nullptr;     // permuted position <-> state index, kept indices first
     double* gdiag = nullptr;                           // diagonal of G in permuted order (the factorisation overwrites it)
     double *shadowA = nullptr, *Utp = nullptr;         // replay form: kept rows of S / U^T in permuted column order (srukf_rank.hip)
-    double *slabW = nullptr, *slabL = nullptr;         // batched replay: the current panel's slabs W and L = W / D (64 x np each)
+    double *slabW = nullptr, *slabL = nullptr;         // batched replay: two panels' slabs W and L = W / D (2 x 64 x np each: the K = 128 trailing update reads a pair)
     // split form of the persistent factorisation (memory-tile sizes, a filter that has the GPU to itself): the slabs of every pivoted panel (gs_panels x 64 x np
     // each), the side stream the tile launch runs on and the events that fork it off / join it to the filter's stream
     double *gsW = nullptr, *gsL = nullptr; int gs_panels = 0;
@@ -315,7 +315,7 @@ extern thread_local std::string g_create_error;
 // srukf_debug_set switches (process-wide; srukf_debug.hip)
 extern std::atomic<int> g_dbg_gmw_persist, g_dbg_gmw_fused, g_dbg_rank_fused, g_dbg_rank_fold, g_dbg_rank_aware, g_dbg_graphs, g_dbg_mem_split, g_dbg_shared_tenants;
 extern std::atomic<int> g_dbg_batch_wide, g_dbg_batch_groups, g_dbg_batch_split, g_dbg_head_fold_free;
-extern std::atomic<int> g_dbg_timing, g_dbg_fold_head, g_dbg_fold_force, g_dbg_ctx_keep, g_dbg_batch_xcd;      // process-wide measurement switches (srukf_debug_set(0, "timing" / "fold_head" / "fold_force", v)): the library reads no environment variable
+extern std::atomic<int> g_dbg_timing, g_dbg_fold_head, g_dbg_fold_force, g_dbg_ctx_keep, g_dbg_batch_xcd, g_dbg_batch_k128;      // process-wide measurement switches (srukf_debug_set(0, "timing" / "fold_head" / "fold_force", v)): the library reads no environment variable
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

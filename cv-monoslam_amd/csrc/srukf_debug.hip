@@ -23,7 +23,7 @@ std::atomic<int> g_dbg_shared_tenants{2};     // "shared_tenants": persistent la
 // srukf_run_frames_batch: "batch_wide" 0: never the batched launches (one stream per filter, persistent launches behind the gate: round 3's form); "batch_groups": groups the batched
 // filters are cut into (0: as many as pay); "batch_split" 0: one k_gmw_step64_b launch per panel (every tile recomputes its slabs) instead of slabs + plain updates
 std::atomic<int> g_dbg_batch_wide{1}, g_dbg_batch_groups{0}, g_dbg_batch_split{1};
-std::atomic<int> g_dbg_timing{0}, g_dbg_fold_head{0}, g_dbg_fold_force{0}, g_dbg_ctx_keep{24}, g_dbg_batch_xcd{1};
+std::atomic<int> g_dbg_timing{0}, g_dbg_fold_head{0}, g_dbg_fold_force{0}, g_dbg_ctx_keep{24}, g_dbg_batch_xcd{1}, g_dbg_batch_k128{1};
 // "head_fold_free": CUs a plan must leave beside the pivot and the workers for the head fold (helper workgroups of the persistent launch); default SRUKF_HEAD_FOLD_MIN_FREE_CUS
 std::atomic<int> g_dbg_head_fold_free{0};
 }  // namespace srukf_impl
@@ -97,6 +97,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     if (!strcmp(key, "batch_wide")) { g_dbg_batch_wide = value ? 1 : 0; return SRUKF_OK; }
     if (!strcmp(key, "timing")) { g_dbg_timing = value ? 1 : 0; return SRUKF_OK; }              // phases of map changes and of flagged frames on stderr
     if (!strcmp(key, "fold_head")) { g_dbg_fold_head = value < 0 ? 0 : value; srukf_gmw_fold_head_override(g_dbg_fold_head); return SRUKF_OK; }   // split fold: block rows formed in front of the pair (0: the rule); before the state is set
+    if (!strcmp(key, "batch_k128")) { g_dbg_batch_k128 = value ? 1 : 0; batch_drop_all_graphs(); return SRUKF_OK; }    // 0: every panel's trailing update a pass of its own over G (K = 64)
     if (!strcmp(key, "batch_xcd")) { g_dbg_batch_xcd = value ? 1 : 0; batch_drop_all_graphs(); return SRUKF_OK; }      // 0: k_syrk_b walks the head tiles in the solo launch's order
     if (!strcmp(key, "ctx_keep")) { g_dbg_ctx_keep = value < 0 ? 0 : value; return SRUKF_OK; }       // contexts a handle keeps across map changes (default 24, and at most ~16 GB of them)
     if (!strcmp(key, "fold_force")) { g_dbg_fold_force = value ? 1 : 0; return SRUKF_OK; }         // split fold also where the tile workgroups do not all fit

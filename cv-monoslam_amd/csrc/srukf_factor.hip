@@ -842,7 +842,8 @@ __global__ __launch_bounds__(256) void k_gmw_step64_b(int n, int ld, int j0, int
 // next diagonal region, factor it) beside one slab workgroup per column block of every filter; launch B = the trailing tiles as plain K = 64 updates from the slab
 // rows — no LDS, few registers, many waves per SIMD.  Same instruction sequences on the same values as k_gmw_step64: bit-identical.
 // A: workgroup index = idx B + f; idx 0: block (0,0); idx 1 + q: the slabs of column blocks 2q and 2q + 1 (four waves: their 32-column halves).
-__global__ __launch_bounds__(256) void k_gmw_pivslab_b(int n, int ld, int j0, int first, const Step64Args* __restrict__ tab, int B, int flip, double eps)
+// (sel: which of the two slab buffers behind a.Wb / a.Lb this panel's slabs go to — the K = 128 trailing update reads two panels' slabs)
+__global__ __launch_bounds__(256) void k_gmw_pivslab_b(int n, int ld, int j0, int first, const Step64Args* __restrict__ tab, int B, int flip, double eps, int sel)
 {
     __shared__ double Lr[64][G64_LS];
     __shared__ double Wc[64][G64_LS];
@@ -856,21 +857,23 @@ __global__ __launch_bounds__(256) void k_gmw_pivslab_b(int n, int ld, int j0, in
         return;
     }
     const int wv = threadIdx.x >> 6, bx = 2 * (idx - 1) + (wv >> 1);
-    gmw_slab_to_global(n, ld, j0, j0 + 64 + 64 * bx + 32 * (wv & 1), a.G, cur, a.Sout, a.Wb, a.Lb, bx >= 1, threadIdx.x & 63);
+    gmw_slab_to_global(n, ld, j0, j0 + 64 + 64 * bx + 32 * (wv & 1), a.G, cur, a.Sout, a.Wb + (size_t)sel * 64 * ld, a.Lb + (size_t)sel * 64 * ld, bx >= 1, threadIdx.x & 63);
 }
 // B: workgroup index = idx B + f, idx -> (by, bx) over rows x cols; tiles below the diagonal and (0,0) leave at once
-__global__ __launch_bounds__(256) void k_gmw_trail_b(int ld, int j0, const Step64Args* __restrict__ tab, int B, int cols)
+// thin: only what the NEXT panel step reads — block row 0 and tile (1, 1) (the K = 128 form: k_gmw_trail2_b applies this panel to everything else together with the next one)
+__global__ __launch_bounds__(256) void k_gmw_trail_b(int ld, int j0, const Step64Args* __restrict__ tab, int B, int cols, int sel, int thin)
 {
     const int f = (int)blockIdx.x % B, idx = (int)blockIdx.x / B;
     const int by = idx / cols, bx = idx % cols;
     if (bx < by || (bx == 0 && by == 0)) return;
+    if (thin && !(by == 0 || (by == 1 && bx == 1))) return;
     const Step64Args a = tab[f];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
     const int base = j0 + 64;
     const int m0 = base + 64 * by + 32 * (wv >> 1), c0 = base + 64 * bx + 32 * (wv & 1);
     if (!((m0 < ld) && (c0 < ld) && (c0 + 32 > m0))) return;
     double* __restrict__ G = a.G;
-    const double* __restrict__ Lb = a.Lb; const double* __restrict__ Wb = a.Wb;
+    const double* __restrict__ Lb = a.Lb + (size_t)sel * 64 * ld; const double* __restrict__ Wb = a.Wb + (size_t)sel * 64 * ld;
     d4 acc[2][2];
 #pragma unroll
     for (int q = 0; q < 2; q++)
@@ -886,6 +889,47 @@ __global__ __launch_bounds__(256) void k_gmw_trail_b(int ld, int j0, const Step6
         acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) G[(size_t)(m0 + 16 * q + lk + 4 * t) * ld + c0 + 16 * b + lr] = acc[q][b][t];
+}
+// K = 128: the trailing tiles of panel step j0 (k_gmw_trail_b's set) take the PREVIOUS panel's update too — slabs sel ^ 1, which the thin launch of step j0 - 64 applied
+// only to what this step's pivots and slabs read — and then this panel's (slabs sel): one pass over G for two panels, the products per element in the same order.
+__global__ __launch_bounds__(256) void k_gmw_trail2_b(int ld, int j0, const Step64Args* __restrict__ tab, int B, int cols, int sel)
+{
+    const int f = (int)blockIdx.x % B, idx = (int)blockIdx.x / B;
+    const int by = idx / cols, bx = idx % cols;
+    if (bx < by || (bx == 0 && by == 0)) return;
+    const Step64Args a = tab[f];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const int base = j0 + 64;
+    const int m0 = base + 64 * by + 32 * (wv >> 1), c0 = base + 64 * bx + 32 * (wv & 1);
+    if (!((m0 < ld) && (c0 < ld) && (c0 + 32 > m0))) return;
+    double* __restrict__ G = a.G;
+    d4 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[q][b][t] = G[(size_t)(m0 + 16 * q + lk + 4 * t) * ld + c0 + 16 * b + lr];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int sl = pass == 0 ? (sel ^ 1) : sel;
+        const double* __restrict__ Lb = a.Lb + (size_t)sl * 64 * ld; const double* __restrict__ Wb = a.Wb + (size_t)sl * 64 * ld;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+            const double a0 = -Lb[(size_t)(k + lk) * ld + m0 + lr], a1 = -Lb[(size_t)(k + lk) * ld + m0 + 16 + lr];
+            const double b0 = Wb[(size_t)(k + lk) * ld + c0 + lr], b1 = Wb[(size_t)(k + lk) * ld + c0 + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 2; q++)
@@ -1105,19 +1149,23 @@ void srukf_launch_gmw_step64(hipStream_t st, int n, int ld, int j0, double eps, 
 }
 int srukf_gmw_panel_bytes(void) { return (int)sizeof(GmwPanel64); }
 // split form of a batched panel step: A (critical-path workgroups + slabs of every column block of the trailing square), B (trailing tiles of `rows` block rows)
-void srukf_launch_gmw_pivslab_b(hipStream_t st, int n, int ld, int j0, double eps, const void* tab, int B, int flip)
+void srukf_launch_gmw_pivslab_b(hipStream_t st, int n, int ld, int j0, double eps, const void* tab, int B, int flip, int sel)
 {
     const int rem = ld - j0 - 64;
     if (rem <= 0) return;
     const int cols = (j0 < 0) ? 0 : rem / 64;                  // j0 = -64: no panel yet, block (0,0) only
-    hipLaunchKernelGGL(k_gmw_pivslab_b, dim3((1 + (cols + 1) / 2) * B), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, (const Step64Args*)tab, B, flip, eps);
+    hipLaunchKernelGGL(k_gmw_pivslab_b, dim3((1 + (cols + 1) / 2) * B), dim3(256), 0, st, n, ld, j0, j0 < 0 ? 1 : 0, (const Step64Args*)tab, B, flip, eps, sel);
 }
-void srukf_launch_gmw_trail_b(hipStream_t st, int ld, int j0, const void* tab, int B, int rows)
+// form: 0 the plain K = 64 update of `rows` block rows; 1 thin (block row 0 and tile (1, 1) only: two block rows of workgroups); 2 K = 128 (this panel's slabs `sel` behind the
+// previous panel's `sel ^ 1`)
+void srukf_launch_gmw_trail_b(hipStream_t st, int ld, int j0, const void* tab, int B, int rows, int sel, int form)
 {
     const int cols = (ld - j0 - 64) / 64;
     if (j0 < 0 || cols <= 0 || rows < 1) return;
     if (rows > cols) rows = cols;
-    hipLaunchKernelGGL(k_gmw_trail_b, dim3(rows * cols * B), dim3(256), 0, st, ld, j0, (const Step64Args*)tab, B, cols);
+    if (form == 1) rows = std::min(rows, 2);
+    if (form == 2) hipLaunchKernelGGL(k_gmw_trail2_b, dim3(rows * cols * B), dim3(256), 0, st, ld, j0, (const Step64Args*)tab, B, cols, sel);
+    else hipLaunchKernelGGL(k_gmw_trail_b, dim3(rows * cols * B), dim3(256), 0, st, ld, j0, (const Step64Args*)tab, B, cols, sel, form == 1 ? 1 : 0);
 }
 // ---- batched launches (srukf_run_frames_batch): B filters of one shape, one launch per stage, arguments per filter in device tables ----
 int srukf_pxy2_b_per(int ntiles, int gx) { return (ntiles + MEAS_SLICES * gx + 1 + 7) & ~7; }

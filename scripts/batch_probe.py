@@ -15,6 +15,8 @@ if len(sys.argv) > 5 and sys.argv[5] == "eager":                # eager launches
     srukf.debug_set_global("graphs", 0)
 if os.environ.get("BATCH_XCD") is not None:                      # 0: k_syrk_b in the solo launch's tile order (A/B of round 6's per-XCD order)
     srukf.debug_set_global("batch_xcd", int(os.environ["BATCH_XCD"]))
+if os.environ.get("BATCH_K128") is not None:                     # 0: one pass over G per panel (K = 64) instead of one per pair
+    srukf.debug_set_global("batch_k128", int(os.environ["BATCH_K128"]))
 K, W, R = 96, 16, 3
 scs = [synth.make_scene(N, W + R * K, seed=0, p=synth.scene_params(), obs_seed=5000 + b) for b in range(max(B_l))]
 for wide, G in [(w, g) for w in wide_l for g in (G_l if w else [0])]:
