@@ -7,6 +7,8 @@ sys.path.insert(0, ".")
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package(); synth, srukf = pkg.synth, pkg.srukf
+if os.environ.get("LIB"):                                        # an A/B build (scripts/build_variants.sh)
+    srukf.load_library(os.path.join(os.getcwd(), os.environ["LIB"]))
 arg = lambda i, d: [int(x) for x in sys.argv[i].split(",")] if len(sys.argv) > i else d
 B_l, wide_l = arg(1, [2, 4, 8, 12, 16]), arg(2, [1, 0])
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 200
