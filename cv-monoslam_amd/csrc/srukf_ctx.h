@@ -61,6 +61,7 @@ void srukf_launch_rank_expand(hipStream_t, int, int, int, double, const double*,
 void srukf_launch_project_table(hipStream_t, KDims, KWeights, srukf_params, double*, double*, double*, double*, double*, double*, FrameScalars*, RankArgs, NullSkip);
 void srukf_launch_sigr_rows(hipStream_t, KDims, KWeights, const double*, const double*, double*, const FrameScalars*, const int*, int);
 void srukf_launch_rank_shadow(hipStream_t, int, int, int, const double*, const int*, double*);
+void srukf_launch_rank_canon(hipStream_t, int, int, int, double, const int*, double*);
 void srukf_launch_rank_round(hipStream_t, int, int, double*);
 void srukf_launch_syrk_own(hipStream_t, int, int, const double*, const double*, int, int, int, double*, void*, const void*, int, int);
 int srukf_gmw_register_form(int, int, int, int);
@@ -211,6 +212,7 @@ struct srukf_ctx {
         int step_spin = 1;                 // "step_spin": the step-wise fast path waits for its two exports by spinning on a pinned flag word (0: hipStreamSynchronize)
         int step_fast = 1;                 // "step_fast": 0: the step-wise API keeps to its own launch sequences (k_motion, k_project, k_meas_*, k_pxy, ...: round 4's path)
         int split_record = 0;              // "split_record": every split-form factorisation first copies its input matrix to Gbak (scripts/split_replay.py)
+        int null_canon = 1;                // "null_canon": a factor of the library's own making that was not produced by a rank-aware tail (NEED_REORDER, map changes) gets its null rows rewritten as sqrt(EPSILON) e_k at once
         int split_fold = 1;                // "split_fold": the split form's tile launch forms the tiles of S^T S - U U^T itself (k_gmw_tiles_fold), k_syrk in front keeps block row 0; 0: k_syrk forms everything first
         int gain_fold = 0;                 // "gain_fold": the staged replay's "fused tail" frames form U^T and the state update in the tile epilogue of k_pxy2 (three launches per frame); 0: k_gain
         int mixed_rank = 1;                // "mixed_rank": SRUKF_STORAGE_F32_MIXED runs the rank-aware refactorisation (fp32-formed S^T S - U U^T over the kept rows, FP64 factorisation
@@ -411,6 +413,7 @@ int mixed_red_ensure(srukf_ctx* c);
 void drop_graphs(srukf_ctx* c);
 void exact_path(srukf_ctx* c, const double* Gbuf, double* Sout);      // the exact column path for Gbuf -> Sout (D, theta, clamp count as side effects)
 void set_null_canonical(srukf_ctx* c);
+void canonicalize_null_rows(srukf_ctx* c);      // after update_null_set on a factor of the library's own making (NEED_REORDER, map changes): the next frame may take the fast path
 int read_fs(srukf_ctx* c);
 int read_fs_host(srukf_ctx* c);
 int set_shared(srukf_ctx* c, int shared, int tenants);

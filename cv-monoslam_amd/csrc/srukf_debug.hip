@@ -126,6 +126,7 @@ int srukf_debug_set(srukf_ctx* c, const char* key, int value)
     else if (!strcmp(key, "f32_fuse")) c->dbg.f32_fuse = value ? 1 : 0;
     else if (!strcmp(key, "split_record")) c->dbg.split_record = value ? 1 : 0;
     else if (!strcmp(key, "gain_fold")) c->dbg.gain_fold = value ? 1 : 0;
+    else if (!strcmp(key, "null_canon")) c->dbg.null_canon = value ? 1 : 0;
     else if (!strcmp(key, "split_fold")) c->dbg.split_fold = value < 0 ? 0 : value > 2 ? 2 : value;      // (2: measurements — the fold's launch behind a k_syrk that has formed everything)
     else if (!strcmp(key, "mixed_rank")) c->dbg.mixed_rank = value ? 1 : 0;
     else if (!strcmp(key, "mixed_f64_robot")) c->dbg.mixed_f64_robot = value ? 1 : 0;

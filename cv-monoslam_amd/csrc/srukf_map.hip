@@ -222,6 +222,7 @@ int srukf_add_landmarks(srukf_ctx* c, int K, const double* uv)
     rc = srukf_set_storage(c, storage); if (rc) return rc;
     mt.mark("set_storage");
     rc = update_null_set(c); if (rc) return rc;
+    canonicalize_null_rows(c);
     mt.mark("null_set");
     return srukf_set_new_landmarks(c, K);
 }
@@ -284,6 +285,7 @@ int srukf_delete_landmark(srukf_ctx* c, int id)
     rc = srukf_set_storage(c, storage); if (rc) return rc;
     mt.mark("set_storage");
     rc = update_null_set(c); if (rc) return rc;
+    canonicalize_null_rows(c);
     mt.mark("null_set");
     return srukf_set_new_landmarks(c, k_new);
 }

@@ -431,6 +431,18 @@ void srukf_launch_rank_expand_b(hipStream_t st, int n, int ld, int r, double eps
     const int per = n + 1 + nchk + 5;
     hipLaunchKernelGGL(k_rank_expand_b, dim3(per * B), dim3(256), sizeof(double) * (size_t)ld, st, n, ld, r, eps, (const ExpandArgs*)tab, per, gamma, d, w, p);
 }
+// The structurally null rows of S made what the reference's clamp leaves there and every rank-aware frame tail rewrites: sqrt(EPSILON) e_k (a factor from a path that
+// factors every pivot — NEED_REORDER, the map operations — holds rounding noise / sqrt(EPSILON) beside that diagonal).  One workgroup per dropped row.
+__global__ __launch_bounds__(256) void k_rank_canon(int n, int ld, int r, double sq, const int* __restrict__ perm, double* __restrict__ S)
+{
+    const int k = perm[r + blockIdx.x];
+    if (k < 0 || k >= n) return;
+    for (int c = threadIdx.x; c < ld; c += 256) S[(size_t)k * ld + c] = (c == k) ? sq : 0.0;
+}
+void srukf_launch_rank_canon(hipStream_t st, int n, int ld, int r, double sq, const int* perm, double* S)
+{
+    if (n - r > 0) hipLaunchKernelGGL(k_rank_canon, dim3(n - r), dim3(256), 0, st, n, ld, r, sq, perm, S);
+}
 void srukf_launch_rank_shadow(hipStream_t st, int n, int ld, int r, const double* S, const int* perm, double* A)
 {
     hipLaunchKernelGGL(k_rank_shadow, dim3(ld), dim3(256), 0, st, n, ld, r, S, perm, A);

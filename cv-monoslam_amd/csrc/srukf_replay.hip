@@ -972,6 +972,16 @@ static int capture_frames(srukf_ctx* c, int nframes, hipGraph_t* g, hipGraphExec
 namespace srukf_impl {
 
 // the null rows are canonical from here on (a rank-aware frame tail has been issued): captured frames of the other launch sequence are stale
+// fp64 storage only (the float-stored modes keep their rounded copies in step elsewhere); "null_canon" 0: the first frame behind such a factor runs the launch sequence that
+// reads the rows as they are and its tail rewrites them (rounds 2 - 5)
+void canonicalize_null_rows(srukf_ctx* c)
+{
+    if (!c->dbg.null_canon || c->red_r <= 0 || c->null_canonical || c->storage != SRUKF_STORAGE_F64 || !c->red_perm) return;
+    srukf_launch_rank_canon(c->stream, c->d.n, c->d.np, c->red_r, sqrt(c->p.epsilon), c->red_perm, c->S);
+    c->null_canonical = true;
+    drop_graphs(c);
+}
+
 void set_null_canonical(srukf_ctx* c)
 {
     if (c->red_r > 0 && !c->null_canonical) { c->null_canonical = true; drop_graphs(c); }

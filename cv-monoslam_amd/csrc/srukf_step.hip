@@ -368,7 +368,7 @@ static int step_update_slow(srukf_ctx* c, const double* z, const int* matched, i
     // rank-aware form: the reorder path and the exact column path write S without the permuted copy, and their factor may have
     // other null rows (a frame that went to the exact path because a skipped direction was found not to be null must not meet the
     // same null set again)
-    if (reorder == SRUKF_NEED_REORDER || exact_ran) { const int rc = update_null_set(c); if (rc) return rc; }
+    if (reorder == SRUKF_NEED_REORDER || exact_ran) { const int rc = update_null_set(c); if (rc) return rc; canonicalize_null_rows(c); }
     else {
         shadow_rebuild(c);
         if (c->storage != SRUKF_STORAGE_F32_MIXED || storage_f32_like(c)) set_null_canonical(c);     // the rank-aware tail (k_rank_expand) has written sqrt(EPSILON) e_k into every skipped row
