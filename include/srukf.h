@@ -291,7 +291,9 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  *   k_gmw_pivslab_persist + k_gmw_tiles_persist; 2: the split form also where a worker would own two register tiles),
  *   round 6: "exact_rl" (0: the left-looking exact path k_gmw_col, one row per launch; 1: right-looking, as many pivots per launch as fit — default; 1 + B: B pivots per
  *   launch), "fold_head" (block rows the k_syrk launch in front of the split fold forms; 0: the rule 2 (Tp - 17)), "fold_force" (the split fold also where the tile workgroups
- *   do not all fit beside the pivot / slab launch), "timing" (1: phases of map changes and of flagged frames on stderr).
+ *   do not all fit beside the pivot / slab launch), "timing" (1: phases of map changes and of flagged frames on stderr), "ctx_keep" (contexts a handle keeps across map
+ *   changes: default 24), "batch_xcd" (0: k_syrk_b walks the head tiles in the solo launch's order), "batch_k128" (0: one pass over G per panel in the batched replay's
+ *   trailing updates instead of one per pair of panels).
  * Per-context keys: "use_graph" (0: eager launches), "fused_motion" (0: k_motion + k_project as two launches, 1: k_project_motion, 2: "table"
  *   mode), "pxy2" (0: k_pxy instead of k_pxy2), "nullskip", "head_fold" (0: k_syrk launch in front of the persistent launch), "tail_fuse"
  *   (0: k_project_table in front of every frame), "table_perm", "f32_fuse", "step_fast" (0: the step-wise API keeps to its own launch sequences instead of the
@@ -301,7 +303,8 @@ int  srukf_debug_allow_mixed(srukf_ctx* ctx, int on);
  *   view is never exported with an update's status), "split_record"; round 6: "gain_fold" (1: k_gain's work in the tile epilogue of k_pxy2_fold — three launches per frame,
  *   slower: off), "split_fold" (0: k_syrk over all kept rows in front of the split form's pair instead of forming jobs inside its tile launch), "mixed_rank" (0: round 2's
  *   full-rank form of SRUKF_STORAGE_F32_MIXED), "mixed_f64_robot" (0: every tile of the mixed downdate on the fp32 pipe), "mixed_bf16" (1: its fp32 products from three bf16
- *   pieces), "mixed_null_ppm".  See srukf_ctx.h (srukf_ctx::DbgSwitches). */
+ *   pieces), "mixed_null_ppm", "null_canon" (0: the null rows of a factor that NEED_REORDER or a map operation produced are left as they are until a frame tail rewrites them).
+ *   See srukf_ctx.h (srukf_ctx::DbgSwitches). */
 int  srukf_debug_set(srukf_ctx* ctx, const char* key, int value);
 /* Diagnostic read-out of device-resident counters ("gmw_aborts", "clamp_rows", "frame", "frozen", "gate_timeouts", "gmw_shared", "split_form", "split_off",
  * "step_fast" / "step_slow": frames the step-wise API ran on the fast / the other path, "view_hits": srukf_get_frame_view calls served from an exported view,
